@@ -1,0 +1,132 @@
+/*
+ * spt_hip.h -- C ABI of libspt_hip.so: SPT's PQ sparse-attention operators for
+ * AMD MI355X (gfx950), hand-written HIP.
+ *
+ * This is the drop-in boundary for the hot path of ytgui/SPT-proto.  Each entry
+ * point replaces one pybind11 export of the reference's `naive_gpt.ext`
+ * (extension/entry.cpp:43-56).  The reference interface takes torch::Tensor; this
+ * ABI takes what those tensors hold: raw DEVICE pointers, sizes and a HIP stream.
+ * No allocation, no synchronisation and no global state inside any call, so calls
+ * are safe from several threads/streams and can be captured into a hipGraph.
+ *
+ * Conventions
+ *   - every pointer is device memory of the current device, contiguous, row-major;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - float = IEEE fp32, indices = int32 (`index_t`, extension/common.h:59);
+ *   - CSR: `indptr` [S+1] is shared by all B batches (batch stride 0), `indices` /
+ *     values are [B, nnz] with nnz = indptr[S] (extension/sddmm.cpp:43-49);
+ *   - return value: SPT_OK (0), a negative SPT_E* precondition code (the checks the
+ *     reference makes with TORCH_CHECK, extension/common.h:13-21), or a positive
+ *     hipError_t from the launch.  spt_strerror() names either.
+ *   - outputs that the algorithm only partially covers are fully written by the
+ *     kernels themselves (zeros included): callers pass uninitialised buffers.
+ */
+#ifndef SPT_HIP_H
+#define SPT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPT_OK 0
+#define SPT_EINVAL (-1)   /* null pointer / non-positive size */
+#define SPT_ESHAPE (-2)   /* shape precondition of the reference violated */
+#define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
+
+/* ABI version; bump on any signature change. */
+#define SPT_ABI_VERSION 1
+int spt_abi_version(void);
+const char *spt_strerror(int code);
+
+/*
+ * cdist_forward_cuda(query, table) -> [distance, indices]
+ *   reference: extension/entry.cpp:7-9, extension/cdist.cu:185-250 (kernel :7-69)
+ * query [M, NQ, D], table [M, C, D] -> distance [M, NQ, C] (may be NULL: the PQ
+ * 'encode' mode of naive_gpt/layers/basic/quantizer.py:74-77 discards it),
+ * indices [M, NQ].  L1 distance summed in fp32 in ascending i, argmin with strict
+ * '<' in ascending c (bit-exact contract).  Requires D % 4 == 0, D <= 32.
+ * (The reference additionally needs NQ % 16 == 0 and C % 16 == 0; not needed here.)
+ */
+int spt_cdist_forward(const float *query, const float *table, float *distance,
+                      int32_t *indices, int n_subspaces, int n_queries,
+                      int n_codewords, int d_code, void *stream);
+
+/*
+ * cdist_backward_cuda(query, table, grad_output) -> [grad_query, grad_table]
+ *   reference: extension/entry.cpp:11-14, extension/cdist.cu:252-333
+ * grad_output [M, NQ, C] -> grad_query [M, NQ, D], grad_table [M, C, D].
+ * `workspace` holds per-workgroup partial sums of grad_table:
+ * spt_cdist_backward_workspace_bytes() bytes, uninitialised.
+ */
+int64_t spt_cdist_backward_workspace_bytes(int n_subspaces, int n_queries,
+                                           int n_codewords, int d_code);
+int spt_cdist_backward(const float *query, const float *table,
+                       const float *grad_output, float *grad_query,
+                       float *grad_table, void *workspace, int n_subspaces,
+                       int n_queries, int n_codewords, int d_code, void *stream);
+
+/*
+ * lookup_forward_cuda(config, query, key) -> indices
+ *   reference: extension/entry.cpp:16-19, extension/lookup.cu:87-174 (kernel :10-84)
+ * query/key [B, S, M] PQ codes -> out [B, S, Z], Z = S / sparsity, where
+ * `sparsity` is the reference's config.size(0) (lookup.cu:99).  Bit-exact with
+ * the reference kernel's bucketed causal selection, including its cursor
+ * saturation and zero padding.  Requires S % 16 == 0, S % sparsity == 0,
+ * Z % 16 == 0 (lookup.cu:103-106), 4 <= M <= 16 (any Z: the reference only
+ * instantiates M in {8,10,16} x Z in {32,64,128}, lookup.cu:113-169).
+ */
+int spt_lookup_forward(const int32_t *query, const int32_t *key, int32_t *out,
+                       int batch_size, int seq_length, int n_subspaces,
+                       int sparsity, void *stream);
+
+/*
+ * sddmm_forward_cuda(trans_lhs=false, trans_rhs=true, indptr, indices, query, key)
+ *   reference: extension/entry.cpp:27-31, extension/sddmm.cpp:3-73 (cusparseSDDMM)
+ * out[b, p] = sum_e query[b, row(p), e] * key[b, indices[b, p], e];
+ * query/key [B, S, E], out [B, nnz].  Requires E % 4 == 0, E <= 256.
+ * `scale`/`clamp`: out = clamp(scale * dot, -clamp, +clamp) when clamp > 0 (the
+ * epilogue of naive_gpt/layers/sparse/attention.py:125-127); pass scale = 1,
+ * clamp = 0 for the plain operator.
+ */
+int spt_sddmm_forward(const int32_t *indptr, const int32_t *indices,
+                      const float *query, const float *key, float *out,
+                      int batch_size, int seq_length, int d_head, int nnz,
+                      float scale, float clamp, void *stream);
+
+/*
+ * spmm_forward_cuda(trans_lhs, trans_rhs=false, indptr, indices, values, x)
+ *   reference: extension/entry.cpp:21-25, extension/spmm.cpp:3-72 (cusparseSpMM)
+ * trans_lhs == 0: y[b, r, :]             = sum_{p in row r} values[b,p] * x[b, indices[b,p], :]
+ * trans_lhs != 0: y[b, indices[b,p], :] += values[b,p] * x[b, row(p), :]   (y zeroed first)
+ * x, y [B, S, E].  Requires E % 4 == 0, E <= 256.
+ */
+int spt_spmm_forward(int trans_lhs, const int32_t *indptr,
+                     const int32_t *indices, const float *values,
+                     const float *x, float *y, int batch_size, int seq_length,
+                     int d_head, int nnz, void *stream);
+
+/*
+ * softmax_forward_cuda(indptr, indices, values) -> output
+ *   reference: extension/entry.cpp:33-36, extension/softmax.cu:84-114 (kernel :7-47)
+ * y = mask * exp(v) / max(1e-9, sum_row mask * exp(v)), mask = indices <= row.
+ */
+int spt_softmax_forward(const int32_t *indptr, const int32_t *indices,
+                        const float *values, float *output, int batch_size,
+                        int seq_length, int nnz, void *stream);
+
+/*
+ * softmax_backward_cuda(indptr, indices, output, grad_output) -> grad_values
+ *   reference: extension/entry.cpp:38-41, extension/softmax.cu:116-148 (kernel :49-81)
+ * c = max(1e-9, sum_row mask*y*dy); dv = mask * y * (dy - c).
+ */
+int spt_softmax_backward(const int32_t *indptr, const int32_t *indices,
+                         const float *output, const float *grad_output,
+                         float *grad_values, int batch_size, int seq_length,
+                         int nnz, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPT_HIP_H */

@@ -1,0 +1,92 @@
+// spt_common.h -- shared device helpers for libspt_hip.so (gfx950 / CDNA4 only).
+//
+// wave = 64 lanes everywhere in this library; a "group" is a power-of-two run of
+// consecutive lanes inside one wave that co-operates on one CSR entry / one row.
+#ifndef SPT_COMMON_H
+#define SPT_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/spt_hip.h"
+
+#define SPT_WAVE 64
+
+#define SPT_LAUNCH_CHECK()                         \
+    do {                                           \
+        hipError_t e__ = hipGetLastError();        \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)
+
+#define SPT_HIP_TRY(expr)                          \
+    do {                                           \
+        hipError_t e__ = (expr);                   \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)
+
+namespace spt {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (SPT_WAVE - 1); }
+
+// ---- DPP helpers: lane movement inside a row of 16 lanes, no LDS traffic ----
+// row_ror:n rotates the 16-lane row right by n lanes.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+
+// One butterfly step of a sum all-reduce.  Steps must be applied in the order
+// 1,2,4,8,16,32: the 4- and 8-lane steps use DPP mirrors, which equal an xor
+// exchange only when the value is already uniform over the smaller sub-group.
+// Every lane of a group ends with the bitwise-identical sum.
+template <int STEP>
+__device__ __forceinline__ float butterfly_partner(float v) {
+    if constexpr (STEP == 1) {
+        return dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    } else if constexpr (STEP == 2) {
+        return dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    } else if constexpr (STEP == 4) {
+        return dpp_mov<0x141>(v);  // row_half_mirror: lane i <-> 7-i
+    } else if constexpr (STEP == 8) {
+        return dpp_mov<0x140>(v);  // row_mirror: lane i <-> 15-i
+    } else if constexpr (STEP == 16) {
+        // ds_swizzle bit mode (and=0x1f, or=0, xor=16): crossbar only, no LDS memory
+        return __builtin_bit_cast(
+            float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (16 << 10) | 0x1F));
+    } else {
+        return __shfl_xor(v, 32, SPT_WAVE);
+    }
+}
+
+// all-reduce (sum) over groups of G consecutive lanes, G a power of two <= 64.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+    if constexpr (G >= 2) v += butterfly_partner<1>(v);
+    if constexpr (G >= 4) v += butterfly_partner<2>(v);
+    if constexpr (G >= 8) v += butterfly_partner<4>(v);
+    if constexpr (G >= 16) v += butterfly_partner<8>(v);
+    if constexpr (G >= 32) v += butterfly_partner<16>(v);
+    if constexpr (G >= 64) v += butterfly_partner<32>(v);
+    return v;
+}
+
+// Blocks that work on the same batch should share an XCD (its 4 MiB L2 then holds
+// that batch's K / V / CSR slice).  Workgroups are dealt round-robin over the 8
+// XCDs, so ids with equal (id % 8) share one: give each residue class a contiguous
+// run of logical ids.  Bijective for any grid size (cdna guide 5, T1).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
+    const unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + j;
+}
+
+__host__ __device__ __forceinline__ int pow2_ceil(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+}  // namespace spt
+
+#endif  // SPT_COMMON_H

@@ -1,0 +1,338 @@
+"""``naive_gpt.ext`` -- the native-operator module of SPT-proto, MI355X edition.
+
+Same seven callables, names and argument order as the reference's pybind11 module
+(``extension/entry.cpp:43-56``); the ``_cuda`` suffix is API, not a dependency.
+Each call validates its tensors the way the reference's ``CHECK_DIM`` /
+``CHECK_TYPE`` macros do (``extension/common.h:13-21``), allocates the outputs
+through torch's caching allocator, and enqueues hand-written gfx950 kernels from
+``libspt_hip.so`` (C ABI: ``include/spt_hip.h``) on torch's *current* HIP stream.
+
+There is no CPU path and no fallback: without the built library, or with CPU
+tensors, every call raises ``RuntimeError``.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libspt_hip.so')
+
+_c_int = ctypes.c_int
+_c_f32 = ctypes.c_float
+_c_ptr = ctypes.c_void_p
+
+# name -> argtypes, exactly the prototypes of include/spt_hip.h
+_PROTOTYPES = {
+    'spt_abi_version': ([], _c_int),
+    'spt_strerror': ([_c_int], ctypes.c_char_p),
+    'spt_cdist_forward': ([_c_ptr] * 4 + [_c_int] * 4 + [_c_ptr], _c_int),
+    'spt_cdist_backward_workspace_bytes': ([_c_int] * 4, ctypes.c_int64),
+    'spt_cdist_backward': ([_c_ptr] * 6 + [_c_int] * 4 + [_c_ptr], _c_int),
+    'spt_lookup_forward': ([_c_ptr] * 3 + [_c_int] * 4 + [_c_ptr], _c_int),
+    'spt_sddmm_forward': (
+        [_c_ptr] * 5 + [_c_int] * 4 + [_c_f32, _c_f32, _c_ptr], _c_int
+    ),
+    'spt_spmm_forward': ([_c_int] + [_c_ptr] * 5 + [_c_int] * 4 + [_c_ptr], _c_int),
+    'spt_softmax_forward': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_softmax_backward': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
+}
+ABI_VERSION = 1
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen libspt_hip.so and bind the C ABI; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'naive_gpt.ext: {} is missing -- build it with '
+            '`make -C spt-proto_amd/csrc` (or __graft_entry__.build()); '
+            'there is no CPU fallback'.format(LIB_PATH)
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in _PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    if lib.spt_abi_version() != ABI_VERSION:
+        raise RuntimeError('naive_gpt.ext: libspt_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def _raise(lib, rc: int, what: str):
+    msg = lib.spt_strerror(rc)
+    msg = msg.decode() if msg else 'unknown'
+    # launch failures surface like the reference's CUDA_CHECH (common.h:23-33)
+    raise RuntimeError('{}: {} ({})'.format(what, msg, rc))
+
+
+def _check_dim(x: torch.Tensor, dim: int, name: str):
+    # CHECK_DIM, extension/common.h:13-18
+    if not isinstance(x, torch.Tensor):
+        raise TypeError('{} must be a torch.Tensor'.format(name))
+    if not x.is_cuda:
+        raise RuntimeError('{} must be a CUDA tensor'.format(name))
+    if x.dim() != dim:
+        raise RuntimeError('{} must be of dim {}'.format(name, dim))
+    if not x.is_contiguous():
+        raise RuntimeError(
+            '{} custom kernel requires contiguous tensor'.format(name)
+        )
+
+
+def _check_type(x: torch.Tensor, dtype: torch.dtype, name: str):
+    # CHECK_TYPE, extension/common.h:20-21
+    if x.dtype != dtype:
+        raise RuntimeError('{} must be type of {}'.format(name, dtype))
+
+
+def _require(cond: bool, msg: str):
+    # TORCH_CHECK
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _same_device(*tensors):
+    dev = tensors[0].device
+    for t in tensors[1:]:
+        _require(t.device == dev, 'all tensors must be on the same device')
+    return dev
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _flag(t) -> bool:
+    # trans_lhs / trans_rhs are CPU bool scalars read on the host (sddmm.cpp:53-56)
+    return bool(t.item()) if isinstance(t, torch.Tensor) else bool(t)
+
+
+def cdist_forward_cuda(query: torch.Tensor, table: torch.Tensor):
+    """extension/cdist.cu:185-250 -> [distance [M,NQ,C] f32, indices [M,NQ] i32]."""
+    _check_dim(query, 3, 'query')
+    _check_dim(table, 3, 'table')
+    _check_type(query, torch.float32, 'query')
+    _require(query.size(0) == table.size(0), 'query.size(0) == table.size(0)')
+    _require(query.size(-1) == table.size(-1), 'query.size(-1) == table.size(-1)')
+    _require(query.dtype == table.dtype, 'query.scalar_type() == table.scalar_type()')
+    dev = _same_device(query, table)
+    M, NQ, D = query.shape
+    C = table.size(1)
+    lib = load_library()
+    with torch.cuda.device(dev):
+        distance = torch.empty([M, NQ, C], dtype=torch.float32, device=dev)
+        indices = torch.empty([M, NQ], dtype=torch.int32, device=dev)
+        rc = lib.spt_cdist_forward(
+            query.data_ptr(), table.data_ptr(), distance.data_ptr(),
+            indices.data_ptr(), M, NQ, C, D, _stream(dev)
+        )
+    if rc != 0:
+        _raise(lib, rc, 'cdist_forward_cuda')
+    return [distance, indices]
+
+
+def cdist_encode(query: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    """Indices-only form of cdist_forward_cuda (distance not materialised)."""
+    _check_dim(query, 3, 'query')
+    _check_dim(table, 3, 'table')
+    _check_type(query, torch.float32, 'query')
+    _check_type(table, torch.float32, 'table')
+    _require(query.size(0) == table.size(0), 'query.size(0) == table.size(0)')
+    _require(query.size(-1) == table.size(-1), 'query.size(-1) == table.size(-1)')
+    dev = _same_device(query, table)
+    M, NQ, D = query.shape
+    lib = load_library()
+    with torch.cuda.device(dev):
+        indices = torch.empty([M, NQ], dtype=torch.int32, device=dev)
+        rc = lib.spt_cdist_forward(
+            query.data_ptr(), table.data_ptr(), None, indices.data_ptr(),
+            M, NQ, table.size(1), D, _stream(dev)
+        )
+    if rc != 0:
+        _raise(lib, rc, 'cdist_encode')
+    return indices
+
+
+def cdist_backward_cuda(query: torch.Tensor, table: torch.Tensor,
+                        grad_output: torch.Tensor):
+    """extension/cdist.cu:252-333 -> [grad_query, grad_table]."""
+    _check_dim(query, 3, 'query')
+    _check_dim(table, 3, 'table')
+    _check_dim(grad_output, 3, 'grad_output')
+    _check_type(query, torch.float32, 'query')
+    _require(query.size(0) == table.size(0), 'query.size(0) == table.size(0)')
+    _require(query.size(-1) == table.size(-1), 'query.size(-1) == table.size(-1)')
+    _require(query.size(0) == grad_output.size(0), 'query.size(0) == grad_output.size(0)')
+    _require(query.size(1) == grad_output.size(1), 'query.size(1) == grad_output.size(1)')
+    _require(table.size(1) == grad_output.size(-1), 'table.size(1) == grad_output.size(-1)')
+    _require(query.dtype == table.dtype, 'query.scalar_type() == table.scalar_type()')
+    _require(query.dtype == grad_output.dtype,
+             'query.scalar_type() == grad_output.scalar_type()')
+    dev = _same_device(query, table, grad_output)
+    M, NQ, D = query.shape
+    C = table.size(1)
+    lib = load_library()
+    with torch.cuda.device(dev):
+        grad_query = torch.empty_like(query)
+        grad_table = torch.empty_like(table)
+        nbytes = lib.spt_cdist_backward_workspace_bytes(M, NQ, C, D)
+        workspace = torch.empty([max(int(nbytes), 16)], dtype=torch.uint8, device=dev)
+        rc = lib.spt_cdist_backward(
+            query.data_ptr(), table.data_ptr(), grad_output.data_ptr(),
+            grad_query.data_ptr(), grad_table.data_ptr(), workspace.data_ptr(),
+            M, NQ, C, D, _stream(dev)
+        )
+    if rc != 0:
+        _raise(lib, rc, 'cdist_backward_cuda')
+    return [grad_query, grad_table]
+
+
+def lookup_forward_cuda(config: torch.Tensor, query: torch.Tensor,
+                        key: torch.Tensor) -> torch.Tensor:
+    """extension/lookup.cu:87-174; ``config.size(0)`` is the sparsity coefficient."""
+    _check_dim(key, 3, 'key')
+    _check_dim(query, 3, 'query')
+    _check_type(key, torch.int32, 'key')
+    _check_type(query, torch.int32, 'query')
+    _require(query.shape == key.shape, 'query.sizes() == key.sizes()')
+    dev = _same_device(query, key)
+    sparsity = int(config.size(0))
+    B, S, M = query.shape
+    _require(S % 16 == 0, 'seq_length % BLOCK_SIZE == 0')
+    _require(sparsity > 0 and S % sparsity == 0, 'seq_length % sparsity == 0')
+    Z = S // sparsity
+    _require(Z % 16 == 0, 'nonzeros % BLOCK_SIZE == 0')
+    lib = load_library()
+    with torch.cuda.device(dev):
+        output = torch.empty([B, S, Z], dtype=torch.int32, device=dev)
+        rc = lib.spt_lookup_forward(
+            query.data_ptr(), key.data_ptr(), output.data_ptr(),
+            B, S, M, sparsity, _stream(dev)
+        )
+    if rc != 0:
+        _raise(lib, rc, 'lookup_forward_cuda')
+    return output
+
+
+def _check_csr(indptr, indices):
+    _check_dim(indptr, 1, 'indptr')
+    _check_dim(indices, 2, 'indices')
+    _check_type(indptr, torch.int32, 'indptr')
+    _check_type(indices, torch.int32, 'indices')
+
+
+def sddmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,
+                       indices: torch.Tensor, query: torch.Tensor,
+                       key: torch.Tensor, scale: float = 1.0,
+                       clamp: float = 0.0) -> torch.Tensor:
+    """extension/sddmm.cpp:3-73.  ``scale``/``clamp`` (extension of the reference
+    signature, defaults = plain operator) fold attention.py:125-127 into the store."""
+    _check_dim(key, 3, 'key')
+    _check_dim(query, 3, 'query')
+    _check_csr(indptr, indices)
+    _check_type(query, torch.float32, 'query')
+    _require(query.shape == key.shape, 'query.sizes() == key.sizes()')
+    _require(query.size(0) == indices.size(0), 'query.size(0) == indices.size(0)')
+    _require(query.dtype == key.dtype, 'query.scalar_type() == key.scalar_type()')
+    _require(not _flag(trans_lhs) and _flag(trans_rhs),
+             'sddmm: only (trans_lhs=False, trans_rhs=True) is implemented')
+    dev = _same_device(indptr, indices, query, key)
+    B, S, E = query.shape
+    nnz = indices.size(-1)
+    _require(indptr.size(-1) == S + 1, 'indptr.size(-1) == seq_length + 1')
+    lib = load_library()
+    with torch.cuda.device(dev):
+        output = torch.empty([B, nnz], dtype=torch.float32, device=dev)
+        rc = lib.spt_sddmm_forward(
+            indptr.data_ptr(), indices.data_ptr(), query.data_ptr(),
+            key.data_ptr(), output.data_ptr(), B, S, E, nnz,
+            float(scale), float(clamp), _stream(dev)
+        )
+    if rc != 0:
+        _raise(lib, rc, 'sddmm_forward_cuda')
+    return output
+
+
+def spmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,
+                      indices: torch.Tensor, values: torch.Tensor,
+                      x: torch.Tensor) -> torch.Tensor:
+    """extension/spmm.cpp:3-72; ``trans_lhs`` selects A.x (False) or A^T.x (True)."""
+    _check_dim(x, 3, 'x')
+    _check_csr(indptr, indices)
+    _check_dim(values, 2, 'values')
+    _check_type(values, torch.float32, 'values')
+    _check_type(x, torch.float32, 'x')
+    _require(indices.shape == values.shape, 'indices.sizes() == values.sizes()')
+    _require(x.size(0) == indices.size(0), 'x.size(0) == indices.size(0)')
+    _require(not _flag(trans_rhs), 'spmm: trans_rhs=True is not implemented')
+    dev = _same_device(indptr, indices, values, x)
+    B, S, E = x.shape
+    nnz = indices.size(-1)
+    _require(indptr.size(-1) == S + 1, 'indptr.size(-1) == seq_length + 1')
+    lib = load_library()
+    with torch.cuda.device(dev):
+        output = torch.empty_like(x)
+        rc = lib.spt_spmm_forward(
+            int(_flag(trans_lhs)), indptr.data_ptr(), indices.data_ptr(),
+            values.data_ptr(), x.data_ptr(), output.data_ptr(),
+            B, S, E, nnz, _stream(dev)
+        )
+    if rc != 0:
+        _raise(lib, rc, 'spmm_forward_cuda')
+    return output
+
+
+def softmax_forward_cuda(indptr: torch.Tensor, indices: torch.Tensor,
+                         values: torch.Tensor) -> torch.Tensor:
+    """extension/softmax.cu:84-114."""
+    _check_csr(indptr, indices)
+    _check_dim(values, 2, 'values')
+    _check_type(values, torch.float32, 'values')
+    _require(indices.shape == values.shape, 'indices.sizes() == values.sizes()')
+    dev = _same_device(indptr, indices, values)
+    B, nnz = indices.shape
+    S = indptr.size(-1) - 1
+    lib = load_library()
+    with torch.cuda.device(dev):
+        output = torch.empty_like(values)
+        rc = lib.spt_softmax_forward(
+            indptr.data_ptr(), indices.data_ptr(), values.data_ptr(),
+            output.data_ptr(), B, S, nnz, _stream(dev)
+        )
+    if rc != 0:
+        _raise(lib, rc, 'softmax_forward_cuda')
+    return output
+
+
+def softmax_backward_cuda(indptr: torch.Tensor, indices: torch.Tensor,
+                          output: torch.Tensor,
+                          grad_output: torch.Tensor) -> torch.Tensor:
+    """extension/softmax.cu:116-148."""
+    _check_csr(indptr, indices)
+    _check_dim(output, 2, 'output')
+    _check_dim(grad_output, 2, 'grad_output')
+    _check_type(output, torch.float32, 'output')
+    _check_type(grad_output, torch.float32, 'grad_output')
+    _require(indices.shape == output.shape, 'indices.sizes() == output.sizes()')
+    _require(indices.shape == grad_output.shape,
+             'indices.sizes() == grad_output.sizes()')
+    dev = _same_device(indptr, indices, output, grad_output)
+    B, nnz = indices.shape
+    S = indptr.size(-1) - 1
+    lib = load_library()
+    with torch.cuda.device(dev):
+        grad_values = torch.empty_like(output)
+        rc = lib.spt_softmax_backward(
+            indptr.data_ptr(), indices.data_ptr(), output.data_ptr(),
+            grad_output.data_ptr(), grad_values.data_ptr(), B, S, nnz,
+            _stream(dev)
+        )
+    if rc != 0:
+        _raise(lib, rc, 'softmax_backward_cuda')
+    return grad_values

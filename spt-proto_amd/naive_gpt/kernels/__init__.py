@@ -1,0 +1,9 @@
+"""naive_gpt.kernels -- the five operators of the SPT hot path
+(reference: ``naive_gpt/kernels/__init__.py:2-14``)."""
+from .cdist import cdist
+from .lookup import lookup
+from .softmax import softmax
+from .sddmm import sddmm
+from .spmm import spmm
+
+__all__ = ['cdist', 'lookup', 'softmax', 'sddmm', 'spmm']

@@ -1,0 +1,79 @@
+"""Shared test helpers: seeded input builders and independent restatements that
+cross-check the oracle (never the product path)."""
+import numpy as np
+
+
+def lookup_closed_form(q, k, coeff):
+    """Closed form of extension/lookup.cu:10-84, written
+    independently of oracle/spt_oracle.c's literal emulation.  Slow: small cases."""
+    B, S, M = q.shape
+    Z = S // coeff
+    Q = Z // 4
+    out = np.zeros([B, S, Z], np.int32)
+    q16, k16 = q & 0xFFFF, k & 0xFFFF
+    div = M // 4
+    for b in range(B):
+        for gy in range(S):
+            cnt = (q16[b, gy][None, :] == k16[b, :gy + 1]).sum(-1)
+            slot = np.minimum(3, cnt // div)
+            cols = np.arange(gy + 1)
+            limit = min(gy + 1, Z)
+            lists = {
+                (s, t): cols[(slot == s) & (cols % 4 == t)]
+                for s in range(4) for t in range(4)
+            }
+            for t in range(4):
+                cap = Q if t < 2 else Q - 1
+                seq = []
+                for s in (3, 2, 1, 0):
+                    own = lists[(s, t)]
+                    kept = list(own[:cap])
+                    if t < 2 and len(own) >= Q:
+                        partner = lists[(s, 3 - t)]
+                        if len(partner) >= Q:
+                            kept[Q - 1] = max(kept[Q - 1], partner[-1])
+                    seq += kept
+                for i, c in enumerate(seq):
+                    pos = t + 4 * i
+                    if pos < limit:
+                        out[b, gy, pos] = c
+    return out
+
+
+def uniform_csr(rng, B, S, Z, causal):
+    """indptr [S+1], indices [B, S*Z]: Z distinct columns per row (sorted like
+    to_sparse_csr gives them); causal rows with fewer than Z legal columns are
+    padded with column 0 duplicates, as lookup's output is."""
+    indptr = (np.arange(S + 1) * Z).astype(np.int32)
+    idx = np.zeros([B, S, Z], np.int32)
+    for b in range(B):
+        for r in range(S):
+            hi = (r + 1) if causal else S
+            n = min(hi, Z)
+            idx[b, r, :n] = np.sort(rng.choice(hi, size=n, replace=False))
+    return indptr, idx.reshape(B, S * Z)
+
+
+def ragged_csr(rng, B, S, max_nnz_row):
+    """A CSR pattern with per-row lengths in [0, max_nnz_row] shared by all batches
+    (indptr has batch stride 0 in the reference, sddmm.cpp:49)."""
+    lens = rng.integers(0, max_nnz_row + 1, size=S)
+    lens[rng.integers(0, S)] = 0
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = int(indptr[-1])
+    idx = np.zeros([B, nnz], np.int32)
+    for b in range(B):
+        for r in range(S):
+            n = lens[r]
+            idx[b, indptr[r]:indptr[r + 1]] = rng.integers(0, S, size=n)
+    return indptr, idx
+
+
+def dense_from_csr(indptr, indices, values, S):
+    B = indices.shape[0]
+    dense = np.zeros([B, S, S], np.float64)
+    for r in range(S):
+        for p in range(indptr[r], indptr[r + 1]):
+            for b in range(B):
+                dense[b, r, indices[b, p]] += values[b, p]
+    return dense
