@@ -1,0 +1,290 @@
+"""bench.py -- throughput of the SPT sparse-attention hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: BERT-large dimensions, sparse MHA only
+(cdist -> lookup -> sddmm -> softmax -> spmm and their backward), seq 512, 16 heads
+x 64, micro-batch 16 per GPU, fp32 (the reference's only dtype).  One step =
+`y = attn(q, k, v); y.sum().backward()` on resident synthetic tensors (protocol of
+script/0-profile.py:203-226).  Data parallel: every rank runs its own micro-batch
+(weak scaling); trainable gradients (the PQ codebook, present when --trigger arms the
+PQ loss as script/4-sparse-tuning-0.py:71-78 does) are all-reduced over RCCL.
+
+Rank 0 prints ONE JSON line: tokens/s over all ranks, plus
+  roofline     -- the dominant HIP kernel: algorithmic bytes / its HIP-event time
+  cpu_baseline -- the CPU oracle (single core port) on a bounded sample, N=1 only
+  dense        -- dense causal attention on the same GPU (the >=2x / <=50% claim)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'spt-proto_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
+
+S, H, E = 512, 16, 64   # BERT-large: d_model 1024 = 16 heads x 64
+M, C, D = E // 8, 16, 8
+Z = S // 8
+
+
+def algorithmic_bytes(op: str, B: int) -> int:
+    """SURVEY.md 8(d) per-(batch*head) figures x B slices handled by one launch."""
+    per = {
+        'cdist_encode': S * E * 4 + S * M * 4,
+        'cdist_forward_cuda': S * E * 4 + S * M * 4 + S * M * C * 4,
+        'cdist_backward_cuda': S * E * 4 + S * M * C * 4 + S * E * 4,
+        'lookup_forward_cuda': 2 * S * M * 4 + S * Z * 4,
+        'sddmm_forward_cuda': 2 * S * E * 4 + 2 * S * Z * 4,
+        'spmm_forward_cuda': 2 * S * Z * 4 + 2 * S * E * 4,
+        'softmax_forward_cuda': 3 * S * Z * 4,
+        'softmax_backward_cuda': 4 * S * Z * 4,
+    }
+    return per[op] * B
+
+
+class EventTimer:
+    """Brackets every naive_gpt.ext call with HIP events on torch's current stream
+    (the stream the kernels are launched on)."""
+
+    OPS = ['cdist_encode', 'cdist_forward_cuda', 'cdist_backward_cuda',
+           'lookup_forward_cuda', 'sddmm_forward_cuda', 'spmm_forward_cuda',
+           'softmax_forward_cuda', 'softmax_backward_cuda']
+
+    def __init__(self):
+        from naive_gpt import ext
+        self.ext = ext
+        self.events = {op: [] for op in self.OPS}
+        self.enabled = False
+        self.orig = {op: getattr(ext, op) for op in self.OPS}
+        for op in self.OPS:
+            setattr(ext, op, self._wrap(op))
+
+    def _wrap(self, op):
+        fn = self.orig[op]
+
+        def timed(*args, **kwargs):
+            if not self.enabled:
+                return fn(*args, **kwargs)
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn(*args, **kwargs)
+            b.record()
+            self.events[op].append((a, b))
+            return out
+        return timed
+
+    def summary(self):
+        out = {}
+        for op, pairs in self.events.items():
+            if pairs:
+                ms = [a.elapsed_time(b) for a, b in pairs]
+                out[op] = {'calls': len(ms), 'avg_us': 1e3 * float(np.mean(ms)),
+                           'total_ms': float(np.sum(ms))}
+        return out
+
+
+def sparse_step(attn, q, k, v, trigger):
+    if trigger:
+        attn.trigger.fill_(True)
+    y = attn(q, k, v, attn_mask=None)
+    loss = y.sum()
+    if trigger:
+        loss = loss + 1e-2 * attn.loss
+    loss.backward()
+
+
+def allreduce_grads(params, world):
+    grads = [p.grad for p in params if p.grad is not None]
+    if world == 1 or not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat)
+    flat /= world
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+def timed_loop(fn, steps, warmup, world):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def cpu_baseline(n_seq: int):
+    """The oracle's single-core chain on `n_seq` sequences x 16 heads (fwd + bwd)."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(0)
+    B = n_seq * H
+    q, k, v, dy = [rng.standard_normal([B, S, E]).astype(np.float32) for _ in range(4)]
+    table = rng.standard_normal([M, C, D]).astype(np.float32)
+    indptr = (np.arange(S + 1) * Z).astype(np.int32)
+
+    def codes(z):
+        zf = np.ascontiguousarray(z.reshape(B * S, M, D).transpose(1, 0, 2))
+        return np.ascontiguousarray(O.cdist_forward(zf, table, False)[1].T).reshape(B, S, M)
+
+    t0 = time.perf_counter()
+    idx = O.lookup_forward(codes(q), codes(k), 8).reshape(B, -1)
+    raw = O.sddmm_forward(indptr, idx, q, k) * np.float32(E ** -0.5)
+    a = O.softmax_forward(indptr, idx, np.clip(raw, -10, 10))
+    O.spmm_forward(False, indptr, idx, a, v)
+    da = O.sddmm_forward(indptr, idx, dy, v)
+    O.spmm_forward(True, indptr, idx, a, dy)
+    dr = O.softmax_backward(indptr, idx, a, da)
+    dr = np.where(np.abs(raw) < 10, dr * np.float32(E ** -0.5), 0).astype(np.float32)
+    O.spmm_forward(False, indptr, idx, dr, k)
+    O.spmm_forward(True, indptr, idx, dr, q)
+    dt = time.perf_counter() - t0
+    return {'value': n_seq * S / dt, 'unit': 'tokens/s', 'cores': 1, 'kind': 'port',
+            'sample': '{} sequences x {} heads x seq {} (fwd+bwd, oracle/spt_oracle.c, '
+                      '{:.1f} s)'.format(n_seq, H, S, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=16, help='micro-batch per GPU')
+    ap.add_argument('--trigger', action='store_true', help='arm the PQ training loss')
+    ap.add_argument('--no-dense', action='store_true')
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--cpu-seqs', type=int, default=40)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, 'launch {} ranks for --gpus {}'.format(args.gpus, args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from naive_gpt import ext, layers
+    ext.load_library()        # fail loudly when the HIP library is missing
+    timer = EventTimer()
+
+    torch.manual_seed(rank)
+    dev = torch.device('cuda', local_rank)
+    N = args.batch
+    attn = layers.SparseVanillaAttentionV2(d_head=E, d_codeword=D, n_codewords=C,
+                                           p_dropout=0.0).to(dev)
+    if world > 1:   # identical replicas
+        for p in attn.parameters():
+            dist.broadcast(p.data, src=0)
+    q, k, v = [torch.randn([N, S, H, E], device=dev, requires_grad=True) for _ in range(3)]
+    params = list(attn.parameters())
+
+    def step():
+        for t in (q, k, v):
+            t.grad = None
+        attn.zero_grad(set_to_none=True)
+        sparse_step(attn, q, k, v, args.trigger)
+        allreduce_grads(params, world)
+
+    torch.cuda.reset_peak_memory_stats()
+    # warm-up untimed and without events, then the timed region with events on
+    timed_loop(step, 0, args.warmup, world)
+    timer.enabled = True
+    dt = timed_loop(step, args.steps, 0, world)
+    timer.enabled = False
+    peak_gb = torch.cuda.max_memory_allocated() / 1e9
+    tokens = N * S * world * args.steps
+    result = {
+        'metric': 'fine-tune tokens/sec, BERT-large sparse-MHA (fwd+bwd), seq=512',
+        'value': tokens / dt, 'unit': 'tokens/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE.json configs[1]: BERT-large sparse-MHA only '
+                               '(cdist/lookup/sddmm/softmax/spmm fwd+bwd)',
+                   'micro_batch_per_gpu': N, 'global_batch': N * world, 'seq_len': S,
+                   'n_heads': H, 'd_head': E, 'nnz_per_row': Z, 'pq': [M, C, D],
+                   'trigger': bool(args.trigger), 'parallelism': 'dp{}'.format(world)},
+        'peak_hbm_gb': peak_gb,
+    }
+
+    if rank == 0:
+        kernels = timer.summary()
+        B = N * H
+        for op, st in kernels.items():
+            st['algorithmic_GBps'] = algorithmic_bytes(op, B) / (st['avg_us'] * 1e-6) / 1e9
+        dominant = max(kernels, key=lambda o: kernels[o]['total_ms'])
+        st = kernels[dominant]
+        result['roofline'] = {
+            'kernel': dominant, 'bound': 'hbm', 'achieved': st['algorithmic_GBps'],
+            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': st['algorithmic_GBps'] / HBM_PEAK_GBS,
+            'traffic': None, 'avg_us': st['avg_us'], 'calls_per_step': st['calls'] / args.steps,
+            'bytes_per_launch': algorithmic_bytes(dominant, B),
+        }
+        result['kernels'] = {op: {'avg_us': round(s_['avg_us'], 2),
+                                  'calls_per_step': s_['calls'] / args.steps,
+                                  'GBps': round(s_['algorithmic_GBps'], 1),
+                                  'frac': round(s_['algorithmic_GBps'] / HBM_PEAK_GBS, 4)}
+                             for op, s_ in kernels.items()}
+
+    # dense causal attention on the same GPU: the baseline of the 2x / 50% claims
+    if not args.no_dense:
+        del attn
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        dense = layers.VanillaAttention(d_head=E, p_dropout=0.0).to(dev)
+        mask = torch.full([S, S], float('-inf'), device=dev).triu(1)
+
+        def dense_step():
+            for t in (q, k, v):
+                t.grad = None
+            dense(q, k, v, attn_mask=mask).sum().backward()
+
+        ddt = timed_loop(dense_step, args.steps, args.warmup, world)
+        result['dense'] = {'value': tokens / ddt, 'unit': 'tokens/s',
+                           'ms_per_step': 1e3 * ddt / args.steps,
+                           'peak_hbm_gb': torch.cuda.max_memory_allocated() / 1e9,
+                           'what': 'layers.VanillaAttention fwd+bwd, causal mask, fp32'}
+        result['speedup_vs_dense'] = result['value'] / result['dense']['value']
+        result['peak_hbm_vs_dense'] = peak_gb / result['dense']['peak_hbm_gb']
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        result['cpu_baseline'] = cpu_baseline(args.cpu_seqs)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == '__main__':
+    main()

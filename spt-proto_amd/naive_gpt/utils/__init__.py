@@ -1,0 +1,4 @@
+"""naive_gpt.utils (reference: ``naive_gpt/utils/__init__.py``)."""
+from .adapter import LoRAHandler
+from .adapter import ModuleUpgrader
+from .adapter import SparseLoRAHandler
