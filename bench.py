@@ -48,6 +48,8 @@ def algorithmic_bytes(op: str, B: int) -> int:
         'lookup_forward_cuda': 2 * S * M * 4 + S * Z * 4,
         'sddmm_forward_cuda': 2 * S * E * 4 + 2 * S * Z * 4,
         'spmm_forward_cuda': 2 * S * Z * 4 + 2 * S * E * 4,
+        'spmm_transposed': 2 * S * Z * 4 + 2 * S * E * 4,
+        'csr_transpose': 3 * S * Z * 4,
         'softmax_forward_cuda': 3 * S * Z * 4,
         'softmax_backward_cuda': 4 * S * Z * 4,
     }
@@ -60,6 +62,7 @@ class EventTimer:
 
     OPS = ['cdist_encode', 'cdist_forward_cuda', 'cdist_backward_cuda',
            'lookup_forward_cuda', 'sddmm_forward_cuda', 'spmm_forward_cuda',
+           'spmm_transposed', 'csr_transpose',
            'softmax_forward_cuda', 'softmax_backward_cuda']
 
     def __init__(self):

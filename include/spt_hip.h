@@ -36,7 +36,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 1
+#define SPT_ABI_VERSION 2
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -99,13 +99,33 @@ int spt_sddmm_forward(const int32_t *indptr, const int32_t *indices,
  * spmm_forward_cuda(trans_lhs, trans_rhs=false, indptr, indices, values, x)
  *   reference: extension/entry.cpp:21-25, extension/spmm.cpp:3-72 (cusparseSpMM)
  * trans_lhs == 0: y[b, r, :]             = sum_{p in row r} values[b,p] * x[b, indices[b,p], :]
- * trans_lhs != 0: y[b, indices[b,p], :] += values[b,p] * x[b, row(p), :]   (y zeroed first)
+ * trans_lhs != 0: y[b, indices[b,p], :] += values[b,p] * x[b, row(p), :]
  * x, y [B, S, E].  Requires E % 4 == 0, E <= 256.
+ * The transposed product is computed as a gather over the transposed CSR structure,
+ * which is built into `workspace` (spt_spmm_workspace_bytes() bytes, uninitialised;
+ * may be NULL when trans_lhs == 0).
  */
+int64_t spt_spmm_workspace_bytes(int trans_lhs, int batch_size, int seq_length, int nnz);
 int spt_spmm_forward(int trans_lhs, const int32_t *indptr,
                      const int32_t *indices, const float *values,
-                     const float *x, float *y, int batch_size, int seq_length,
-                     int d_head, int nnz, void *stream);
+                     const float *x, float *y, void *workspace, int batch_size,
+                     int seq_length, int d_head, int nnz, void *stream);
+
+/*
+ * The two halves of the transposed product, for callers that use one CSR pattern for
+ * several products (the backward of naive_gpt/kernels/sddmm.py:25-51 and
+ * spmm.py:23-49 needs A^T twice per attention layer):
+ *   spt_csr_transpose   builds the transposed structure of (indptr, indices) into
+ *                       `transposed` (spt_csr_transpose_workspace_bytes() bytes);
+ *   spt_spmm_transposed y = A^T . x using that structure and the CSR-ordered `values`.
+ */
+int64_t spt_csr_transpose_workspace_bytes(int batch_size, int seq_length, int nnz);
+int spt_csr_transpose(const int32_t *indptr, const int32_t *indices,
+                      void *transposed, int batch_size, int seq_length, int nnz,
+                      void *stream);
+int spt_spmm_transposed(const void *transposed, const float *values,
+                        const float *x, float *y, int batch_size,
+                        int seq_length, int d_head, int nnz, void *stream);
 
 /*
  * softmax_forward_cuda(indptr, indices, values) -> output

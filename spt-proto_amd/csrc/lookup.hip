@@ -15,12 +15,17 @@
 //   worker tx emits slot 3, 2, 1, 0 kept entries at output positions tx, tx+4, ...
 //   while position < min(row+1, Z); everything else stays 0.
 //
-// MI355X mapping: one wave per query row, lane l owns columns 64w + l (so a lane's
-// worker id l % 4 never changes), membership of the 16 lists is four wave ballots
-// per 64-column window, ranks inside a list are mbcnt prefix popcounts.  Key codes of
-// the batch are packed to uint16 pairs in LDS once per block (the reference compares
-// uint16 truncations, lookup.cu:22,43).  The output row is assembled in LDS and
-// written with one coalesced store, zeros included, so no memset pass is needed.
+// MI355X mapping: one wave per query row.  The row's candidate columns are cut into
+// 64 contiguous segments of whole 4-column groups, one per lane, so a lane meets its
+// columns in ascending order and the rank of a column inside its (slot, worker) list
+// is: (entries of that list in lower lanes) + (a running count in the lane).  The
+// first term is ONE wave-wide exclusive scan of the 16 per-lane list sizes (packed
+// two per register, DPP row_shr / row_bcast, no LDS); no per-column cross-lane work.
+// PQ codes are nibble-packed (one 32-bit word per token at M <= 8, C <= 16: a match
+// count is xor + 3 bit-ops + popcount); any code outside [0,16) switches the block
+// to the exact uint16 comparison of the reference (lookup.cu:22,43).  The output
+// row is assembled in LDS with ds_max (the two writers of a saturated word resolve
+// to the larger column, as in the reference) and stored coalesced, zeros included.
 #include "spt_common.h"
 
 namespace spt {
@@ -29,166 +34,265 @@ constexpr int LK_THREADS = 256;
 constexpr int LK_WAVES = LK_THREADS / SPT_WAVE;
 constexpr int LK_ROWS = 16;  // query rows per block
 
-template <int M2>
-struct Codes {
-    uint32_t w[M2];
-};
-
-// number of equal uint16 halves between a (per-lane key) and b (wave-uniform query)
-template <int M2>
-__device__ __forceinline__ int match_count(const Codes<M2> &a, const Codes<M2> &b) {
-    int cnt = 0;
-#pragma unroll
-    for (int i = 0; i < M2; i++) {
-        const uint32_t x = a.w[i] ^ b.w[i];
-        cnt += ((x & 0xFFFFu) == 0u) + ((x >> 16) == 0u);
-    }
-    return cnt;
-}
-
 __device__ __forceinline__ int sel4(int v0, int v1, int v2, int v3, int s) {
     const int lo = (s & 1) ? v1 : v0;
     const int hi = (s & 1) ? v3 : v2;
     return (s & 2) ? hi : lo;
 }
 
-template <int M2>
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+
+// wave-wide inclusive prefix sum (GCN sequence: 4 shifts inside each row of 16 lanes,
+// then lane 15 -> next row, lane 31 -> upper half).  Fields packed in v must not carry.
+__device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v) {
+    v += dpp_u32<0x111, 0xF>(v);  // row_shr:1
+    v += dpp_u32<0x112, 0xF>(v);  // row_shr:2
+    v += dpp_u32<0x114, 0xF>(v);  // row_shr:4
+    v += dpp_u32<0x118, 0xF>(v);  // row_shr:8
+    v += dpp_u32<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_u32<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+    return v;
+}
+
+// ---- code representations -------------------------------------------------------
+// NIB: W words per token, 4 bits per code; pad nibbles are 0xF in keys and 0 in
+// queries so that they never match.  U16: W = ceil(M/2) words, 16 bits per code.
+template <int W>
+struct Code {
+    uint32_t w[W];
+};
+
+template <int W, bool NIB>
+__device__ __forceinline__ int match_count(const Code<W> &k, const Code<W> &q) {
+    int cnt = 0;
+    if (NIB) {
+        int diff = 0;
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            uint32_t x = k.w[i] ^ q.w[i];
+            x |= x >> 1;
+            x |= x >> 2;
+            diff += __popc(x & 0x11111111u);
+        }
+        cnt = 8 * W - diff;
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            const uint32_t x = k.w[i] ^ q.w[i];
+            cnt += ((x & 0xFFFFu) == 0u) + ((x >> 16) == 0u);
+        }
+    }
+    return cnt;
+}
+
+template <int W, bool NIB>
+__device__ __forceinline__ Code<W> pack_codes(const int32_t *__restrict__ src, int M,
+                                              bool is_key) {
+    Code<W> c;
+    if (NIB) {
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int k = 8 * i + j;
+                const uint32_t nib = (k < M) ? ((uint32_t)src[k] & 0xFu) : (is_key ? 0xFu : 0u);
+                word |= nib << (4 * j);
+            }
+            c.w[i] = word;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            const int k0 = 2 * i, k1 = 2 * i + 1;
+            const uint32_t lo = (k0 < M) ? ((uint32_t)src[k0] & 0xFFFFu) : (is_key ? 0xFFFFu : 0u);
+            const uint32_t hi = (k1 < M) ? ((uint32_t)src[k1] & 0xFFFFu) : (is_key ? 0xFFFFu : 0u);
+            c.w[i] = lo | (hi << 16);
+        }
+    }
+    return c;
+}
+
+// One query row, one wave.  kcodes: LDS, Code<W> per column.
+template <int W, bool NIB>
+__device__ __forceinline__ void lookup_row(const uint32_t *__restrict__ kcodes,
+                                           const int32_t *__restrict__ qsrc,
+                                           int32_t *__restrict__ myrow,
+                                           int32_t *__restrict__ dst, int gy, int M, int Z) {
+    const int lane = lane_id();
+    const int Q = Z >> 2;
+    const int div = M >> 2;  // matches per slot, lookup.cu:62
+    const int limit = min(gy + 1, Z);
+    const int ngroups = (gy + 4) >> 2;              // 4-column groups holding a candidate
+    const int gpl = (ngroups + SPT_WAVE - 1) >> 6;  // groups per lane
+    const int g0 = lane * gpl;
+    const int g1 = min(ngroups, g0 + gpl);
+
+    const Code<W> qc = pack_codes<W, NIB>(qsrc, M, false);  // wave-uniform
+
+    for (int i = lane; i < Z; i += SPT_WAVE) myrow[i] = 0;
+
+    // slots of the 4 columns of group g (4 = not a candidate).  The group's codes are
+    // 4*W consecutive LDS words, 16-byte aligned: W ds_read_b128.
+    auto group_slots = [&](int g, int (&slot)[4]) {
+        uint32_t raw[4 * W];
+        const uint4 *src = reinterpret_cast<const uint4 *>(kcodes + (size_t)g * 4 * W);
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            const uint4 t = src[i];
+            raw[4 * i + 0] = t.x; raw[4 * i + 1] = t.y; raw[4 * i + 2] = t.z; raw[4 * i + 3] = t.w;
+        }
+#pragma unroll
+        for (int tx = 0; tx < 4; tx++) {
+            Code<W> kc;
+#pragma unroll
+            for (int d = 0; d < W; d++) kc.w[d] = raw[tx * W + d];
+            const int cnt = match_count<W, NIB>(kc, qc);
+            const int sl = (cnt >= div) + (cnt >= 2 * div) + (cnt >= 3 * div);
+            slot[tx] = (4 * g + tx <= gy) ? sl : 4;
+        }
+    };
+
+    // ---- pass 1: per-lane sizes of the 16 (worker, slot) lists -------------------
+    int c[4][4];
+#pragma unroll
+    for (int tx = 0; tx < 4; tx++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) c[tx][s] = 0;
+    for (int g = g0; g < g1; g++) {
+        int slot[4];
+        group_slots(g, slot);
+#pragma unroll
+        for (int tx = 0; tx < 4; tx++) {
+            c[tx][0] += (slot[tx] == 0);
+            c[tx][1] += (slot[tx] == 1);
+            c[tx][2] += (slot[tx] == 2);
+            c[tx][3] += (slot[tx] == 3);
+        }
+    }
+
+    // ---- exclusive scan over lanes; totals are wave-uniform ------------------------
+    int pos[4][4];  // rank of this lane's next entry in list (tx, s)
+    int n[4][4];    // list sizes
+#pragma unroll
+    for (int tx = 0; tx < 4; tx++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned own = (unsigned)c[tx][2 * h] | ((unsigned)c[tx][2 * h + 1] << 16);
+            const unsigned inc = wave_inclusive_scan(own);
+            const unsigned exc = inc - own;
+            const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
+            pos[tx][2 * h] = exc & 0xFFFF;
+            pos[tx][2 * h + 1] = exc >> 16;
+            n[tx][2 * h] = tot & 0xFFFF;
+            n[tx][2 * h + 1] = tot >> 16;
+        }
+    }
+    // kept entries per list and output offset of each slot (slot 3 first)
+    int off[4][4];
+#pragma unroll
+    for (int tx = 0; tx < 4; tx++) {
+        const int cap = (tx < 2) ? Q : Q - 1;
+        const int k3 = min(n[tx][3], cap), k2 = min(n[tx][2], cap), k1 = min(n[tx][1], cap);
+        off[tx][3] = 0;
+        off[tx][2] = k3;
+        off[tx][1] = k3 + k2;
+        off[tx][0] = k3 + k2 + k1;
+    }
+
+    // ---- pass 2: placement ------------------------------------------------------------
+    for (int g = g0; g < g1; g++) {
+        int slot[4];
+        group_slots(g, slot);
+#pragma unroll
+        for (int tx = 0; tx < 4; tx++) {
+            const int col = 4 * g + tx;
+            const int s = slot[tx];
+            const int rank = sel4(pos[tx][0], pos[tx][1], pos[tx][2], pos[tx][3], s);
+            pos[tx][0] += (s == 0);
+            pos[tx][1] += (s == 1);
+            pos[tx][2] += (s == 2);
+            pos[tx][3] += (s == 3);
+            const int cap = (tx < 2) ? Q : Q - 1;
+            if (s < 4 && rank < cap) {
+                const int p =
+                    tx + 4 * (sel4(off[tx][0], off[tx][1], off[tx][2], off[tx][3], s) + rank);
+                if (p < limit) atomicMax(&myrow[p], col);
+            }
+            if (tx >= 2) {
+                // reference quirk: this worker's cursor saturates on the word that holds
+                // entry Q-1 of worker 3 - tx; its LAST candidate survives there if larger
+                // (ds_max resolves the two writers)
+                const int ptx = 3 - tx;
+                const int n_own = sel4(n[tx][0], n[tx][1], n[tx][2], n[tx][3], s);
+                const int n_par = sel4(n[ptx][0], n[ptx][1], n[ptx][2], n[ptx][3], s);
+                if (s < 4 && rank == n_own - 1 && n_own >= Q && n_par >= Q) {
+                    const int p = ptx + 4 * (sel4(off[ptx][0], off[ptx][1], off[ptx][2],
+                                                  off[ptx][3], s) + Q - 1);
+                    if (p < limit) atomicMax(&myrow[p], col);
+                }
+            }
+        }
+    }
+
+    // ---- coalesced store of the row (zeros included) -----------------------------------
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < Z; i += SPT_WAVE) dst[i] = myrow[i];
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int WN, int WU>  // words per token: nibble form, uint16 form
 __global__ __launch_bounds__(LK_THREADS) void lookup_forward_kernel(
     const int32_t *__restrict__ query, const int32_t *__restrict__ key,
     int32_t *__restrict__ out, int B, int S, int M, int Z, int tiles_per_batch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t *kcodes = reinterpret_cast<uint32_t *>(smem);                 // [cols][M2]
-    int32_t *rowbuf = reinterpret_cast<int32_t *>(smem) + (size_t)S * M2;  // [LK_WAVES][Z]
+    uint32_t *kcodes = reinterpret_cast<uint32_t *>(smem);                 // [cols][W]
+    int32_t *rowbuf = reinterpret_cast<int32_t *>(smem) + (size_t)S * WU;  // [LK_WAVES][Z]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // heavy (late) row tiles first: they take longest, so they should start earliest
     const int b = blockIdx.x % B;
     const int tile = tiles_per_batch - 1 - (blockIdx.x / B);
     const int row0 = tile * LK_ROWS;
     const int ncols = row0 + LK_ROWS;  // columns any row of this block may look at
+    const int32_t *ksrc = key + (size_t)b * S * M;
+    const int32_t *qsrc = query + ((size_t)b * S + row0) * M;
 
-    // ---- pack this batch's key codes (columns < ncols) into uint16 pairs ----
-    {
-        const int32_t *ksrc = key + (size_t)b * S * M;
-        for (int i = tid; i < ncols * M2; i += LK_THREADS) {
-            const int col = i / M2, d = i - col * M2;
-            const int k0 = 2 * d, k1 = 2 * d + 1;
-            const uint32_t lo = (uint32_t)ksrc[(size_t)col * M + k0] & 0xFFFFu;
-            // an odd M pads the last half so that it can never match (query pad = 0)
-            const uint32_t hi = (k1 < M) ? ((uint32_t)ksrc[(size_t)col * M + k1] & 0xFFFFu) : 0xFFFFu;
-            kcodes[i] = lo | (hi << 16);
-        }
-    }
-    __syncthreads();
+    // ---- can this block use the 4-bit form?  (all codes it touches in [0, 16)) --------
+    int wide = 0;
+    for (int i = tid; i < ncols * M; i += LK_THREADS) wide |= ksrc[i];
+    for (int i = tid; i < LK_ROWS * M; i += LK_THREADS) wide |= qsrc[i];
+    const bool use_u16 = __syncthreads_or((wide & ~0xF) != 0);
 
-    const int tx = lane & 3;
-    const unsigned long long wm_own = 0x1111111111111111ull << tx;   // lanes of my worker
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const int Q = Z >> 2;
-    const int div = M >> 2;  // matches per slot, lookup.cu:62
-    const int cap = (tx < 2) ? Q : Q - 1;
     int32_t *myrow = rowbuf + wave * Z;
-
-    for (int r = wave; r < LK_ROWS; r += LK_WAVES) {
-        const int gy = row0 + r;
-        const int limit = min(gy + 1, Z);
-        const int nwin = (gy >> 6) + 1;
-
-        // query codes of this row: wave-uniform
-        Codes<M2> qc;
-        {
-            const int32_t *qsrc = query + ((size_t)b * S + gy) * M;
+    if (!use_u16) {
+        for (int col = tid; col < ncols; col += LK_THREADS) {
+            const Code<WN> c = pack_codes<WN, true>(ksrc + (size_t)col * M, M, true);
 #pragma unroll
-            for (int d = 0; d < M2; d++) {
-                const uint32_t lo = (uint32_t)qsrc[2 * d] & 0xFFFFu;
-                const uint32_t hi = (2 * d + 1 < M) ? ((uint32_t)qsrc[2 * d + 1] & 0xFFFFu) : 0u;
-                qc.w[d] = lo | (hi << 16);
-            }
+            for (int d = 0; d < WN; d++) kcodes[col * WN + d] = c.w[d];
         }
-
-        // zero the staging row
-        for (int i = lane; i < Z; i += SPT_WAVE) myrow[i] = 0;
-
-        // ---------------- pass 1: sizes of the 16 lists, last column of tx=2,3 ----
-        // n_own[s]  : |L[s][my tx]|          (per lane, identical for equal tx)
-        // n_par[s]  : |L[s][3 - my tx]|      (partner worker: 0<->3, 1<->2)
-        // last_par[s]: last column of the partner list
-        int n_own1 = 0, n_own2 = 0, n_own3 = 0;
-        int n_par0 = 0, n_par1 = 0, n_par2 = 0, n_par3 = 0;
-        int lp0 = 0, lp1 = 0, lp2 = 0, lp3 = 0;
-        const unsigned long long wm_par = 0x1111111111111111ull << (3 - tx);
-        for (int w = 0; w < nwin; w++) {
-            const int col = (w << 6) + lane;
-            int slot = 4;  // invalid
-            if (col <= gy) {
-                Codes<M2> kc;
+        __syncthreads();
+        for (int r = wave; r < LK_ROWS; r += LK_WAVES) {
+            const int gy = row0 + r;
+            lookup_row<WN, true>(kcodes, qsrc + (size_t)r * M, myrow,
+                                 out + ((size_t)b * S + gy) * Z, gy, M, Z);
+        }
+    } else {
+        for (int col = tid; col < ncols; col += LK_THREADS) {
+            const Code<WU> c = pack_codes<WU, false>(ksrc + (size_t)col * M, M, true);
 #pragma unroll
-                for (int d = 0; d < M2; d++) kc.w[d] = kcodes[col * M2 + d];
-                const int cnt = match_count<M2>(kc, qc);
-                slot = (cnt >= div) + (cnt >= 2 * div) + (cnt >= 3 * div);
-            }
-            const unsigned long long m0 = __ballot(slot == 0);
-            const unsigned long long m1 = __ballot(slot == 1);
-            const unsigned long long m2 = __ballot(slot == 2);
-            const unsigned long long m3 = __ballot(slot == 3);
-            n_own1 += __popcll(m1 & wm_own);
-            n_own2 += __popcll(m2 & wm_own); n_own3 += __popcll(m3 & wm_own);
-            const unsigned long long p0 = m0 & wm_par, p1 = m1 & wm_par;
-            const unsigned long long p2 = m2 & wm_par, p3 = m3 & wm_par;
-            n_par0 += __popcll(p0); n_par1 += __popcll(p1);
-            n_par2 += __popcll(p2); n_par3 += __popcll(p3);
-            if (p0) lp0 = (w << 6) + 63 - __clzll(p0);
-            if (p1) lp1 = (w << 6) + 63 - __clzll(p1);
-            if (p2) lp2 = (w << 6) + 63 - __clzll(p2);
-            if (p3) lp3 = (w << 6) + 63 - __clzll(p3);
+            for (int d = 0; d < WU; d++) kcodes[col * WU + d] = c.w[d];
         }
-        // kept entries per slot for my worker and the output offset of each slot
-        const int k3 = min(n_own3, cap), k2 = min(n_own2, cap), k1 = min(n_own1, cap);
-        const int off3 = 0, off2 = k3, off1 = k3 + k2, off0 = k3 + k2 + k1;
-
-        // ---------------- pass 2: ranks and placement -------------------------------
-        int b0 = 0, b1 = 0, b2 = 0, b3 = 0;  // entries of L[s][my tx] before this window
-        for (int w = 0; w < nwin; w++) {
-            const int col = (w << 6) + lane;
-            int slot = 4;
-            if (col <= gy) {
-                Codes<M2> kc;
-#pragma unroll
-                for (int d = 0; d < M2; d++) kc.w[d] = kcodes[col * M2 + d];
-                const int cnt = match_count<M2>(kc, qc);
-                slot = (cnt >= div) + (cnt >= 2 * div) + (cnt >= 3 * div);
-            }
-            const unsigned long long m0 = __ballot(slot == 0) & wm_own;
-            const unsigned long long m1 = __ballot(slot == 1) & wm_own;
-            const unsigned long long m2 = __ballot(slot == 2) & wm_own;
-            const unsigned long long m3 = __ballot(slot == 3) & wm_own;
-            if (slot < 4) {
-                const unsigned long long mine =
-                    (slot & 2) ? ((slot & 1) ? m3 : m2) : ((slot & 1) ? m1 : m0);
-                const int rank = sel4(b0, b1, b2, b3, slot) + __popcll(mine & lt_mask);
-                if (rank < cap) {
-                    int val = col;
-                    if (tx < 2 && rank == Q - 1) {
-                        // reference quirk: the partner worker's cursor saturates on
-                        // this word; the later (= larger) column survives
-                        const int npar = sel4(n_par0, n_par1, n_par2, n_par3, slot);
-                        const int lpar = sel4(lp0, lp1, lp2, lp3, slot);
-                        if (npar >= Q) val = max(val, lpar);
-                    }
-                    const int pos = tx + 4 * (sel4(off0, off1, off2, off3, slot) + rank);
-                    if (pos < limit) myrow[pos] = val;
-                }
-            }
-            b0 += __popcll(m0); b1 += __popcll(m1); b2 += __popcll(m2); b3 += __popcll(m3);
+        __syncthreads();
+        for (int r = wave; r < LK_ROWS; r += LK_WAVES) {
+            const int gy = row0 + r;
+            lookup_row<WU, false>(kcodes, qsrc + (size_t)r * M, myrow,
+                                  out + ((size_t)b * S + gy) * Z, gy, M, Z);
         }
-
-        // ---------------- coalesced store of the row (zeros included) ---------------
-        __builtin_amdgcn_wave_barrier();
-        int32_t *dst = out + ((size_t)b * S + gy) * Z;
-        for (int i = lane; i < Z; i += SPT_WAVE) dst[i] = myrow[i];
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -208,31 +312,31 @@ extern "C" int spt_lookup_forward(const int32_t *query, const int32_t *key, int3
     if (Z % 16 != 0) return SPT_ESHAPE;                        // lookup.cu:106
     if (M < 4 || M > 16) return SPT_EUNSUP;                    // lookup.cu:167-169
     if (S > 65536) return SPT_EUNSUP;                          // uint16 columns, lookup.cu:32
-    const int M2 = (M + 1) / 2;
-    const size_t lds = (size_t)S * M2 * 4 + (size_t)LK_WAVES * Z * 4;
+    const int WU = (M + 1) / 2;
+    const size_t lds = (size_t)S * WU * 4 + (size_t)LK_WAVES * Z * 4;
     if (lds > 160 * 1024) return SPT_EUNSUP;
     const int tiles = S / LK_ROWS;
     const long long nblk = (long long)batch_size * tiles;
     if (nblk > 0x7FFFFFFFLL) return SPT_EUNSUP;
     dim3 grid((unsigned)nblk);
     hipStream_t s = (hipStream_t)stream;
-#define SPT_LK(MM2)                                                                          \
-    do {                                                                                     \
-        if (lds > 64 * 1024)                                                                 \
-            SPT_HIP_TRY(hipFuncSetAttribute(                                                 \
-                reinterpret_cast<const void *>(&lookup_forward_kernel<MM2>),                 \
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
-        hipLaunchKernelGGL((lookup_forward_kernel<MM2>), grid, dim3(LK_THREADS), lds, s,     \
-                           query, key, out, batch_size, S, M, Z, tiles);                                 \
+#define SPT_LK(WN_, WU_)                                                                      \
+    do {                                                                                      \
+        if (lds > 64 * 1024)                                                                  \
+            SPT_HIP_TRY(hipFuncSetAttribute(                                                  \
+                reinterpret_cast<const void *>(&lookup_forward_kernel<WN_, WU_>),             \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+        hipLaunchKernelGGL((lookup_forward_kernel<WN_, WU_>), grid, dim3(LK_THREADS), lds, s, \
+                           query, key, out, batch_size, S, M, Z, tiles);                      \
     } while (0)
-    switch (M2) {
-        case 2: SPT_LK(2); break;
-        case 3: SPT_LK(3); break;
-        case 4: SPT_LK(4); break;
-        case 5: SPT_LK(5); break;
-        case 6: SPT_LK(6); break;
-        case 7: SPT_LK(7); break;
-        case 8: SPT_LK(8); break;
+    switch (WU) {
+        case 2: SPT_LK(1, 2); break;
+        case 3: SPT_LK(1, 3); break;
+        case 4: SPT_LK(1, 4); break;
+        case 5: SPT_LK(2, 5); break;
+        case 6: SPT_LK(2, 6); break;
+        case 7: SPT_LK(2, 7); break;
+        case 8: SPT_LK(2, 8); break;
         default: return SPT_EUNSUP;
     }
 #undef SPT_LK

@@ -19,7 +19,8 @@
 //                 2*S*E*4 + 2*nnz*4 bytes per batch.
 //   KLDS = false: any shape; key rows are gathered from global memory (L2 hits when
 //                 the batch's blocks share an XCD, see xcd_remap).
-#include "spt_common.h"
+#include "gather4.h"
+#include "sparse_rows.h"
 
 namespace spt {
 
@@ -32,32 +33,32 @@ __device__ __forceinline__ float epilogue(float v, float scale, float clampv) {
     return v;
 }
 
-template <int LPE, bool KLDS>
+// One CSR row: dot of the (register-resident) query row with every gathered key row.
+// `chunk` holds the row's first 64 column ids (already loaded); longer rows load on.
+template <int LPE>
 __device__ __forceinline__ void sddmm_row(const int32_t *__restrict__ idx_b,
-                                          const float *__restrict__ qrow,
+                                          const float4 q4,
                                           const float *__restrict__ kbase,  // global or LDS
-                                          float *__restrict__ out_b, int start, int end,
+                                          float *__restrict__ out_b, const RowChunk &chunk,
                                           int E, float scale, float clampv) {
     constexpr int EPS = SPT_WAVE / LPE;  // entries per step
     const int lane = lane_id();
     const int sub = lane & (LPE - 1);
     const int grp = lane / LPE;
     const bool sub_live = (4 * sub) < E;
+    const float *krow0 = kbase + 4 * sub;
 
-    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (sub_live) q4 = *reinterpret_cast<const float4 *>(qrow + 4 * sub);
-
-    for (int p0 = start; p0 < end; p0 += SPT_WAVE) {
-        const int remaining = end - p0;
-        const int my_idx = (lane < remaining) ? idx_b[p0 + lane] : 0;
-        const int nsteps = min(LPE, (remaining + EPS - 1) / EPS);
+    int my_idx = chunk.idx;
+    for (int p0 = chunk.start; p0 < chunk.end; p0 += SPT_WAVE) {
+        const int remaining = chunk.end - p0;
+        if (p0 != chunk.start) my_idx = (lane < remaining) ? idx_b[p0 + lane] : 0;
         float res = 0.0f;
         auto step = [&](int s) {
             const int e = s * EPS + grp;
             const int col = __shfl(my_idx, e, SPT_WAVE);
             float part = 0.0f;
             if (sub_live) {
-                const float4 k4 = *reinterpret_cast<const float4 *>(kbase + (size_t)col * E + 4 * sub);
+                const float4 k4 = *reinterpret_cast<const float4 *>(krow0 + (size_t)col * E);
                 part = q4.x * k4.x;
                 part = fmaf(q4.y, k4.y, part);
                 part = fmaf(q4.z, k4.z, part);
@@ -71,12 +72,34 @@ __device__ __forceinline__ void sddmm_row(const int32_t *__restrict__ idx_b,
 #pragma unroll
             for (int s = 0; s < LPE; s++) step(s);
         } else {
+            const int nsteps = (remaining + EPS - 1) / EPS;
             for (int s = 0; s < nsteps; s++) step(s);
         }
         // lane (grp, sub) now holds entry e = sub * EPS + grp of this chunk
         const int e = sub * EPS + grp;
         if (e < remaining) out_b[p0 + e] = epilogue(res, scale, clampv);
     }
+}
+
+template <int LPE>
+__device__ __forceinline__ void sddmm_rows(const int32_t *__restrict__ indptr,
+                                           const int32_t *__restrict__ idx_b,
+                                           const float *__restrict__ q_b,
+                                           const float *__restrict__ kbase,
+                                           float *__restrict__ out_b, int first, int stride,
+                                           int S, int E, float scale, float clampv) {
+    const int sub = lane_id() & (LPE - 1);
+    const bool sub_live = (4 * sub) < E;
+    auto load_q = [&](int row) {
+        float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sub_live && row < S)
+            q4 = *reinterpret_cast<const float4 *>(q_b + (size_t)row * E + 4 * sub);
+        return q4;
+    };
+    for_each_row<false>(indptr, idx_b, nullptr, first, stride, S, load_q,
+                        [&](int row, const RowChunk &chunk, const float4 &q4) {
+                            sddmm_row<LPE>(idx_b, q4, kbase, out_b, chunk, E, scale, clampv);
+                        });
 }
 
 template <int LPE>
@@ -90,16 +113,12 @@ __global__ __launch_bounds__(SD_THREADS) void sddmm_global_kernel(
     const int b = lid / tiles_per_batch;
     const int tile = lid - b * tiles_per_batch;
     if (b >= B) return;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row0 = tile * rows_per_block;
     const int row1 = min(S, row0 + rows_per_block);
-    const int32_t *idx_b = indices + (size_t)b * nnz;
-    float *out_b = out + (size_t)b * nnz;
-    const float *kb = key + (size_t)b * S * E;
-    for (int r = row0 + wave; r < row1; r += SD_THREADS / SPT_WAVE) {
-        sddmm_row<LPE, false>(idx_b, query + ((size_t)b * S + r) * E, kb, out_b, indptr[r],
-                              indptr[r + 1], E, scale, clampv);
-    }
+    sddmm_rows<LPE>(indptr, indices + (size_t)b * nnz, query + (size_t)b * S * E,
+                    key + (size_t)b * S * E, out + (size_t)b * nnz, row0 + wave,
+                    SD_THREADS / SPT_WAVE, row1, E, scale, clampv);
 }
 
 template <int LPE>
@@ -113,24 +132,82 @@ __global__ __launch_bounds__(SD_THREADS_LDS) void sddmm_lds_kernel(
     const int part = blockIdx.x - b * splits;
     const int tid = threadIdx.x;
 
-    // stage K[b] : S*E floats, coalesced float4, 16 B per lane per instruction
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(key + (size_t)b * S * E);
-        float4 *dst = reinterpret_cast<float4 *>(ktile);
-        const int n4 = (S * E) >> 2;
-        for (int i = tid; i < n4; i += SD_THREADS_LDS) dst[i] = src[i];
-    }
+    stage_tile(ktile, key + (size_t)b * S * E, (S * E) >> 2, tid, SD_THREADS_LDS);
     __syncthreads();
 
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = SD_THREADS_LDS / SPT_WAVE;
-    const int32_t *idx_b = indices + (size_t)b * nnz;
-    float *out_b = out + (size_t)b * nnz;
     // interleave rows over (split, wave) so that causal patterns stay balanced
-    for (int r = part * NW + wave; r < S; r += splits * NW) {
-        sddmm_row<LPE, true>(idx_b, query + ((size_t)b * S + r) * E, ktile, out_b, indptr[r],
-                             indptr[r + 1], E, scale, clampv);
+    sddmm_rows<LPE>(indptr, indices + (size_t)b * nnz, query + (size_t)b * S * E, ktile,
+                    out + (size_t)b * nnz, part * NW + wave, splits * NW, S, E, scale, clampv);
+}
+
+// ---- fast path, E = 16 * LPE in {64, 128}: see gather4.h ----------------------------
+
+template <int LPE>
+__global__ __launch_bounds__(SD_THREADS_LDS) void sddmm_g4_lds_kernel(
+    const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ query, const float *__restrict__ key, float *__restrict__ out,
+    int S, int nnz, int splits, float scale, float clampv) {
+    constexpr int E = 16 * LPE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *ktile = reinterpret_cast<float *>(smem);  // [S][E]
+    const int b = blockIdx.x / splits;
+    const int part = blockIdx.x - b * splits;
+    const int tid = threadIdx.x;
+    stage_tile(ktile, key + (size_t)b * S * E, (S * E) >> 2, tid, SD_THREADS_LDS);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = SD_THREADS_LDS / SPT_WAVE;
+    gather_rows<LPE, G_SDDMM>(indptr, indices + (size_t)b * nnz, nullptr, nullptr, ktile,
+                              query + (size_t)b * S * E, out + (size_t)b * nnz,
+                              part * NW + wave, splits * NW, S, scale, clampv);
+}
+
+template <int LPE>
+__global__ __launch_bounds__(SD_THREADS) void sddmm_g4_global_kernel(
+    const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ query, const float *__restrict__ key, float *__restrict__ out,
+    int B, int S, int nnz, int blocks_per_batch, float scale, float clampv) {
+    constexpr int E = 16 * LPE;
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / blocks_per_batch;
+    const int part = lid - b * blocks_per_batch;
+    if (b >= B) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int NW = SD_THREADS / SPT_WAVE;
+    gather_rows<LPE, G_SDDMM>(indptr, indices + (size_t)b * nnz, nullptr, nullptr,
+                              key + (size_t)b * S * E, query + (size_t)b * S * E,
+                              out + (size_t)b * nnz, part * NW + wave, blocks_per_batch * NW, S,
+                              scale, clampv);
+}
+
+template <int LPE>
+static int sddmm_g4_launch(const int32_t *indptr, const int32_t *indices, const float *query,
+                           const float *key, float *out, int B, int S, int nnz, float scale,
+                           float clampv, hipStream_t s) {
+    constexpr int E = 16 * LPE;
+    const size_t kbytes = (size_t)S * E * sizeof(float);
+    if (kbytes <= 128 * 1024 && (long long)B * 8 >= 256) {
+        int splits = 1;
+        while ((long long)B * splits < 256 && splits < 8) splits <<= 1;
+        SPT_HIP_TRY(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&sddmm_g4_lds_kernel<LPE>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kbytes));
+        hipLaunchKernelGGL((sddmm_g4_lds_kernel<LPE>), dim3((unsigned)(B * splits)),
+                           dim3(SD_THREADS_LDS), kbytes, s, indptr, indices, query, key, out, S,
+                           nnz, splits, scale, clampv);
+    } else {
+        // one block per 64 CSR rows of a batch
+        int bpb = (S + 63) / 64;
+        if (bpb < 1) bpb = 1;
+        const long long nblk = (long long)B * bpb;
+        if (nblk > 0x7FFFFFFFLL) return SPT_EUNSUP;
+        hipLaunchKernelGGL((sddmm_g4_global_kernel<LPE>), dim3((unsigned)nblk), dim3(SD_THREADS),
+                           0, s, indptr, indices, query, key, out, B, S, nnz, bpb, scale, clampv);
     }
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
 }
 
 }  // namespace spt
@@ -149,6 +226,10 @@ extern "C" int spt_sddmm_forward(const int32_t *indptr, const int32_t *indices,
     const int B = batch_size, S = seq_length, E = d_head;
     const int LPE = pow2_ceil(E / 4);
     hipStream_t s = (hipStream_t)stream;
+    if (E == 64)
+        return sddmm_g4_launch<4>(indptr, indices, query, key, out, B, S, nnz, scale, clampv, s);
+    if (E == 128)
+        return sddmm_g4_launch<8>(indptr, indices, query, key, out, B, S, nnz, scale, clampv, s);
 
     const size_t kbytes = (size_t)S * E * sizeof(float);
     const bool use_lds = kbytes <= 128 * 1024 && (long long)B * 8 >= 256 && S >= 64;

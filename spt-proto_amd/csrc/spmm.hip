@@ -4,52 +4,65 @@
 //   N: y[b,r,:]             = sum_{p in row r} values[b,p] * x[b, indices[b,p], :]
 //   T: y[b,indices[b,p],:] += values[b,p] * x[b, row(p), :]
 //
-// N uses the same group-per-entry gather as sddmm.hip: LPE = E/4 lanes read one whole
-// x row per entry (float4 each), 64/LPE entries per wave-instruction, per-lane float4
-// accumulators, one cross-group butterfly per output row.  With X LDS-resident
-// (S*E*4 <= 128 KiB) HBM traffic is the algorithmic 2*S*E*4 + 2*nnz*4 bytes per batch.
+// N is a row gather: see gather4.h (E = 64 / 128, X LDS-resident when S*E*4 <= 128 KiB)
+// and sparse_rows.h (any other shape).
 //
-// T is a scatter.  cuSPARSE does it with global atomics; global float atomics on
-// MI355X run at ~1.3 TB/s of added bytes (MI355X_MICROARCH "Global float atomics"),
-// 6x under the HBM stream this op should be bound by.  Here the batch's whole output
-// [S,E] is an LDS accumulator: entries are added with ds_add_f32 (LDS atomics, no
-// HBM traffic) and the tile is written once, coalesced, zeros included.  Lanes are
-// rotated over the four 16-word quarters of a row so that the two entry groups of a
-// half-wave always hit disjoint LDS banks.
-#include "spt_common.h"
+// T is a scatter.  cuSPARSE does it with global atomics; on MI355X global float atomics
+// run at ~1.3 TB/s of added bytes (MI355X_MICROARCH "Global float atomics") and LDS
+// float atomics (ds_add_f32) were measured here at ~3 cycles PER LANE (2.7 ms for the
+// 256-slice BERT-large case, profiles/r01_run1_kernel_stats.csv) -- both far under the
+// HBM stream this op should be bound by.  So T is turned into a gather:
+//   1. csr_transpose_kernel: per batch, a counting sort of the entries by column builds
+//      the transposed structure  t_ptr [S+1], t_row [nnz] (source row of each entry),
+//      t_perm [nnz] (position of the entry's value in `values`).  Integer LDS atomics on
+//      per-wave private cursors; a wave walks its rows in ascending order, so the
+//      transposed order -- and therefore the fp32 summation order -- is reproducible.
+//   2. the N gather kernels run on (t_ptr, t_row) with values fetched through t_perm.
+// The structure depends only on `indices`: the backward of one attention layer needs it
+// twice (grad_K, grad_V), spt_csr_transpose + spt_spmm_transposed let callers share it.
+#include "gather4.h"
+#include "sparse_rows.h"
 
 namespace spt {
 
 constexpr int SP_THREADS = 256;
 constexpr int SP_THREADS_LDS = 1024;
+constexpr int TR_THREADS = 1024;
+constexpr int TR_WAVES = TR_THREADS / SPT_WAVE;
 
-// ------------------------------------------------------------------ N (gather)
+// ------------------------------------------------------------------ generic N (any E % 4 == 0)
 
-template <int LPE, bool XLDS>
+template <int LPE, bool PERM>
 __device__ __forceinline__ void spmm_row(const int32_t *__restrict__ idx_b,
+                                         const int32_t *__restrict__ perm_b,
                                          const float *__restrict__ val_b,
                                          const float *__restrict__ xbase,  // global or LDS
-                                         float *__restrict__ yrow, int start, int end, int E) {
+                                         float *__restrict__ yrow, const RowChunk &chunk,
+                                         int E) {
     constexpr int EPS = SPT_WAVE / LPE;
     const int lane = lane_id();
     const int sub = lane & (LPE - 1);
     const int grp = lane / LPE;
     const bool sub_live = (4 * sub) < E;
+    const float *xrow0 = xbase + 4 * sub;
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p0 = start; p0 < end; p0 += SPT_WAVE) {
-        const int remaining = end - p0;
-        const bool in = lane < remaining;
-        const int my_idx = in ? idx_b[p0 + lane] : 0;
-        const float my_val = in ? val_b[p0 + lane] : 0.0f;  // 0 weight: padding adds nothing
-        const int nsteps = min(LPE, (remaining + EPS - 1) / EPS);
+    int my_idx = chunk.idx;
+    float my_val = chunk.val;  // 0 weight beyond the row end: padding adds nothing
+    for (int p0 = chunk.start; p0 < chunk.end; p0 += SPT_WAVE) {
+        const int remaining = chunk.end - p0;
+        if (p0 != chunk.start) {
+            const bool in = lane < remaining;
+            my_idx = in ? idx_b[p0 + lane] : 0;
+            if (PERM) my_val = in ? val_b[perm_b[p0 + lane]] : 0.0f;
+            else my_val = in ? val_b[p0 + lane] : 0.0f;
+        }
         auto step = [&](int s) {
             const int e = s * EPS + grp;
             const int col = __shfl(my_idx, e, SPT_WAVE);
             const float v = __shfl(my_val, e, SPT_WAVE);
             if (sub_live) {
-                const float4 x4 =
-                    *reinterpret_cast<const float4 *>(xbase + (size_t)col * E + 4 * sub);
+                const float4 x4 = *reinterpret_cast<const float4 *>(xrow0 + (size_t)col * E);
                 acc.x = fmaf(v, x4.x, acc.x);
                 acc.y = fmaf(v, x4.y, acc.y);
                 acc.z = fmaf(v, x4.z, acc.z);
@@ -60,10 +73,11 @@ __device__ __forceinline__ void spmm_row(const int32_t *__restrict__ idx_b,
 #pragma unroll
             for (int s = 0; s < LPE; s++) step(s);
         } else {
+            const int nsteps = (remaining + EPS - 1) / EPS;
             for (int s = 0; s < nsteps; s++) step(s);
         }
     }
-    // sum the EPS groups (lanes with equal `sub`)
+    // sum the EPS groups (lanes with equal `sub`): true xor exchanges
     if constexpr (LPE <= 1) { acc.x += butterfly_partner<1>(acc.x); acc.y += butterfly_partner<1>(acc.y); acc.z += butterfly_partner<1>(acc.z); acc.w += butterfly_partner<1>(acc.w); }
     if constexpr (LPE <= 2) { acc.x += butterfly_partner<2>(acc.x); acc.y += butterfly_partner<2>(acc.y); acc.z += butterfly_partner<2>(acc.z); acc.w += butterfly_partner<2>(acc.w); }
     if constexpr (LPE <= 4) { acc.x += __shfl_xor(acc.x, 4, SPT_WAVE); acc.y += __shfl_xor(acc.y, 4, SPT_WAVE); acc.z += __shfl_xor(acc.z, 4, SPT_WAVE); acc.w += __shfl_xor(acc.w, 4, SPT_WAVE); }
@@ -73,291 +87,328 @@ __device__ __forceinline__ void spmm_row(const int32_t *__restrict__ idx_b,
     if (grp == 0 && sub_live) *reinterpret_cast<float4 *>(yrow + 4 * sub) = acc;
 }
 
-template <int LPE>
-__global__ __launch_bounds__(SP_THREADS) void spmm_n_global_kernel(
-    const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-    const float *__restrict__ values, const float *__restrict__ x, float *__restrict__ y,
-    int B, int S, int E, int nnz, int tiles_per_batch, int rows_per_block) {
+template <int LPE, bool PERM>
+__global__ __launch_bounds__(SP_THREADS) void spmm_generic_kernel(
+    const int32_t *__restrict__ ptr, int ptr_stride, const int32_t *__restrict__ indices,
+    const int32_t *__restrict__ perm, const float *__restrict__ values,
+    const float *__restrict__ x, float *__restrict__ y, int B, int S, int E, int nnz,
+    int tiles_per_batch, int rows_per_block) {
     const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
     const int b = lid / tiles_per_batch;
     const int tile = lid - b * tiles_per_batch;
     if (b >= B) return;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row0 = tile * rows_per_block;
     const int row1 = min(S, row0 + rows_per_block);
+    const int32_t *idx_b = indices + (size_t)b * nnz;
+    const int32_t *perm_b = PERM ? perm + (size_t)b * nnz : nullptr;
+    const float *val_b = values + (size_t)b * nnz;
     const float *xb = x + (size_t)b * S * E;
-    for (int r = row0 + wave; r < row1; r += SP_THREADS / SPT_WAVE) {
-        spmm_row<LPE, false>(indices + (size_t)b * nnz, values + (size_t)b * nnz, xb,
-                             y + ((size_t)b * S + r) * E, indptr[r], indptr[r + 1], E);
-    }
+    float *y_b = y + (size_t)b * S * E;
+    // in PERM mode the chunk prefetcher must not read `values` in CSR order: it fetches
+    // ids only and the values are gathered through perm here
+    for_each_row<!PERM>(ptr + (size_t)b * ptr_stride, idx_b, val_b, row0 + wave,
+                        SP_THREADS / SPT_WAVE, row1, [](int) { return 0; },
+                        [&](int row, const RowChunk &chunk, int) {
+                            RowChunk c = chunk;
+                            if (PERM) {
+                                const int lane = lane_id();
+                                c.val = (lane < c.end - c.start)
+                                            ? val_b[perm_b[c.start + lane]] : 0.0f;
+                            }
+                            spmm_row<LPE, PERM>(idx_b, perm_b, val_b, xb,
+                                                y_b + (size_t)row * E, c, E);
+                        });
 }
 
-template <int LPE>
-__global__ __launch_bounds__(SP_THREADS_LDS) void spmm_n_lds_kernel(
-    const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-    const float *__restrict__ values, const float *__restrict__ x, float *__restrict__ y,
-    int B, int S, int E, int nnz, int splits) {
+// ------------------------------------------------------------------ fast path (gather4.h)
+
+template <int LPE, int MODE>
+__global__ __launch_bounds__(SP_THREADS_LDS) void spmm_g4_lds_kernel(
+    const int32_t *__restrict__ ptr, int ptr_stride, const int32_t *__restrict__ indices,
+    const int32_t *__restrict__ perm, const float *__restrict__ values,
+    const float *__restrict__ x, float *__restrict__ y, int S, int nnz, int splits) {
+    constexpr int E = 16 * LPE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *xtile = reinterpret_cast<float *>(smem);  // [S][E]
     const int b = blockIdx.x / splits;
     const int part = blockIdx.x - b * splits;
     const int tid = threadIdx.x;
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(x + (size_t)b * S * E);
-        float4 *dst = reinterpret_cast<float4 *>(xtile);
-        const int n4 = (S * E) >> 2;
-        for (int i = tid; i < n4; i += SP_THREADS_LDS) dst[i] = src[i];
-    }
+    stage_tile(xtile, x + (size_t)b * S * E, (S * E) >> 2, tid, SP_THREADS_LDS);
     __syncthreads();
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = SP_THREADS_LDS / SPT_WAVE;
-    for (int r = part * NW + wave; r < S; r += splits * NW) {
-        spmm_row<LPE, true>(indices + (size_t)b * nnz, values + (size_t)b * nnz, xtile,
-                            y + ((size_t)b * S + r) * E, indptr[r], indptr[r + 1], E);
-    }
+    gather_rows<LPE, MODE>(ptr + (size_t)b * ptr_stride, indices + (size_t)b * nnz,
+                           MODE == G_SPMM_PERM ? perm + (size_t)b * nnz : nullptr,
+                           values + (size_t)b * nnz, xtile, nullptr, y + (size_t)b * S * E,
+                           part * NW + wave, splits * NW, S, 1.0f, 0.0f);
 }
 
-// ------------------------------------------------------------------ T (scatter)
-
-// LDS accumulator layout: word(col, e) = col * E + e (no padding: a row of E = 64
-// words spans both 32-bank halves exactly twice; conflicts are avoided by the lane
-// rotation below, not by padding).
-//
-// One group of 16 lanes per entry (E <= 64: four 16-word quarters per row, lane `sub`
-// owns words sub, sub+16, sub+32, sub+48).  At add-instruction j group g touches
-// quarter (j + g) & 3, so the two groups of each half-wave are always on different
-// 16-bank halves: no bank conflict for any column pair.
-template <int QUARTERS>  // ceil(E / 16), 1..4
-__global__ __launch_bounds__(SP_THREADS_LDS) void spmm_t_lds_kernel(
-    const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-    const float *__restrict__ values, const float *__restrict__ x, float *__restrict__ y,
-    int B, int S, int E, int nnz, int splits, int atomic_flush) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *acc = reinterpret_cast<float *>(smem);  // [S][E]
-    const int b = blockIdx.x / splits;
-    const int part = blockIdx.x - b * splits;
-    const int tid = threadIdx.x;
-    const int n = S * E;
-    for (int i = tid; i < (n >> 2); i += SP_THREADS_LDS)
-        reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int sub = lane & 15;
-    const int grp = lane >> 4;
-    constexpr int NW = SP_THREADS_LDS / SPT_WAVE;
-    const int32_t *idx_b = indices + (size_t)b * nnz;
-    const float *val_b = values + (size_t)b * nnz;
-
-    for (int r = part * NW + wave; r < S; r += splits * NW) {
-        const int start = indptr[r], end = indptr[r + 1];
-        // this lane's four words of x[b, r, :], rotated by the group id
-        const float *xrow = x + ((size_t)b * S + r) * E;
-        float xq[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int e = 16 * k + sub;
-            xq[k] = (k < QUARTERS && e < E) ? xrow[e] : 0.0f;
-        }
-        float xr[4];  // xr[j] = xq[(j + grp) & 3]
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = (j + grp) & 3;
-            xr[j] = (k & 2) ? ((k & 1) ? xq[3] : xq[2]) : ((k & 1) ? xq[1] : xq[0]);
-        }
-        for (int p0 = start; p0 < end; p0 += SPT_WAVE) {
-            const int remaining = end - p0;
-            const bool in = lane < remaining;
-            const int my_idx = in ? idx_b[p0 + lane] : 0;
-            const float my_val = in ? val_b[p0 + lane] : 0.0f;
-            const int nsteps = min(16, (remaining + 3) >> 2);
-            for (int s = 0; s < nsteps; s++) {
-                const int e = s * 4 + grp;
-                const int col = __shfl(my_idx, e, SPT_WAVE);
-                const float v = __shfl(my_val, e, SPT_WAVE);
-                if (e < remaining) {
-                    float *arow = acc + (size_t)col * E + sub;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int k = (j + grp) & 3;
-                        if (k < QUARTERS && (16 * k + sub) < E) atomicAdd(arow + 16 * k, v * xr[j]);
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    float *yb = y + (size_t)b * n;
-    if (atomic_flush) {
-        for (int i = tid; i < n; i += SP_THREADS_LDS) {
-            const float v = acc[i];
-            if (v != 0.0f) atomicAdd(yb + i, v);
-        }
-    } else {
-        for (int i = tid; i < (n >> 2); i += SP_THREADS_LDS)
-            reinterpret_cast<float4 *>(yb)[i] = reinterpret_cast<const float4 *>(acc)[i];
-    }
-}
-
-// fallback for shapes whose [S,E] tile does not fit LDS: global float atomics into a
-// zeroed y.  One group of LPE lanes per entry, float4 per lane.
-template <int LPE>
-__global__ __launch_bounds__(SP_THREADS) void spmm_t_global_kernel(
-    const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-    const float *__restrict__ values, const float *__restrict__ x, float *__restrict__ y,
-    int B, int S, int E, int nnz, int tiles_per_batch, int rows_per_block) {
-    constexpr int EPS = SPT_WAVE / LPE;
+template <int LPE, int MODE>
+__global__ __launch_bounds__(SP_THREADS) void spmm_g4_global_kernel(
+    const int32_t *__restrict__ ptr, int ptr_stride, const int32_t *__restrict__ indices,
+    const int32_t *__restrict__ perm, const float *__restrict__ values,
+    const float *__restrict__ x, float *__restrict__ y, int B, int S, int nnz,
+    int blocks_per_batch) {
+    constexpr int E = 16 * LPE;
     const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = lid / tiles_per_batch;
-    const int tile = lid - b * tiles_per_batch;
+    const int b = lid / blocks_per_batch;
+    const int part = lid - b * blocks_per_batch;
     if (b >= B) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int sub = lane & (LPE - 1);
-    const int grp = lane / LPE;
-    const bool sub_live = (4 * sub) < E;
-    const int row0 = tile * rows_per_block;
-    const int row1 = min(S, row0 + rows_per_block);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int NW = SP_THREADS / SPT_WAVE;
+    gather_rows<LPE, MODE>(ptr + (size_t)b * ptr_stride, indices + (size_t)b * nnz,
+                           MODE == G_SPMM_PERM ? perm + (size_t)b * nnz : nullptr,
+                           values + (size_t)b * nnz, x + (size_t)b * S * E, nullptr,
+                           y + (size_t)b * S * E, part * NW + wave, blocks_per_batch * NW, S,
+                           1.0f, 0.0f);
+}
+
+// ------------------------------------------------------------------ CSR transpose
+
+// One block per batch.  wcnt[w][c] = entries of column c in the rows owned by wave w
+// (waves own contiguous row ranges).  After a scan over (c, w) each wave has private
+// cursors, walks its rows in ascending order and places entries with ds_add_rtn_u32.
+// When 16*S ints do not fit LDS a single shared cursor array is used (order then
+// depends on wave timing).
+template <bool PRIVATE>
+__global__ __launch_bounds__(TR_THREADS) void csr_transpose_kernel(
+    const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+    int32_t *__restrict__ t_ptr, int32_t *__restrict__ t_row, int32_t *__restrict__ t_perm,
+    int S, int nnz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *wave_tot = reinterpret_cast<int *>(smem);  // [TR_WAVES]
+    int *wcnt = wave_tot + TR_WAVES;                // [PRIVATE ? TR_WAVES : 1][S]
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NC = PRIVATE ? TR_WAVES : 1;
     const int32_t *idx_b = indices + (size_t)b * nnz;
-    const float *val_b = values + (size_t)b * nnz;
-    float *yb = y + (size_t)b * S * E;
-    for (int r = row0 + wave; r < row1; r += SP_THREADS / SPT_WAVE) {
+
+    for (int i = tid; i < NC * S; i += TR_THREADS) wcnt[i] = 0;
+    __syncthreads();
+
+    // contiguous row range of this wave
+    const int rows_per_wave = (S + TR_WAVES - 1) / TR_WAVES;
+    const int r0 = wave * rows_per_wave;
+    const int r1 = min(S, r0 + rows_per_wave);
+    int *mycnt = wcnt + (PRIVATE ? wave * S : 0);
+
+    // ---- 1. histogram ----
+    for (int r = r0; r < r1; r++) {
         const int start = indptr[r], end = indptr[r + 1];
-        float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (sub_live)
-            x4 = *reinterpret_cast<const float4 *>(x + ((size_t)b * S + r) * E + 4 * sub);
-        for (int p0 = start; p0 < end; p0 += SPT_WAVE) {
-            const int remaining = end - p0;
-            const bool in = lane < remaining;
-            const int my_idx = in ? idx_b[p0 + lane] : 0;
-            const float my_val = in ? val_b[p0 + lane] : 0.0f;
-            const int nsteps = min(LPE, (remaining + EPS - 1) / EPS);
-            for (int s = 0; s < nsteps; s++) {
-                const int e = s * EPS + grp;
-                const int col = __shfl(my_idx, e, SPT_WAVE);
-                const float v = __shfl(my_val, e, SPT_WAVE);
-                if (e < remaining && sub_live) {
-                    float *dst = yb + (size_t)col * E + 4 * sub;
-                    atomicAdd(dst + 0, v * x4.x);
-                    atomicAdd(dst + 1, v * x4.y);
-                    atomicAdd(dst + 2, v * x4.z);
-                    atomicAdd(dst + 3, v * x4.w);
-                }
-            }
+        for (int p = start + lane; p < end; p += SPT_WAVE) atomicAdd(&mycnt[idx_b[p]], 1);
+    }
+    __syncthreads();
+
+    // ---- 2. exclusive scan over (column major, wave minor) ----
+    // thread tid owns columns [c0, c1); its total, then a block scan of the totals
+    const int cols_per_thread = (S + TR_THREADS - 1) / TR_THREADS;
+    const int c0 = min(S, tid * cols_per_thread);
+    const int c1 = min(S, c0 + cols_per_thread);
+    int mine = 0;
+    for (int c = c0; c < c1; c++)
+        for (int w = 0; w < NC; w++) mine += wcnt[w * S + c];
+    int inc = mine;  // wave inclusive scan
+#pragma unroll
+    for (int d = 1; d < SPT_WAVE; d <<= 1) {
+        const int o = __shfl_up(inc, d, SPT_WAVE);
+        if (lane >= d) inc += o;
+    }
+    if (lane == SPT_WAVE - 1) wave_tot[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += wave_tot[w];
+    int run = base + inc - mine;  // first position of column c0
+    int32_t *tp = t_ptr + (size_t)b * (S + 1);
+    for (int c = c0; c < c1; c++) {
+        tp[c] = run;
+        for (int w = 0; w < NC; w++) {
+            const int n = wcnt[w * S + c];
+            wcnt[w * S + c] = run;  // becomes the cursor of (wave w, column c)
+            run += n;
         }
     }
+    if (tid == TR_THREADS - 1) tp[S] = nnz;
+    __syncthreads();
+
+    // ---- 3. placement: rows ascending per wave ----
+    int32_t *trow = t_row + (size_t)b * nnz;
+    int32_t *tperm = t_perm + (size_t)b * nnz;
+    for (int r = r0; r < r1; r++) {
+        const int start = indptr[r], end = indptr[r + 1];
+        for (int p = start + lane; p < end; p += SPT_WAVE) {
+            const int pos = atomicAdd(&mycnt[idx_b[p]], 1);
+            trow[pos] = r;
+            tperm[pos] = p;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+
+struct TransposedCsr {
+    int32_t *t_ptr, *t_row, *t_perm;
+};
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int64_t transpose_bytes(int B, int S, int nnz) {
+    return (int64_t)(align256((size_t)B * (S + 1) * 4) + 2 * align256((size_t)B * nnz * 4));
+}
+
+static TransposedCsr carve(void *workspace, int B, int S, int nnz) {
+    char *p = reinterpret_cast<char *>(workspace);
+    TransposedCsr t;
+    t.t_ptr = reinterpret_cast<int32_t *>(p);
+    p += align256((size_t)B * (S + 1) * 4);
+    t.t_row = reinterpret_cast<int32_t *>(p);
+    p += align256((size_t)B * nnz * 4);
+    t.t_perm = reinterpret_cast<int32_t *>(p);
+    return t;
+}
+
+static int launch_transpose(const int32_t *indptr, const int32_t *indices, TransposedCsr t,
+                            int B, int S, int nnz, hipStream_t s) {
+    const size_t head = TR_WAVES * sizeof(int);
+    const size_t priv = head + (size_t)TR_WAVES * S * sizeof(int);
+    const size_t shared = head + (size_t)S * sizeof(int);
+    if (priv <= 144 * 1024) {
+        SPT_HIP_TRY(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&csr_transpose_kernel<true>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)priv));
+        hipLaunchKernelGGL((csr_transpose_kernel<true>), dim3(B), dim3(TR_THREADS), priv, s,
+                           indptr, indices, t.t_ptr, t.t_row, t.t_perm, S, nnz);
+    } else {
+        if (shared > 144 * 1024) return SPT_EUNSUP;
+        SPT_HIP_TRY(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&csr_transpose_kernel<false>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shared));
+        hipLaunchKernelGGL((csr_transpose_kernel<false>), dim3(B), dim3(TR_THREADS), shared, s,
+                           indptr, indices, t.t_ptr, t.t_row, t.t_perm, S, nnz);
+    }
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
+// y = A . x on the structure (ptr, indices); PERM: values are fetched through `perm`
+template <bool PERM>
+static int launch_gather(const int32_t *ptr, int ptr_stride, const int32_t *indices,
+                         const int32_t *perm, const float *values, const float *x, float *y,
+                         int B, int S, int E, int nnz, hipStream_t s) {
+    constexpr int MODE = PERM ? G_SPMM_PERM : G_SPMM;
+    const size_t tile_bytes = (size_t)S * E * sizeof(float);
+    if (E == 64 || E == 128) {
+        const bool lds = tile_bytes <= 128 * 1024 && B >= 32;
+        int splits = 1;
+        while ((long long)B * splits < 256 && splits < 8) splits <<= 1;
+        const int bpb = (S + 63) / 64;
+#define SPT_G4(L)                                                                              \
+    do {                                                                                       \
+        if (lds) {                                                                             \
+            SPT_HIP_TRY(hipFuncSetAttribute(                                                   \
+                reinterpret_cast<const void *>(&spmm_g4_lds_kernel<L, MODE>),                  \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));                 \
+            hipLaunchKernelGGL((spmm_g4_lds_kernel<L, MODE>), dim3((unsigned)(B * splits)),    \
+                               dim3(SP_THREADS_LDS), tile_bytes, s, ptr, ptr_stride, indices,  \
+                               perm, values, x, y, S, nnz, splits);                            \
+        } else {                                                                               \
+            hipLaunchKernelGGL((spmm_g4_global_kernel<L, MODE>), dim3((unsigned)(B * bpb)),    \
+                               dim3(SP_THREADS), 0, s, ptr, ptr_stride, indices, perm, values, \
+                               x, y, B, S, nnz, bpb);                                          \
+        }                                                                                      \
+    } while (0)
+        if (E == 64) SPT_G4(4);
+        else SPT_G4(8);
+#undef SPT_G4
+    } else {
+        const int LPE = pow2_ceil(E / 4);
+        const int rows_per_block = 16;
+        const int tiles = (S + rows_per_block - 1) / rows_per_block;
+        const long long nblk = (long long)B * tiles;
+        if (nblk > 0x7FFFFFFFLL) return SPT_EUNSUP;
+        dim3 grid((unsigned)nblk);
+#define SPT_GEN(L)                                                                             \
+    hipLaunchKernelGGL((spmm_generic_kernel<L, PERM>), grid, dim3(SP_THREADS), 0, s, ptr,      \
+                       ptr_stride, indices, perm, values, x, y, B, S, E, nnz, tiles,           \
+                       rows_per_block)
+        switch (LPE) {
+            case 1: SPT_GEN(1); break;
+            case 2: SPT_GEN(2); break;
+            case 4: SPT_GEN(4); break;
+            case 8: SPT_GEN(8); break;
+            case 16: SPT_GEN(16); break;
+            case 32: SPT_GEN(32); break;
+            default: SPT_GEN(64); break;
+        }
+#undef SPT_GEN
+    }
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
+static int check_spmm_args(const void *a, const void *b, const void *c, const void *d,
+                           const void *e, int B, int S, int E, int nnz) {
+    if (!a || !b || !c || !d || !e) return SPT_EINVAL;
+    if (B <= 0 || S <= 0 || E <= 0 || nnz < 0) return SPT_EINVAL;
+    if (E % 4 != 0) return SPT_ESHAPE;
+    if (E > 256) return SPT_EUNSUP;
+    return SPT_OK;
 }
 
 }  // namespace spt
 
 using namespace spt;
 
+extern "C" int64_t spt_csr_transpose_workspace_bytes(int batch_size, int seq_length, int nnz) {
+    if (batch_size <= 0 || seq_length <= 0 || nnz < 0) return 0;
+    return transpose_bytes(batch_size, seq_length, nnz);
+}
+
+extern "C" int spt_csr_transpose(const int32_t *indptr, const int32_t *indices, void *transposed,
+                                 int batch_size, int seq_length, int nnz, void *stream) {
+    if (!indptr || !indices || !transposed) return SPT_EINVAL;
+    if (batch_size <= 0 || seq_length <= 0 || nnz <= 0) return SPT_EINVAL;
+    return launch_transpose(indptr, indices, carve(transposed, batch_size, seq_length, nnz),
+                            batch_size, seq_length, nnz, (hipStream_t)stream);
+}
+
+extern "C" int spt_spmm_transposed(const void *transposed, const float *values, const float *x,
+                                   float *y, int batch_size, int seq_length, int d_head, int nnz,
+                                   void *stream) {
+    const int rc =
+        check_spmm_args(transposed, values, x, y, y, batch_size, seq_length, d_head, nnz);
+    if (rc != SPT_OK) return rc;
+    if (nnz == 0) return SPT_EINVAL;
+    const TransposedCsr t = carve(const_cast<void *>(transposed), batch_size, seq_length, nnz);
+    return launch_gather<true>(t.t_ptr, seq_length + 1, t.t_row, t.t_perm, values, x, y,
+                               batch_size, seq_length, d_head, nnz, (hipStream_t)stream);
+}
+
+extern "C" int64_t spt_spmm_workspace_bytes(int trans_lhs, int batch_size, int seq_length,
+                                            int nnz) {
+    return trans_lhs ? spt_csr_transpose_workspace_bytes(batch_size, seq_length, nnz) : 0;
+}
+
 extern "C" int spt_spmm_forward(int trans_lhs, const int32_t *indptr, const int32_t *indices,
-                                const float *values, const float *x, float *y,
+                                const float *values, const float *x, float *y, void *workspace,
                                 int batch_size, int seq_length, int d_head, int nnz,
                                 void *stream) {
-    if (!indptr || !indices || !values || !x || !y) return SPT_EINVAL;
-    if (batch_size <= 0 || seq_length <= 0 || d_head <= 0 || nnz < 0) return SPT_EINVAL;
-    if (d_head % 4 != 0) return SPT_ESHAPE;
-    if (d_head > 256) return SPT_EUNSUP;
+    const int rc =
+        check_spmm_args(indptr, indices, values, x, y, batch_size, seq_length, d_head, nnz);
+    if (rc != SPT_OK) return rc;
     const int B = batch_size, S = seq_length, E = d_head;
     hipStream_t s = (hipStream_t)stream;
-    const size_t ybytes = (size_t)B * S * E * sizeof(float);
     if (nnz == 0) {
-        SPT_HIP_TRY(hipMemsetAsync(y, 0, ybytes, s));
+        SPT_HIP_TRY(hipMemsetAsync(y, 0, (size_t)B * S * E * sizeof(float), s));
         return SPT_OK;
     }
-    const int LPE = pow2_ceil(E / 4);
-    const size_t tile_bytes = (size_t)S * E * sizeof(float);
-    const bool fits = tile_bytes <= 128 * 1024 && S >= 64;
-    int splits = 1;
-    while ((long long)B * splits < 256 && splits < 8) splits <<= 1;
-
-    if (!trans_lhs) {
-        if (fits && B >= 32) {
-            dim3 grid((unsigned)(B * splits));
-#define SPT_SPN_LDS(L)                                                                        \
-    do {                                                                                      \
-        SPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_n_lds_kernel<L>), \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,           \
-                                        (int)tile_bytes));                                    \
-        hipLaunchKernelGGL((spmm_n_lds_kernel<L>), grid, dim3(SP_THREADS_LDS), tile_bytes, s, \
-                           indptr, indices, values, x, y, B, S, E, nnz, splits);              \
-    } while (0)
-            switch (LPE) {
-                case 1: SPT_SPN_LDS(1); break;
-                case 2: SPT_SPN_LDS(2); break;
-                case 4: SPT_SPN_LDS(4); break;
-                case 8: SPT_SPN_LDS(8); break;
-                case 16: SPT_SPN_LDS(16); break;
-                case 32: SPT_SPN_LDS(32); break;
-                default: SPT_SPN_LDS(64); break;
-            }
-#undef SPT_SPN_LDS
-        } else {
-            const int rows_per_block = 16;
-            const int tiles = (S + rows_per_block - 1) / rows_per_block;
-            const long long nblk = (long long)B * tiles;
-            if (nblk > 0x7FFFFFFFLL) return SPT_EUNSUP;
-            dim3 grid((unsigned)nblk);
-#define SPT_SPN_G(L)                                                                       \
-    hipLaunchKernelGGL((spmm_n_global_kernel<L>), grid, dim3(SP_THREADS), 0, s, indptr,    \
-                       indices, values, x, y, B, S, E, nnz, tiles, rows_per_block)
-            switch (LPE) {
-                case 1: SPT_SPN_G(1); break;
-                case 2: SPT_SPN_G(2); break;
-                case 4: SPT_SPN_G(4); break;
-                case 8: SPT_SPN_G(8); break;
-                case 16: SPT_SPN_G(16); break;
-                case 32: SPT_SPN_G(32); break;
-                default: SPT_SPN_G(64); break;
-            }
-#undef SPT_SPN_G
-        }
-    } else {
-        if (fits && E <= 64) {
-            const int atomic_flush = splits > 1;
-            if (atomic_flush) SPT_HIP_TRY(hipMemsetAsync(y, 0, ybytes, s));
-            dim3 grid((unsigned)(B * splits));
-            const int quarters = (E + 15) / 16;
-#define SPT_SPT_LDS(QQ)                                                                        \
-    do {                                                                                       \
-        SPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_t_lds_kernel<QQ>), \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,            \
-                                        (int)tile_bytes));                                     \
-        hipLaunchKernelGGL((spmm_t_lds_kernel<QQ>), grid, dim3(SP_THREADS_LDS), tile_bytes, s, \
-                           indptr, indices, values, x, y, B, S, E, nnz, splits, atomic_flush); \
-    } while (0)
-            switch (quarters) {
-                case 1: SPT_SPT_LDS(1); break;
-                case 2: SPT_SPT_LDS(2); break;
-                case 3: SPT_SPT_LDS(3); break;
-                default: SPT_SPT_LDS(4); break;
-            }
-#undef SPT_SPT_LDS
-        } else {
-            SPT_HIP_TRY(hipMemsetAsync(y, 0, ybytes, s));
-            const int rows_per_block = 16;
-            const int tiles = (S + rows_per_block - 1) / rows_per_block;
-            const long long nblk = (long long)B * tiles;
-            if (nblk > 0x7FFFFFFFLL) return SPT_EUNSUP;
-            dim3 grid((unsigned)nblk);
-#define SPT_SPT_G(L)                                                                       \
-    hipLaunchKernelGGL((spmm_t_global_kernel<L>), grid, dim3(SP_THREADS), 0, s, indptr,    \
-                       indices, values, x, y, B, S, E, nnz, tiles, rows_per_block)
-            switch (LPE) {
-                case 1: SPT_SPT_G(1); break;
-                case 2: SPT_SPT_G(2); break;
-                case 4: SPT_SPT_G(4); break;
-                case 8: SPT_SPT_G(8); break;
-                case 16: SPT_SPT_G(16); break;
-                case 32: SPT_SPT_G(32); break;
-                default: SPT_SPT_G(64); break;
-            }
-#undef SPT_SPT_G
-        }
-    }
-    SPT_LAUNCH_CHECK();
-    return SPT_OK;
+    if (!trans_lhs)
+        return launch_gather<false>(indptr, 0, indices, nullptr, values, x, y, B, S, E, nnz, s);
+    if (!workspace) return SPT_EINVAL;
+    const TransposedCsr t = carve(workspace, B, S, nnz);
+    const int rc2 = launch_transpose(indptr, indices, t, B, S, nnz, s);
+    if (rc2 != SPT_OK) return rc2;
+    return launch_gather<true>(t.t_ptr, S + 1, t.t_row, t.t_perm, values, x, y, B, S, E, nnz, s);
 }

@@ -81,6 +81,25 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + j;
 }
 
+// Copy n4 float4 from global memory into an LDS tile.  Four independent loads per
+// thread are issued before the first ds_write so their HBM latencies overlap.
+__device__ __forceinline__ void stage_tile(float *__restrict__ lds_dst,
+                                           const float *__restrict__ src, int n4, int tid,
+                                           int nthreads) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *d4 = reinterpret_cast<float4 *>(lds_dst);
+    int i = tid;
+    for (; i + 3 * nthreads < n4; i += 4 * nthreads) {
+        const float4 a = s4[i], b = s4[i + nthreads], c = s4[i + 2 * nthreads],
+                     d = s4[i + 3 * nthreads];
+        d4[i] = a;
+        d4[i + nthreads] = b;
+        d4[i + 2 * nthreads] = c;
+        d4[i + 3 * nthreads] = d;
+    }
+    for (; i < n4; i += nthreads) d4[i] = s4[i];
+}
+
 __host__ __device__ __forceinline__ int pow2_ceil(int v) {
     int p = 1;
     while (p < v) p <<= 1;

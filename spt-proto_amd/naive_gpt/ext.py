@@ -33,11 +33,15 @@ _PROTOTYPES = {
     'spt_sddmm_forward': (
         [_c_ptr] * 5 + [_c_int] * 4 + [_c_f32, _c_f32, _c_ptr], _c_int
     ),
-    'spt_spmm_forward': ([_c_int] + [_c_ptr] * 5 + [_c_int] * 4 + [_c_ptr], _c_int),
+    'spt_spmm_workspace_bytes': ([_c_int] * 4, ctypes.c_int64),
+    'spt_spmm_forward': ([_c_int] + [_c_ptr] * 6 + [_c_int] * 4 + [_c_ptr], _c_int),
+    'spt_csr_transpose_workspace_bytes': ([_c_int] * 3, ctypes.c_int64),
+    'spt_csr_transpose': ([_c_ptr] * 3 + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_spmm_transposed': ([_c_ptr] * 4 + [_c_int] * 4 + [_c_ptr], _c_int),
     'spt_softmax_forward': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_backward': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
 }
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -259,10 +263,7 @@ def sddmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,
     return output
 
 
-def spmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,
-                      indices: torch.Tensor, values: torch.Tensor,
-                      x: torch.Tensor) -> torch.Tensor:
-    """extension/spmm.cpp:3-72; ``trans_lhs`` selects A.x (False) or A^T.x (True)."""
+def _check_spmm(indptr, indices, values, x):
     _check_dim(x, 3, 'x')
     _check_csr(indptr, indices)
     _check_dim(values, 2, 'values')
@@ -270,17 +271,87 @@ def spmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,
     _check_type(x, torch.float32, 'x')
     _require(indices.shape == values.shape, 'indices.sizes() == values.sizes()')
     _require(x.size(0) == indices.size(0), 'x.size(0) == indices.size(0)')
-    _require(not _flag(trans_rhs), 'spmm: trans_rhs=True is not implemented')
-    dev = _same_device(indptr, indices, values, x)
-    B, S, E = x.shape
-    nnz = indices.size(-1)
-    _require(indptr.size(-1) == S + 1, 'indptr.size(-1) == seq_length + 1')
+    _require(indptr.size(-1) == x.size(1) + 1, 'indptr.size(-1) == seq_length + 1')
+    return _same_device(indptr, indices, values, x)
+
+
+def csr_transpose(indptr: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
+    """Transposed structure of a batched CSR pattern, as an opaque uint8 buffer for
+    ``spmm_transposed``.  Depends on (indptr, indices) only, so one build serves every
+    A^T product of a backward pass."""
+    _check_csr(indptr, indices)
+    dev = _same_device(indptr, indices)
+    B, nnz = indices.shape
+    S = indptr.size(-1) - 1
     lib = load_library()
     with torch.cuda.device(dev):
+        nbytes = lib.spt_csr_transpose_workspace_bytes(B, S, nnz)
+        buf = torch.empty([max(int(nbytes), 16)], dtype=torch.uint8, device=dev)
+        if nnz > 0:
+            rc = lib.spt_csr_transpose(indptr.data_ptr(), indices.data_ptr(),
+                                       buf.data_ptr(), B, S, nnz, _stream(dev))
+            if rc != 0:
+                _raise(lib, rc, 'csr_transpose')
+    return buf
+
+
+def transposed_for(indptr: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
+    """``csr_transpose`` memoised on the ``indices`` tensor object itself (keyed by the
+    tensors' in-place version counters), so the A^T products of one backward pass --
+    grad_K in sddmm's backward, grad_V in spmm's -- share one build.  The cache dies
+    with the tensor."""
+    key = (indices._version, indptr.data_ptr(), indptr._version)
+    cached = getattr(indices, '_spt_transposed', None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    buf = csr_transpose(indptr, indices)
+    indices._spt_transposed = (key, buf)
+    return buf
+
+
+def spmm_transposed(transposed: torch.Tensor, indptr: torch.Tensor,
+                    indices: torch.Tensor, values: torch.Tensor,
+                    x: torch.Tensor) -> torch.Tensor:
+    """y = A^T . x with a structure from ``csr_transpose`` (same result as
+    ``spmm_forward_cuda(True, False, ...)``)."""
+    dev = _check_spmm(indptr, indices, values, x)
+    B, S, E = x.shape
+    nnz = indices.size(-1)
+    lib = load_library()
+    with torch.cuda.device(dev):
+        if nnz == 0:
+            return torch.zeros_like(x)
         output = torch.empty_like(x)
+        rc = lib.spt_spmm_transposed(transposed.data_ptr(), values.data_ptr(),
+                                     x.data_ptr(), output.data_ptr(), B, S, E, nnz,
+                                     _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'spmm_transposed')
+    return output
+
+
+def spmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,
+                      indices: torch.Tensor, values: torch.Tensor,
+                      x: torch.Tensor) -> torch.Tensor:
+    """extension/spmm.cpp:3-72; ``trans_lhs`` selects A.x (False) or A^T.x (True)."""
+    dev = _check_spmm(indptr, indices, values, x)
+    _require(not _flag(trans_rhs), 'spmm: trans_rhs=True is not implemented')
+    trans = int(_flag(trans_lhs))
+    B, S, E = x.shape
+    nnz = indices.size(-1)
+    lib = load_library()
+    with torch.cuda.device(dev):
+        if nnz == 0:
+            return torch.zeros_like(x)
+        output = torch.empty_like(x)
+        workspace = None
+        if trans:
+            nbytes = lib.spt_spmm_workspace_bytes(trans, B, S, nnz)
+            workspace = torch.empty([max(int(nbytes), 16)], dtype=torch.uint8, device=dev)
         rc = lib.spt_spmm_forward(
-            int(_flag(trans_lhs)), indptr.data_ptr(), indices.data_ptr(),
-            values.data_ptr(), x.data_ptr(), output.data_ptr(),
+            trans, indptr.data_ptr(), indices.data_ptr(), values.data_ptr(),
+            x.data_ptr(), output.data_ptr(),
+            workspace.data_ptr() if workspace is not None else None,
             B, S, E, nnz, _stream(dev)
         )
     if rc != 0:

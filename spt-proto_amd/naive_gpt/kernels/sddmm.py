@@ -7,6 +7,8 @@ Mirror of the reference's ``naive_gpt/kernels/sddmm.py:6-60``:
 The reference forks a second CUDA stream for the transposed SpMM
 (``sddmm.py:43-50``).  On MI355X each of the two kernels already occupies all 256
 CUs (one 1024-thread workgroup per CU), so both are enqueued on the current stream.
+The transposed product is a gather over the transposed CSR structure, built once per
+pattern and shared by every A^T product of the backward pass (``ext.transposed_for``).
 """
 import torch
 
@@ -29,8 +31,9 @@ class SDDMM(torch.autograd.Function):
                 False, False, indptr, indices, grad_output, key
             )
         if ctx.needs_input_grad[3]:
-            grad_key = ext.spmm_forward_cuda(
-                True, False, indptr, indices, grad_output, query
+            grad_key = ext.spmm_transposed(
+                ext.transposed_for(indptr, indices),
+                indptr, indices, grad_output, query
             )
         return None, None, grad_query, grad_key
 

@@ -25,8 +25,9 @@ class SPMM(torch.autograd.Function):
                 False, True, indptr, indices, grad_output, x
             )
         if ctx.needs_input_grad[3]:
-            grad_x = ext.spmm_forward_cuda(
-                True, False, indptr, indices, values, grad_output
+            grad_x = ext.spmm_transposed(
+                ext.transposed_for(indptr, indices),
+                indptr, indices, values, grad_output
             )
         return None, None, grad_values, grad_x
 

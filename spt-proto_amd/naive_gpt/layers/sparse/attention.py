@@ -47,7 +47,8 @@ class _ScaledClampedSDDMM(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             grad_query = ext.spmm_forward_cuda(False, False, indptr, indices, grad_raw, key)
         if ctx.needs_input_grad[3]:
-            grad_key = ext.spmm_forward_cuda(True, False, indptr, indices, grad_raw, query)
+            grad_key = ext.spmm_transposed(ext.transposed_for(indptr, indices),
+                                           indptr, indices, grad_raw, query)
         return None, None, grad_query, grad_key, None
 
 

@@ -36,7 +36,7 @@ def close(got: torch.Tensor, want: np.ndarray, rtol=RTOL, atol=ATOL):
 def test_library_is_the_native_one():
     from naive_gpt import ext
     lib = ext.load_library()
-    assert lib.spt_abi_version() == 1
+    assert lib.spt_abi_version() == 2
     assert torch.cuda.is_available()
     assert 'gfx950' in torch.cuda.get_device_properties(0).gcnArchName
 
@@ -225,6 +225,28 @@ def test_sparse_ops_on_ragged_csr_with_duplicates_and_empty_rows(B, S, E):
     dy = rng.standard_normal(idx.shape).astype(np.float32)
     close(ext.softmax_backward_cuda(*args, dev(y_o), dev(dy)),
           O.softmax_backward(indptr, idx, y_o, dy))
+
+
+def test_transposed_structure_is_shared_and_reproducible():
+    """csr_transpose + spmm_transposed == spmm(trans_lhs=True); one build serves both
+    A^T products of a backward; two runs give bitwise identical sums."""
+    from naive_gpt import ext
+    rng = np.random.default_rng(21)
+    B, S, E, Z = 32, 512, 64, 64
+    indptr, idx = uniform_csr(rng, 2, S, Z, True)
+    idx = np.ascontiguousarray(np.tile(idx, [B // 2, 1]))
+    vals = rng.standard_normal([B, S * Z]).astype(np.float32)
+    x = rng.standard_normal([B, S, E]).astype(np.float32)
+    d_indptr, d_idx, d_vals, d_x = dev(indptr), dev(idx), dev(vals), dev(x)
+    t1 = ext.transposed_for(d_indptr, d_idx)
+    assert ext.transposed_for(d_indptr, d_idx) is t1          # memoised on the tensor
+    y1 = ext.spmm_transposed(t1, d_indptr, d_idx, d_vals, d_x)
+    y2 = ext.spmm_forward_cuda(True, False, d_indptr, d_idx, d_vals, d_x)
+    y3 = ext.spmm_transposed(ext.csr_transpose(d_indptr, d_idx), d_indptr, d_idx, d_vals, d_x)
+    assert torch.equal(y1, y2) and torch.equal(y1, y3)        # reproducible order
+    close(y1, O.spmm_forward(True, indptr, idx, vals, x), atol=2e-3)
+    d_idx[0, 5] = 0                                            # in-place edit invalidates
+    assert ext.transposed_for(d_indptr, d_idx) is not t1
 
 
 # ------------------------------------------------------------------ softmax

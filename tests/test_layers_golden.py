@@ -46,6 +46,10 @@ def oracle_ext(monkeypatch):
         monkeypatch.setattr(ext, name, getattr(ext_stub, name))
     monkeypatch.setattr(ext, 'sddmm_forward_cuda', sddmm)
     monkeypatch.setattr(ext, 'spmm_forward_cuda', spmm)
+    monkeypatch.setattr(ext, 'transposed_for', lambda indptr, indices: None)
+    monkeypatch.setattr(ext, 'spmm_transposed',
+                        lambda t, indptr, indices, values, x: spmm(True, False, indptr, indices,
+                                                                   values, x))
     monkeypatch.setattr(ext, 'cdist_encode',
                         lambda q, t: ext_stub.cdist_forward_cuda(q, t)[1])
     from naive_gpt.layers.sparse.attention import _SparseCore

@@ -1,0 +1,46 @@
+"""Run each HIP operator a few times on config-2 shaped inputs (for rocprofv3)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'spt-proto_amd'))
+import torch  # noqa: E402
+from naive_gpt import ext  # noqa: E402
+
+ops = sys.argv[1].split(',') if len(sys.argv) > 1 else ['sddmm', 'spmm_n', 'spmm_t', 'lookup', 'cdist', 'softmax']
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+N, S, H, E = 16, 512, 16, 64
+B, M, Z = N * H, E // 8, S // 8
+torch.manual_seed(0)
+dev = 'cuda'
+q = torch.randn([B, S, E], device=dev)
+k = torch.randn([B, S, E], device=dev)
+table = torch.randn([M, 16, 8], device=dev)
+
+
+def codes(z):
+    zf = z.reshape(B * S, M, 8).transpose(0, 1).contiguous()
+    return ext.cdist_encode(zf, table).t().contiguous().view(B, S, M)
+
+
+qc, kc = codes(q), codes(k)
+idx = ext.lookup_forward_cuda(torch.empty([8]), qc, kc).flatten(1)
+indptr = torch.arange(0, S * Z + 1, Z, dtype=torch.int32, device=dev)
+vals = torch.rand([B, S * Z], device=dev)
+torch.cuda.synchronize()
+for _ in range(reps):
+    if 'sddmm' in ops:
+        ext.sddmm_forward_cuda(False, True, indptr, idx, q, k)
+    if 'spmm_n' in ops:
+        ext.spmm_forward_cuda(False, False, indptr, idx, vals, k)
+    if 'spmm_t' in ops:
+        ext.spmm_forward_cuda(True, False, indptr, idx, vals, k)
+    if 'lookup' in ops:
+        ext.lookup_forward_cuda(torch.empty([8]), qc, kc)
+    if 'cdist' in ops:
+        codes(q)
+    if 'softmax' in ops:
+        y = ext.softmax_forward_cuda(indptr, idx, vals)
+        ext.softmax_backward_cuda(indptr, idx, y, vals)
+torch.cuda.synchronize()
+print('done')
