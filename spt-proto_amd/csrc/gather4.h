@@ -263,6 +263,160 @@ __device__ __forceinline__ void gather_rows(const int32_t *__restrict__ ptr,    
     }
 }
 
+// ---- transposed (PERM) products: skewed row lengths ------------------------------------
+//
+// Rows of a transposed attention pattern are its key columns: their lengths are far from
+// uniform (column 0 of a causal top-Z pattern carries ~2400 of the 32768 entries at S=512,
+// the next ones ~400, the median 30).  Two measures keep the waves of a workgroup level:
+//   * row groups are handed out dynamically (an LDS ticket counter), heavy groups first;
+//   * a group whose longest row would cost more 64-entry rounds than handling its rows
+//     one by one at 256 entries per round runs in WIDE mode: all 64 / LPE lane groups
+//     work on ONE row; row slot j takes entries [64j, 64j+64) of each 256-entry round.
+//     Slot j holds quarter (i + j) % 4 of the output row in acc[i], so the four slots are
+//     summed with three DPP row rotations and a static register shift:
+//         tot[i] = acc[i] + ror4(acc[i+1]) + ror8(acc[i+2]) + ror12(acc[i+3]).
+template <int LPE>
+__device__ __forceinline__ void accumulate16(const Seg4 &seg, const float *__restrict__ tile,
+                                             const int (&choff)[4], float4 (&acc)[4]) {
+    constexpr int E = 16 * LPE;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const int col = (s >> 2) == 0   ? quad_bcast_i<0>(seg.idx[s & 3])
+                        : (s >> 2) == 1 ? quad_bcast_i<1>(seg.idx[s & 3])
+                        : (s >> 2) == 2 ? quad_bcast_i<2>(seg.idx[s & 3])
+                                        : quad_bcast_i<3>(seg.idx[s & 3]);
+        const float v = (s >> 2) == 0   ? quad_bcast_f<0>(seg.val[s & 3])
+                        : (s >> 2) == 1 ? quad_bcast_f<1>(seg.val[s & 3])
+                        : (s >> 2) == 2 ? quad_bcast_f<2>(seg.val[s & 3])
+                                        : quad_bcast_f<3>(seg.val[s & 3]);
+        const float *krow = tile + (size_t)col * E;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float4 x4 = *reinterpret_cast<const float4 *>(krow + choff[i]);
+            acc[i].x = fmaf(v, x4.x, acc[i].x);
+            acc[i].y = fmaf(v, x4.y, acc[i].y);
+            acc[i].z = fmaf(v, x4.z, acc[i].z);
+            acc[i].w = fmaf(v, x4.w, acc[i].w);
+        }
+    }
+}
+
+template <int ROR>
+__device__ __forceinline__ float4 ror_f4(const float4 &v) {
+    constexpr int ctrl = 0x120 + ROR;  // DPP row_ror:ROR
+    return make_float4(dpp_mov<ctrl>(v.x), dpp_mov<ctrl>(v.y), dpp_mov<ctrl>(v.z),
+                       dpp_mov<ctrl>(v.w));
+}
+
+__device__ __forceinline__ void add_f4(float4 &a, const float4 &b) {
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+}
+
+__device__ __forceinline__ void reduce_t(float4 (&acc)[4]) {
+    // sum over the four entry groups of a row slot (lane offsets 16 and 32)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        acc[i].x += lane_xor_bperm<16>(acc[i].x);
+        acc[i].y += lane_xor_bperm<16>(acc[i].y);
+        acc[i].z += lane_xor_bperm<16>(acc[i].z);
+        acc[i].w += lane_xor_bperm<16>(acc[i].w);
+        acc[i].x += lane_xor_bperm<32>(acc[i].x);
+        acc[i].y += lane_xor_bperm<32>(acc[i].y);
+        acc[i].z += lane_xor_bperm<32>(acc[i].z);
+        acc[i].w += lane_xor_bperm<32>(acc[i].w);
+    }
+}
+
+// LPE == 4 only (E = 64): R = 4 row slots.  `ticket` is an LDS word zeroed by the caller.
+template <int MODE>
+__device__ __forceinline__ void gather_rows_dynamic(
+    const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx_b,
+    const int32_t *__restrict__ perm_b, const float *__restrict__ val_b,
+    const float *__restrict__ tile, float *__restrict__ out_b, int *ticket, int nrows) {
+    constexpr int LPE = 4, E = 64, R = 4;
+    const Lane4<LPE> L;
+    const int ngroups = (nrows + R - 1) / R;
+    const int lane = lane_id();
+
+    for (;;) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(ticket, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= ngroups) break;
+        const int row = g * R + L.j;
+        int start = 0, end = 0;
+        if (row < nrows) {
+            start = ptr[row];
+            end = ptr[row + 1];
+        }
+        const int len = end - start;
+        int lens[R], starts[R];
+        int maxlen = 0, wide_rounds = 0;
+#pragma unroll
+        for (int jj = 0; jj < R; jj++) {
+            lens[jj] = __builtin_amdgcn_readlane(len, jj * LPE);
+            starts[jj] = __builtin_amdgcn_readlane(start, jj * LPE);
+            maxlen = max(maxlen, lens[jj]);
+            wide_rounds += (lens[jj] + 255) >> 8;
+        }
+        const int normal_rounds = (maxlen + 63) >> 6;
+
+        if (normal_rounds <= wide_rounds + 1) {
+            // ---- normal: four rows side by side, 64 entries of each per round ----
+            float4 acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            Seg4 seg = load_seg<MODE>(idx_b, perm_b, val_b, start + 16 * L.t + 4 * L.qs, end);
+            for (int c = 0; c < normal_rounds; c++) {
+                const Seg4 nseg = load_seg<MODE>(idx_b, perm_b, val_b,
+                                                 start + 64 * (c + 1) + 16 * L.t + 4 * L.qs, end);
+                accumulate16<LPE>(seg, tile, L.choff, acc);
+                seg = nseg;
+            }
+            reduce_t(acc);
+            if (L.t == 0 && row < nrows) {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    *reinterpret_cast<float4 *>(out_b + (size_t)row * E + L.choff[i]) = acc[i];
+            }
+        } else {
+            // ---- wide: one row at a time, 256 entries per round -------------------
+#pragma unroll
+            for (int jj = 0; jj < R; jj++) {
+                const int wrow = g * R + jj;
+                const int wstart = starts[jj], wend = wstart + lens[jj];
+                float4 acc[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int rounds = (lens[jj] + 255) >> 8;
+                const int lane_off = 64 * L.j + 16 * L.t + 4 * L.qs;
+                Seg4 seg = load_seg<MODE>(idx_b, perm_b, val_b, wstart + lane_off, wend);
+                for (int c = 0; c < rounds; c++) {
+                    const Seg4 nseg = load_seg<MODE>(idx_b, perm_b, val_b,
+                                                     wstart + 256 * (c + 1) + lane_off, wend);
+                    accumulate16<LPE>(seg, tile, L.choff, acc);
+                    seg = nseg;
+                }
+                reduce_t(acc);
+                // slot j holds quarter (i + j) % 4 in acc[i]: rotate-and-shift sum
+                float4 tot[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    tot[i] = acc[i];
+                    add_f4(tot[i], ror_f4<4>(acc[(i + 1) & 3]));
+                    add_f4(tot[i], ror_f4<8>(acc[(i + 2) & 3]));
+                    add_f4(tot[i], ror_f4<12>(acc[(i + 3) & 3]));
+                }
+                if (L.t == 0 && L.j == 0 && wrow < nrows) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        *reinterpret_cast<float4 *>(out_b + (size_t)wrow * E + L.choff[i]) = tot[i];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace spt
 
 #endif  // SPT_GATHER4_H

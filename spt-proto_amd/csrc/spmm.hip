@@ -144,6 +144,26 @@ __global__ __launch_bounds__(SP_THREADS_LDS) void spmm_g4_lds_kernel(
                            part * NW + wave, splits * NW, S, 1.0f, 0.0f);
 }
 
+// transposed product, E = 64, one workgroup per batch: dynamic, wide-row aware
+// (gather_rows_dynamic).  The ticket word lives behind the tile in the dynamic region.
+__global__ __launch_bounds__(SP_THREADS_LDS) void spmm_t64_lds_kernel(
+    const int32_t *__restrict__ t_ptr, const int32_t *__restrict__ t_row,
+    const int32_t *__restrict__ t_perm, const float *__restrict__ values,
+    const float *__restrict__ x, float *__restrict__ y, int S, int nnz) {
+    constexpr int E = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xtile = reinterpret_cast<float *>(smem);  // [S][E]
+    int *ticket = reinterpret_cast<int *>(smem + (size_t)S * E * sizeof(float));
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid == 0) *ticket = 0;
+    stage_tile(xtile, x + (size_t)b * S * E, (S * E) >> 2, tid, SP_THREADS_LDS);
+    __syncthreads();
+    gather_rows_dynamic<G_SPMM_PERM>(t_ptr + (size_t)b * (S + 1), t_row + (size_t)b * nnz,
+                                     t_perm + (size_t)b * nnz, values + (size_t)b * nnz, xtile,
+                                     y + (size_t)b * S * E, ticket, S);
+}
+
 template <int LPE, int MODE>
 __global__ __launch_bounds__(SP_THREADS) void spmm_g4_global_kernel(
     const int32_t *__restrict__ ptr, int ptr_stride, const int32_t *__restrict__ indices,
@@ -189,16 +209,25 @@ __global__ __launch_bounds__(TR_THREADS) void csr_transpose_kernel(
     for (int i = tid; i < NC * S; i += TR_THREADS) wcnt[i] = 0;
     __syncthreads();
 
-    // contiguous row range of this wave
+    // contiguous row range of this wave = contiguous entry range [p_lo, p_hi)
     const int rows_per_wave = (S + TR_WAVES - 1) / TR_WAVES;
-    const int r0 = wave * rows_per_wave;
+    const int r0 = min(S, wave * rows_per_wave);
     const int r1 = min(S, r0 + rows_per_wave);
+    const int p_lo = indptr[r0], p_hi = indptr[r1];
     int *mycnt = wcnt + (PRIVATE ? wave * S : 0);
+    constexpr int KB = 16;  // 64-entry chunks whose loads are kept in flight together
 
     // ---- 1. histogram ----
-    for (int r = r0; r < r1; r++) {
-        const int start = indptr[r], end = indptr[r + 1];
-        for (int p = start + lane; p < end; p += SPT_WAVE) atomicAdd(&mycnt[idx_b[p]], 1);
+    for (int base = p_lo; base < p_hi; base += KB * SPT_WAVE) {
+        int cols[KB];
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const int p = base + i * SPT_WAVE + lane;
+            cols[i] = (p < p_hi) ? idx_b[p] : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < KB; i++)
+            if (cols[i] >= 0) atomicAdd(&mycnt[cols[i]], 1);
     }
     __syncthreads();
 
@@ -218,9 +247,9 @@ __global__ __launch_bounds__(TR_THREADS) void csr_transpose_kernel(
     }
     if (lane == SPT_WAVE - 1) wave_tot[wave] = inc;
     __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; w++) base += wave_tot[w];
-    int run = base + inc - mine;  // first position of column c0
+    int base_pos = 0;
+    for (int w = 0; w < wave; w++) base_pos += wave_tot[w];
+    int run = base_pos + inc - mine;  // first position of column c0
     int32_t *tp = t_ptr + (size_t)b * (S + 1);
     for (int c = c0; c < c1; c++) {
         tp[c] = run;
@@ -233,16 +262,217 @@ __global__ __launch_bounds__(TR_THREADS) void csr_transpose_kernel(
     if (tid == TR_THREADS - 1) tp[S] = nnz;
     __syncthreads();
 
-    // ---- 3. placement: rows ascending per wave ----
+    // ---- 3. placement: entries in ascending order per wave ----
     int32_t *trow = t_row + (size_t)b * nnz;
     int32_t *tperm = t_perm + (size_t)b * nnz;
-    for (int r = r0; r < r1; r++) {
-        const int start = indptr[r], end = indptr[r + 1];
-        for (int p = start + lane; p < end; p += SPT_WAVE) {
-            const int pos = atomicAdd(&mycnt[idx_b[p]], 1);
-            trow[pos] = r;
-            tperm[pos] = p;
+    int r = r0;  // row of this lane's current entry (entries only move forward)
+    for (int base = p_lo; base < p_hi; base += KB * SPT_WAVE) {
+        int cols[KB];
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const int p = base + i * SPT_WAVE + lane;
+            cols[i] = (p < p_hi) ? idx_b[p] : -1;
         }
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const int p = base + i * SPT_WAVE + lane;
+            if (cols[i] >= 0) {
+                while (indptr[r + 1] <= p) r++;
+                const int pos = atomicAdd(&mycnt[cols[i]], 1);
+                trow[pos] = r;
+                tperm[pos] = p;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ CSR transpose, bitmap form
+//
+// LDS atomics are the bottleneck of the counting sort above (measured ~7 cycles per lane,
+// 212 us for 256 slices of 32768 entries).  For S <= 768 the (row, column) incidence
+// matrix fits LDS as a bitmap, and the position of a DISTINCT entry needs no atomic:
+//     pos(r, c) = start[c] + #{ r' < r : c in row r' }
+//               = start[c] + cum[c][r / 32] + popcount(MT[c][r / 32] & lowbits(r % 32))
+// MT[c][w] holds the bits of rows 32w .. 32w+31 for column c and is written only by the
+// wave that owns those 32 rows (plain read-or-write, no atomics, no races).  Entries that
+// repeat a (row, column) pair already seen in their row -- in the attention path only
+// lookup's column-0 padding of rows < Z-1 -- are appended behind the column's distinct
+// entries through a cursor (LDS atomic with return; rare).  The distinct part of every
+// column is therefore in ascending row order, reproducibly; only the relative order of
+// duplicate entries depends on wave timing.
+__global__ __launch_bounds__(TR_THREADS) void csr_transpose_bitmap_kernel(
+    const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+    int32_t *__restrict__ t_ptr, int32_t *__restrict__ t_row, int32_t *__restrict__ t_perm,
+    int S, int nnz, int fb_words) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int W = (S + 31) >> 5;                                   // 32-row words per column
+    // all carve offsets are multiples of 8 bytes (sizes rounded by the host the same way)
+    uint32_t *MT = reinterpret_cast<uint32_t *>(smem);             // [S][W] incidence bits
+    unsigned long long *firstbits =
+        reinterpret_cast<unsigned long long *>(MT + (((size_t)S * W + 1) & ~(size_t)1));
+    int *colstart = reinterpret_cast<int *>(firstbits + fb_words);  // [S]
+    int *dupcur = colstart + S;                                    // [S] count, then cursor
+    int *rowptr = dupcur + S;                                      // [S + 1] copy of indptr
+    int *wave_tot = rowptr + ((S + 2) & ~1);                       // [TR_WAVES]
+    int *wave_chunks = wave_tot + TR_WAVES;                        // [TR_WAVES]
+    uint16_t *cum = reinterpret_cast<uint16_t *>(wave_chunks + TR_WAVES);      // [S][W]
+    uint16_t *stage = cum + (((size_t)S * W + 3) & ~(size_t)3);    // [nnz] entry id by position
+    uint8_t *scratch_all = reinterpret_cast<uint8_t *>(stage + (((size_t)nnz + 3) & ~(size_t)3));
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int32_t *idx_b = indices + (size_t)b * nnz;
+    uint8_t *scratch = scratch_all + (size_t)wave * S;   // "who saw this column first" bytes
+
+    for (int i = tid; i < S * W; i += TR_THREADS) MT[i] = 0u;
+    for (int i = tid; i < S; i += TR_THREADS) dupcur[i] = 0;
+    for (int i = tid; i <= S; i += TR_THREADS) rowptr[i] = indptr[i];
+    __syncthreads();
+
+    // rows of this wave: 32-row words wave, wave + TR_WAVES, ...
+    // how many 64-entry chunks will this wave visit?  (offset of its ballot words)
+    int my_chunks = 0;
+    for (int wi = wave; wi < W; wi += TR_WAVES) {
+        const int r = 32 * wi + (lane & 31);
+        int n = 0;
+        if (lane < 32 && r < S) n = (rowptr[r + 1] - rowptr[r] + 63) >> 6;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) n += __shfl_xor(n, d, SPT_WAVE);
+        my_chunks += __builtin_amdgcn_readlane(n, 0);
+    }
+    if (lane == 0) wave_chunks[wave] = my_chunks;
+    __syncthreads();
+    int fb_base = 0;
+    for (int w = 0; w < wave; w++) fb_base += wave_chunks[w];
+    unsigned long long *myfb = firstbits + fb_base;
+
+    // the first 64 column ids of the NEXT row are requested before the current row is
+    // processed: the serial walk over rows is otherwise bound by HBM latency per row
+    auto first_chunk = [&](int r) {
+        int v = 0;
+        if (r < S) {
+            const int st = rowptr[r], en = rowptr[r + 1];
+            if (st + lane < en) v = idx_b[st + lane];
+        }
+        return v;
+    };
+
+    // ---- A. bitmap of distinct entries, count of duplicates ----
+    int chunk_no = 0;
+    for (int wi = wave; wi < W; wi += TR_WAVES) {
+        int ncol = first_chunk(32 * wi);
+        for (int rr = 0; rr < 32; rr++) {
+            const int r = 32 * wi + rr;
+            if (r >= S) break;
+            const int start = rowptr[r], end = rowptr[r + 1];
+            const int col0 = ncol;
+            if (rr + 1 < 32) ncol = first_chunk(r + 1);
+            for (int p0 = start; p0 < end; p0 += SPT_WAVE, chunk_no++) {
+                const int p = p0 + lane;
+                const bool live = p < end;
+                const int col = (p0 == start) ? col0 : (live ? idx_b[p] : 0);
+                // first occurrence within the row?  a later 64-entry chunk of the same row
+                // must also lose against earlier chunks: test the bitmap bit first
+                bool first = false;
+                if (live) {
+                    const bool seen = (MT[(size_t)col * W + wi] >> rr) & 1u;
+                    if (!seen) scratch[col] = (uint8_t)lane;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (live) {
+                    const bool seen = (MT[(size_t)col * W + wi] >> rr) & 1u;
+                    first = !seen && scratch[col] == (uint8_t)lane;
+                    if (first) MT[(size_t)col * W + wi] |= (1u << rr);
+                    else atomicAdd(&dupcur[col], 1);
+                }
+                const unsigned long long fb = __ballot(first);
+                if (lane == 0) myfb[chunk_no] = fb;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- B. per column: prefix over words, totals, block scan -> column starts ----
+    const int cols_per_thread = (S + TR_THREADS - 1) / TR_THREADS;
+    const int c0 = min(S, tid * cols_per_thread);
+    const int c1 = min(S, c0 + cols_per_thread);
+    int mine = 0;
+    for (int c = c0; c < c1; c++) {
+        int runc = 0;
+        for (int w = 0; w < W; w++) {
+            cum[(size_t)c * W + w] = (uint16_t)runc;
+            runc += __popc(MT[(size_t)c * W + w]);
+        }
+        colstart[c] = runc;            // distinct entries, for now
+        mine += runc + dupcur[c];
+    }
+    int inc = mine;
+#pragma unroll
+    for (int d = 1; d < SPT_WAVE; d <<= 1) {
+        const int o = __shfl_up(inc, d, SPT_WAVE);
+        if (lane >= d) inc += o;
+    }
+    if (lane == SPT_WAVE - 1) wave_tot[wave] = inc;
+    __syncthreads();
+    int base_pos = 0;
+    for (int w = 0; w < wave; w++) base_pos += wave_tot[w];
+    int run = base_pos + inc - mine;
+    int32_t *tp = t_ptr + (size_t)b * (S + 1);
+    for (int c = c0; c < c1; c++) {
+        const int distinct = colstart[c], dups = dupcur[c];
+        tp[c] = run;
+        colstart[c] = run;
+        dupcur[c] = run + distinct;    // duplicates go behind the distinct entries
+        run += distinct + dups;
+    }
+    if (tid == TR_THREADS - 1) tp[S] = nnz;
+    __syncthreads();
+
+    // ---- C. placement into the LDS stage (entry id by transposed position) ----
+    chunk_no = 0;
+    for (int wi = wave; wi < W; wi += TR_WAVES) {
+        int ncol = first_chunk(32 * wi);
+        for (int rr = 0; rr < 32; rr++) {
+            const int r = 32 * wi + rr;
+            if (r >= S) break;
+            const int start = rowptr[r], end = rowptr[r + 1];
+            const int col0 = ncol;
+            if (rr + 1 < 32) ncol = first_chunk(r + 1);
+            for (int p0 = start; p0 < end; p0 += SPT_WAVE, chunk_no++) {
+                const int p = p0 + lane;
+                if (p < end) {
+                    const int col = (p0 == start) ? col0 : idx_b[p];
+                    const unsigned long long fb = myfb[chunk_no];
+                    int pos;
+                    if ((fb >> lane) & 1ull) {
+                        const uint32_t below = MT[(size_t)col * W + wi] & ((1u << rr) - 1u);
+                        pos = colstart[col] + (int)cum[(size_t)col * W + wi] + __popc(below);
+                    } else {
+                        pos = atomicAdd(&dupcur[col], 1);
+                    }
+                    stage[pos] = (uint16_t)p;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- D. coalesced write-out; the source row of entry p by binary search in rowptr ----
+    int32_t *trow = t_row + (size_t)b * nnz;
+    int32_t *tperm = t_perm + (size_t)b * nnz;
+    for (int pos = tid; pos < nnz; pos += TR_THREADS) {
+        const int p = stage[pos];
+        int lo = 0, hi = S;            // largest r with rowptr[r] <= p
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (rowptr[mid] <= p) lo = mid;
+            else hi = mid;
+        }
+        tperm[pos] = p;
+        trow[pos] = lo;
     }
 }
 
@@ -271,6 +501,29 @@ static TransposedCsr carve(void *workspace, int B, int S, int nnz) {
 
 static int launch_transpose(const int32_t *indptr, const int32_t *indices, TransposedCsr t,
                             int B, int S, int nnz, hipStream_t s) {
+    // bitmap form (LDS carve must match csr_transpose_bitmap_kernel)
+    if (nnz <= 65536) {
+        const size_t W = (size_t)(S + 31) / 32;
+        const size_t fb_words = ((size_t)nnz + 63) / 64 + (size_t)S;   // >= chunks visited
+        size_t need = (((size_t)S * W + 1) & ~(size_t)1) * 4;          // MT
+        need += fb_words * 8;                                          // firstbits
+        need += 2 * (size_t)S * 4;                                     // colstart, dupcur
+        need += (((size_t)S + 2) & ~(size_t)1) * 4;                    // rowptr
+        need += 2 * (size_t)TR_WAVES * 4;                              // wave_tot, wave_chunks
+        need += (((size_t)S * W + 3) & ~(size_t)3) * 2;                // cum
+        need += (((size_t)nnz + 3) & ~(size_t)3) * 2;                  // stage
+        need += (size_t)TR_WAVES * S;                                  // scratch
+        if (need <= 158 * 1024) {
+            SPT_HIP_TRY(hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&csr_transpose_bitmap_kernel),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+            hipLaunchKernelGGL(csr_transpose_bitmap_kernel, dim3(B), dim3(TR_THREADS), need, s,
+                               indptr, indices, t.t_ptr, t.t_row, t.t_perm, S, nnz,
+                               (int)fb_words);
+            SPT_LAUNCH_CHECK();
+            return SPT_OK;
+        }
+    }
     const size_t head = TR_WAVES * sizeof(int);
     const size_t priv = head + (size_t)TR_WAVES * S * sizeof(int);
     const size_t shared = head + (size_t)S * sizeof(int);
@@ -299,7 +552,14 @@ static int launch_gather(const int32_t *ptr, int ptr_stride, const int32_t *indi
                          int B, int S, int E, int nnz, hipStream_t s) {
     constexpr int MODE = PERM ? G_SPMM_PERM : G_SPMM;
     const size_t tile_bytes = (size_t)S * E * sizeof(float);
-    if (E == 64 || E == 128) {
+    if (PERM && E == 64 && tile_bytes <= 128 * 1024 && B >= 128) {
+        const size_t lds_bytes = tile_bytes + 16;
+        SPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_t64_lds_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_bytes));
+        hipLaunchKernelGGL(spmm_t64_lds_kernel, dim3((unsigned)B), dim3(SP_THREADS_LDS), lds_bytes,
+                           s, ptr, indices, perm, values, x, y, S, nnz);
+    } else if (E == 64 || E == 128) {
         const bool lds = tile_bytes <= 128 * 1024 && B >= 32;
         int splits = 1;
         while ((long long)B * splits < 256 && splits < 8) splits <<= 1;

@@ -35,6 +35,9 @@ for _ in range(reps):
         ext.spmm_forward_cuda(False, False, indptr, idx, vals, k)
     if 'spmm_t' in ops:
         ext.spmm_forward_cuda(True, False, indptr, idx, vals, k)
+    if 'transpose' in ops:
+        t = ext.csr_transpose(indptr, idx)
+        ext.spmm_transposed(t, indptr, idx, vals, k)
     if 'lookup' in ops:
         ext.lookup_forward_cuda(torch.empty([8]), qc, kc)
     if 'cdist' in ops:
