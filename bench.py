@@ -110,16 +110,9 @@ def sparse_step(attn, q, k, v, trigger):
 
 
 def allreduce_grads(params, world):
-    grads = [p.grad for p in params if p.grad is not None]
-    if world == 1 or not grads:
-        return
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat)
-    flat /= world
-    off = 0
-    for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g))
-        off += g.numel()
+    # one flat fp32 buffer, one RCCL all-reduce (naive_gpt/utils/distributed.py)
+    from naive_gpt import utils
+    utils.allreduce_gradients(params, world_size=world)
 
 
 def timed_loop(fn, steps, warmup, world):
@@ -205,8 +198,8 @@ def main():
     attn = layers.SparseVanillaAttentionV2(d_head=E, d_codeword=D, n_codewords=C,
                                            p_dropout=0.0).to(dev)
     if world > 1:   # identical replicas
-        for p in attn.parameters():
-            dist.broadcast(p.data, src=0)
+        from naive_gpt import utils
+        utils.broadcast_parameters(attn, src=0)
     q, k, v = [torch.randn([N, S, H, E], device=dev, requires_grad=True) for _ in range(3)]
     params = list(attn.parameters())
 

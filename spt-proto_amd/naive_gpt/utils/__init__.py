@@ -2,3 +2,6 @@
 from .adapter import LoRAHandler
 from .adapter import ModuleUpgrader
 from .adapter import SparseLoRAHandler
+from .distributed import allreduce_gradients
+from .distributed import broadcast_parameters
+from .distributed import trainable_parameters

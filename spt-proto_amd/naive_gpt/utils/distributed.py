@@ -1,0 +1,60 @@
+"""Data-parallel gradient exchange for SPT fine-tuning.
+
+The reference trains through Lightning's DDP (``script/4-sparse-tuning-0.py:183-187``):
+one process per GPU, NCCL all-reduce of the trainable gradients.  Here the same
+exchange is explicit: every rank holds the full frozen replica, only LoRA / router /
+PQ-codebook / norm parameters carry gradients (36 MB fp32 at BERT-large dimensions,
+SURVEY.md 8e), and they travel as ONE flat fp32 buffer in ONE all-reduce per step --
+on MI355X the backend name ``nccl`` is RCCL, which spreads a single large message over
+the 7 xGMI links of a GPU, where many small per-parameter messages would be latency
+bound.
+"""
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def trainable_parameters(module: torch.nn.Module) -> List[torch.nn.Parameter]:
+    return [p for p in module.parameters() if p.requires_grad]
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Make every replica identical to rank ``src`` (parameters and buffers)."""
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None,
+                        world_size: Optional[int] = None) -> int:
+    """Average ``p.grad`` over the ranks of ``group`` with a single flat all-reduce.
+
+    Parameters whose gradient is ``None`` on this rank contribute zeros, so every rank
+    must pass the same parameter list (true for replicas).  Returns the number of
+    elements exchanged."""
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return 0
+    if world_size is None:
+        world_size = dist.get_world_size(group)
+    if world_size == 1:
+        return 0
+    device = params[0].device
+    sizes = [p.numel() for p in params]
+    flat = torch.zeros([sum(sizes)], dtype=torch.float32, device=device)
+    offset = 0
+    for p, n in zip(params, sizes):
+        if p.grad is not None:
+            flat[offset:offset + n].copy_(p.grad.reshape(-1))
+        offset += n
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(world_size)
+    offset = 0
+    for p, n in zip(params, sizes):
+        g = flat[offset:offset + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        offset += n
+    return int(flat.numel())
