@@ -36,7 +36,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 2
+#define SPT_ABI_VERSION 3
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -145,6 +145,25 @@ int spt_softmax_backward(const int32_t *indptr, const int32_t *indices,
                          const float *output, const float *grad_output,
                          float *grad_values, int batch_size, int seq_length,
                          int nnz, void *stream);
+
+/*
+ * Routed FFN: token-bucketed grouped GEMM on the fp32 matrix cores.
+ *   reference: the per-block loop of naive_gpt/layers/tuning/lora_ffn.py:87-111 and
+ *   naive_gpt/layers/sparse/feedforward.py:66-85 (boolean-mask gather + cuBLAS per block;
+ *   there is no native routed-FFN kernel in the reference).
+ * Rows [offsets[g], offsets[g+1]) of the (block-sorted) row space belong to block g:
+ *     out[p, n] = rowscale[p] * ( sum_k a[src(p), k] * W_g(n, k) + bias[g, n] )
+ *     src(p) = gather ? gather[p] : p
+ *     W_g(n, k) = w[g * w_group_stride + n * w_ldn + k * w_ldk]   (w_ldk == 1 or w_ldn == 1)
+ * a [*, lda] (lda >= k), out [n_rows, n]; gather / bias [n_groups, n] / rowscale may be
+ * NULL.  offsets is DEVICE memory (bucket sizes never visit the host).  Requires
+ * k % 4 == 0, lda % 4 == 0 and 16-byte aligned weight rows.
+ */
+int spt_grouped_gemm(const float *a, const int32_t *gather, const float *w,
+                     const float *bias, const float *rowscale,
+                     const int32_t *offsets, float *out, int n_rows, int k, int n,
+                     int n_groups, int lda, long long w_group_stride, int w_ldn,
+                     int w_ldk, void *stream);
 
 #ifdef __cplusplus
 }

@@ -38,10 +38,12 @@ _PROTOTYPES = {
     'spt_csr_transpose_workspace_bytes': ([_c_int] * 3, ctypes.c_int64),
     'spt_csr_transpose': ([_c_ptr] * 3 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_spmm_transposed': ([_c_ptr] * 4 + [_c_int] * 4 + [_c_ptr], _c_int),
+    'spt_grouped_gemm': ([_c_ptr] * 7 + [_c_int] * 5 + [ctypes.c_longlong, _c_int, _c_int, _c_ptr],
+                         _c_int),
     'spt_softmax_forward': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_backward': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
 }
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -407,3 +409,43 @@ def softmax_backward_cuda(indptr: torch.Tensor, indices: torch.Tensor,
     if rc != 0:
         _raise(lib, rc, 'softmax_backward_cuda')
     return grad_values
+
+
+def grouped_gemm(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Tensor,
+                 n_groups: int, n: int, k: int, w_group_stride: int, w_ldn: int,
+                 w_ldk: int, gather: torch.Tensor = None, bias: torch.Tensor = None,
+                 rowscale: torch.Tensor = None, n_rows: int = None) -> torch.Tensor:
+    """Token-bucketed grouped GEMM (``spt_grouped_gemm``): for the rows of bucket g,
+    ``out = rowscale * (a[gather] @ W_g^T + bias[g])`` with
+    ``W_g(n, k) = weight.flatten()[g * w_group_stride + n * w_ldn + k * w_ldk]``.
+    ``offsets`` [n_groups + 1] int32 stays on the device."""
+    _check_type(a, torch.float32, 'a')
+    _check_type(weight, torch.float32, 'weight')
+    _check_type(offsets, torch.int32, 'offsets')
+    _require(a.is_cuda and weight.is_cuda and offsets.is_cuda, 'grouped_gemm needs CUDA tensors')
+    _require(a.dim() == 2 and a.stride(1) == 1, 'a must be [rows, k] with unit inner stride')
+    _require(weight.is_contiguous(), 'weight must be contiguous')
+    _require(offsets.numel() == n_groups + 1, 'offsets must have n_groups + 1 entries')
+    dev = _same_device(a, weight, offsets)
+    if n_rows is None:
+        n_rows = gather.numel() if gather is not None else a.size(0)
+    for t, name in ((gather, 'gather'), (bias, 'bias'), (rowscale, 'rowscale')):
+        if t is not None:
+            _require(t.is_cuda and t.is_contiguous(), name + ' must be a contiguous CUDA tensor')
+    if gather is not None:
+        _check_type(gather, torch.int32, 'gather')
+    lib = load_library()
+    with torch.cuda.device(dev):
+        out = torch.empty([n_rows, n], dtype=torch.float32, device=dev)
+        if n_rows == 0:
+            return out
+        rc = lib.spt_grouped_gemm(
+            a.data_ptr(), gather.data_ptr() if gather is not None else None,
+            weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+            rowscale.data_ptr() if rowscale is not None else None,
+            offsets.data_ptr(), out.data_ptr(), n_rows, k, n, n_groups, a.stride(0),
+            w_group_stride, w_ldn, w_ldk, _stream(dev)
+        )
+    if rc != 0:
+        _raise(lib, rc, 'grouped_gemm')
+    return out

@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from naive_gpt import layers
-from naive_gpt.layers.sparse import routing
+from naive_gpt.layers.sparse import grouped, routing
 
 
 def _load_routed(model: nn.Module, source: nn.Module):
@@ -47,9 +47,40 @@ class LoRARoutedFFN(layers.RoutedFFN):
                               activation=source.activation)
         return _load_routed(model, source)
 
+    def _forward_grouped(self, x: torch.Tensor):
+        """MI355X path: device-side bucketing + grouped MFMA GEMMs for the frozen base
+        weights (layers/sparse/grouped.py); LoRA side paths as dense K = n_blocks * r
+        matmuls on the same row space.  No host synchronisation."""
+        nb, bs, d, r = self.n_blocks, self.block_size, self.d_model, self.fc1.lora.left.weight.size(1)
+        prob = self.router(x)
+        bk = grouped.make_buckets(prob, k=nb // 2)
+        coeff = (2.0 * bk.coeff).contiguous()
+        rows = torch.arange(bk.block.numel(), device=x.device)
+
+        g1 = grouped.grouped_linear(
+            x, self.fc1.weight, bk.offsets, (bs, d, bs * d, d, 1), gather=bk.token,
+            gather_long=bk.token_long, bias=self.fc1.bias.view([nb, bs]), rowscale=coeff)
+        # (x L1) R1_g^T as one dense product: the row's r coefficients sit in slice g
+        u = torch.matmul(x, self.fc1.lora.left.weight).index_select(0, bk.token_long)
+        u_exp = torch.zeros([u.size(0), nb, r], dtype=u.dtype, device=u.device)
+        u_exp[rows, bk.block] = u
+        r1cat = self.fc1.lora.right.weight.view([nb, bs, r]).permute(1, 0, 2).reshape(bs, nb * r)
+        h = self.activation(g1 + torch.matmul(u_exp.view(-1, nb * r), r1cat.T))
+
+        y2 = grouped.grouped_linear(
+            h, self.fc2.weight, bk.offsets, (d, bs, bs, self.d_feedforward, 1), rowscale=coeff)
+        l2cat = self.fc2.lora.left.weight.view([nb, bs, r]).permute(1, 0, 2).reshape(bs, nb * r)
+        z = torch.matmul(h, l2cat).view(-1, nb, r)[rows, bk.block]
+        ys = y2 + torch.matmul(z, self.fc2.lora.right.weight.T)
+        y = torch.zeros_like(x).index_add_(0, bk.token_long, ys)
+        return y + self.fc2.bias.view([1, -1])
+
     def forward(self, x: torch.Tensor):
         x_size = x.size()
         x = x.view([-1, self.d_model])
+        if grouped.usable(x, self.fc1.weight, self.fc1.bias, self.fc2.weight) \
+                and self.d_model % 4 == 0 and self.block_size % 4 == 0:
+            return self._forward_grouped(x.contiguous()).view(x_size)
         prob = self.router(x)
         route = routing.route_topk(prob, k=self.n_blocks // 2)
 
@@ -95,9 +126,38 @@ class LoRARoutedLLaMaFFN(layers.RoutedLLaMaFFN):
                                    activation=source.activation)
         return _load_routed(model, source)
 
+    def _forward_grouped(self, x: torch.Tensor):
+        """MI355X path, see LoRARoutedFFN._forward_grouped."""
+        nb, bs, d, r = self.n_blocks, self.block_size, self.d_model, self.gate.lora.left.weight.size(1)
+        prob = self.router(x)
+        bk = grouped.make_buckets(prob, k=nb // 2)
+        coeff = (2.0 * bk.coeff).contiguous()
+        rows = torch.arange(bk.block.numel(), device=x.device)
+
+        def up(linear):
+            base = grouped.grouped_linear(
+                x, linear.weight, bk.offsets, (bs, d, bs * d, d, 1), gather=bk.token,
+                gather_long=bk.token_long, rowscale=coeff)
+            u = torch.matmul(x, linear.lora.left.weight).index_select(0, bk.token_long)
+            u_exp = torch.zeros([u.size(0), nb, r], dtype=u.dtype, device=u.device)
+            u_exp[rows, bk.block] = u
+            rcat = linear.lora.right.weight.view([nb, bs, r]).permute(1, 0, 2).reshape(bs, nb * r)
+            return base + torch.matmul(u_exp.view(-1, nb * r), rcat.T)
+
+        h = self.activation(up(self.gate)) * up(self.side)
+        y2 = grouped.grouped_linear(
+            h, self.down.weight, bk.offsets, (d, bs, bs, self.d_feedforward, 1), rowscale=coeff)
+        ldcat = self.down.lora.left.weight.view([nb, bs, r]).permute(1, 0, 2).reshape(bs, nb * r)
+        z = torch.matmul(h, ldcat).view(-1, nb, r)[rows, bk.block]
+        ys = y2 + torch.matmul(z, self.down.lora.right.weight.T)
+        return torch.zeros_like(x).index_add_(0, bk.token_long, ys)
+
     def forward(self, x: torch.Tensor):
         x_size = x.size()
         x = x.view([-1, self.d_model])
+        if grouped.usable(x, self.gate.weight, self.side.weight, self.down.weight) \
+                and self.d_model % 4 == 0 and self.block_size % 4 == 0:
+            return self._forward_grouped(x.contiguous()).view(x_size)
         prob = self.router(x)
         route = routing.route_topk(prob, k=self.n_blocks // 2)
 

@@ -1,0 +1,132 @@
+"""GPU tier: the token-bucketed grouped GEMM (fp32 MFMA) and the routed-FFN layers on it.
+
+The oracle for a grouped GEMM is the per-bucket dense product in float64 (the
+mathematical definition of the reference's per-block loop,
+naive_gpt/layers/tuning/lora_ffn.py:87-111); the layer-level parity against the
+imported reference lives in tests/test_layers_golden.py (gpu variants)."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_grouped(a, gather, w_full, view, bias, rowscale, offsets):
+    n, k, gs, ldn, ldk = view
+    a = a.double().cpu()
+    out = torch.zeros([len(gather) if gather is not None else a.size(0), n], dtype=torch.float64)
+    flat = w_full.double().cpu().reshape(-1)
+    for g in range(len(offsets) - 1):
+        lo, hi = offsets[g], offsets[g + 1]
+        if hi == lo:
+            continue
+        idx = (g * gs + torch.arange(n)[:, None] * ldn + torch.arange(k)[None, :] * ldk)
+        wg = flat[idx]                                           # [n, k]
+        rows = torch.arange(lo, hi)
+        src = gather.cpu().long()[rows] if gather is not None else rows
+        o = a[src] @ wg.T
+        if bias is not None:
+            o = o + bias.double().cpu()[g]
+        out[rows] = o
+    if rowscale is not None:
+        out = out * rowscale.double().cpu()[:, None]
+    return out
+
+
+@pytest.mark.parametrize('P,K,N,G,layout', [
+    (1000, 64, 128, 4, 'bt'), (1000, 64, 128, 4, 'bn'),
+    (4096, 256, 384, 4, 'bt'), (4096, 256, 384, 4, 'bn'),
+    (333, 16, 16, 4, 'bt'), (333, 16, 16, 4, 'bn'),          # K < 32, N < 128: tails
+    (770, 36, 200, 3, 'bt'), (770, 36, 200, 3, 'bn'),        # K % 32 != 0, N % 128 != 0
+    (64, 1024, 1024, 8, 'bt'),                                # more buckets than rows/128
+])
+def test_grouped_gemm_matches_per_bucket_product(P, K, N, G, layout):
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(P + K + N)
+    T = max(P // 2, 8)
+    a = torch.randn([T, K], generator=gen)
+    gather = torch.randint(0, T, [P], generator=gen, dtype=torch.int32)
+    cuts = sorted(torch.randint(0, P + 1, [G - 1], generator=gen).tolist())
+    if G > 2:
+        cuts[1] = cuts[0]                                       # an empty bucket
+    offsets = [0] + cuts + [P]
+    bias = torch.randn([G, N], generator=gen)
+    scale = torch.rand([P], generator=gen) + 0.5
+    if layout == 'bt':          # blocks of rows of a [G*N, K] matrix
+        w = torch.randn([G * N, K], generator=gen)
+        view = (N, K, N * K, K, 1)
+    else:                       # blocks of columns... W_g(n, k) = w[k, g*N + n]
+        w = torch.randn([K, G * N], generator=gen)
+        view = (N, K, N, 1, G * N)
+    want = ref_grouped(a, gather, w, view, bias, scale, offsets)
+    off_dev = torch.tensor(offsets, dtype=torch.int32, device='cuda')
+    got = ext.grouped_gemm(a.cuda(), w.cuda(), off_dev, G, N, K, view[2], view[3], view[4],
+                           gather=gather.cuda(), bias=bias.cuda(), rowscale=scale.cuda())
+    err = (got.double().cpu() - want).abs()
+    tol = 1e-4 * np.sqrt(K) + 1e-3 * want.abs()                 # fp32 values within 1e-3 rel
+    assert (err <= tol).all(), err.max()
+    # plain form: no gather / bias / scale
+    a2 = torch.randn([P, K], generator=gen)
+    want2 = ref_grouped(a2, None, w, view, None, None, offsets)
+    got2 = ext.grouped_gemm(a2.cuda(), w.cuda(), off_dev, G, N, K, view[2], view[3], view[4])
+    assert ((got2.double().cpu() - want2).abs() <= 1e-4 * np.sqrt(K) + 1e-3 * want2.abs()).all()
+
+
+def test_mfma_path_is_exact_fp32_product_order_free():
+    """v_mfma_f32_32x32x2_f32 is a k-ordered fp32 fmaf chain: integer-valued inputs whose
+    products and sums are exactly representable must come out exact."""
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(5)
+    P, K, N, G = 512, 128, 256, 2
+    a = torch.randint(-8, 9, [P, K], generator=gen).float()
+    w = torch.randint(-8, 9, [G * N, K], generator=gen).float()     # asymmetric operand
+    offsets = [0, 200, P]
+    want = ref_grouped(a, None, w, (N, K, N * K, K, 1), None, None, offsets)
+    got = ext.grouped_gemm(a.cuda(), w.cuda(), torch.tensor(offsets, dtype=torch.int32, device='cuda'),
+                           G, N, K, N * K, K, 1)
+    assert torch.equal(got.double().cpu(), want)
+
+
+@pytest.mark.parametrize('kind', ['opt', 'llama'])
+def test_routed_ffn_grouped_path_equals_torch_path(kind):
+    """Same layer, same weights: grouped-MFMA forward/backward vs the per-block torch
+    evaluation (the restatement of the reference loop)."""
+    from naive_gpt import layers
+    from naive_gpt.layers.sparse import grouped
+    torch.manual_seed(3)
+    d, dff, bs, r = 64, 512, 128, 8
+    if kind == 'opt':
+        m = layers.LoRARoutedFFN(d_lora=r, block_size=bs, d_model=d, d_feedforward=dff,
+                                 activation=nn.ReLU())
+    else:
+        m = layers.LoRARoutedLLaMaFFN(d_lora=r, block_size=bs, d_model=d, d_feedforward=dff,
+                                      activation=nn.SiLU())
+    for name, p in m.named_parameters():
+        if name.endswith('lora.right.weight'):
+            p.data.normal_(0, 0.05)
+    m = m.cuda()
+    x = torch.randn([4, 300, d], device='cuda', requires_grad=True)
+    w = torch.randn([4, 300, d], device='cuda')
+
+    assert grouped.usable(x.view(-1, d), *(p for n, p in m.named_parameters()
+                                           if not p.requires_grad))
+    y1 = m(x)
+    (y1 * w).sum().backward()
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    gx1 = x.grad.clone()
+    x.grad = None
+    m.zero_grad()
+    orig = grouped.usable
+    grouped.usable = lambda *a, **k: False          # force the torch evaluation
+    try:
+        y2 = m(x)
+        (y2 * w).sum().backward()
+    finally:
+        grouped.usable = orig
+    assert torch.allclose(y1, y2, rtol=1e-3, atol=1e-4)
+    assert torch.allclose(gx1, x.grad, rtol=1e-3, atol=1e-4)
+    g2 = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    assert set(g1) == set(g2)
+    for n in g1:
+        assert torch.allclose(g1[n], g2[n], rtol=2e-3, atol=2e-4), n
