@@ -43,6 +43,8 @@ def algorithmic_bytes(op: str, B: int) -> int:
     """SURVEY.md 8(d) per-(batch*head) figures x B slices handled by one launch."""
     per = {
         'cdist_encode': S * E * 4 + S * M * 4,
+        'pq_encode_heads': S * E * 4 + S * M * 4,
+        'softmax_backward_clamped': 5 * S * Z * 4,
         'cdist_forward_cuda': S * E * 4 + S * M * 4 + S * M * C * 4,
         'cdist_backward_cuda': S * E * 4 + S * M * C * 4 + S * E * 4,
         'lookup_forward_cuda': 2 * S * M * 4 + S * Z * 4,
@@ -60,7 +62,8 @@ class EventTimer:
     """Brackets every naive_gpt.ext call with HIP events on torch's current stream
     (the stream the kernels are launched on)."""
 
-    OPS = ['cdist_encode', 'cdist_forward_cuda', 'cdist_backward_cuda',
+    OPS = ['cdist_encode', 'pq_encode_heads', 'softmax_backward_clamped',
+           'cdist_forward_cuda', 'cdist_backward_cuda',
            'lookup_forward_cuda', 'sddmm_forward_cuda', 'spmm_forward_cuda',
            'spmm_transposed', 'csr_transpose',
            'softmax_forward_cuda', 'softmax_backward_cuda']

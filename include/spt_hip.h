@@ -20,6 +20,12 @@
  *     hipError_t from the launch.  spt_strerror() names either.
  *   - outputs that the algorithm only partially covers are fully written by the
  *     kernels themselves (zeros included): callers pass uninitialised buffers.
+ *   - `*_heads` arguments: a dense per-batch operand [B, S, E] may instead live inside the
+ *     attention layers' [N, S, heads, E] tensor (batch b = n * heads + h, row stride
+ *     heads * E); pass heads > 0 for that layout, 0 for plain [B, S, E].  This removes
+ *     the transpose(1,2).contiguous() copies of naive_gpt/layers/sparse/attention.py:92-95.
+ *     The head layout is implemented for d_head in {64, 128} with S * d_head * 4 <= 128 KiB
+ *     (SPT_EUNSUP otherwise: callers then copy to [B, S, E] as the reference does).
  */
 #ifndef SPT_HIP_H
 #define SPT_HIP_H
@@ -36,7 +42,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 3
+#define SPT_ABI_VERSION 4
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -52,6 +58,17 @@ const char *spt_strerror(int code);
 int spt_cdist_forward(const float *query, const float *table, float *distance,
                       int32_t *indices, int n_subspaces, int n_queries,
                       int n_codewords, int d_code, void *stream);
+
+/*
+ * PQ 'encode' straight from the attention layout: z [batch, seq, heads, M * D] (the q / k
+ * of naive_gpt/layers/sparse/attention.py:84-95) -> codes [batch * heads, seq, M], the
+ * input of lookup.  Equivalent to the reference's transpose + PQBase.forward('encode')
+ * (quantizer.py:44-48,64-77) without the three layout copies; same bit-exact
+ * distance / argmin contract as spt_cdist_forward.
+ */
+int spt_pq_encode_heads(const float *z, const float *table, int32_t *codes,
+                        int batch, int seq_length, int n_heads, int n_subspaces,
+                        int n_codewords, int d_code, void *stream);
 
 /*
  * cdist_backward_cuda(query, table, grad_output) -> [grad_query, grad_table]
@@ -93,7 +110,8 @@ int spt_lookup_forward(const int32_t *query, const int32_t *key, int32_t *out,
 int spt_sddmm_forward(const int32_t *indptr, const int32_t *indices,
                       const float *query, const float *key, float *out,
                       int batch_size, int seq_length, int d_head, int nnz,
-                      float scale, float clamp, void *stream);
+                      float scale, float clamp, int query_heads, int key_heads,
+                      void *stream);
 
 /*
  * spmm_forward_cuda(trans_lhs, trans_rhs=false, indptr, indices, values, x)
@@ -109,7 +127,8 @@ int64_t spt_spmm_workspace_bytes(int trans_lhs, int batch_size, int seq_length, 
 int spt_spmm_forward(int trans_lhs, const int32_t *indptr,
                      const int32_t *indices, const float *values,
                      const float *x, float *y, void *workspace, int batch_size,
-                     int seq_length, int d_head, int nnz, void *stream);
+                     int seq_length, int d_head, int nnz, int x_heads, int y_heads,
+                     void *stream);
 
 /*
  * The two halves of the transposed product, for callers that use one CSR pattern for
@@ -125,7 +144,8 @@ int spt_csr_transpose(const int32_t *indptr, const int32_t *indices,
                       void *stream);
 int spt_spmm_transposed(const void *transposed, const float *values,
                         const float *x, float *y, int batch_size,
-                        int seq_length, int d_head, int nnz, void *stream);
+                        int seq_length, int d_head, int nnz, int x_heads,
+                        int y_heads, void *stream);
 
 /*
  * softmax_forward_cuda(indptr, indices, values) -> output
@@ -145,6 +165,18 @@ int spt_softmax_backward(const int32_t *indptr, const int32_t *indices,
                          const float *output, const float *grad_output,
                          float *grad_values, int batch_size, int seq_length,
                          int nnz, void *stream);
+
+/*
+ * softmax_backward chained through the attention layer's score epilogue
+ * clamp(scale * raw, -clamp, clamp) (naive_gpt/layers/sparse/attention.py:125-127):
+ * grad_scores = (|clamped_scores| < clamp) ? scale * softmax_backward(...) : 0, i.e. the
+ * gradient wrt the RAW sddmm output, in one pass.
+ */
+int spt_softmax_backward_clamped(const int32_t *indptr, const int32_t *indices,
+                                 const float *output, const float *grad_output,
+                                 const float *clamped_scores, float scale, float clamp,
+                                 float *grad_scores, int batch_size, int seq_length,
+                                 int nnz, void *stream);
 
 /*
  * Routed FFN: token-bucketed grouped GEMM on the fp32 matrix cores.

@@ -285,3 +285,98 @@ extern "C" int spt_cdist_backward(const float *query, const float *table,
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }
+
+// ------------------------------------------------------------------ PQ encode, head layout
+//
+// The attention layers hold q / k as [N, S, H, E]; the reference first copies them to
+// [N*H, S, E], then again to the [M, NQ, D] layout of cdist, and transposes the codes
+// back (attention.py:92-95, quantizer.py:44-48,75-77).  This kernel reads the original
+// layout and writes the codes where lookup wants them ([N*H, S, M]): one lane per
+// (token, head, subspace), so a wave reads 8 whole 256-byte head vectors per
+// instruction (E = 64) and writes 8 x 32 bytes of codes.  Same bit-exact distance /
+// argmin contract as cdist_forward_kernel.
+namespace spt {
+
+template <int D>
+__global__ __launch_bounds__(CD_THREADS) void pq_encode_heads_kernel(
+    const float *__restrict__ z, const float *__restrict__ table, int32_t *__restrict__ codes,
+    int n_vectors, int S, int H, int M, int C) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *tab = reinterpret_cast<float *>(smem);  // [M][C][D]
+    for (int i = threadIdx.x; i < M * C * D; i += CD_THREADS) tab[i] = table[i];
+    __syncthreads();
+    // 32-bit index math throughout (the host guarantees n_vectors * M < 2^31): 64-bit
+    // divisions by run-time values cost ~100 instructions each on this ISA
+    const int total = n_vectors * M;
+    for (int t = blockIdx.x * CD_THREADS + threadIdx.x; t < total;
+         t += gridDim.x * CD_THREADS) {
+        const int vec = t / M;                // index into [N, S, H]
+        const int m = t - vec * M;
+        float qv[D];
+        const float4 *qp = reinterpret_cast<const float4 *>(z + (size_t)vec * (M * D) + m * D);
+#pragma unroll
+        for (int i = 0; i < D / 4; i++) {
+            const float4 v = qp[i];
+            qv[4 * i + 0] = v.x; qv[4 * i + 1] = v.y; qv[4 * i + 2] = v.z; qv[4 * i + 3] = v.w;
+        }
+        int best_i = 0;
+        float best_d = 1e13f;
+        const float *tm = tab + m * C * D;
+        for (int c = 0; c < C; c++) {
+            const float4 *tp = reinterpret_cast<const float4 *>(tm + c * D);
+            float r = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D / 4; i++) {
+                const float4 tv = tp[i];
+                r += fabsf(qv[4 * i + 0] - tv.x);
+                r += fabsf(qv[4 * i + 1] - tv.y);
+                r += fabsf(qv[4 * i + 2] - tv.z);
+                r += fabsf(qv[4 * i + 3] - tv.w);
+            }
+            const bool cond = r < best_d;
+            best_i = cond ? c : best_i;
+            best_d = cond ? r : best_d;
+        }
+        // vec = (n * S + s) * H + h  ->  code row (n * H + h) * S + s
+        const int ns = vec / H;
+        const int h = vec - ns * H;
+        const int n = ns / S;
+        const int s = ns - n * S;
+        codes[((size_t)(n * H + h) * S + s) * M + m] = best_i;
+    }
+}
+
+}  // namespace spt
+
+extern "C" int spt_pq_encode_heads(const float *z, const float *table, int32_t *codes,
+                                   int batch, int seq_length, int n_heads, int n_subspaces,
+                                   int n_codewords, int d_code, void *stream) {
+    if (!z || !table || !codes) return SPT_EINVAL;
+    if (batch <= 0 || seq_length <= 0 || n_heads <= 0 || n_subspaces <= 0 || n_codewords <= 0 ||
+        d_code <= 0)
+        return SPT_EINVAL;
+    if (d_code % 4 != 0) return SPT_ESHAPE;
+    const size_t lds = (size_t)n_subspaces * n_codewords * d_code * sizeof(float);
+    if (lds > 64 * 1024) return SPT_EUNSUP;
+    const long long n_vectors = (long long)batch * seq_length * n_heads;
+    const long long total = n_vectors * n_subspaces;
+    if (total >= 0x7FFFFFFFLL - 256 * 1024) return SPT_EUNSUP;
+    long long nblk = (total + CD_THREADS - 1) / CD_THREADS;
+    if (nblk > 256 * 8) nblk = 256 * 8;  // grid-stride: the codebook load is per block
+    hipStream_t s = (hipStream_t)stream;
+#define SPT_PQ(DD)                                                                       \
+    hipLaunchKernelGGL((spt::pq_encode_heads_kernel<DD>), dim3((unsigned)nblk),          \
+                       dim3(spt::CD_THREADS), lds, s, z, table, codes, (int)n_vectors,   \
+                       seq_length, n_heads, n_subspaces, n_codewords)
+    switch (d_code) {
+        case 4: SPT_PQ(4); break;
+        case 8: SPT_PQ(8); break;
+        case 16: SPT_PQ(16); break;
+        case 24: SPT_PQ(24); break;
+        case 32: SPT_PQ(32); break;
+        default: return SPT_EUNSUP;
+    }
+#undef SPT_PQ
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}

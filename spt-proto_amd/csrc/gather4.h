@@ -122,7 +122,8 @@ __device__ __forceinline__ void gather_rows(const int32_t *__restrict__ ptr,    
                                             const float *__restrict__ q_b,       // sddmm: [S, E]
                                             float *__restrict__ out_b,  // sddmm: [nnz]; spmm: [S,E]
                                             int g_first, int g_stride, int nrows, float scale,
-                                            float clampv) {
+                                            float clampv, int ld_q = 16 * LPE,
+                                            int ld_out = 16 * LPE) {
     constexpr int E = 16 * LPE;
     constexpr int R = 16 / LPE;
     const Lane4<LPE> L;
@@ -152,7 +153,7 @@ __device__ __forceinline__ void gather_rows(const int32_t *__restrict__ ptr,    
         for (int i = 0; i < 4; i++) {
             qr.c[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (MODE == G_SDDMM && g < ngroups && row < nrows)
-                qr.c[i] = *reinterpret_cast<const float4 *>(q_b + (size_t)row * E + L.choff[i]);
+                qr.c[i] = *reinterpret_cast<const float4 *>(q_b + (size_t)row * ld_q + L.choff[i]);
         }
         return qr;
     };
@@ -253,7 +254,7 @@ __device__ __forceinline__ void gather_rows(const int32_t *__restrict__ ptr,    
             if (L.t == 0 && row < nrows) {
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                    *reinterpret_cast<float4 *>(out_b + (size_t)row * E + L.choff[i]) = acc[i];
+                    *reinterpret_cast<float4 *>(out_b + (size_t)row * ld_out + L.choff[i]) = acc[i];
             }
         }
         seg = nseg;
@@ -332,7 +333,8 @@ template <int MODE>
 __device__ __forceinline__ void gather_rows_dynamic(
     const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx_b,
     const int32_t *__restrict__ perm_b, const float *__restrict__ val_b,
-    const float *__restrict__ tile, float *__restrict__ out_b, int *ticket, int nrows) {
+    const float *__restrict__ tile, float *__restrict__ out_b, int *ticket, int nrows,
+    int ld_out = 64) {
     constexpr int LPE = 4, E = 64, R = 4;
     const Lane4<LPE> L;
     const int ngroups = (nrows + R - 1) / R;
@@ -377,7 +379,7 @@ __device__ __forceinline__ void gather_rows_dynamic(
             if (L.t == 0 && row < nrows) {
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                    *reinterpret_cast<float4 *>(out_b + (size_t)row * E + L.choff[i]) = acc[i];
+                    *reinterpret_cast<float4 *>(out_b + (size_t)row * ld_out + L.choff[i]) = acc[i];
             }
         } else {
             // ---- wide: one row at a time, 256 entries per round -------------------
@@ -410,7 +412,7 @@ __device__ __forceinline__ void gather_rows_dynamic(
                 if (L.t == 0 && L.j == 0 && wrow < nrows) {
 #pragma unroll
                     for (int i = 0; i < 4; i++)
-                        *reinterpret_cast<float4 *>(out_b + (size_t)wrow * E + L.choff[i]) = tot[i];
+                        *reinterpret_cast<float4 *>(out_b + (size_t)wrow * ld_out + L.choff[i]) = tot[i];
                 }
             }
         }

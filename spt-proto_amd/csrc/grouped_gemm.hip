@@ -102,9 +102,10 @@ __global__ __launch_bounds__(GG_THREADS) void grouped_gemm_kernel(GroupedArgs g)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    for (int k0 = 0; k0 < g.K; k0 += GG_BK) {
-        // ---- global -> registers ----
-        float4 av[4], bv[4];
+    // ---- software pipeline: the global loads of tile t+1 are in flight while the MFMAs
+    // of tile t run; registers -> LDS happens at the top of the next iteration ----
+    float4 av[4], bv[4];
+    auto load_tile = [&](int k0) {
         const int k = k0 + 4 * s_kq;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -131,6 +132,10 @@ __global__ __launch_bounds__(GG_THREADS) void grouped_gemm_kernel(GroupedArgs g)
                     bv[u] = *reinterpret_cast<const float4 *>(wg + (size_t)kk * g.ldk + n);
             }
         }
+    };
+    load_tile(0);
+
+    for (int k0 = 0; k0 < g.K; k0 += GG_BK) {
         __syncthreads();  // previous tile fully consumed
         // ---- registers -> LDS (parity-split rows) ----
 #pragma unroll
@@ -161,6 +166,7 @@ __global__ __launch_bounds__(GG_THREADS) void grouped_gemm_kernel(GroupedArgs g)
             }
         }
         __syncthreads();
+        if (k0 + GG_BK < g.K) load_tile(k0 + GG_BK);
 
         // ---- MFMA: lane l holds A[row = l & 31][k = kk + (l >> 5)], B likewise ----
         const int frow = lane & 31, fh = lane >> 5;

@@ -148,20 +148,21 @@ template <int LPE>
 __global__ __launch_bounds__(SD_THREADS_LDS) void sddmm_g4_lds_kernel(
     const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
     const float *__restrict__ query, const float *__restrict__ key, float *__restrict__ out,
-    int S, int nnz, int splits, float scale, float clampv) {
+    int S, int nnz, int splits, float scale, float clampv, int q_heads, int k_heads) {
     constexpr int E = 16 * LPE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *ktile = reinterpret_cast<float *>(smem);  // [S][E]
     const int b = blockIdx.x / splits;
     const int part = blockIdx.x - b * splits;
     const int tid = threadIdx.x;
-    stage_tile(ktile, key + (size_t)b * S * E, (S * E) >> 2, tid, SD_THREADS_LDS);
+    const DenseView kv = dense_view(b, S, E, k_heads), qv = dense_view(b, S, E, q_heads);
+    stage_rows(ktile, key + kv.base, kv.ld, S, E, tid, SD_THREADS_LDS);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = SD_THREADS_LDS / SPT_WAVE;
     gather_rows<LPE, G_SDDMM>(indptr, indices + (size_t)b * nnz, nullptr, nullptr, ktile,
-                              query + (size_t)b * S * E, out + (size_t)b * nnz,
-                              part * NW + wave, splits * NW, S, scale, clampv);
+                              query + qv.base, out + (size_t)b * nnz, part * NW + wave,
+                              splits * NW, S, scale, clampv, qv.ld);
 }
 
 template <int LPE>
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(SD_THREADS) void sddmm_g4_global_kernel(
 template <int LPE>
 static int sddmm_g4_launch(const int32_t *indptr, const int32_t *indices, const float *query,
                            const float *key, float *out, int B, int S, int nnz, float scale,
-                           float clampv, hipStream_t s) {
+                           float clampv, int q_heads, int k_heads, hipStream_t s) {
     constexpr int E = 16 * LPE;
     const size_t kbytes = (size_t)S * E * sizeof(float);
     if (kbytes <= 128 * 1024 && (long long)B * 8 >= 256) {
@@ -196,8 +197,9 @@ static int sddmm_g4_launch(const int32_t *indptr, const int32_t *indices, const 
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kbytes));
         hipLaunchKernelGGL((sddmm_g4_lds_kernel<LPE>), dim3((unsigned)(B * splits)),
                            dim3(SD_THREADS_LDS), kbytes, s, indptr, indices, query, key, out, S,
-                           nnz, splits, scale, clampv);
+                           nnz, splits, scale, clampv, q_heads, k_heads);
     } else {
+        if (q_heads > 0 || k_heads > 0) return SPT_EUNSUP;  // head layout: LDS path only
         // one block per 64 CSR rows of a batch
         int bpb = (S + 63) / 64;
         if (bpb < 1) bpb = 1;
@@ -217,7 +219,8 @@ using namespace spt;
 extern "C" int spt_sddmm_forward(const int32_t *indptr, const int32_t *indices,
                                  const float *query, const float *key, float *out,
                                  int batch_size, int seq_length, int d_head, int nnz,
-                                 float scale, float clampv, void *stream) {
+                                 float scale, float clampv, int q_heads, int k_heads,
+                                 void *stream) {
     if (!indptr || !indices || !query || !key || !out) return SPT_EINVAL;
     if (batch_size <= 0 || seq_length <= 0 || d_head <= 0 || nnz < 0) return SPT_EINVAL;
     if (d_head % 4 != 0) return SPT_ESHAPE;
@@ -226,10 +229,15 @@ extern "C" int spt_sddmm_forward(const int32_t *indptr, const int32_t *indices,
     const int B = batch_size, S = seq_length, E = d_head;
     const int LPE = pow2_ceil(E / 4);
     hipStream_t s = (hipStream_t)stream;
+    if (q_heads < 0 || k_heads < 0) return SPT_EINVAL;
+    if ((q_heads > 0 && B % q_heads != 0) || (k_heads > 0 && B % k_heads != 0)) return SPT_ESHAPE;
     if (E == 64)
-        return sddmm_g4_launch<4>(indptr, indices, query, key, out, B, S, nnz, scale, clampv, s);
+        return sddmm_g4_launch<4>(indptr, indices, query, key, out, B, S, nnz, scale, clampv,
+                                  q_heads, k_heads, s);
     if (E == 128)
-        return sddmm_g4_launch<8>(indptr, indices, query, key, out, B, S, nnz, scale, clampv, s);
+        return sddmm_g4_launch<8>(indptr, indices, query, key, out, B, S, nnz, scale, clampv,
+                                  q_heads, k_heads, s);
+    if (q_heads > 0 || k_heads > 0) return SPT_EUNSUP;
 
     const size_t kbytes = (size_t)S * E * sizeof(float);
     const bool use_lds = kbytes <= 128 * 1024 && (long long)B * 8 >= 256 && S >= 64;

@@ -17,11 +17,16 @@ namespace spt {
 constexpr int SM_THREADS = 256;
 
 // MODE 0: forward, a = values.  MODE 1: backward, a = output (y), b = grad_output.
+// MODE 2: backward chained through the layer's clamp(scale * raw, -clampv, clampv)
+// (naive_gpt/layers/sparse/attention.py:125-127): `cin` holds the clamped scores that
+// fed the softmax; the gradient is scaled by `scale` where |cin| < clampv and zeroed
+// on the rails.  Saves four elementwise passes over the [B, nnz] tensor.
 template <int G, int MODE>
 __global__ __launch_bounds__(SM_THREADS) void softmax_kernel(
     const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
     const float *__restrict__ a, const float *__restrict__ bgrad, float *__restrict__ out,
-    int S, int nnz, long long total_rows) {
+    int S, int nnz, long long total_rows, const float *__restrict__ cin, float scale,
+    float clampv) {
     const int gl = threadIdx.x & (G - 1);
     const long long grow = ((long long)blockIdx.x * SM_THREADS + threadIdx.x) / G;
     // whole groups are in or out together, and G divides 64: reductions stay uniform
@@ -91,12 +96,21 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_kernel(
                 y.y = (ix.y <= row) ? v.y * (g.y - sum) : 0.0f;
                 y.z = (ix.z <= row) ? v.z * (g.z - sum) : 0.0f;
                 y.w = (ix.w <= row) ? v.w * (g.w - sum) : 0.0f;
+                if (MODE == 2) {
+                    const float4 c = *reinterpret_cast<const float4 *>(cin + base + p);
+                    y.x = (fabsf(c.x) < clampv) ? y.x * scale : 0.0f;
+                    y.y = (fabsf(c.y) < clampv) ? y.y * scale : 0.0f;
+                    y.z = (fabsf(c.z) < clampv) ? y.z * scale : 0.0f;
+                    y.w = (fabsf(c.w) < clampv) ? y.w * scale : 0.0f;
+                }
                 *reinterpret_cast<float4 *>(out + base + p) = y;
             }
         } else {
             for (int p = start + gl; p < end; p += G) {
                 const bool keep = indices[base + p] <= row;
-                out[base + p] = keep ? a[base + p] * (bgrad[base + p] - sum) : 0.0f;
+                float y = keep ? a[base + p] * (bgrad[base + p] - sum) : 0.0f;
+                if (MODE == 2) y = (fabsf(cin[base + p]) < clampv) ? y * scale : 0.0f;
+                out[base + p] = y;
             }
         }
     }
@@ -105,7 +119,8 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_kernel(
 template <int MODE>
 static int softmax_launch(const int32_t *indptr, const int32_t *indices, const float *a,
                           const float *bgrad, float *out, int B, int S, int nnz,
-                          hipStream_t s) {
+                          hipStream_t s, const float *cin = nullptr, float scale = 1.0f,
+                          float clampv = 0.0f) {
     const long long rows = (long long)B * S;
     // lanes per row: one float4 per lane covers the mean row, at least 4, at most 64
     int G = pow2_ceil((nnz / S + 3) / 4);
@@ -117,7 +132,7 @@ static int softmax_launch(const int32_t *indptr, const int32_t *indices, const f
     dim3 grid((unsigned)nblk);
 #define SPT_SM(GG)                                                                     \
     hipLaunchKernelGGL((softmax_kernel<GG, MODE>), grid, dim3(SM_THREADS), 0, s, indptr, \
-                       indices, a, bgrad, out, S, nnz, rows)
+                       indices, a, bgrad, out, S, nnz, rows, cin, scale, clampv)
     switch (G) {
         case 4: SPT_SM(4); break;
         case 8: SPT_SM(8); break;
@@ -153,4 +168,17 @@ extern "C" int spt_softmax_backward(const int32_t *indptr, const int32_t *indice
     if (nnz == 0) return SPT_OK;
     return softmax_launch<1>(indptr, indices, output, grad_output, grad_values, batch_size,
                              seq_length, nnz, (hipStream_t)stream);
+}
+
+extern "C" int spt_softmax_backward_clamped(const int32_t *indptr, const int32_t *indices,
+                                            const float *output, const float *grad_output,
+                                            const float *clamped_scores, float scale, float clampv,
+                                            float *grad_scores, int batch_size, int seq_length,
+                                            int nnz, void *stream) {
+    if (!indptr || !indices || !output || !grad_output || !clamped_scores || !grad_scores)
+        return SPT_EINVAL;
+    if (batch_size <= 0 || seq_length <= 0 || nnz < 0 || !(clampv > 0.0f)) return SPT_EINVAL;
+    if (nnz == 0) return SPT_OK;
+    return softmax_launch<2>(indptr, indices, output, grad_output, grad_scores, batch_size,
+                             seq_length, nnz, (hipStream_t)stream, clamped_scores, scale, clampv);
 }

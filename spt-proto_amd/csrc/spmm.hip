@@ -127,21 +127,23 @@ template <int LPE, int MODE>
 __global__ __launch_bounds__(SP_THREADS_LDS) void spmm_g4_lds_kernel(
     const int32_t *__restrict__ ptr, int ptr_stride, const int32_t *__restrict__ indices,
     const int32_t *__restrict__ perm, const float *__restrict__ values,
-    const float *__restrict__ x, float *__restrict__ y, int S, int nnz, int splits) {
+    const float *__restrict__ x, float *__restrict__ y, int S, int nnz, int splits,
+    int x_heads, int y_heads) {
     constexpr int E = 16 * LPE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *xtile = reinterpret_cast<float *>(smem);  // [S][E]
     const int b = blockIdx.x / splits;
     const int part = blockIdx.x - b * splits;
     const int tid = threadIdx.x;
-    stage_tile(xtile, x + (size_t)b * S * E, (S * E) >> 2, tid, SP_THREADS_LDS);
+    const DenseView xv = dense_view(b, S, E, x_heads), yv = dense_view(b, S, E, y_heads);
+    stage_rows(xtile, x + xv.base, xv.ld, S, E, tid, SP_THREADS_LDS);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = SP_THREADS_LDS / SPT_WAVE;
     gather_rows<LPE, MODE>(ptr + (size_t)b * ptr_stride, indices + (size_t)b * nnz,
                            MODE == G_SPMM_PERM ? perm + (size_t)b * nnz : nullptr,
-                           values + (size_t)b * nnz, xtile, nullptr, y + (size_t)b * S * E,
-                           part * NW + wave, splits * NW, S, 1.0f, 0.0f);
+                           values + (size_t)b * nnz, xtile, nullptr, y + yv.base,
+                           part * NW + wave, splits * NW, S, 1.0f, 0.0f, E, yv.ld);
 }
 
 // transposed product, E = 64, one workgroup per batch: dynamic, wide-row aware
@@ -149,7 +151,8 @@ __global__ __launch_bounds__(SP_THREADS_LDS) void spmm_g4_lds_kernel(
 __global__ __launch_bounds__(SP_THREADS_LDS) void spmm_t64_lds_kernel(
     const int32_t *__restrict__ t_ptr, const int32_t *__restrict__ t_row,
     const int32_t *__restrict__ t_perm, const float *__restrict__ values,
-    const float *__restrict__ x, float *__restrict__ y, int S, int nnz) {
+    const float *__restrict__ x, float *__restrict__ y, int S, int nnz, int x_heads,
+    int y_heads) {
     constexpr int E = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *xtile = reinterpret_cast<float *>(smem);  // [S][E]
@@ -157,11 +160,12 @@ __global__ __launch_bounds__(SP_THREADS_LDS) void spmm_t64_lds_kernel(
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     if (tid == 0) *ticket = 0;
-    stage_tile(xtile, x + (size_t)b * S * E, (S * E) >> 2, tid, SP_THREADS_LDS);
+    const DenseView xv = dense_view(b, S, E, x_heads), yv = dense_view(b, S, E, y_heads);
+    stage_rows(xtile, x + xv.base, xv.ld, S, E, tid, SP_THREADS_LDS);
     __syncthreads();
     gather_rows_dynamic<G_SPMM_PERM>(t_ptr + (size_t)b * (S + 1), t_row + (size_t)b * nnz,
                                      t_perm + (size_t)b * nnz, values + (size_t)b * nnz, xtile,
-                                     y + (size_t)b * S * E, ticket, S);
+                                     y + yv.base, ticket, S, yv.ld);
 }
 
 template <int LPE, int MODE>
@@ -549,8 +553,11 @@ static int launch_transpose(const int32_t *indptr, const int32_t *indices, Trans
 template <bool PERM>
 static int launch_gather(const int32_t *ptr, int ptr_stride, const int32_t *indices,
                          const int32_t *perm, const float *values, const float *x, float *y,
-                         int B, int S, int E, int nnz, hipStream_t s) {
+                         int B, int S, int E, int nnz, int x_heads, int y_heads, hipStream_t s) {
     constexpr int MODE = PERM ? G_SPMM_PERM : G_SPMM;
+    if (x_heads < 0 || y_heads < 0) return SPT_EINVAL;
+    if ((x_heads > 0 && B % x_heads != 0) || (y_heads > 0 && B % y_heads != 0)) return SPT_ESHAPE;
+    const bool strided = x_heads > 0 || y_heads > 0;
     const size_t tile_bytes = (size_t)S * E * sizeof(float);
     if (PERM && E == 64 && tile_bytes <= 128 * 1024 && B >= 128) {
         const size_t lds_bytes = tile_bytes + 16;
@@ -558,9 +565,10 @@ static int launch_gather(const int32_t *ptr, int ptr_stride, const int32_t *indi
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_bytes));
         hipLaunchKernelGGL(spmm_t64_lds_kernel, dim3((unsigned)B), dim3(SP_THREADS_LDS), lds_bytes,
-                           s, ptr, indices, perm, values, x, y, S, nnz);
+                           s, ptr, indices, perm, values, x, y, S, nnz, x_heads, y_heads);
     } else if (E == 64 || E == 128) {
         const bool lds = tile_bytes <= 128 * 1024 && B >= 32;
+        if (strided && !lds) return SPT_EUNSUP;  // head layout: LDS-resident path only
         int splits = 1;
         while ((long long)B * splits < 256 && splits < 8) splits <<= 1;
         const int bpb = (S + 63) / 64;
@@ -572,7 +580,7 @@ static int launch_gather(const int32_t *ptr, int ptr_stride, const int32_t *indi
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));                 \
             hipLaunchKernelGGL((spmm_g4_lds_kernel<L, MODE>), dim3((unsigned)(B * splits)),    \
                                dim3(SP_THREADS_LDS), tile_bytes, s, ptr, ptr_stride, indices,  \
-                               perm, values, x, y, S, nnz, splits);                            \
+                               perm, values, x, y, S, nnz, splits, x_heads, y_heads);          \
         } else {                                                                               \
             hipLaunchKernelGGL((spmm_g4_global_kernel<L, MODE>), dim3((unsigned)(B * bpb)),    \
                                dim3(SP_THREADS), 0, s, ptr, ptr_stride, indices, perm, values, \
@@ -583,6 +591,7 @@ static int launch_gather(const int32_t *ptr, int ptr_stride, const int32_t *indi
         else SPT_G4(8);
 #undef SPT_G4
     } else {
+        if (strided) return SPT_EUNSUP;
         const int LPE = pow2_ceil(E / 4);
         const int rows_per_block = 16;
         const int tiles = (S + rows_per_block - 1) / rows_per_block;
@@ -636,14 +645,15 @@ extern "C" int spt_csr_transpose(const int32_t *indptr, const int32_t *indices, 
 
 extern "C" int spt_spmm_transposed(const void *transposed, const float *values, const float *x,
                                    float *y, int batch_size, int seq_length, int d_head, int nnz,
-                                   void *stream) {
+                                   int x_heads, int y_heads, void *stream) {
     const int rc =
         check_spmm_args(transposed, values, x, y, y, batch_size, seq_length, d_head, nnz);
     if (rc != SPT_OK) return rc;
     if (nnz == 0) return SPT_EINVAL;
     const TransposedCsr t = carve(const_cast<void *>(transposed), batch_size, seq_length, nnz);
     return launch_gather<true>(t.t_ptr, seq_length + 1, t.t_row, t.t_perm, values, x, y,
-                               batch_size, seq_length, d_head, nnz, (hipStream_t)stream);
+                               batch_size, seq_length, d_head, nnz, x_heads, y_heads,
+                               (hipStream_t)stream);
 }
 
 extern "C" int64_t spt_spmm_workspace_bytes(int trans_lhs, int batch_size, int seq_length,
@@ -654,7 +664,7 @@ extern "C" int64_t spt_spmm_workspace_bytes(int trans_lhs, int batch_size, int s
 extern "C" int spt_spmm_forward(int trans_lhs, const int32_t *indptr, const int32_t *indices,
                                 const float *values, const float *x, float *y, void *workspace,
                                 int batch_size, int seq_length, int d_head, int nnz,
-                                void *stream) {
+                                int x_heads, int y_heads, void *stream) {
     const int rc =
         check_spmm_args(indptr, indices, values, x, y, batch_size, seq_length, d_head, nnz);
     if (rc != SPT_OK) return rc;
@@ -665,10 +675,12 @@ extern "C" int spt_spmm_forward(int trans_lhs, const int32_t *indptr, const int3
         return SPT_OK;
     }
     if (!trans_lhs)
-        return launch_gather<false>(indptr, 0, indices, nullptr, values, x, y, B, S, E, nnz, s);
+        return launch_gather<false>(indptr, 0, indices, nullptr, values, x, y, B, S, E, nnz,
+                                    x_heads, y_heads, s);
     if (!workspace) return SPT_EINVAL;
     const TransposedCsr t = carve(workspace, B, S, nnz);
     const int rc2 = launch_transpose(indptr, indices, t, B, S, nnz, s);
     if (rc2 != SPT_OK) return rc2;
-    return launch_gather<true>(t.t_ptr, S + 1, t.t_row, t.t_perm, values, x, y, B, S, E, nnz, s);
+    return launch_gather<true>(t.t_ptr, S + 1, t.t_row, t.t_perm, values, x, y, B, S, E, nnz,
+                               x_heads, y_heads, s);
 }

@@ -100,6 +100,50 @@ __device__ __forceinline__ void stage_tile(float *__restrict__ lds_dst,
     for (; i < n4; i += nthreads) d4[i] = s4[i];
 }
 
+// Dense per-batch operands are either [B, S, E] (heads == 0) or live inside an
+// [N, S, heads, E] tensor with batch b = n * heads + h (the attention layers' layout):
+// row r of batch b starts at  base + r * ld.
+struct DenseView {
+    size_t base;
+    int ld;
+};
+__device__ __forceinline__ DenseView dense_view(int b, int S, int E, int heads) {
+    DenseView v;
+    if (heads > 0) {
+        const int n = b / heads, h = b - n * heads;
+        v.base = ((size_t)n * S * heads + h) * E;
+        v.ld = heads * E;
+    } else {
+        v.base = (size_t)b * S * E;
+        v.ld = E;
+    }
+    return v;
+}
+
+// Copy S rows of E floats (row stride ld) into a packed [S][E] LDS tile; four independent
+// 16-byte loads per thread in flight.
+__device__ __forceinline__ void stage_rows(float *__restrict__ lds_dst,
+                                           const float *__restrict__ src, int ld, int S, int E,
+                                           int tid, int nthreads) {
+    const int e4 = E >> 2;
+    const int n4 = S * e4;
+    float4 *d4 = reinterpret_cast<float4 *>(lds_dst);
+    auto ld4 = [&](int i) {
+        const int r = i / e4, c = i - r * e4;
+        return *reinterpret_cast<const float4 *>(src + (size_t)r * ld + 4 * c);
+    };
+    int i = tid;
+    for (; i + 3 * nthreads < n4; i += 4 * nthreads) {
+        const float4 a = ld4(i), b = ld4(i + nthreads), c = ld4(i + 2 * nthreads),
+                     d = ld4(i + 3 * nthreads);
+        d4[i] = a;
+        d4[i + nthreads] = b;
+        d4[i + 2 * nthreads] = c;
+        d4[i + 3 * nthreads] = d;
+    }
+    for (; i < n4; i += nthreads) d4[i] = ld4(i);
+}
+
 __host__ __device__ __forceinline__ int pow2_ceil(int v) {
     int p = 1;
     while (p < v) p <<= 1;

@@ -30,20 +30,23 @@ _PROTOTYPES = {
     'spt_cdist_backward_workspace_bytes': ([_c_int] * 4, ctypes.c_int64),
     'spt_cdist_backward': ([_c_ptr] * 6 + [_c_int] * 4 + [_c_ptr], _c_int),
     'spt_lookup_forward': ([_c_ptr] * 3 + [_c_int] * 4 + [_c_ptr], _c_int),
+    'spt_pq_encode_heads': ([_c_ptr] * 3 + [_c_int] * 6 + [_c_ptr], _c_int),
     'spt_sddmm_forward': (
-        [_c_ptr] * 5 + [_c_int] * 4 + [_c_f32, _c_f32, _c_ptr], _c_int
+        [_c_ptr] * 5 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int
     ),
     'spt_spmm_workspace_bytes': ([_c_int] * 4, ctypes.c_int64),
-    'spt_spmm_forward': ([_c_int] + [_c_ptr] * 6 + [_c_int] * 4 + [_c_ptr], _c_int),
+    'spt_spmm_forward': ([_c_int] + [_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr], _c_int),
     'spt_csr_transpose_workspace_bytes': ([_c_int] * 3, ctypes.c_int64),
     'spt_csr_transpose': ([_c_ptr] * 3 + [_c_int] * 3 + [_c_ptr], _c_int),
-    'spt_spmm_transposed': ([_c_ptr] * 4 + [_c_int] * 4 + [_c_ptr], _c_int),
+    'spt_spmm_transposed': ([_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr], _c_int),
     'spt_grouped_gemm': ([_c_ptr] * 7 + [_c_int] * 5 + [ctypes.c_longlong, _c_int, _c_int, _c_ptr],
                          _c_int),
     'spt_softmax_forward': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_backward': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
+                                     _c_int),
 }
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -233,23 +236,57 @@ def _check_csr(indptr, indices):
     _check_type(indices, torch.int32, 'indices')
 
 
+def _dense_dims(t: torch.Tensor, heads: int, name: str):
+    """(B, S, E) of a dense operand given as [B, S, E] (heads == 0) or [N, S, heads, E]."""
+    if heads > 0:
+        _check_dim(t, 4, name)
+        _require(t.size(2) == heads, '{}.size(2) must equal heads'.format(name))
+        return t.size(0) * heads, t.size(1), t.size(3)
+    _check_dim(t, 3, name)
+    return t.size(0), t.size(1), t.size(2)
+
+
+def head_layout_supported(S: int, E: int, B: int) -> bool:
+    """Shapes for which the kernels read / write the [N, S, H, E] layout directly."""
+    return E in (64, 128) and S * E * 4 <= 128 * 1024 and B >= 32
+
+
+def pq_encode_heads(z: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    """z [N, S, H, E] fp32 -> PQ codes [N * H, S, M] int32 (``spt_pq_encode_heads``)."""
+    _check_dim(z, 4, 'z')
+    _check_dim(table, 3, 'table')
+    _check_type(z, torch.float32, 'z')
+    _check_type(table, torch.float32, 'table')
+    dev = _same_device(z, table)
+    N, S, H, E = z.shape
+    M, C, D = table.shape
+    _require(E == M * D, 'z.size(-1) == n_subspaces * d_codeword')
+    lib = load_library()
+    with torch.cuda.device(dev):
+        codes = torch.empty([N * H, S, M], dtype=torch.int32, device=dev)
+        rc = lib.spt_pq_encode_heads(z.data_ptr(), table.data_ptr(), codes.data_ptr(),
+                                     N, S, H, M, C, D, _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'pq_encode_heads')
+    return codes
+
+
 def sddmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,
                        indices: torch.Tensor, query: torch.Tensor,
                        key: torch.Tensor, scale: float = 1.0,
-                       clamp: float = 0.0) -> torch.Tensor:
+                       clamp: float = 0.0, query_heads: int = 0,
+                       key_heads: int = 0) -> torch.Tensor:
     """extension/sddmm.cpp:3-73.  ``scale``/``clamp`` (extension of the reference
     signature, defaults = plain operator) fold attention.py:125-127 into the store."""
-    _check_dim(key, 3, 'key')
-    _check_dim(query, 3, 'query')
+    B, S, E = _dense_dims(query, query_heads, 'query')
+    _require((B, S, E) == _dense_dims(key, key_heads, 'key'), 'query.sizes() == key.sizes()')
     _check_csr(indptr, indices)
     _check_type(query, torch.float32, 'query')
-    _require(query.shape == key.shape, 'query.sizes() == key.sizes()')
-    _require(query.size(0) == indices.size(0), 'query.size(0) == indices.size(0)')
+    _require(B == indices.size(0), 'query.size(0) == indices.size(0)')
     _require(query.dtype == key.dtype, 'query.scalar_type() == key.scalar_type()')
     _require(not _flag(trans_lhs) and _flag(trans_rhs),
              'sddmm: only (trans_lhs=False, trans_rhs=True) is implemented')
     dev = _same_device(indptr, indices, query, key)
-    B, S, E = query.shape
     nnz = indices.size(-1)
     _require(indptr.size(-1) == S + 1, 'indptr.size(-1) == seq_length + 1')
     lib = load_library()
@@ -258,23 +295,29 @@ def sddmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,
         rc = lib.spt_sddmm_forward(
             indptr.data_ptr(), indices.data_ptr(), query.data_ptr(),
             key.data_ptr(), output.data_ptr(), B, S, E, nnz,
-            float(scale), float(clamp), _stream(dev)
+            float(scale), float(clamp), int(query_heads), int(key_heads), _stream(dev)
         )
     if rc != 0:
         _raise(lib, rc, 'sddmm_forward_cuda')
     return output
 
 
-def _check_spmm(indptr, indices, values, x):
-    _check_dim(x, 3, 'x')
+def _check_spmm(indptr, indices, values, x, x_heads=0):
+    B, S, E = _dense_dims(x, x_heads, 'x')
     _check_csr(indptr, indices)
     _check_dim(values, 2, 'values')
     _check_type(values, torch.float32, 'values')
     _check_type(x, torch.float32, 'x')
     _require(indices.shape == values.shape, 'indices.sizes() == values.sizes()')
-    _require(x.size(0) == indices.size(0), 'x.size(0) == indices.size(0)')
-    _require(indptr.size(-1) == x.size(1) + 1, 'indptr.size(-1) == seq_length + 1')
-    return _same_device(indptr, indices, values, x)
+    _require(B == indices.size(0), 'x.size(0) == indices.size(0)')
+    _require(indptr.size(-1) == S + 1, 'indptr.size(-1) == seq_length + 1')
+    return _same_device(indptr, indices, values, x), B, S, E
+
+
+def _alloc_dense(B, S, E, heads, dev):
+    if heads > 0:
+        return torch.empty([B // heads, S, heads, E], dtype=torch.float32, device=dev)
+    return torch.empty([B, S, E], dtype=torch.float32, device=dev)
 
 
 def csr_transpose(indptr: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
@@ -313,20 +356,19 @@ def transposed_for(indptr: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
 
 def spmm_transposed(transposed: torch.Tensor, indptr: torch.Tensor,
                     indices: torch.Tensor, values: torch.Tensor,
-                    x: torch.Tensor) -> torch.Tensor:
+                    x: torch.Tensor, x_heads: int = 0, y_heads: int = 0) -> torch.Tensor:
     """y = A^T . x with a structure from ``csr_transpose`` (same result as
     ``spmm_forward_cuda(True, False, ...)``)."""
-    dev = _check_spmm(indptr, indices, values, x)
-    B, S, E = x.shape
+    dev, B, S, E = _check_spmm(indptr, indices, values, x, x_heads)
     nnz = indices.size(-1)
     lib = load_library()
     with torch.cuda.device(dev):
+        output = _alloc_dense(B, S, E, y_heads, dev)
         if nnz == 0:
-            return torch.zeros_like(x)
-        output = torch.empty_like(x)
+            return output.zero_()
         rc = lib.spt_spmm_transposed(transposed.data_ptr(), values.data_ptr(),
                                      x.data_ptr(), output.data_ptr(), B, S, E, nnz,
-                                     _stream(dev))
+                                     int(x_heads), int(y_heads), _stream(dev))
     if rc != 0:
         _raise(lib, rc, 'spmm_transposed')
     return output
@@ -334,18 +376,17 @@ def spmm_transposed(transposed: torch.Tensor, indptr: torch.Tensor,
 
 def spmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,
                       indices: torch.Tensor, values: torch.Tensor,
-                      x: torch.Tensor) -> torch.Tensor:
+                      x: torch.Tensor, x_heads: int = 0, y_heads: int = 0) -> torch.Tensor:
     """extension/spmm.cpp:3-72; ``trans_lhs`` selects A.x (False) or A^T.x (True)."""
-    dev = _check_spmm(indptr, indices, values, x)
+    dev, B, S, E = _check_spmm(indptr, indices, values, x, x_heads)
     _require(not _flag(trans_rhs), 'spmm: trans_rhs=True is not implemented')
     trans = int(_flag(trans_lhs))
-    B, S, E = x.shape
     nnz = indices.size(-1)
     lib = load_library()
     with torch.cuda.device(dev):
+        output = _alloc_dense(B, S, E, y_heads, dev)
         if nnz == 0:
-            return torch.zeros_like(x)
-        output = torch.empty_like(x)
+            return output.zero_()
         workspace = None
         if trans:
             nbytes = lib.spt_spmm_workspace_bytes(trans, B, S, nnz)
@@ -354,7 +395,7 @@ def spmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,
             trans, indptr.data_ptr(), indices.data_ptr(), values.data_ptr(),
             x.data_ptr(), output.data_ptr(),
             workspace.data_ptr() if workspace is not None else None,
-            B, S, E, nnz, _stream(dev)
+            B, S, E, nnz, int(x_heads), int(y_heads), _stream(dev)
         )
     if rc != 0:
         _raise(lib, rc, 'spmm_forward_cuda')
@@ -449,3 +490,30 @@ def grouped_gemm(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Tensor,
     if rc != 0:
         _raise(lib, rc, 'grouped_gemm')
     return out
+
+
+def softmax_backward_clamped(indptr: torch.Tensor, indices: torch.Tensor,
+                             output: torch.Tensor, grad_output: torch.Tensor,
+                             clamped_scores: torch.Tensor, scale: float,
+                             clamp: float) -> torch.Tensor:
+    """softmax backward chained through ``clamp(scale * raw, -clamp, clamp)``: returns the
+    gradient wrt the raw sddmm output (``spt_softmax_backward_clamped``)."""
+    _check_csr(indptr, indices)
+    for t, name in ((output, 'output'), (grad_output, 'grad_output'),
+                    (clamped_scores, 'clamped_scores')):
+        _check_dim(t, 2, name)
+        _check_type(t, torch.float32, name)
+        _require(t.shape == indices.shape, 'indices.sizes() == {}.sizes()'.format(name))
+    dev = _same_device(indptr, indices, output, grad_output, clamped_scores)
+    B, nnz = indices.shape
+    S = indptr.size(-1) - 1
+    lib = load_library()
+    with torch.cuda.device(dev):
+        grad = torch.empty_like(output)
+        rc = lib.spt_softmax_backward_clamped(
+            indptr.data_ptr(), indices.data_ptr(), output.data_ptr(),
+            grad_output.data_ptr(), clamped_scores.data_ptr(), float(scale), float(clamp),
+            grad.data_ptr(), B, S, nnz, _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'softmax_backward_clamped')
+    return grad

@@ -11,7 +11,13 @@ Differences from the reference's orchestration, none of them observable:
   (``spt_sddmm_forward(scale, clamp)``); its gradient mask is applied in the
   backward of the same autograd node;
 * the uniform ``indptr`` (``arange * S/8``) is cached per (S, device);
-* PQ 'encode' does not materialise the distance tensor.
+* PQ 'encode' does not materialise the distance tensor;
+* on the MI355X fast path (d_head 64 / 128, S * d_head * 4 <= 128 KiB, fp32 CUDA) the
+  kernels read q, k, v and write their gradients in the layers' own ``[N, S, H, E]``
+  layout (``*_heads`` arguments of the C ABI), so the reference's seven
+  ``transpose(1, 2).contiguous()`` copies per call shrink to the one that produces the
+  reference's output layout, and sddmm -> clamp -> softmax is one autograd node whose
+  backward is a single fused kernel.
 """
 import torch
 
@@ -52,6 +58,61 @@ class _ScaledClampedSDDMM(torch.autograd.Function):
         return None, None, grad_query, grad_key, None
 
 
+class _HeadScores(torch.autograd.Function):
+    """attn = softmax(clamp(scale * sddmm(q, k))) with q, k in [N, S, H, E] layout.
+    One autograd node: the backward is spt_softmax_backward_clamped (softmax VJP chained
+    through the clamp and the scale) followed by the two gather products."""
+
+    @staticmethod
+    def forward(ctx, indptr, indices, q, k, scale: float, heads: int):
+        scores = ext.sddmm_forward_cuda(False, True, indptr, indices, q, k, scale=scale,
+                                        clamp=CLAMP, query_heads=heads, key_heads=heads)
+        attn = ext.softmax_forward_cuda(indptr, indices, scores)
+        ctx.scale, ctx.heads = scale, heads
+        ctx.save_for_backward(indptr, indices, q, k, scores, attn)
+        return attn
+
+    @staticmethod
+    def backward(ctx, grad_attn: torch.Tensor):
+        indptr, indices, q, k, scores, attn = ctx.saved_tensors
+        h = ctx.heads
+        grad_raw = ext.softmax_backward_clamped(indptr, indices, attn, grad_attn.contiguous(),
+                                                scores, ctx.scale, CLAMP)
+        grad_q = grad_k = None
+        if ctx.needs_input_grad[2]:
+            grad_q = ext.spmm_forward_cuda(False, False, indptr, indices, grad_raw, k,
+                                           x_heads=h, y_heads=h)
+        if ctx.needs_input_grad[3]:
+            grad_k = ext.spmm_transposed(ext.transposed_for(indptr, indices), indptr, indices,
+                                         grad_raw, q, x_heads=h, y_heads=h)
+        return None, None, grad_q, grad_k, None, None
+
+
+class _HeadSPMM(torch.autograd.Function):
+    """y [N*H, S, E] = A . v with v in [N, S, H, E] layout; grad_v comes back in that layout."""
+
+    @staticmethod
+    def forward(ctx, indptr, indices, values, v, heads: int):
+        ctx.heads = heads
+        ctx.save_for_backward(indptr, indices, values, v)
+        return ext.spmm_forward_cuda(False, False, indptr, indices, values, v,
+                                     x_heads=heads, y_heads=0)
+
+    @staticmethod
+    def backward(ctx, grad_y: torch.Tensor):
+        indptr, indices, values, v = ctx.saved_tensors
+        h = ctx.heads
+        grad_y = grad_y.contiguous()
+        grad_values = grad_v = None
+        if ctx.needs_input_grad[2]:
+            grad_values = ext.sddmm_forward_cuda(False, True, indptr, indices, grad_y, v,
+                                                 query_heads=0, key_heads=h)
+        if ctx.needs_input_grad[3]:
+            grad_v = ext.spmm_transposed(ext.transposed_for(indptr, indices), indptr, indices,
+                                         values, grad_y, x_heads=0, y_heads=h)
+        return None, None, grad_values, grad_v, None
+
+
 class _SparseCore:
     """Mixin with the CSR attention shared by the Vanilla and Rotary V2 layers."""
 
@@ -77,9 +138,36 @@ class _SparseCore:
             loss_k = self.quantizer('train', z=k)[-1]
             self.register_buffer('loss', loss_q + loss_k, persistent=False)
 
+    @staticmethod
+    def _head_layout_ok(t: torch.Tensor) -> bool:
+        n, s, h, e = t.shape
+        return (t.is_cuda and t.dtype == torch.float32
+                and ext.head_layout_supported(s, e, n * h))
+
+    def _sparse_attn_heads(self, q: torch.Tensor, k: torch.Tensor):
+        """MI355X fast path: no layout copies (see module docstring)."""
+        seq_length, heads = q.size(1), q.size(2)
+        q, k = q.contiguous(), k.contiguous()
+        if self.trigger.is_nonzero():
+            # the PQ loss is a mean over all sub-vectors: the head layout holds the same set
+            self.trigger.logical_not_()
+            loss_q = self.quantizer('train', z=q)[-1]
+            loss_k = self.quantizer('train', z=k)[-1]
+            self.register_buffer('loss', loss_q + loss_k, persistent=False)
+        table = self.quantizer.weight.detach()
+        q_c = ext.pq_encode_heads(q.detach(), table)
+        k_c = ext.pq_encode_heads(k.detach(), table)
+        topk_indices = kernels.lookup(q_c, k_c, sparse_coeff=SPARSE_COEFF)
+        csr_indices = topk_indices.flatten(start_dim=1)
+        indptr = self._uniform_indptr(seq_length, q.device)
+        values = _HeadScores.apply(indptr, csr_indices, q, k, self.scaling, heads)
+        return indptr, csr_indices, values, heads
+
     def _sparse_attn(self, q: torch.Tensor, k: torch.Tensor):
         # q, k: [N, S, H, E] -> [N*H, S, E]
         assert q.size() == k.size()
+        if self._head_layout_ok(q) and self.quantizer.method == 'v2':
+            return self._sparse_attn_heads(q, k)
         seq_length = q.size(1)
         q = q.transpose(1, 2).contiguous()
         k = k.transpose(1, 2).contiguous()
@@ -100,6 +188,11 @@ class _SparseCore:
 
     def _sparse_apply(self, attn, v: torch.Tensor):
         v_size = v.size()
+        if len(attn) == 4:
+            indptr, indices, values, heads = attn
+            y = _HeadSPMM.apply(indptr, indices, values, v.contiguous(), heads)
+            # REFERENCE QUIRK, see below
+            return y.transpose(1, 2).contiguous().view(v_size)
         indptr, indices, values = attn
         v = v.transpose(1, 2).contiguous()
         v = v.view([-1, v.size(-2), v.size(-1)])

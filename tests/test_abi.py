@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), name
     lib.spt_abi_version.restype = ctypes.c_int
-    assert lib.spt_abi_version() == 3
+    assert lib.spt_abi_version() == 4
     lib.spt_strerror.restype = ctypes.c_char_p
     lib.spt_strerror.argtypes = [ctypes.c_int]
     assert lib.spt_strerror(0) == b'ok'
@@ -51,7 +51,7 @@ def test_precondition_codes_without_gpu():
     lib = ext.load_library()
     # null pointers -> SPT_EINVAL, checked before anything touches the device
     assert lib.spt_sddmm_forward(None, None, None, None, None, 1, 16, 16, 32,
-                                 1.0, 0.0, None) == -1
+                                 1.0, 0.0, 0, 0, None) == -1
     assert lib.spt_lookup_forward(None, None, None, 1, 16, 8, 8, None) == -1
     assert lib.spt_cdist_backward_workspace_bytes(8, 1024, 16, 8) > 0
 

@@ -36,7 +36,7 @@ def close(got: torch.Tensor, want: np.ndarray, rtol=RTOL, atol=ATOL):
 def test_library_is_the_native_one():
     from naive_gpt import ext
     lib = ext.load_library()
-    assert lib.spt_abi_version() == 3
+    assert lib.spt_abi_version() == 4
     assert torch.cuda.is_available()
     assert 'gfx950' in torch.cuda.get_device_properties(0).gcnArchName
 
@@ -326,3 +326,112 @@ def test_kernels_autograd_matches_dense_reference_formulas():
     assert torch.allclose(gx1, x.grad, atol=1e-3)
     with pytest.raises(NotImplementedError):
         kernels.lookup.__globals__['Lookup'].backward(None, None)
+
+
+# ------------------------------------------------------------------ head layout ([N,S,H,E])
+
+def test_pq_encode_heads_equals_reference_layout_chain():
+    from naive_gpt import ext
+    rng = np.random.default_rng(31)
+    N, S, H, E, M, C, D = 3, 128, 4, 64, 8, 16, 8
+    z = rng.standard_normal([N, S, H, E]).astype(np.float32)
+    table = rng.standard_normal([M, C, D]).astype(np.float32)
+    # reference chain: [N,S,H,E] -> [N*H,S,E] -> [M,NQ,D] -> argmin -> [N*H,S,M]
+    zb = np.ascontiguousarray(z.transpose(0, 2, 1, 3)).reshape(N * H * S, M, D)
+    want = O.cdist_forward(np.ascontiguousarray(zb.transpose(1, 0, 2)), table, False)[1]
+    want = np.ascontiguousarray(want.T).reshape(N * H, S, M)
+    got = ext.pq_encode_heads(dev(z), dev(table))
+    assert got.dtype == torch.int32 and np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('N,S,H,E', [(8, 256, 4, 64), (16, 512, 16, 64), (4, 128, 8, 128)])
+def test_head_layout_operands_equal_contiguous_ones(N, S, H, E):
+    from naive_gpt import ext
+    rng = np.random.default_rng(N + S + H)
+    B, Z = N * H, S // 8
+    indptr, idx = uniform_csr(rng, 2, S, Z, True)
+    idx = np.ascontiguousarray(np.tile(idx, [B // 2, 1]))
+    d_indptr, d_idx = dev(indptr), dev(idx)
+    q4 = torch.randn([N, S, H, E], device='cuda')
+    k4 = torch.randn([N, S, H, E], device='cuda')
+    vals = torch.randn([B, S * Z], device='cuda')
+
+    def flat(t):
+        return t.transpose(1, 2).contiguous().view(B, S, E)
+
+    def heads(t):                        # [B,S,E] -> [N,S,H,E]
+        return t.view(N, H, S, E).transpose(1, 2).contiguous()
+
+    a = ext.sddmm_forward_cuda(False, True, d_indptr, d_idx, q4, k4, query_heads=H, key_heads=H)
+    b = ext.sddmm_forward_cuda(False, True, d_indptr, d_idx, flat(q4), flat(k4))
+    assert torch.equal(a, b)
+    c = ext.sddmm_forward_cuda(False, True, d_indptr, d_idx, flat(q4), k4, key_heads=H)
+    assert torch.equal(c, b)
+    y1 = ext.spmm_forward_cuda(False, False, d_indptr, d_idx, vals, k4, x_heads=H, y_heads=H)
+    y0 = ext.spmm_forward_cuda(False, False, d_indptr, d_idx, vals, flat(k4))
+    assert y1.shape == (N, S, H, E) and torch.equal(y1, heads(y0))
+    y2 = ext.spmm_forward_cuda(False, False, d_indptr, d_idx, vals, k4, x_heads=H, y_heads=0)
+    assert torch.equal(y2, y0)
+    t = ext.transposed_for(d_indptr, d_idx)
+    t1 = ext.spmm_transposed(t, d_indptr, d_idx, vals, k4, x_heads=H, y_heads=H)
+    t0 = ext.spmm_transposed(t, d_indptr, d_idx, vals, flat(k4))
+    assert torch.allclose(t1, heads(t0), rtol=1e-5, atol=1e-4)
+    t2 = ext.spmm_transposed(t, d_indptr, d_idx, vals, flat(k4), x_heads=0, y_heads=H)
+    assert torch.allclose(t2, heads(t0), rtol=1e-5, atol=1e-4)
+
+
+def test_softmax_backward_clamped_is_the_chained_gradient():
+    from naive_gpt import ext
+    rng = np.random.default_rng(77)
+    B, S, Z = 8, 256, 32
+    indptr, idx = uniform_csr(rng, 2, S, Z, True)
+    idx = np.ascontiguousarray(np.tile(idx, [B // 2, 1]))
+    raw = rng.uniform(-14, 14, [B, S * Z]).astype(np.float32)
+    scale, clamp = 0.7, 10.0
+    scores = np.clip(raw * np.float32(scale), -clamp, clamp).astype(np.float32)
+    y = O.softmax_forward(indptr, idx, scores)
+    dy = rng.standard_normal([B, S * Z]).astype(np.float32)
+    want = O.softmax_backward(indptr, idx, y, dy)
+    want = np.where(np.abs(scores) < clamp, want * np.float32(scale), 0).astype(np.float32)
+    got = ext.softmax_backward_clamped(dev(indptr), dev(idx), dev(y), dev(dy), dev(scores),
+                                       scale, clamp)
+    close(got, want, atol=1e-6)
+
+
+def test_layer_head_layout_path_equals_copying_path():
+    """SparseVanillaAttentionV2 on a shape that takes the [N,S,H,E] fast path, against the
+    same layer forced through the reference-style transposing path."""
+    from naive_gpt import ext, layers
+    torch.manual_seed(4)
+    N, S, H, E = 8, 256, 4, 64
+    attn = layers.SparseVanillaAttentionV2(d_head=E, d_codeword=8, n_codewords=16,
+                                           p_dropout=0.0).cuda()
+    q, k, v = [torch.randn([N, S, H, E], device='cuda', requires_grad=True) for _ in range(3)]
+    w = torch.randn([N, S, H, E], device='cuda')
+
+    def run(trigger):
+        for t in (q, k, v):
+            t.grad = None
+        attn.zero_grad()
+        if trigger:
+            attn.trigger.fill_(True)
+        y = attn(q, k, v, attn_mask=None)
+        loss = (y * w).sum()
+        if trigger:
+            loss = loss + 1e-2 * attn.loss
+        loss.backward()
+        return [y.detach().clone(), q.grad.clone(), k.grad.clone(), v.grad.clone(),
+                attn.quantizer.weight.grad.clone() if trigger else None]
+
+    assert ext.head_layout_supported(S, E, N * H)
+    for trigger in (False, True):
+        fast = run(trigger)
+        orig = ext.head_layout_supported
+        ext.head_layout_supported = lambda *a: False
+        try:
+            slow = run(trigger)
+        finally:
+            ext.head_layout_supported = orig
+        for a, b in zip(fast, slow):
+            if a is not None:
+                assert torch.allclose(a, b, rtol=1e-3, atol=2e-4)
