@@ -302,8 +302,14 @@ __global__ __launch_bounds__(CD_THREADS) void pq_encode_heads_kernel(
     const float *__restrict__ z, const float *__restrict__ table, int32_t *__restrict__ codes,
     int n_vectors, int S, int H, int M, int C) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *tab = reinterpret_cast<float *>(smem);  // [M][C][D]
-    for (int i = threadIdx.x; i < M * C * D; i += CD_THREADS) tab[i] = table[i];
+    // [M][C*D + 4]: the 8 lanes of a token read the SAME codeword of 8 DIFFERENT subspaces;
+    // unpadded, those rows are C*D*4 = 512 bytes apart = the same LDS banks (8-way conflict)
+    float *tab = reinterpret_cast<float *>(smem);
+    const int tstride = C * D + 4;
+    for (int i = threadIdx.x; i < M * C * D; i += CD_THREADS) {
+        const int mm = i / (C * D);
+        tab[mm * tstride + (i - mm * C * D)] = table[i];
+    }
     __syncthreads();
     // 32-bit index math throughout (the host guarantees n_vectors * M < 2^31): 64-bit
     // divisions by run-time values cost ~100 instructions each on this ISA
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(CD_THREADS) void pq_encode_heads_kernel(
         }
         int best_i = 0;
         float best_d = 1e13f;
-        const float *tm = tab + m * C * D;
+        const float *tm = tab + m * tstride;
         for (int c = 0; c < C; c++) {
             const float4 *tp = reinterpret_cast<const float4 *>(tm + c * D);
             float r = 0.0f;
@@ -356,7 +362,7 @@ extern "C" int spt_pq_encode_heads(const float *z, const float *table, int32_t *
         d_code <= 0)
         return SPT_EINVAL;
     if (d_code % 4 != 0) return SPT_ESHAPE;
-    const size_t lds = (size_t)n_subspaces * n_codewords * d_code * sizeof(float);
+    const size_t lds = (size_t)n_subspaces * (n_codewords * d_code + 4) * sizeof(float);
     if (lds > 64 * 1024) return SPT_EUNSUP;
     const long long n_vectors = (long long)batch * seq_length * n_heads;
     const long long total = n_vectors * n_subspaces;

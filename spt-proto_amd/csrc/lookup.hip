@@ -117,6 +117,14 @@ __device__ __forceinline__ Code<W> pack_codes(const int32_t *__restrict__ src, i
 }
 
 // One query row, one wave.  kcodes: LDS, Code<W> per column.
+//
+// Register budget of the inner loops (per 4-column group): pass 1 counts into one
+// register per worker (four 8-bit fields, one per slot) and remembers the 3-bit slot of
+// every column in a 64-bit word, so pass 2 neither re-reads LDS nor re-compares codes
+// (rows with more than 20 columns per lane recompute instead).  Ranks live in 16-bit
+// fields, two per register, exactly as the wave scan leaves them.  Output words are
+// written with plain LDS stores: the only word with two writers is the one behind the
+// reference's cursor-saturation quirk, fixed up after the loop by one lane.
 template <int W, bool NIB>
 __device__ __forceinline__ void lookup_row(const uint32_t *__restrict__ kcodes,
                                            const int32_t *__restrict__ qsrc,
@@ -124,12 +132,16 @@ __device__ __forceinline__ void lookup_row(const uint32_t *__restrict__ kcodes,
                                            int32_t *__restrict__ dst, int gy, int M, int Z) {
     const int lane = lane_id();
     const int Q = Z >> 2;
-    const int div = M >> 2;  // matches per slot, lookup.cu:62
     const int limit = min(gy + 1, Z);
     const int ngroups = (gy + 4) >> 2;              // 4-column groups holding a candidate
     const int gpl = (ngroups + SPT_WAVE - 1) >> 6;  // groups per lane
     const int g0 = lane * gpl;
     const int g1 = min(ngroups, g0 + gpl);
+    const bool keep_slots = gpl <= 5;               // 20 columns x 3 bits
+    // slot = min(3, matches / (M / 4)) (lookup.cu:61-63) as a multiply-shift: exact for
+    // matches <= 16 and M / 4 in 1..4
+    const int div = M >> 2;
+    const unsigned magic = (32u + div - 1) / div;
 
     const Code<W> qc = pack_codes<W, NIB>(qsrc, M, false);  // wave-uniform
 
@@ -150,46 +162,54 @@ __device__ __forceinline__ void lookup_row(const uint32_t *__restrict__ kcodes,
             Code<W> kc;
 #pragma unroll
             for (int d = 0; d < W; d++) kc.w[d] = raw[tx * W + d];
-            const int cnt = match_count<W, NIB>(kc, qc);
-            const int sl = (cnt >= div) + (cnt >= 2 * div) + (cnt >= 3 * div);
+            const unsigned cnt = (unsigned)match_count<W, NIB>(kc, qc);
+            const int sl = (int)min(3u, (cnt * magic) >> 5);
             slot[tx] = (4 * g + tx <= gy) ? sl : 4;
         }
     };
 
-    // ---- pass 1: per-lane sizes of the 16 (worker, slot) lists -------------------
-    int c[4][4];
-#pragma unroll
-    for (int tx = 0; tx < 4; tx++)
-#pragma unroll
-        for (int s = 0; s < 4; s++) c[tx][s] = 0;
+    // ---- pass 1: per-lane sizes of the 16 (worker, slot) lists -------------------------
+    unsigned cnt8[4] = {0u, 0u, 0u, 0u};      // worker tx: four 8-bit counters (slot 0..3)
+    int last2[4] = {-1, -1, -1, -1};          // worker 2: last column seen per slot
+    int last3[4] = {-1, -1, -1, -1};          // worker 3
+    unsigned long long saved = 0ull;
     for (int g = g0; g < g1; g++) {
         int slot[4];
         group_slots(g, slot);
 #pragma unroll
         for (int tx = 0; tx < 4; tx++) {
-            c[tx][0] += (slot[tx] == 0);
-            c[tx][1] += (slot[tx] == 1);
-            c[tx][2] += (slot[tx] == 2);
-            c[tx][3] += (slot[tx] == 3);
+            // slot 4 (not a candidate) shifts the 1 out of the register
+            cnt8[tx] += (unsigned)((1ull << (8 * slot[tx])) & 0xFFFFFFFFull);
+        }
+#pragma unroll
+        for (int sl = 0; sl < 4; sl++) {
+            last2[sl] = (slot[2] == sl) ? 4 * g + 2 : last2[sl];
+            last3[sl] = (slot[3] == sl) ? 4 * g + 3 : last3[sl];
+        }
+        if (keep_slots) {
+            const unsigned four = (unsigned)slot[0] | ((unsigned)slot[1] << 3) |
+                                  ((unsigned)slot[2] << 6) | ((unsigned)slot[3] << 9);
+            saved |= (unsigned long long)four << (12 * (g - g0));
         }
     }
 
-    // ---- exclusive scan over lanes; totals are wave-uniform ------------------------
-    int pos[4][4];  // rank of this lane's next entry in list (tx, s)
-    int n[4][4];    // list sizes
+    // ---- exclusive scan over lanes; totals are wave-uniform ----------------------------
+    unsigned posA[4], posB[4];   // worker tx: ranks of slots (0,1) and (2,3), 16 bits each
+    int n[4][4];                 // list sizes
 #pragma unroll
     for (int tx = 0; tx < 4; tx++) {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const unsigned own = (unsigned)c[tx][2 * h] | ((unsigned)c[tx][2 * h + 1] << 16);
-            const unsigned inc = wave_inclusive_scan(own);
-            const unsigned exc = inc - own;
-            const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
-            pos[tx][2 * h] = exc & 0xFFFF;
-            pos[tx][2 * h + 1] = exc >> 16;
-            n[tx][2 * h] = tot & 0xFFFF;
-            n[tx][2 * h + 1] = tot >> 16;
-        }
+        const unsigned ownA = (cnt8[tx] & 0xFFu) | ((cnt8[tx] & 0xFF00u) << 8);
+        const unsigned ownB = ((cnt8[tx] >> 16) & 0xFFu) | ((cnt8[tx] >> 24) << 16);
+        const unsigned incA = wave_inclusive_scan(ownA);
+        const unsigned incB = wave_inclusive_scan(ownB);
+        posA[tx] = incA - ownA;
+        posB[tx] = incB - ownB;
+        const unsigned totA = (unsigned)__builtin_amdgcn_readlane((int)incA, 63);
+        const unsigned totB = (unsigned)__builtin_amdgcn_readlane((int)incB, 63);
+        n[tx][0] = totA & 0xFFFF;
+        n[tx][1] = totA >> 16;
+        n[tx][2] = totB & 0xFFFF;
+        n[tx][3] = totB >> 16;
     }
     // kept entries per list and output offset of each slot (slot 3 first)
     int off[4][4];
@@ -203,37 +223,50 @@ __device__ __forceinline__ void lookup_row(const uint32_t *__restrict__ kcodes,
         off[tx][0] = k3 + k2 + k1;
     }
 
-    // ---- pass 2: placement ------------------------------------------------------------
+    // ---- pass 2: placement -------------------------------------------------------------------
     for (int g = g0; g < g1; g++) {
         int slot[4];
-        group_slots(g, slot);
+        if (keep_slots) {
+            const unsigned four = (unsigned)(saved >> (12 * (g - g0))) & 0xFFFu;
+            slot[0] = four & 7; slot[1] = (four >> 3) & 7; slot[2] = (four >> 6) & 7;
+            slot[3] = (four >> 9) & 7;
+        } else {
+            group_slots(g, slot);
+        }
 #pragma unroll
         for (int tx = 0; tx < 4; tx++) {
-            const int col = 4 * g + tx;
-            const int s = slot[tx];
-            const int rank = sel4(pos[tx][0], pos[tx][1], pos[tx][2], pos[tx][3], s);
-            pos[tx][0] += (s == 0);
-            pos[tx][1] += (s == 1);
-            pos[tx][2] += (s == 2);
-            pos[tx][3] += (s == 3);
+            const int sl = slot[tx];
+            const unsigned both = (sl & 2) ? posB[tx] : posA[tx];
+            const int rank = (int)((sl & 1) ? (both >> 16) : (both & 0xFFFFu));
+            const unsigned inc = (sl & 1) ? 0x10000u : 1u;
+            posA[tx] += (sl < 2) ? inc : 0u;
+            posB[tx] += (sl == 2 || sl == 3) ? inc : 0u;
             const int cap = (tx < 2) ? Q : Q - 1;
-            if (s < 4 && rank < cap) {
+            if (sl < 4 && rank < cap) {
                 const int p =
-                    tx + 4 * (sel4(off[tx][0], off[tx][1], off[tx][2], off[tx][3], s) + rank);
-                if (p < limit) atomicMax(&myrow[p], col);
+                    tx + 4 * (sel4(off[tx][0], off[tx][1], off[tx][2], off[tx][3], sl) + rank);
+                if (p < limit) myrow[p] = 4 * g + tx;
             }
-            if (tx >= 2) {
-                // reference quirk: this worker's cursor saturates on the word that holds
-                // entry Q-1 of worker 3 - tx; its LAST candidate survives there if larger
-                // (ds_max resolves the two writers)
-                const int ptx = 3 - tx;
-                const int n_own = sel4(n[tx][0], n[tx][1], n[tx][2], n[tx][3], s);
-                const int n_par = sel4(n[ptx][0], n[ptx][1], n[ptx][2], n[ptx][3], s);
-                if (s < 4 && rank == n_own - 1 && n_own >= Q && n_par >= Q) {
-                    const int p = ptx + 4 * (sel4(off[ptx][0], off[ptx][1], off[ptx][2],
-                                                  off[ptx][3], s) + Q - 1);
-                    if (p < limit) atomicMax(&myrow[p], col);
-                }
+        }
+    }
+
+    // ---- reference quirk: the cursor of worker 2 (3) saturates on the word that holds
+    // entry Q-1 of worker 1 (0); its LAST candidate of the slot survives there if larger.
+    // Wave-uniform and rare (both lists need >= Q entries).
+#pragma unroll
+    for (int sl = 0; sl < 4; sl++) {
+#pragma unroll
+        for (int tx = 2; tx < 4; tx++) {
+            const int ptx = 3 - tx;
+            if (n[tx][sl] >= Q && n[ptx][sl] >= Q) {      // uniform
+                int lastcol = (tx == 2) ? last2[sl] : last3[sl];
+#pragma unroll
+                for (int d = 1; d < SPT_WAVE; d <<= 1)
+                    lastcol = max(lastcol, __shfl_xor(lastcol, d, SPT_WAVE));
+                const int p = ptx + 4 * (off[ptx][sl] + Q - 1);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0 && p < limit) myrow[p] = max(myrow[p], lastcol);
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
@@ -311,7 +344,7 @@ extern "C" int spt_lookup_forward(const int32_t *query, const int32_t *key, int3
     const int Z = S / sparsity;
     if (Z % 16 != 0) return SPT_ESHAPE;                        // lookup.cu:106
     if (M < 4 || M > 16) return SPT_EUNSUP;                    // lookup.cu:167-169
-    if (S > 65536) return SPT_EUNSUP;                          // uint16 columns, lookup.cu:32
+    if (S > 32768) return SPT_EUNSUP;                          // 8-bit per-lane counters (ref: uint16 columns, lookup.cu:32)
     const int WU = (M + 1) / 2;
     const size_t lds = (size_t)S * WU * 4 + (size_t)LK_WAVES * Z * 4;
     if (lds > 160 * 1024) return SPT_EUNSUP;
