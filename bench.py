@@ -58,6 +58,34 @@ def algorithmic_bytes(op: str, B: int) -> int:
     return per[op] * B
 
 
+# op (naive_gpt.ext entry) -> the HIP kernel that does its work at this workload, for the
+# committed rocprofv3 PMC summary (profiles/*_traffic.json, tools/pmc_traffic.sh)
+OP_KERNEL = {
+    'sddmm_forward_cuda': 'spt::sddmm_g4_lds_kernel<4>',
+    'spmm_forward_cuda': 'spt::spmm_g4_lds_kernel<4, 1>',
+    'spmm_transposed': 'spt::spmm_t64_lds_kernel',
+    'csr_transpose': 'spt::csr_transpose_bitmap_kernel',
+    'lookup_forward_cuda': 'spt::lookup_forward_kernel<1, 4>',
+    'softmax_forward_cuda': 'spt::softmax_kernel<16, 0>',
+    'softmax_backward_cuda': 'spt::softmax_kernel<16, 1>',
+    'softmax_backward_clamped': 'spt::softmax_kernel<16, 2>',
+    'pq_encode_heads': 'spt::pq_encode_heads_kernel<8>',
+    'cdist_encode': 'spt::cdist_forward_kernel<8>',
+}
+
+
+def measured_traffic(op: str):
+    """HBM bytes per launch of the op's kernel from the committed PMC passes (FETCH_SIZE
+    doubled per the gfx950 note, + WRITE_SIZE), or None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json')))
+    if not files or op not in OP_KERNEL:
+        return None
+    table = json.load(open(files[-1]))
+    entry = table.get(OP_KERNEL[op])
+    return entry['hbm_bytes_per_launch'] if entry else None
+
+
 class EventTimer:
     """Brackets every naive_gpt.ext call with HIP events on torch's current stream
     (the stream the kernels are launched on)."""
@@ -245,7 +273,8 @@ def main():
         result['roofline'] = {
             'kernel': dominant, 'bound': 'hbm', 'achieved': st['algorithmic_GBps'],
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': st['algorithmic_GBps'] / HBM_PEAK_GBS,
-            'traffic': None, 'avg_us': st['avg_us'], 'calls_per_step': st['calls'] / args.steps,
+            'traffic': measured_traffic(dominant), 'avg_us': st['avg_us'],
+            'calls_per_step': st['calls'] / args.steps,
             'bytes_per_launch': algorithmic_bytes(dominant, B),
         }
         result['kernels'] = {op: {'avg_us': round(s_['avg_us'], 2),

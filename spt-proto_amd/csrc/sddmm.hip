@@ -25,7 +25,7 @@
 namespace spt {
 
 constexpr int SD_THREADS = 256;        // gather-from-global variant
-constexpr int SD_THREADS_LDS = 1024;   // LDS-resident variant: one block per CU
+constexpr int SD_THREADS_LDS = 512;    // LDS-resident variant: one block per CU, 2 waves per SIMD (256 VGPRs each: no spills)
 
 __device__ __forceinline__ float epilogue(float v, float scale, float clampv) {
     v *= scale;

@@ -22,7 +22,12 @@ def trainable_parameters(module: torch.nn.Module) -> List[torch.nn.Parameter]:
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
     """Make every replica identical to rank ``src`` (parameters and buffers)."""
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        if t.dtype == torch.bool:          # e.g. the `trigger` buffers: not a collective dtype
+            tmp = t.data.to(torch.uint8)
+            dist.broadcast(tmp, src=src, group=group)
+            t.data.copy_(tmp.to(torch.bool))
+        else:
+            dist.broadcast(t.data, src=src, group=group)
 
 
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None,
