@@ -42,7 +42,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 4
+#define SPT_ABI_VERSION 5
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -136,14 +136,18 @@ int spt_spmm_forward(int trans_lhs, const int32_t *indptr,
  * spmm.py:23-49 needs A^T twice per attention layer):
  *   spt_csr_transpose   builds the transposed structure of (indptr, indices) into
  *                       `transposed` (spt_csr_transpose_workspace_bytes() bytes);
- *   spt_spmm_transposed y = A^T . x using that structure and the CSR-ordered `values`.
+ *   spt_spmm_transposed y = A^T . x using that structure and the CSR-ordered `values`;
+ *                       `workspace` (spt_spmm_transposed_workspace_bytes() bytes, may be
+ *                       NULL) receives the values in transposed order: with it the product
+ *                       streams them instead of gathering through the permutation.
  */
 int64_t spt_csr_transpose_workspace_bytes(int batch_size, int seq_length, int nnz);
 int spt_csr_transpose(const int32_t *indptr, const int32_t *indices,
                       void *transposed, int batch_size, int seq_length, int nnz,
                       void *stream);
+int64_t spt_spmm_transposed_workspace_bytes(int batch_size, int nnz);
 int spt_spmm_transposed(const void *transposed, const float *values,
-                        const float *x, float *y, int batch_size,
+                        const float *x, float *y, void *workspace, int batch_size,
                         int seq_length, int d_head, int nnz, int x_heads,
                         int y_heads, void *stream);
 

@@ -340,17 +340,39 @@ __device__ __forceinline__ void gather_rows_dynamic(
     const int ngroups = (nrows + R - 1) / R;
     const int lane = lane_id();
 
-    for (;;) {
+    // Software pipeline over tickets: the bounds of the group after next and the first
+    // segment of the next group are requested before the current group is computed (a
+    // freshly drawn group otherwise costs two dependent HBM latencies before its first
+    // gather).  A wave therefore holds up to three tickets; the tail is at most two
+    // groups per wave.
+    auto draw = [&]() {
         int g = 0;
         if (lane == 0) g = atomicAdd(ticket, 1);
-        g = __builtin_amdgcn_readfirstlane(g);
-        if (g >= ngroups) break;
+        return __builtin_amdgcn_readfirstlane(g);
+    };
+    auto bounds = [&](int g, int &st, int &en) {
         const int row = g * R + L.j;
-        int start = 0, end = 0;
-        if (row < nrows) {
-            start = ptr[row];
-            end = ptr[row + 1];
+        st = 0;
+        en = 0;
+        if (g < ngroups && row < nrows) {
+            st = ptr[row];
+            en = ptr[row + 1];
         }
+    };
+    int g = draw(), g1 = draw(), g2;
+    int start, end, start1, end1, start2, end2;
+    bounds(g, start, end);
+    bounds(g1, start1, end1);
+    Seg4 seg0 = load_seg<MODE>(idx_b, perm_b, val_b, start + 16 * L.t + 4 * L.qs, end);
+
+    for (; g < ngroups; g = g1, g1 = g2, start = start1, end = end1, start1 = start2,
+                        end1 = end2) {
+        g2 = draw();
+        bounds(g2, start2, end2);
+        // first (normal-mode) segment of the next group: in flight during this group
+        const Seg4 seg_next =
+            load_seg<MODE>(idx_b, perm_b, val_b, start1 + 16 * L.t + 4 * L.qs, end1);
+        const int row = g * R + L.j;
         const int len = end - start;
         int lens[R], starts[R];
         int maxlen = 0, wide_rounds = 0;
@@ -368,7 +390,7 @@ __device__ __forceinline__ void gather_rows_dynamic(
             float4 acc[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            Seg4 seg = load_seg<MODE>(idx_b, perm_b, val_b, start + 16 * L.t + 4 * L.qs, end);
+            Seg4 seg = seg0;
             for (int c = 0; c < normal_rounds; c++) {
                 const Seg4 nseg = load_seg<MODE>(idx_b, perm_b, val_b,
                                                  start + 64 * (c + 1) + 16 * L.t + 4 * L.qs, end);
@@ -416,6 +438,7 @@ __device__ __forceinline__ void gather_rows_dynamic(
                 }
             }
         }
+        seg0 = seg_next;
     }
 }
 

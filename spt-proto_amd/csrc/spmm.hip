@@ -146,8 +146,34 @@ __global__ __launch_bounds__(SP_THREADS_LDS) void spmm_g4_lds_kernel(
                            part * NW + wave, splits * NW, S, 1.0f, 0.0f, E, yv.ld);
 }
 
+// values in transposed order: vt[b, j] = values[b, t_perm[b, j]].  One workgroup per batch;
+// the batch's values (nnz * 4 <= 128 KiB) are staged in LDS with coalesced loads, so the
+// random 4-byte reads hit LDS instead of L2 (where 32 batches x 128 KiB per XCD thrash:
+// the gather through t_perm inside the product cost 2.6x the algorithmic HBM bytes).
+__global__ __launch_bounds__(SP_THREADS_LDS) void permute_values_kernel(
+    const int32_t *__restrict__ t_perm, const float *__restrict__ values,
+    float *__restrict__ vt, int nnz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *tile = reinterpret_cast<float *>(smem);
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    stage_tile(tile, values + (size_t)b * nnz, nnz >> 2, tid, SP_THREADS_LDS);
+    for (int i = (nnz & ~3) + tid; i < nnz; i += SP_THREADS_LDS) tile[i] = values[(size_t)b * nnz + i];
+    __syncthreads();
+    const int4 *perm4 = reinterpret_cast<const int4 *>(t_perm + (size_t)b * nnz);
+    float4 *out4 = reinterpret_cast<float4 *>(vt + (size_t)b * nnz);
+    for (int i = tid; i < (nnz >> 2); i += SP_THREADS_LDS) {
+        const int4 p = perm4[i];
+        out4[i] = make_float4(tile[p.x], tile[p.y], tile[p.z], tile[p.w]);
+    }
+    for (int i = (nnz & ~3) + tid; i < nnz; i += SP_THREADS_LDS)
+        vt[(size_t)b * nnz + i] = tile[t_perm[(size_t)b * nnz + i]];
+}
+
 // transposed product, E = 64, one workgroup per batch: dynamic, wide-row aware
 // (gather_rows_dynamic).  The ticket word lives behind the tile in the dynamic region.
+// MODE G_SPMM: `values` are already in transposed order (permute_values_kernel).
+template <int MODE>
 __global__ __launch_bounds__(SP_THREADS_LDS) void spmm_t64_lds_kernel(
     const int32_t *__restrict__ t_ptr, const int32_t *__restrict__ t_row,
     const int32_t *__restrict__ t_perm, const float *__restrict__ values,
@@ -163,9 +189,9 @@ __global__ __launch_bounds__(SP_THREADS_LDS) void spmm_t64_lds_kernel(
     const DenseView xv = dense_view(b, S, E, x_heads), yv = dense_view(b, S, E, y_heads);
     stage_rows(xtile, x + xv.base, xv.ld, S, E, tid, SP_THREADS_LDS);
     __syncthreads();
-    gather_rows_dynamic<G_SPMM_PERM>(t_ptr + (size_t)b * (S + 1), t_row + (size_t)b * nnz,
-                                     t_perm + (size_t)b * nnz, values + (size_t)b * nnz, xtile,
-                                     y + yv.base, ticket, S, yv.ld);
+    gather_rows_dynamic<MODE>(t_ptr + (size_t)b * (S + 1), t_row + (size_t)b * nnz,
+                              MODE == G_SPMM_PERM ? t_perm + (size_t)b * nnz : nullptr,
+                              values + (size_t)b * nnz, xtile, y + yv.base, ticket, S, yv.ld);
 }
 
 template <int LPE, int MODE>
@@ -553,7 +579,8 @@ static int launch_transpose(const int32_t *indptr, const int32_t *indices, Trans
 template <bool PERM>
 static int launch_gather(const int32_t *ptr, int ptr_stride, const int32_t *indices,
                          const int32_t *perm, const float *values, const float *x, float *y,
-                         int B, int S, int E, int nnz, int x_heads, int y_heads, hipStream_t s) {
+                         int B, int S, int E, int nnz, int x_heads, int y_heads, hipStream_t s,
+                         float *vt_scratch = nullptr) {
     constexpr int MODE = PERM ? G_SPMM_PERM : G_SPMM;
     if (x_heads < 0 || y_heads < 0) return SPT_EINVAL;
     if ((x_heads > 0 && B % x_heads != 0) || (y_heads > 0 && B % y_heads != 0)) return SPT_ESHAPE;
@@ -561,11 +588,29 @@ static int launch_gather(const int32_t *ptr, int ptr_stride, const int32_t *indi
     const size_t tile_bytes = (size_t)S * E * sizeof(float);
     if (PERM && E == 64 && tile_bytes <= 128 * 1024 && B >= 128) {
         const size_t lds_bytes = tile_bytes + 16;
-        SPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_t64_lds_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds_bytes));
-        hipLaunchKernelGGL(spmm_t64_lds_kernel, dim3((unsigned)B), dim3(SP_THREADS_LDS), lds_bytes,
-                           s, ptr, indices, perm, values, x, y, S, nnz, x_heads, y_heads);
+        const size_t val_bytes = (size_t)nnz * sizeof(float);
+        if (vt_scratch && val_bytes <= 128 * 1024) {
+            // values -> transposed order through LDS, then the product streams them
+            SPT_HIP_TRY(hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&permute_values_kernel),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)val_bytes));
+            hipLaunchKernelGGL(permute_values_kernel, dim3((unsigned)B), dim3(SP_THREADS_LDS),
+                               val_bytes, s, perm, values, vt_scratch, nnz);
+            SPT_LAUNCH_CHECK();
+            SPT_HIP_TRY(hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&spmm_t64_lds_kernel<G_SPMM>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL(spmm_t64_lds_kernel<G_SPMM>, dim3((unsigned)B),
+                               dim3(SP_THREADS_LDS), lds_bytes, s, ptr, indices, perm,
+                               vt_scratch, x, y, S, nnz, x_heads, y_heads);
+        } else {
+            SPT_HIP_TRY(hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&spmm_t64_lds_kernel<G_SPMM_PERM>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL(spmm_t64_lds_kernel<G_SPMM_PERM>, dim3((unsigned)B),
+                               dim3(SP_THREADS_LDS), lds_bytes, s, ptr, indices, perm, values, x,
+                               y, S, nnz, x_heads, y_heads);
+        }
     } else if (E == 64 || E == 128) {
         const bool lds = tile_bytes <= 128 * 1024 && B >= 32;
         if (strided && !lds) return SPT_EUNSUP;  // head layout: LDS-resident path only
@@ -643,9 +688,14 @@ extern "C" int spt_csr_transpose(const int32_t *indptr, const int32_t *indices, 
                             batch_size, seq_length, nnz, (hipStream_t)stream);
 }
 
+extern "C" int64_t spt_spmm_transposed_workspace_bytes(int batch_size, int nnz) {
+    if (batch_size <= 0 || nnz <= 0) return 0;
+    return (int64_t)batch_size * nnz * (int64_t)sizeof(float);
+}
+
 extern "C" int spt_spmm_transposed(const void *transposed, const float *values, const float *x,
-                                   float *y, int batch_size, int seq_length, int d_head, int nnz,
-                                   int x_heads, int y_heads, void *stream) {
+                                   float *y, void *workspace, int batch_size, int seq_length,
+                                   int d_head, int nnz, int x_heads, int y_heads, void *stream) {
     const int rc =
         check_spmm_args(transposed, values, x, y, y, batch_size, seq_length, d_head, nnz);
     if (rc != SPT_OK) return rc;
@@ -653,12 +703,14 @@ extern "C" int spt_spmm_transposed(const void *transposed, const float *values, 
     const TransposedCsr t = carve(const_cast<void *>(transposed), batch_size, seq_length, nnz);
     return launch_gather<true>(t.t_ptr, seq_length + 1, t.t_row, t.t_perm, values, x, y,
                                batch_size, seq_length, d_head, nnz, x_heads, y_heads,
-                               (hipStream_t)stream);
+                               (hipStream_t)stream, reinterpret_cast<float *>(workspace));
 }
 
 extern "C" int64_t spt_spmm_workspace_bytes(int trans_lhs, int batch_size, int seq_length,
                                             int nnz) {
-    return trans_lhs ? spt_csr_transpose_workspace_bytes(batch_size, seq_length, nnz) : 0;
+    if (!trans_lhs) return 0;
+    return (int64_t)align256((size_t)spt_csr_transpose_workspace_bytes(batch_size, seq_length, nnz)) +
+           spt_spmm_transposed_workspace_bytes(batch_size, nnz);
 }
 
 extern "C" int spt_spmm_forward(int trans_lhs, const int32_t *indptr, const int32_t *indices,
@@ -681,6 +733,9 @@ extern "C" int spt_spmm_forward(int trans_lhs, const int32_t *indptr, const int3
     const TransposedCsr t = carve(workspace, B, S, nnz);
     const int rc2 = launch_transpose(indptr, indices, t, B, S, nnz, s);
     if (rc2 != SPT_OK) return rc2;
+    float *vt = reinterpret_cast<float *>(
+        reinterpret_cast<char *>(workspace) +
+        align256((size_t)spt_csr_transpose_workspace_bytes(B, S, nnz)));
     return launch_gather<true>(t.t_ptr, S + 1, t.t_row, t.t_perm, values, x, y, B, S, E, nnz,
-                               x_heads, y_heads, s);
+                               x_heads, y_heads, s, vt);
 }

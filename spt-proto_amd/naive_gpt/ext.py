@@ -38,7 +38,8 @@ _PROTOTYPES = {
     'spt_spmm_forward': ([_c_int] + [_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr], _c_int),
     'spt_csr_transpose_workspace_bytes': ([_c_int] * 3, ctypes.c_int64),
     'spt_csr_transpose': ([_c_ptr] * 3 + [_c_int] * 3 + [_c_ptr], _c_int),
-    'spt_spmm_transposed': ([_c_ptr] * 4 + [_c_int] * 6 + [_c_ptr], _c_int),
+    'spt_spmm_transposed_workspace_bytes': ([_c_int] * 2, ctypes.c_int64),
+    'spt_spmm_transposed': ([_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr], _c_int),
     'spt_grouped_gemm': ([_c_ptr] * 7 + [_c_int] * 5 + [ctypes.c_longlong, _c_int, _c_int, _c_ptr],
                          _c_int),
     'spt_softmax_forward': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
@@ -46,7 +47,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -366,9 +367,11 @@ def spmm_transposed(transposed: torch.Tensor, indptr: torch.Tensor,
         output = _alloc_dense(B, S, E, y_heads, dev)
         if nnz == 0:
             return output.zero_()
+        nbytes = lib.spt_spmm_transposed_workspace_bytes(B, nnz)
+        scratch = torch.empty([max(int(nbytes), 16)], dtype=torch.uint8, device=dev)
         rc = lib.spt_spmm_transposed(transposed.data_ptr(), values.data_ptr(),
-                                     x.data_ptr(), output.data_ptr(), B, S, E, nnz,
-                                     int(x_heads), int(y_heads), _stream(dev))
+                                     x.data_ptr(), output.data_ptr(), scratch.data_ptr(),
+                                     B, S, E, nnz, int(x_heads), int(y_heads), _stream(dev))
     if rc != 0:
         _raise(lib, rc, 'spmm_transposed')
     return output
