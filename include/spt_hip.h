@@ -42,7 +42,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 5
+#define SPT_ABI_VERSION 6
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -69,6 +69,28 @@ int spt_cdist_forward(const float *query, const float *table, float *distance,
 int spt_pq_encode_heads(const float *z, const float *table, int32_t *codes,
                         int batch, int seq_length, int n_heads, int n_subspaces,
                         int n_codewords, int d_code, void *stream);
+
+/*
+ * PQ codebook training loss, PQBase.forward(mode='train')[-1] of the reference
+ * (naive_gpt/layers/basic/quantizer.py:80-111; armed every step by
+ * script/4-sparse-tuning-0.py:71-78), as one forward and one backward pass over z:
+ *   loss = mean((softmax(-log max(d, 1e-5)) . W - W[argmin d])^2) + mean((z - W[argmin d])^2)
+ * with d the L1 distances of spt_cdist_forward.  z is any contiguous tensor of
+ * n_vectors rows of M * D floats ([N,S,H,E] or [B,S,E] alike: the loss is a mean over all
+ * sub-vectors); table [M, C, D]; loss / grad_loss are single device floats, grad_z has
+ * the shape of z, grad_table the shape of table.  Supported: C == 16, D in {4, 8}, M a
+ * power of two <= 32 (SPT_EUNSUP otherwise: callers compose the loss from spt_cdist_*).
+ * workspace: spt_pq_loss_workspace_bytes() bytes, used by both passes.
+ */
+int64_t spt_pq_loss_workspace_bytes(int64_t n_vectors, int n_subspaces, int n_codewords,
+                                    int d_code);
+int spt_pq_loss_forward(const float *z, const float *table, float *loss, void *workspace,
+                        int64_t n_vectors, int n_subspaces, int n_codewords, int d_code,
+                        void *stream);
+int spt_pq_loss_backward(const float *z, const float *table, const float *grad_loss,
+                         float *grad_z, float *grad_table, void *workspace,
+                         int64_t n_vectors, int n_subspaces, int n_codewords, int d_code,
+                         void *stream);
 
 /*
  * cdist_backward_cuda(query, table, grad_output) -> [grad_query, grad_table]

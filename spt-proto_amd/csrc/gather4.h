@@ -335,7 +335,7 @@ __device__ __forceinline__ void gather_rows_dynamic(
     const int32_t *__restrict__ perm_b, const float *__restrict__ val_b,
     const float *__restrict__ tile, float *__restrict__ out_b, int *ticket, int nrows,
     int ld_out = 64) {
-    constexpr int LPE = 4, E = 64, R = 4;
+    constexpr int LPE = 4, R = 4;  // E = 64
     const Lane4<LPE> L;
     const int ngroups = (nrows + R - 1) / R;
     const int lane = lane_id();

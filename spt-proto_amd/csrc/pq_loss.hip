@@ -1,0 +1,483 @@
+// pq_loss.hip -- the PQ codebook training loss and its gradient as two kernels, gfx950.
+//
+// Reference: PQBase.forward(mode='train'), naive_gpt/layers/basic/quantizer.py:80-111,
+// which the recipe runs for q and k of every layer on every step
+// (script/4-sparse-tuning-0.py:71-78).  For each D-dim sub-vector z of subspace m, with
+// W = weight[m] ([C, D]):
+//
+//   d_c  = sum_i |z_i - W_ci|                        (cdist, extension/cdist.cu:47-51)
+//   best = argmin_c d_c  (strict '<', ascending c)   (cdist.cu:52-54)
+//   zq   = W[best]                                   (gather, quantizer.py:86-90)
+//   soft = softmax_c(-log max(d_c, 1e-5))            (quantizer.py:98-101)
+//   zw   = sum_c soft_c W_c                          (quantizer.py:102)
+//   loss = mean((zw - zq)^2) + mean((z - zq)^2)      (quantizer.py:105-110)
+//
+// The reference materialises z three times ([NQ,M,D] -> [M,NQ,D] copies), the
+// [M,NQ,C] distance tensor four times (distance, clamp, log, softmax) and launches ~25
+// kernels forward + backward; at BERT-large / S=512 / batch 16 that is 3.1 ms per layer
+// per step, 3x everything else in the attention.  Here the forward reads z once and
+// writes one float per block; the backward reads z once, recomputes the 16 distances of
+// each sub-vector in registers and writes grad_z plus one [M,C,D] slab per block.
+// HBM-bound: 4 B/element forward, 8 B/element backward.
+//
+// Layout: z is any contiguous tensor whose last dimension is M*D (the [N,S,H,E] head
+// layout as well as [B,S,E]): sub-vector j starts at element j*D and belongs to subspace
+// j % M.  The loss is a mean over all sub-vectors, so their order does not matter.
+//
+// Mapping: one lane per sub-vector, grid-stride with a stride that is a multiple of M so
+// a lane's subspace never changes and its slice of grad_weight ([C][D] = 128 floats for
+// D = 8) lives in registers for the whole kernel.  The codebook sits in LDS with a
+// padded subspace stride (the 8 lanes of a token read the same codeword of 8 different
+// subspaces: unpadded that is an 8-way bank conflict, see pq_encode_heads_kernel).
+//
+// Numerics: softmax(-log d) is evaluated as (dmin/d_c) / sum_c (dmin/d_c), which is what
+// exp(-log d_c - max) is up to rounding; sums run in a different order than torch's.
+// Parity is therefore "fp32 within 1e-3 rel" (tests/test_gpu_pq_loss.py), not bit-exact.
+#include "spt_common.h"
+
+namespace spt {
+
+constexpr int PQL_THREADS = 256;
+constexpr int PQL_C = 16;
+
+template <int D>
+struct PQSub {
+    float z[D];
+    float d[PQL_C];     // raw L1 distances
+    float soft[PQL_C];  // softmax(-log clamp(d))
+    float zw[D];
+    float zq[D];
+    int best;
+};
+
+template <int D>
+__device__ __forceinline__ void pq_sub_forward(const float *__restrict__ zp,
+                                               const float *__restrict__ tm, PQSub<D> &s) {
+#pragma unroll
+    for (int i = 0; i < D / 4; i++) {
+        const float4 v = reinterpret_cast<const float4 *>(zp)[i];
+        s.z[4 * i + 0] = v.x; s.z[4 * i + 1] = v.y; s.z[4 * i + 2] = v.z; s.z[4 * i + 3] = v.w;
+    }
+    int best_i = 0;
+    float best_d = 1e13f;
+#pragma unroll
+    for (int c = 0; c < PQL_C; c++) {
+        const float4 *tp = reinterpret_cast<const float4 *>(tm + c * D);
+        float r = 0.0f;
+#pragma unroll
+        for (int i = 0; i < D / 4; i++) {
+            const float4 tv = tp[i];
+            r += fabsf(s.z[4 * i + 0] - tv.x);
+            r += fabsf(s.z[4 * i + 1] - tv.y);
+            r += fabsf(s.z[4 * i + 2] - tv.z);
+            r += fabsf(s.z[4 * i + 3] - tv.w);
+        }
+        s.d[c] = r;
+        const bool cond = r < best_d;
+        best_i = cond ? c : best_i;
+        best_d = cond ? r : best_d;
+    }
+    s.best = best_i;
+    const float dmin = fmaxf(best_d, 1e-5f);
+    float wsum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < PQL_C; c++) {
+        s.soft[c] = dmin * __builtin_amdgcn_rcpf(fmaxf(s.d[c], 1e-5f));   // 1 ulp
+        wsum += s.soft[c];
+    }
+    const float inv = __builtin_amdgcn_rcpf(wsum);
+#pragma unroll
+    for (int i = 0; i < D; i++) s.zw[i] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < PQL_C; c++) {
+        s.soft[c] *= inv;
+        const float4 *tp = reinterpret_cast<const float4 *>(tm + c * D);
+#pragma unroll
+        for (int i = 0; i < D / 4; i++) {
+            const float4 tv = tp[i];
+            s.zw[4 * i + 0] = fmaf(s.soft[c], tv.x, s.zw[4 * i + 0]);
+            s.zw[4 * i + 1] = fmaf(s.soft[c], tv.y, s.zw[4 * i + 1]);
+            s.zw[4 * i + 2] = fmaf(s.soft[c], tv.z, s.zw[4 * i + 2]);
+            s.zw[4 * i + 3] = fmaf(s.soft[c], tv.w, s.zw[4 * i + 3]);
+        }
+    }
+    const float4 *bp = reinterpret_cast<const float4 *>(tm + best_i * D);
+#pragma unroll
+    for (int i = 0; i < D / 4; i++) {
+        const float4 tv = bp[i];
+        s.zq[4 * i + 0] = tv.x; s.zq[4 * i + 1] = tv.y; s.zq[4 * i + 2] = tv.z; s.zq[4 * i + 3] = tv.w;
+    }
+}
+
+__device__ __forceinline__ void pq_stage_table(const float *__restrict__ table, float *tab,
+                                               int M, int CD, int tstride) {
+    for (int i = threadIdx.x; i < M * CD; i += PQL_THREADS) {
+        const int mm = i / CD;
+        tab[mm * tstride + (i - mm * CD)] = table[i];
+    }
+    __syncthreads();
+}
+
+// partial[block] = sum over the block's sub-vectors of |zw - zq|^2 + |z - zq|^2
+template <int D>
+__global__ __launch_bounds__(PQL_THREADS) void pq_loss_forward_kernel(
+    const float *__restrict__ z, const float *__restrict__ table, float *__restrict__ partial,
+    int total, int M) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *tab = reinterpret_cast<float *>(smem);
+    constexpr int CD = PQL_C * D;
+    const int tstride = CD + 4;
+    pq_stage_table(table, tab, M, CD, tstride);
+    __shared__ float wsum[PQL_THREADS / 64];
+
+    const int first = blockIdx.x * PQL_THREADS + threadIdx.x;
+    const float *tm = tab + (first % M) * tstride;
+    float acc = 0.0f;
+    for (int j = first; j < total; j += gridDim.x * PQL_THREADS) {
+        PQSub<D> s;
+        pq_sub_forward<D>(z + (size_t)j * D, tm, s);
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            const float e1 = s.zw[i] - s.zq[i];
+            const float e2 = s.z[i] - s.zq[i];
+            acc = fmaf(e1, e1, acc);
+            acc = fmaf(e2, e2, acc);
+        }
+    }
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < PQL_THREADS / 64; w++) t += wsum[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+__global__ void pq_loss_finish_kernel(const float *__restrict__ partial, float *__restrict__ loss,
+                                      int nblk, float inv_count) {
+    // one wave, fixed order: deterministic
+    float acc = 0.0f;
+    for (int b = threadIdx.x; b < nblk; b += 64) acc += partial[b];
+    acc = group_sum<64>(acc);
+    if (threadIdx.x == 0) loss[0] = acc * inv_count;
+}
+
+// grad_z and one [M][C][D] slab of grad_weight per block.
+//
+// Two lanes per sub-vector: lane `half` owns codewords {8*half .. 8*half+7}, i.e. 8*D
+// accumulators of grad_weight instead of 16*D (which, with the loop temporaries, does not
+// fit a 256-VGPR budget: 340 registers + scratch, one wave per SIMD, measured 153 us at
+// the BASELINE size).  The pair exchanges through DPP quad_perm [1,0,3,2]: the argmin, the
+// softmax denominator, the partial zw and <soft, gs>, and the grad_z halves.
+constexpr int PQL_HC = PQL_C / 2;
+
+__device__ __forceinline__ float pair_other(float v) { return dpp_mov<0xB1>(v); }
+__device__ __forceinline__ int pair_other(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+}
+
+template <int D>
+__global__ __launch_bounds__(PQL_THREADS, 2) void pq_loss_backward_kernel(
+    const float *__restrict__ z, const float *__restrict__ table,
+    const float *__restrict__ grad_loss, float *__restrict__ grad_z,
+    float *__restrict__ partial, int total, int M, float inv_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *tab = reinterpret_cast<float *>(smem);
+    constexpr int CD = PQL_C * D;
+    const int tstride = CD + 4;
+    pq_stage_table(table, tab, M, CD, tstride);
+    float *red = tab + M * tstride;  // [waves][M][CD]
+
+    const int gtid = blockIdx.x * PQL_THREADS + threadIdx.x;
+    const int half = gtid & 1;
+    const int first = gtid >> 1;
+    const int m = first % M;
+    const float *tsub = tab + m * tstride;          // the whole subspace (for zq)
+    const float *tm = tsub + half * PQL_HC * D;     // this lane's codewords
+    const float g = grad_loss[0] * inv_count;
+
+    float gt[PQL_HC][D];
+#pragma unroll
+    for (int c = 0; c < PQL_HC; c++)
+#pragma unroll
+        for (int i = 0; i < D; i++) gt[c][i] = 0.0f;
+
+    const int stride = gridDim.x * (PQL_THREADS / 2);
+    float4 znext[D / 4];
+    if (first < total) {
+#pragma unroll
+        for (int i = 0; i < D / 4; i++)
+            znext[i] = reinterpret_cast<const float4 *>(z + (size_t)first * D)[i];
+    }
+    for (int j = first; j < total; j += stride) {
+        float zv[D];
+#pragma unroll
+        for (int i = 0; i < D / 4; i++) {
+            zv[4 * i + 0] = znext[i].x; zv[4 * i + 1] = znext[i].y;
+            zv[4 * i + 2] = znext[i].z; zv[4 * i + 3] = znext[i].w;
+        }
+        if (j + stride < total) {   // next sub-vector: in flight during this one's arithmetic
+#pragma unroll
+            for (int i = 0; i < D / 4; i++)
+                znext[i] = reinterpret_cast<const float4 *>(z + (size_t)(j + stride) * D)[i];
+        }
+        asm volatile("" ::: "memory");   // keep the codebook in LDS, not in registers
+        // ---- forward, recomputed: distances, argmin, soft assignment, zw, zq ----------
+        float d[PQL_HC], soft[PQL_HC];
+        int best_i = 0;
+        float best_d = 1e13f;
+#pragma unroll
+        for (int c = 0; c < PQL_HC; c++) {
+            const float4 *tp = reinterpret_cast<const float4 *>(tm + c * D);
+            float r = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D / 4; i++) {
+                const float4 tv = tp[i];
+                r += fabsf(zv[4 * i + 0] - tv.x);
+                r += fabsf(zv[4 * i + 1] - tv.y);
+                r += fabsf(zv[4 * i + 2] - tv.z);
+                r += fabsf(zv[4 * i + 3] - tv.w);
+            }
+            d[c] = r;
+            const bool cond = r < best_d;
+            best_i = cond ? (half * PQL_HC + c) : best_i;
+            best_d = cond ? r : best_d;
+        }
+        {   // smaller distance, then smaller index: the sequential strict-'<' scan's pick
+            const float od = pair_other(best_d);
+            const int oi = pair_other(best_i);
+            const bool take = (od < best_d) || (od == best_d && oi < best_i);
+            best_d = take ? od : best_d;
+            best_i = take ? oi : best_i;
+        }
+        // 1 / max(d, 1e-5) by v_rcp_f32 (1 ulp): used for the soft assignment and again
+        // for d(-log d)/dd; sixteen IEEE divisions were a third of the kernel
+        const float dmin = fmaxf(best_d, 1e-5f);
+        float rd[PQL_HC];
+        float wsum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < PQL_HC; c++) {
+            rd[c] = __builtin_amdgcn_rcpf(fmaxf(d[c], 1e-5f));
+            soft[c] = dmin * rd[c];
+            wsum += soft[c];
+        }
+        wsum += pair_other(wsum);
+        const float inv = __builtin_amdgcn_rcpf(wsum);
+        float zw[D];
+#pragma unroll
+        for (int i = 0; i < D; i++) zw[i] = 0.0f;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < PQL_HC; c++) {
+            soft[c] *= inv;
+            const float4 *tp = reinterpret_cast<const float4 *>(tm + c * D);
+#pragma unroll
+            for (int i = 0; i < D / 4; i++) {
+                const float4 tv = tp[i];
+                zw[4 * i + 0] = fmaf(soft[c], tv.x, zw[4 * i + 0]);
+                zw[4 * i + 1] = fmaf(soft[c], tv.y, zw[4 * i + 1]);
+                zw[4 * i + 2] = fmaf(soft[c], tv.z, zw[4 * i + 2]);
+                zw[4 * i + 3] = fmaf(soft[c], tv.w, zw[4 * i + 3]);
+            }
+        }
+        float gzw[D], hard[D], gz[D];
+        {
+            const float4 *bp = reinterpret_cast<const float4 *>(tsub + best_i * D);
+#pragma unroll
+            for (int i = 0; i < D / 4; i++) {
+                const float4 tv = bp[i];
+                const float zq[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int ii = 4 * i + u;
+                    const float zwi = zw[ii] + pair_other(zw[ii]);
+                    gzw[ii] = 2.0f * g * (zwi - zq[u]);
+                    const float e2 = 2.0f * g * (zv[ii] - zq[u]);   // d/dz of the second term
+                    hard[ii] = -gzw[ii] - e2;            // d/dzq of both terms -> W[best]
+                    gz[ii] = half == 0 ? e2 : 0.0f;      // counted once per pair
+                }
+            }
+        }
+        // ---- softmax backward: ga_c = soft_c (gs_c - <soft, gs>), gs_c = <gzw, W_c> ----
+        asm volatile("" ::: "memory");
+        float gs[PQL_HC];
+        float dot = 0.0f;
+#pragma unroll
+        for (int c = 0; c < PQL_HC; c++) {
+            const float4 *tp = reinterpret_cast<const float4 *>(tm + c * D);
+            float r = 0.0f;
+#pragma unroll
+            for (int i = 0; i < D / 4; i++) {
+                const float4 tv = tp[i];
+                r = fmaf(gzw[4 * i + 0], tv.x, r);
+                r = fmaf(gzw[4 * i + 1], tv.y, r);
+                r = fmaf(gzw[4 * i + 2], tv.z, r);
+                r = fmaf(gzw[4 * i + 3], tv.w, r);
+            }
+            gs[c] = r;
+            dot = fmaf(soft[c], r, dot);
+        }
+        dot += pair_other(dot);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < PQL_HC; c++) {
+            // a = -log(max(d, 1e-5)): da/dd = -1/d where d >= 1e-5 (torch.clamp passes the
+            // gradient at the boundary), 0 below
+            const float ga = soft[c] * (gs[c] - dot);
+            const float gd = (d[c] >= 1e-5f) ? -ga * rd[c] : 0.0f;
+            const bool is_best = (half * PQL_HC + c == best_i);
+            const float4 *tp = reinterpret_cast<const float4 *>(tm + c * D);
+#pragma unroll
+            for (int i = 0; i < D / 4; i++) {
+                const float4 tv = tp[i];
+                const float w[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int ii = 4 * i + u;
+                    // cdist backward, extension/cdist.cu:113-119,167-174
+                    const float sg = (zv[ii] - w[u]) > 0.0f ? gd : -gd;
+                    gz[ii] += sg;
+                    float t = fmaf(soft[c], gzw[ii], -sg);
+                    t += is_best ? hard[ii] : 0.0f;
+                    gt[c][ii] += t;
+                }
+            }
+        }
+        // grad_z: each lane of the pair stores one half of the sub-vector
+#pragma unroll
+        for (int i = 0; i < D; i++) gz[i] += pair_other(gz[i]);
+        float *gp = grad_z + (size_t)j * D + half * (D / 2);
+        if constexpr (D == 8) {
+            *reinterpret_cast<float4 *>(gp) =
+                half == 0 ? make_float4(gz[0], gz[1], gz[2], gz[3])
+                          : make_float4(gz[4], gz[5], gz[6], gz[7]);
+        } else {
+            *reinterpret_cast<float2 *>(gp) =
+                half == 0 ? make_float2(gz[0], gz[1]) : make_float2(gz[2], gz[3]);
+        }
+    }
+
+    // lanes l, l+2M, l+4M .. of a wave hold the same (subspace, half): butterfly over
+    // those, then the waves of the block through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int step = 2 * M; step < 64; step <<= 1) {
+#pragma unroll
+        for (int c = 0; c < PQL_HC; c++)
+#pragma unroll
+            for (int i = 0; i < D; i++) gt[c][i] += __shfl_xor(gt[c][i], step, 64);
+    }
+    if (lane < 2 * M) {
+        float *dst = red + ((size_t)wave * M + m) * CD + half * PQL_HC * D;
+#pragma unroll
+        for (int c = 0; c < PQL_HC; c++)
+#pragma unroll
+            for (int i = 0; i < D; i++) dst[c * D + i] = gt[c][i];
+    }
+    __syncthreads();
+    float *out = partial + (size_t)blockIdx.x * M * CD;
+    for (int e = threadIdx.x; e < M * CD; e += PQL_THREADS) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < PQL_THREADS / 64; w++) t += red[(size_t)w * M * CD + e];
+        out[e] = t;
+    }
+}
+
+// grad_table[e] = sum_b partial[b][e]: 64 elements x 16 slab groups per block, fixed order
+__global__ __launch_bounds__(1024) void pq_loss_table_reduce_kernel(
+    const float *__restrict__ partial, float *__restrict__ grad_table, int nblk, int elems) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    float acc = 0.0f;
+    if (e < elems)
+        for (int b = grp; b < nblk; b += 16) acc += partial[(size_t)b * elems + e];
+    red[grp][lane] = acc;
+    __syncthreads();
+    if (grp == 0 && e < elems) {
+        float t = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 16; g++) t += red[g][lane];
+        grad_table[e] = t;
+    }
+}
+
+static bool pq_loss_shape_ok(long long n_vectors, int M, int C, int D) {
+    if (C != PQL_C || (D != 4 && D != 8)) return false;
+    if (M <= 0 || M > 32 || (M & (M - 1)) != 0) return false;
+    return n_vectors * M < 0x7FFFFFFFLL - 4 * 1024 * 1024;
+}
+
+static int pq_loss_blocks(long long total) {
+    long long nblk = (total + PQL_THREADS - 1) / PQL_THREADS;
+    if (nblk > 512) nblk = 512;  // two blocks per CU; grid stride 512*256 is a multiple of M
+    return (int)nblk;
+}
+
+}  // namespace spt
+
+using namespace spt;
+
+extern "C" int64_t spt_pq_loss_workspace_bytes(int64_t n_vectors, int n_subspaces,
+                                               int n_codewords, int d_code) {
+    if (n_vectors <= 0 || !pq_loss_shape_ok(n_vectors, n_subspaces, n_codewords, d_code)) return 0;
+    const int nblk = pq_loss_blocks(2 * n_vectors * n_subspaces);   // backward: 2 lanes each
+    return (int64_t)nblk * n_subspaces * n_codewords * d_code * (int64_t)sizeof(float);
+}
+
+extern "C" int spt_pq_loss_forward(const float *z, const float *table, float *loss,
+                                   void *workspace, int64_t n_vectors, int n_subspaces,
+                                   int n_codewords, int d_code, void *stream) {
+    if (!z || !table || !loss || !workspace) return SPT_EINVAL;
+    if (n_vectors <= 0 || n_subspaces <= 0 || n_codewords <= 0 || d_code <= 0) return SPT_EINVAL;
+    if (!pq_loss_shape_ok(n_vectors, n_subspaces, n_codewords, d_code)) return SPT_EUNSUP;
+    const int total = (int)(n_vectors * n_subspaces);
+    const int nblk = pq_loss_blocks(total);
+    const size_t lds = (size_t)n_subspaces * (n_codewords * d_code + 4) * sizeof(float);
+    const float inv_count = 1.0f / ((float)total * (float)d_code);
+    float *partial = reinterpret_cast<float *>(workspace);
+    hipStream_t s = (hipStream_t)stream;
+    if (d_code == 4)
+        hipLaunchKernelGGL((pq_loss_forward_kernel<4>), dim3(nblk), dim3(PQL_THREADS), lds, s, z,
+                           table, partial, total, n_subspaces);
+    else
+        hipLaunchKernelGGL((pq_loss_forward_kernel<8>), dim3(nblk), dim3(PQL_THREADS), lds, s, z,
+                           table, partial, total, n_subspaces);
+    SPT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pq_loss_finish_kernel, dim3(1), dim3(64), 0, s, partial, loss, nblk,
+                       inv_count);
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
+extern "C" int spt_pq_loss_backward(const float *z, const float *table, const float *grad_loss,
+                                    float *grad_z, float *grad_table, void *workspace,
+                                    int64_t n_vectors, int n_subspaces, int n_codewords,
+                                    int d_code, void *stream) {
+    if (!z || !table || !grad_loss || !grad_z || !grad_table || !workspace) return SPT_EINVAL;
+    if (n_vectors <= 0 || n_subspaces <= 0 || n_codewords <= 0 || d_code <= 0) return SPT_EINVAL;
+    if (!pq_loss_shape_ok(n_vectors, n_subspaces, n_codewords, d_code)) return SPT_EUNSUP;
+    const int total = (int)(n_vectors * n_subspaces);
+    const int nblk = pq_loss_blocks(2LL * total);
+    const int CD = n_codewords * d_code;
+    const size_t lds = ((size_t)n_subspaces * (CD + 4) +
+                        (size_t)(PQL_THREADS / 64) * n_subspaces * CD) * sizeof(float);
+    if (lds > 64 * 1024) return SPT_EUNSUP;
+    const float inv_count = 1.0f / ((float)total * (float)d_code);
+    float *partial = reinterpret_cast<float *>(workspace);
+    hipStream_t s = (hipStream_t)stream;
+    if (d_code == 4)
+        hipLaunchKernelGGL((pq_loss_backward_kernel<4>), dim3(nblk), dim3(PQL_THREADS), lds, s, z,
+                           table, grad_loss, grad_z, partial, total, n_subspaces, inv_count);
+    else
+        hipLaunchKernelGGL((pq_loss_backward_kernel<8>), dim3(nblk), dim3(PQL_THREADS), lds, s, z,
+                           table, grad_loss, grad_z, partial, total, n_subspaces, inv_count);
+    SPT_LAUNCH_CHECK();
+    const int elems = n_subspaces * CD;
+    hipLaunchKernelGGL(pq_loss_table_reduce_kernel, dim3((elems + 63) / 64), dim3(1024), 0, s,
+                       partial, grad_table, nblk, elems);
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}

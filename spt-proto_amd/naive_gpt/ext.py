@@ -31,6 +31,9 @@ _PROTOTYPES = {
     'spt_cdist_backward': ([_c_ptr] * 6 + [_c_int] * 4 + [_c_ptr], _c_int),
     'spt_lookup_forward': ([_c_ptr] * 3 + [_c_int] * 4 + [_c_ptr], _c_int),
     'spt_pq_encode_heads': ([_c_ptr] * 3 + [_c_int] * 6 + [_c_ptr], _c_int),
+    'spt_pq_loss_workspace_bytes': ([ctypes.c_int64] + [_c_int] * 3, ctypes.c_int64),
+    'spt_pq_loss_forward': ([_c_ptr] * 4 + [ctypes.c_int64] + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_pq_loss_backward': ([_c_ptr] * 6 + [ctypes.c_int64] + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_sddmm_forward': (
         [_c_ptr] * 5 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int
     ),
@@ -47,7 +50,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -270,6 +273,61 @@ def pq_encode_heads(z: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
     if rc != 0:
         _raise(lib, rc, 'pq_encode_heads')
     return codes
+
+
+def pq_loss_supported(z: torch.Tensor, table: torch.Tensor) -> bool:
+    """Shapes the fused PQ training loss covers (``spt_pq_loss_*``, pq_loss.hip)."""
+    if table.dim() != 3 or z.dim() < 2:
+        return False
+    M, C, D = table.shape
+    return (z.is_cuda and z.dtype == torch.float32 and table.dtype == torch.float32
+            and z.size(-1) == M * D and C == 16 and D in (4, 8)
+            and 0 < M <= 32 and (M & (M - 1)) == 0 and z.numel() > 0)
+
+
+def _pq_loss_args(z: torch.Tensor, table: torch.Tensor):
+    _check_type(z, torch.float32, 'z')
+    _check_type(table, torch.float32, 'table')
+    _check_dim(table, 3, 'table')
+    _require(z.is_contiguous() and table.is_contiguous(), 'z, table contiguous')
+    dev = _same_device(z, table)
+    M, C, D = table.shape
+    _require(z.size(-1) == M * D, 'z.size(-1) == n_subspaces * d_codeword')
+    n_vectors = z.numel() // (M * D)
+    lib = load_library()
+    nbytes = lib.spt_pq_loss_workspace_bytes(n_vectors, M, C, D)
+    _require(nbytes > 0, 'pq_loss: unsupported codebook shape (C == 16, D in {4, 8}, M = 2^k)')
+    return lib, dev, n_vectors, (M, C, D), nbytes
+
+
+def pq_loss_forward(z: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    """-> 0-dim loss of ``PQBase.forward('train', z)`` (quantizer.py:80-111)."""
+    lib, dev, n_vectors, (M, C, D), nbytes = _pq_loss_args(z, table)
+    with torch.cuda.device(dev):
+        loss = torch.empty([], dtype=torch.float32, device=dev)
+        scratch = torch.empty([nbytes // 4], dtype=torch.float32, device=dev)
+        rc = lib.spt_pq_loss_forward(z.data_ptr(), table.data_ptr(), loss.data_ptr(),
+                                     scratch.data_ptr(), n_vectors, M, C, D, _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'pq_loss_forward')
+    return loss
+
+
+def pq_loss_backward(z: torch.Tensor, table: torch.Tensor, grad_loss: torch.Tensor):
+    """-> (grad_z, grad_table) for a 0-dim device ``grad_loss`` (no host read)."""
+    lib, dev, n_vectors, (M, C, D), nbytes = _pq_loss_args(z, table)
+    _check_type(grad_loss, torch.float32, 'grad_loss')
+    _require(grad_loss.numel() == 1 and grad_loss.device == z.device, 'grad_loss: device scalar')
+    with torch.cuda.device(dev):
+        grad_z = torch.empty_like(z)
+        grad_table = torch.empty_like(table)
+        scratch = torch.empty([nbytes // 4], dtype=torch.float32, device=dev)
+        rc = lib.spt_pq_loss_backward(z.data_ptr(), table.data_ptr(), grad_loss.data_ptr(),
+                                      grad_z.data_ptr(), grad_table.data_ptr(),
+                                      scratch.data_ptr(), n_vectors, M, C, D, _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'pq_loss_backward')
+    return grad_z, grad_table
 
 
 def sddmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,

@@ -5,5 +5,6 @@ from .lookup import lookup
 from .softmax import softmax
 from .sddmm import sddmm
 from .spmm import spmm
+from .pq_loss import pq_loss      # MI355X addition: fused PQ training loss
 
-__all__ = ['cdist', 'lookup', 'softmax', 'sddmm', 'spmm']
+__all__ = ['cdist', 'lookup', 'softmax', 'sddmm', 'spmm', 'pq_loss']

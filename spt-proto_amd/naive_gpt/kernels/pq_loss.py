@@ -1,0 +1,28 @@
+"""kernels.pq_loss -- fused PQ codebook training loss (no reference counterpart).
+
+The reference composes this loss from ~25 torch ops around ``kernels.cdist``
+(``naive_gpt/layers/basic/quantizer.py:80-111``); ``spt_pq_loss_*`` (pq_loss.hip) is the
+same function of ``(z, weight)`` as two kernels.  Gradients flow to both, as in the
+reference (the second MSE term pulls the inputs towards their centroids).
+"""
+import torch
+
+from naive_gpt import ext
+
+
+class PQLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z: torch.Tensor, table: torch.Tensor):
+        z, table = z.contiguous(), table.contiguous()
+        ctx.save_for_backward(z, table)
+        return ext.pq_loss_forward(z, table)
+
+    @staticmethod
+    def backward(ctx, grad_loss: torch.Tensor):
+        z, table = ctx.saved_tensors
+        grad_z, grad_table = ext.pq_loss_backward(z, table, grad_loss.contiguous())
+        return grad_z, grad_table
+
+
+def pq_loss(z: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    return PQLoss.apply(z, table)

@@ -54,6 +54,15 @@ class PQBase(nn.Module):
             return distance, indices.unsqueeze(-1)
         raise RuntimeError
 
+    def train_loss(self, z: torch.Tensor) -> torch.Tensor:
+        """``self('train', z)[-1]``.  For the v2 quantiser on the GPU this is the fused
+        operator ``kernels.pq_loss`` (two kernels, no [M, NQ, C] intermediates); any
+        other case composes the loss exactly as the reference does."""
+        if self.method == 'v2' and ext.pq_loss_supported(z, self.weight):
+            assert z.size(-1) == self.d_codeword * self.n_subspaces
+            return kernels.pq_loss(z, self.weight)
+        return self('train', z=z)[-1]
+
     def forward(self, mode: str, z: torch.Tensor):
         assert mode in _MODES
         assert z.dim() > 1

@@ -129,13 +129,32 @@ class _SparseCore:
             _SparseCore._indptr_cache[key] = cached
         return cached
 
+    def _take_trigger(self) -> bool:
+        """One-shot flag: the training loop arms the device buffer `trigger`, the layer
+        disarms it (reference: attention.py:98-104, which reads it with a blocking
+        ``.item()`` on every forward).  The buffer's autograd version counter tells whether
+        anything wrote to it since the last look, so the device is only asked (one host
+        sync) after a write: unarmed steps never synchronise."""
+        t = self.trigger
+        if t.is_inference():                      # no version counter to consult
+            armed = bool(t.is_nonzero())
+            if armed:
+                t.logical_not_()
+            return armed
+        seen = self.__dict__.get('_trigger_seen')
+        if seen is not None and seen[0] == (t.data_ptr(), t._version):
+            armed = seen[1]
+        else:
+            armed = bool(t.is_nonzero())
+        if armed:
+            t.logical_not_()
+        self.__dict__['_trigger_seen'] = ((t.data_ptr(), t._version), False)
+        return armed
+
     def _pq_loss(self, q: torch.Tensor, k: torch.Tensor):
-        # one-shot: the training loop arms `trigger`, the layer disarms it
-        # (reference: attention.py:98-104)
-        if self.trigger.is_nonzero():
-            self.trigger.logical_not_()
-            loss_q = self.quantizer('train', z=q)[-1]
-            loss_k = self.quantizer('train', z=k)[-1]
+        if self._take_trigger():
+            loss_q = self.quantizer.train_loss(q)
+            loss_k = self.quantizer.train_loss(k)
             self.register_buffer('loss', loss_q + loss_k, persistent=False)
 
     @staticmethod
@@ -148,11 +167,10 @@ class _SparseCore:
         """MI355X fast path: no layout copies (see module docstring)."""
         seq_length, heads = q.size(1), q.size(2)
         q, k = q.contiguous(), k.contiguous()
-        if self.trigger.is_nonzero():
+        if self._take_trigger():
             # the PQ loss is a mean over all sub-vectors: the head layout holds the same set
-            self.trigger.logical_not_()
-            loss_q = self.quantizer('train', z=q)[-1]
-            loss_k = self.quantizer('train', z=k)[-1]
+            loss_q = self.quantizer.train_loss(q)
+            loss_k = self.quantizer.train_loss(k)
             self.register_buffer('loss', loss_q + loss_k, persistent=False)
         table = self.quantizer.weight.detach()
         q_c = ext.pq_encode_heads(q.detach(), table)

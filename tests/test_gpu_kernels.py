@@ -36,7 +36,7 @@ def close(got: torch.Tensor, want: np.ndarray, rtol=RTOL, atol=ATOL):
 def test_library_is_the_native_one():
     from naive_gpt import ext
     lib = ext.load_library()
-    assert lib.spt_abi_version() == 5
+    assert lib.spt_abi_version() == ext.ABI_VERSION
     assert torch.cuda.is_available()
     assert 'gfx950' in torch.cuda.get_device_properties(0).gcnArchName
 
