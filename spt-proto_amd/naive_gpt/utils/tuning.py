@@ -1,0 +1,140 @@
+"""SPT fine-tuning step without Lightning.
+
+Restates ``script/4-sparse-tuning-0.py``: ``LightningModel`` (:12-126) and the
+``L.Trainer`` settings it runs under (:176-187) --
+
+* model from a ``{'config', 'state_dict'}`` checkpoint, upgraded in the four stages
+  ``lora -> ffn -> mha_v1 -> mha_v2`` with ``SparseLoRAHandler`` (:33-39);
+* AdamW(lr 1e-4, weight_decay 1e-1) + ExponentialLR(gamma 0.9) stepped per epoch (:45-53);
+* one step: arm every ``*.trigger`` buffer (:71-78), next-token cross entropy on
+  ``batch[:, 1:-1] -> batch[:, 2:]`` (column 0 carries the MMLU answer position)
+  (:79-81), plus ``1e-2 *`` the sum of the ``*.loss`` buffers the sparse attentions
+  registered (:83-90);
+* ``accumulate_grad_batches``, ``gradient_clip_val=1.0`` (L2 norm), fp32 (:183-187);
+* DDP over the GPUs of the node (:183) -- here: identical replicas, gradients averaged
+  with one flat RCCL all-reduce (``utils.distributed``) before clipping, so every rank
+  clips by the same norm and takes the same step.
+
+No dataset code: ``training_step`` takes the token batch the reference's data module
+would deliver.
+"""
+import contextlib
+import io
+import math
+from typing import Iterable, Optional
+
+import torch
+from torch import nn, optim
+
+from . import adapter, checkpoint, distributed
+
+STAGES = ('lora', 'ffn', 'mha_v1', 'mha_v2')
+
+
+def upgrade_sparse(model: nn.Module, d_lora: int, stages: Iterable[str] = STAGES,
+                   verbose: bool = False) -> nn.Module:
+    """The four-stage upgrade of script/4-sparse-tuning-0.py:33-39 (the handler prints one
+    line per replaced module; silenced unless ``verbose``)."""
+    sink = contextlib.nullcontext() if verbose else contextlib.redirect_stdout(io.StringIO())
+    with sink:
+        for stage in stages:
+            handler = adapter.SparseLoRAHandler(d_lora=d_lora, stage=stage)
+            model = adapter.ModuleUpgrader(handler=handler).visit(model)
+    return model
+
+
+class SparseTuner:
+    def __init__(self, model: nn.Module, lr: float = 1e-4, weight_decay: float = 1e-1,
+                 gamma: float = 0.9, clip_norm: Optional[float] = 1.0,
+                 aux_weight: float = 1e-2, n_accumulate: int = 1, group=None):
+        self.model = model
+        self.group = group
+        self.world_size = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world_size = torch.distributed.get_world_size(group)
+        if self.world_size > 1:
+            distributed.broadcast_parameters(model, src=0, group=group)
+        self.params = distributed.trainable_parameters(model)
+        self.optimizer = optim.AdamW(self.params, lr=lr, weight_decay=weight_decay)
+        self.scheduler = optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=gamma)
+        self.loss_fn = nn.CrossEntropyLoss()
+        self.clip_norm = clip_norm
+        self.aux_weight = aux_weight
+        self.n_accumulate = max(1, int(n_accumulate))
+        self._micro = 0
+        self._triggers = [b for n, b in model.named_buffers() if n.endswith('.trigger')]
+        self.last_grad_norm = None
+
+    @classmethod
+    def from_checkpoint(cls, path: str, d_lora: int = 16, device=None, **kwargs):
+        model = checkpoint.model_from_checkpoint(path)
+        model = upgrade_sparse(model, d_lora=d_lora)
+        if device is not None:
+            model = model.to(device)
+        return cls(model, **kwargs)
+
+    # ------------------------------------------------------------------ pieces of a step
+    def arm_triggers(self) -> None:
+        for trigger in self._triggers:
+            trigger.fill_(True)
+
+    def aux_loss(self):
+        """Sum of the PQ codebook losses the armed attentions left in ``*.loss``."""
+        total = 0.0
+        for name, buffer in self.model.named_buffers():
+            if name.endswith('.loss'):
+                total = total + buffer
+        return total
+
+    def shared_step(self, src: torch.Tensor, target: torch.Tensor):
+        output = self.model(src)
+        loss = self.loss_fn(output.flatten(end_dim=-2), target=target.flatten())
+        return output, loss
+
+    def training_step(self, batch: torch.Tensor, pq_loss: bool = True) -> torch.Tensor:
+        """One micro-batch: forward, backward; every ``n_accumulate``-th call also
+        exchanges, clips and applies the gradients.  Returns the (detached) loss."""
+        assert batch.dim() == 2
+        self.model.train()
+        if pq_loss:
+            self.arm_triggers()
+        loss = self.shared_step(batch[:, 1:-1], target=batch[:, 2:])[-1]
+        if pq_loss:
+            loss = loss + self.aux_weight * self.aux_loss()
+        (loss / self.n_accumulate).backward()
+        self._micro += 1
+        if self._micro % self.n_accumulate == 0:
+            self.apply_gradients()
+        return loss.detach()
+
+    def apply_gradients(self) -> None:
+        if self.world_size > 1:
+            distributed.allreduce_gradients(self.params, group=self.group,
+                                            world_size=self.world_size)
+        if self.clip_norm is not None:
+            self.last_grad_norm = nn.utils.clip_grad_norm_(self.params, self.clip_norm)
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=True)
+
+    def end_epoch(self) -> None:
+        self.scheduler.step()
+
+    @torch.no_grad()
+    def validation_step(self, batch: torch.Tensor) -> dict:
+        """Perplexity and the MMLU answer accuracy of script/4-sparse-tuning-0.py:95-126.
+        The accuracy keeps the reference's indexing: ``batch[:, position]`` with a vector
+        ``position`` selects a [B, B] grid (every row against every row's answer
+        position), and the mean runs over that grid."""
+        assert batch.dim() == 2
+        self.model.eval()
+        target = batch[:, 2:]
+        output, loss = self.shared_step(batch[:, 1:-1], target=target)
+        position = batch[:, 0]
+        answers = batch[:, position]
+        predict = torch.argmax(output[:, position - 2, :], dim=-1)
+        accuracy = torch.eq(predict, answers).float().mean()
+        return {'loss': loss, 'ppl': torch.exp(loss), 'accuracy': accuracy}
+
+    @property
+    def lr(self) -> float:
+        return self.optimizer.param_groups[0]['lr']

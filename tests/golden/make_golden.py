@@ -63,7 +63,8 @@ torch.cuda.stream = lambda s: s
 
 
 def t2n(t):
-    return t.detach().cpu().numpy()
+    # a copy: golden_models() steps the optimiser in place after taking its snapshots
+    return t.detach().cpu().numpy().copy()
 
 
 def sd2n(module, prefix='sd.'):
@@ -267,9 +268,68 @@ def golden_block():
     save('block', **out)
 
 
+# --------------------------------------------------------------------------- models + one tuning step
+
+def golden_models():
+    """OPTModel / LLaMAModel of the reference (naive_gpt/models): dense logits, then the
+    four-stage upgrade and ONE optimisation step restated from
+    script/4-sparse-tuning-0.py:45-93,183-187 (Lightning itself is not installed: the
+    step below is its training_step + AdamW + clip 1.0, written out)."""
+    from naive_gpt import models
+    from torch import optim
+    out = {}
+    config = dict(d_model=64, n_heads=1, n_layers=2, max_length=128, vocab_size=96,
+                  d_feedforward=128, p_dropout=0.0)
+    out['config'] = np.array([config[k] for k in
+                              ['d_model', 'n_heads', 'n_layers', 'max_length', 'vocab_size',
+                               'd_feedforward']])
+    gen = torch.Generator().manual_seed(123)
+    batch = torch.randint(3, 96, [2, 130], generator=gen)
+    batch[:, 0] = torch.tensor([17, 90])          # MMLU answer positions
+    out['batch'] = t2n(batch)
+    skip = ('attn_mask', 'cos_cached', 'sin_cached', 'cached_ids')
+    for kind, cls in [('opt', models.OPTModel), ('llama', models.LLaMAModel)]:
+        torch.manual_seed(31 if kind == 'opt' else 32)
+        model = cls(**config)
+        model.eval()
+        with torch.no_grad():
+            out[kind + '.dense.logits'] = t2n(model(batch[:, 1:-1]))
+        model = quiet_upgrade(model, d_lora=4)
+        randomize_lora(model, gen)
+        model.train()
+        for k, v in sd2n(model, kind + '.sd.').items():
+            if not k.endswith(skip):
+                out[k] = v
+        params = [p for p in model.parameters() if p.requires_grad]
+        optimizer = optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-1)
+        true_tensor = torch.scalar_tensor(True, dtype=torch.bool)
+        for name, trigger in model.named_buffers():
+            if name.endswith('.trigger'):
+                trigger.fill_(true_tensor)
+        logits = model(batch[:, 1:-1])
+        loss = nn.CrossEntropyLoss()(logits.flatten(end_dim=-2), target=batch[:, 2:].flatten())
+        aux = 0.0
+        for name, buffer in model.named_buffers():
+            if name.endswith('.loss'):
+                aux += buffer
+        total = loss + 1e-2 * aux
+        total.backward()
+        out.update({kind + '.logits': t2n(logits), kind + '.ce': t2n(loss),
+                    kind + '.aux': t2n(aux), kind + '.loss': t2n(total)})
+        out.update(grads2n(model, kind + '.grad.'))
+        norm = nn.utils.clip_grad_norm_(params, 1.0)
+        out[kind + '.grad_norm'] = t2n(norm)
+        optimizer.step()
+        for name, p in model.named_parameters():
+            if p.requires_grad:
+                out[kind + '.stepped.' + name] = t2n(p)
+    save('models', **out)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
     golden_ffn()
     golden_pq()
     golden_attention()
     golden_block()
+    golden_models()

@@ -82,3 +82,69 @@ def test_allreduce_is_a_noop_for_one_rank():
     model = _build()
     model(_batch(0)).sum().backward()
     assert utils.allreduce_gradients(utils.trainable_parameters(model), world_size=1) == 0
+
+
+# ------------------------------------------------------------------ the tuner under DP
+
+def _tiny_lm():
+    from naive_gpt import models, utils
+    torch.manual_seed(4)
+    model = models.OPTModel(d_model=16, n_heads=2, n_layers=1, max_length=24, vocab_size=32,
+                            d_feedforward=64, p_dropout=0.0)
+    model = utils.upgrade_sparse(model, d_lora=4, stages=('lora', 'ffn'))   # pure PyTorch on CPU
+    gen = torch.Generator().manual_seed(5)
+    for name, p in model.named_parameters():
+        if name.endswith('lora.right.weight'):
+            p.data.copy_(0.1 * torch.randn(p.shape, generator=gen))
+    return model
+
+
+def _tokens(rank):
+    return torch.randint(0, 32, [2, 20], generator=torch.Generator().manual_seed(200 + rank))
+
+
+def _tuner_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from naive_gpt import utils
+    model = _tiny_lm()
+    if rank == 1:
+        for p in model.parameters():
+            p.data.mul_(1.5)               # the tuner's broadcast must undo this
+    tuner = utils.SparseTuner(model, clip_norm=0.05)      # small enough to clip for real
+    assert tuner.world_size == world
+    for _ in range(2):
+        tuner.training_step(_tokens(rank), pq_loss=False)
+    torch.save({k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad},
+               out.format(rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tuner_replicas_stay_identical_and_match_the_global_batch(tmp_path):
+    """Two ranks, two steps: both ranks end with the same parameters, equal to a single
+    process that takes the mean gradient of both micro-batches, clips it by the same norm
+    and applies the same AdamW step."""
+    world = 2
+    out = str(tmp_path / 'rank{}.pt')
+    mp.spawn(_tuner_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r0 = torch.load(out.format(0), weights_only=True)
+    r1 = torch.load(out.format(1), weights_only=True)
+    assert set(r0) == set(r1) and len(r0) > 5
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
+
+    from naive_gpt import utils
+    model = _tiny_lm()
+    tuner = utils.SparseTuner(model, clip_norm=0.05)
+    for _ in range(2):
+        for r in range(world):           # mean of the per-rank losses == global-batch loss
+            batch = _tokens(r)
+            loss = tuner.shared_step(batch[:, 1:-1], target=batch[:, 2:])[-1]
+            (loss / world).backward()
+        tuner.apply_gradients()
+        assert float(tuner.last_grad_norm) > 0.05        # the clip was active
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            assert torch.allclose(p, r0[k], rtol=1e-5, atol=1e-7), k

@@ -26,38 +26,6 @@ def T(a, device='cpu'):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
-@pytest.fixture
-def oracle_ext(monkeypatch):
-    """Install the CPU oracle behind naive_gpt.ext for host-logic tests."""
-    from naive_gpt import ext
-
-    def sddmm(tl, tr, indptr, indices, query, key, scale=1.0, clamp=0.0):
-        out = ext_stub.sddmm_forward_cuda(torch.scalar_tensor(False), torch.scalar_tensor(True),
-                                          indptr, indices, query, key)
-        out = out * np.float32(scale)
-        return out.clamp_(-clamp, clamp) if clamp > 0 else out
-
-    def spmm(tl, tr, indptr, indices, values, x):
-        return ext_stub.spmm_forward_cuda(torch.scalar_tensor(bool(tl)), torch.scalar_tensor(False),
-                                          indptr, indices, values, x)
-
-    for name in ['cdist_forward_cuda', 'cdist_backward_cuda', 'lookup_forward_cuda',
-                 'softmax_forward_cuda', 'softmax_backward_cuda']:
-        monkeypatch.setattr(ext, name, getattr(ext_stub, name))
-    monkeypatch.setattr(ext, 'sddmm_forward_cuda', sddmm)
-    monkeypatch.setattr(ext, 'spmm_forward_cuda', spmm)
-    monkeypatch.setattr(ext, 'transposed_for', lambda indptr, indices: None)
-    monkeypatch.setattr(ext, 'spmm_transposed',
-                        lambda t, indptr, indices, values, x: spmm(True, False, indptr, indices,
-                                                                   values, x))
-    monkeypatch.setattr(ext, 'cdist_encode',
-                        lambda q, t: ext_stub.cdist_forward_cuda(q, t)[1])
-    from naive_gpt.layers.sparse.attention import _SparseCore
-    _SparseCore._indptr_cache.clear()
-    yield
-    _SparseCore._indptr_cache.clear()
-
-
 def load_sd(module, g, prefix, device='cpu'):
     sd = {k[len(prefix):]: T(v) for k, v in g.items() if k.startswith(prefix)}
     missing = module.load_state_dict(sd, strict=False)

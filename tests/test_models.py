@@ -1,0 +1,245 @@
+"""naive_gpt.models, the checkpoint format and the Lightning-free tuning step.
+
+Pins, in order of independence:
+* HuggingFace `transformers` (installed here, random-init from a config: no download) --
+  OPTForCausalLM / LlamaForCausalLM logits after the weight map of utils.checkpoint
+  (the check script/1-convert.py:162-181 makes);
+* tests/golden/models.npz from the IMPORTED REFERENCE: dense logits, and ONE
+  optimisation step of the four-stage-upgraded model (loss, aux loss, every gradient,
+  clip norm, every stepped parameter) restated from script/4-sparse-tuning-0.py.
+CPU tier runs the sparse attentions through the oracle (conftest.oracle_ext); the GPU
+tier runs the same goldens through the HIP library.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+CONFIG_KEYS = ['d_model', 'n_heads', 'n_layers', 'max_length', 'vocab_size', 'd_feedforward']
+
+
+def golden():
+    g = dict(np.load(os.path.join(GOLD, 'models.npz'), allow_pickle=False))
+    config = {k: int(v) for k, v in zip(CONFIG_KEYS, g['config'])}
+    config['p_dropout'] = 0.0
+    return g, config
+
+
+def T(a, device='cpu'):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def close(got, want, rtol, atol, what):
+    got = got.detach().cpu().numpy()
+    assert got.shape == want.shape, what
+    err = np.abs(got - want)
+    bound = atol + rtol * np.abs(want)
+    assert (err <= bound).all(), '{}: max err {:.3e}'.format(what, err.max())
+
+
+def upgraded_from_golden(kind, device):
+    from naive_gpt import utils
+    from naive_gpt.utils import checkpoint
+    g, config = golden()
+    model = checkpoint.build_model(kind, config)
+    model = utils.upgrade_sparse(model, d_lora=4)
+    prefix = kind + '.sd.'
+    sd = {k[len(prefix):]: T(v) for k, v in g.items() if k.startswith(prefix)}
+    report = model.load_state_dict(sd, strict=False)
+    assert not report.unexpected_keys
+    assert all(k.endswith(('attn_mask', 'cos_cached', 'sin_cached', 'cached_ids'))
+               for k in report.missing_keys), report.missing_keys
+    return g, model.to(device)
+
+
+def run_tuning_step(kind, device, rtol, atol):
+    from naive_gpt import utils
+    g, model = upgraded_from_golden(kind, device)
+    batch = T(g['batch'], device)
+    tuner = utils.SparseTuner(model)          # recipe defaults: AdamW 1e-4 / 0.1, clip 1.0
+    assert sorted(n for n, p in model.named_parameters() if p.requires_grad)
+
+    # the step, piece by piece (training_step == these pieces, checked below)
+    model.train()
+    tuner.arm_triggers()
+    logits, ce = tuner.shared_step(batch[:, 1:-1], target=batch[:, 2:])
+    aux = tuner.aux_loss()
+    loss = ce + tuner.aux_weight * aux
+    loss.backward()
+    close(logits, g[kind + '.logits'], rtol, atol * 10, 'logits')
+    close(ce, g[kind + '.ce'], rtol, atol, 'ce')
+    close(aux, g[kind + '.aux'], rtol, atol, 'aux')
+    close(loss, g[kind + '.loss'], rtol, atol, 'loss')
+    n = 0
+    for name, p in model.named_parameters():
+        key = kind + '.grad.' + name
+        if key in g:
+            assert p.grad is not None, name
+            close(p.grad, g[key], rtol, atol, 'grad ' + name)
+            n += 1
+        else:
+            assert p.grad is None, name
+    assert n > 10
+    tuner.apply_gradients()
+    close(tuner.last_grad_norm, g[kind + '.grad_norm'], rtol, atol, 'grad_norm')
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            close(p, g[kind + '.stepped.' + name], rtol, atol, 'stepped ' + name)
+    assert all(p.grad is None for p in tuner.params)
+
+
+# ------------------------------------------------------------------ dense models
+
+@pytest.mark.parametrize('kind', ['opt', 'llama'])
+def test_dense_logits_match_imported_reference(kind):
+    """Seeded construction draws the same initial weights as the reference's model, so
+    the logits agree without loading anything."""
+    from naive_gpt.utils import checkpoint
+    g, config = golden()
+    torch.manual_seed(31 if kind == 'opt' else 32)
+    model = checkpoint.build_model(kind, config).eval()
+    with torch.no_grad():
+        logits = model(T(g['batch'])[:, 1:-1])
+    close(logits, g[kind + '.dense.logits'], 1e-5, 1e-5, 'logits')
+
+
+def test_parameter_names_are_the_checkpoint_format():
+    from naive_gpt import models
+    opt = models.OPTModel(d_model=32, n_heads=2, n_layers=1, max_length=16, vocab_size=20,
+                          d_feedforward=64, p_dropout=0.0)
+    names = set(opt.state_dict())
+    for key in ['embedding.weight', 'learned_pe.weight', 'final_norm.bias', 'lm_output.weight',
+                'attn_mask', 'decoders.0.mha.linear_q.bias', 'decoders.0.ffd.fc1.weight',
+                'decoders.0.norm2.weight']:
+        assert key in names, key
+    assert opt.learned_pe.weight.shape == (16 + 2, 32) and opt.attn_mask.shape == (18, 18)
+    llama = models.LLaMAModel(d_model=32, n_heads=2, n_layers=1, max_length=16, vocab_size=20,
+                              d_feedforward=64, p_dropout=0.0)
+    names = set(llama.state_dict())
+    assert 'learned_pe.weight' not in names and 'final_norm.bias' not in names
+    for key in ['decoders.0.ffd.gate.weight', 'decoders.0.ffd.side.weight',
+                'decoders.0.ffd.down.weight', 'final_norm.weight']:
+        assert key in names, key
+    assert llama.attn_mask.shape == (16, 16)
+    mask = llama.attn_mask
+    assert mask[3, 3] == 0 and mask[3, 2] == 0 and mask[2, 3] == float('-inf')
+
+
+@pytest.mark.parametrize('kind', ['opt', 'llama'])
+def test_logits_match_huggingface_after_weight_map(kind):
+    T5 = pytest.importorskip('transformers')
+    from naive_gpt.utils import checkpoint
+    torch.manual_seed(0)
+    if kind == 'opt':
+        cfg = T5.OPTConfig(vocab_size=96, hidden_size=64, num_hidden_layers=2, ffn_dim=128,
+                           num_attention_heads=4, max_position_embeddings=64,
+                           word_embed_proj_dim=64, dropout=0.0, attention_dropout=0.0,
+                           activation_function='relu', do_layer_norm_before=True)
+        hf = T5.OPTForCausalLM(cfg).eval()
+    else:
+        cfg = T5.LlamaConfig(vocab_size=96, hidden_size=64, num_hidden_layers=2,
+                             intermediate_size=176, num_attention_heads=4,
+                             num_key_value_heads=4, max_position_embeddings=64,
+                             rms_norm_eps=1e-6, attention_dropout=0.0)
+        hf = T5.LlamaForCausalLM(cfg).eval()
+    model = checkpoint.build_model(kind, checkpoint.config_from_hf(cfg)).eval()
+    checkpoint.load_hf_state(model, kind, hf.state_dict())
+    x = torch.randint(0, 96, [3, 40])
+    with torch.no_grad():
+        want, got = hf(x)['logits'], model(x)
+    assert torch.allclose(got, want, atol=1e-5), (got - want).abs().max()   # 1-convert.py:181: 1e-3
+
+
+def test_weight_map_rejects_unknown_tensors():
+    from naive_gpt.utils import checkpoint
+    with pytest.raises(RuntimeError):
+        checkpoint.opt_state_from_hf({'model.decoder.layers.0.mystery.weight': torch.zeros(1)})
+
+
+def test_checkpoint_round_trip(tmp_path):
+    from naive_gpt import utils
+    from naive_gpt.utils import checkpoint
+    _, config = golden()
+    torch.manual_seed(3)
+    model = checkpoint.build_model('llama', config)
+    path = str(tmp_path / 'tiny-llama.ckpt')
+    utils.save_checkpoint(path, config, model)
+    loaded_config, state = utils.load_checkpoint(path)
+    assert loaded_config == config and set(state) == set(model.state_dict())
+    again = utils.model_from_checkpoint(path)          # family from the file name
+    assert type(again).__name__ == 'LLaMAModel'
+    x = torch.randint(0, config['vocab_size'], [1, 32])
+    with torch.no_grad():
+        assert torch.equal(again(x), model(x))
+    with pytest.raises(RuntimeError):
+        checkpoint.model_family('bert-large.ckpt')
+    torch.save({'weights': 1}, str(tmp_path / 'opt-bad.ckpt'))
+    with pytest.raises(RuntimeError):
+        utils.load_checkpoint(str(tmp_path / 'opt-bad.ckpt'))
+
+
+# ------------------------------------------------------------------ the tuning step
+
+@pytest.mark.parametrize('kind', ['opt', 'llama'])
+def test_tuning_step_matches_imported_reference_cpu(kind, oracle_ext):
+    run_tuning_step(kind, 'cpu', 1e-4, 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['opt', 'llama'])
+def test_tuning_step_matches_imported_reference_gpu(kind):
+    run_tuning_step(kind, 'cuda', 2e-3, 2e-5)
+
+
+def test_training_step_is_the_pieces_and_accumulates(oracle_ext):
+    from naive_gpt import utils
+    g, model_a = upgraded_from_golden('opt', 'cpu')
+    _, model_b = upgraded_from_golden('opt', 'cpu')
+    batch = T(g['batch'])
+    a = utils.SparseTuner(model_a)
+    loss = a.training_step(batch)
+    close(loss, g['opt.loss'], 1e-4, 1e-6, 'loss')
+    for name, p in model_a.named_parameters():
+        if p.requires_grad:
+            close(p, g['opt.stepped.' + name], 1e-4, 1e-6, name)
+    # two half-weight micro-batches of the same data == one full step
+    b = utils.SparseTuner(model_b, n_accumulate=2)
+    b.training_step(batch)
+    assert all(p.grad is not None for p in b.params)
+    before = [p.detach().clone() for p in b.params]
+    assert all(torch.equal(x, y) for x, y in zip(before, b.params))     # no step yet
+    b.training_step(batch)
+    for pa, pb in zip(a.params, b.params):
+        assert torch.allclose(pa, pb, rtol=1e-4, atol=1e-6)
+    # the scheduler decays per epoch
+    lr0 = a.lr
+    a.end_epoch()
+    assert abs(a.lr - 0.9 * lr0) < 1e-12
+
+
+def test_unarmed_step_registers_no_pq_loss(oracle_ext):
+    from naive_gpt import utils
+    g, model = upgraded_from_golden('opt', 'cpu')
+    tuner = utils.SparseTuner(model)
+    tuner.training_step(T(g['batch']), pq_loss=False)
+    assert not [n for n, _ in model.named_buffers() if n.endswith('.loss')]
+    quant = [p for n, p in model.named_parameters() if n.endswith('quantizer.weight')]
+    assert quant and all(p.grad is None for p in quant)
+
+
+def test_validation_step_metrics(oracle_ext):
+    from naive_gpt import utils
+    g, model = upgraded_from_golden('llama', 'cpu')
+    tuner = utils.SparseTuner(model)
+    batch = T(g['batch'])
+    out = tuner.validation_step(batch)
+    assert abs(out['ppl'].item() - float(np.exp(out['loss'].item()))) < 1e-3 * out['ppl'].item()
+    # the reference's [B, B] accuracy grid (script/4-sparse-tuning-0.py:110-121)
+    with torch.no_grad():
+        logits = model(batch[:, 1:-1])
+    pos = batch[:, 0]
+    grid = torch.stack([torch.stack([(logits[i, pos[j] - 2].argmax() == batch[i, pos[j]]).float()
+                                     for j in range(2)]) for i in range(2)])
+    assert abs(out['accuracy'].item() - grid.mean().item()) < 1e-6
