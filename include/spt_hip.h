@@ -42,7 +42,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 6
+#define SPT_ABI_VERSION 7
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -222,6 +222,66 @@ int spt_grouped_gemm(const float *a, const int32_t *gather, const float *w,
                      const int32_t *offsets, float *out, int n_rows, int k, int n,
                      int n_groups, int lda, long long w_group_stride, int w_ldn,
                      int w_ldk, void *stream);
+
+/*
+ * The same product with the rest of a routed-FFN layer folded in (the torch glue around
+ * the four block GEMMs cost as much as the GEMMs: DESIGN.md section 7):
+ *
+ *   v[p, n]  = rowscale[p] * ( sum_k a[src(p), k] * W_g(n, k) + bias[g, n] )
+ *            + sum_{j < r} a2[src2(p), j] * b2[g * b2_group_stride + n * b2_ldn + j]
+ *   epilogue SPT_EPI_PLAIN: out = v
+ *            SPT_EPI_ACT  : out = act(v); out2 = v when out2 != NULL
+ *            SPT_EPI_DACT : out = v * act'(s);
+ *                           pdot_main[p, c] = sum_{n in c} t[p, n] * h[p, n]
+ *                           pdot_act[p, c]  = sum_{n in c} out[p, n] * s[p, n]
+ *              with t = v / rowscale - bias (the k-sum plus the second term over rowscale:
+ *              the kernel accumulates a2 / rowscale first and scales once), c the
+ *              64-column half tile of n (pdot_ld >= spt_grouped_gemm_pdot_width(n) of them
+ *              per row; the caller adds them up), s = s_in, h = act(s_in) -- or, when
+ *              s_in == NULL (ReLU only), s = h = h_in.
+ * The second term is the LoRA side path (lora_ffn.py:97-100,108-110): r <= 32, r % 4 == 0.
+ * The pdot rows are the two inner products the gradient of the router coefficient needs
+ * (<dY W2_g^T, h> -- after subtracting <a2, h B2_g> / rowscale, which the caller has from the
+ * forward pass -- and <dS, s>), which would otherwise each cost a pass over [P, n].
+ * activation: 0 ReLU, 1 GELU (erf), 2 SiLU.
+ */
+enum { SPT_EPI_PLAIN = 0, SPT_EPI_ACT = 1, SPT_EPI_DACT = 2 };
+enum { SPT_ACT_RELU = 0, SPT_ACT_GELU = 1, SPT_ACT_SILU = 2 };
+typedef struct SptGroupedGemm {
+    const float *a;
+    const int32_t *gather;
+    const float *w;
+    const float *bias;
+    const float *rowscale;
+    const int32_t *offsets;
+    float *out;
+    int32_t n_rows, k, n, n_groups, lda;
+    int64_t w_group_stride;
+    int32_t w_ldn, w_ldk;
+    const float *a2;           /* NULL: no second term */
+    const int32_t *gather2;
+    const float *b2;
+    int32_t lda2, r;
+    int64_t b2_group_stride;
+    int32_t b2_ldn;
+    int32_t epilogue, activation;
+    float *out2;
+    const float *h_in;
+    const float *s_in;
+    float *pdot_main;
+    float *pdot_act;
+    int32_t pdot_ld;
+} SptGroupedGemm;
+int spt_grouped_gemm_fused(const SptGroupedGemm *desc, void *stream);
+int spt_grouped_gemm_pdot_width(int n);
+
+/*
+ * Un-bucketing: out[t, :] = bias + sum_{j < k} rows[pos[t * k + j], :] (bias may be NULL).
+ * Replaces the reference's per-block `y[mask] += ...` scatter (lora_ffn.py:107-111) with a
+ * gather in a fixed order: deterministic, no atomics.  d % 4 == 0.
+ */
+int spt_rows_combine(const float *rows, const int32_t *pos, const float *bias, float *out,
+                     int n_tokens, int k, int d, void *stream);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,9 @@ constexpr int GG_BNROW = GG_BN + 4;  // floats per LDS row of an n-contiguous we
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DACT = 2 };
+enum { ACT_RELU = 0, ACT_GELU = 1, ACT_SILU = 2 };
+
 struct GroupedArgs {
     const float *a;         // [*, K] row-major, leading dimension lda
     const int32_t *gather;  // [P] or null
@@ -49,12 +52,48 @@ struct GroupedArgs {
     int lda;
     long long gstride;
     int ldn, ldk;
+    // K extension (the LoRA side product), added AFTER rowscale / bias:
+    //   v[p, n] += sum_{j < R} a2[src2(p), j] * b2[g * b2_gstride + n * b2_ldn + j]
+    const float *a2;
+    const int32_t *gather2;
+    const float *b2;
+    int lda2, R;
+    long long b2_gstride;
+    int b2_ldn;
+    // epilogue
+    int act;
+    float *out2;            // EPI_ACT: pre-activation (null: not kept, e.g. ReLU)
+    const float *h_in;      // EPI_DACT: activated values [P, N] (used when s_in is null: ReLU)
+    const float *s_in;      // EPI_DACT: pre-activation values [P, N] or null
+    float *pdot_main;       // EPI_DACT: [P, pdot_ld]: sum_n (v / rowscale - bias)[p, n] * h[p, n]
+    float *pdot_act;        // EPI_DACT: [P, pdot_ld]: sum_n out[p, n] * s[p, n] per half tile
+    int pdot_ld;
 };
 
-template <bool BN_LAYOUT>
-__global__ __launch_bounds__(GG_THREADS) void grouped_gemm_kernel(GroupedArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[GG_BM * GG_ROW];
-    __shared__ __attribute__((aligned(16))) float Bs[GG_BN * GG_ROW];
+__device__ __forceinline__ float act_forward(int act, float s) {
+    if (act == ACT_RELU) return fmaxf(s, 0.0f);
+    if (act == ACT_GELU) return 0.5f * s * (1.0f + erff(s * 0.70710678118654752f));
+    return s / (1.0f + __expf(-s));
+}
+
+__device__ __forceinline__ float act_derivative(int act, float s) {
+    if (act == ACT_RELU) return s > 0.0f ? 1.0f : 0.0f;
+    if (act == ACT_GELU) {
+        const float cdf = 0.5f * (1.0f + erff(s * 0.70710678118654752f));
+        return cdf + s * 0.3989422804014327f * __expf(-0.5f * s * s);
+    }
+    const float sg = 1.0f / (1.0f + __expf(-s));
+    return sg * (1.0f + s * (1.0f - sg));
+}
+
+template <bool BN_LAYOUT, int EPI, bool EXT>
+// two workgroups per CU (256 VGPRs); the EPI_DACT epilogue spills ~25 registers, outside
+// the k loop
+__global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_kernel(GroupedArgs g) {
+    // As | Bs; the epilogue reuses the whole buffer as four per-wave C staging areas
+    __shared__ __attribute__((aligned(16))) float smem[(GG_BM + GG_BN) * GG_ROW];
+    float *As = smem;
+    float *Bs = smem + GG_BM * GG_ROW;
 
     // ---- which bucket / row tile is this workgroup? ----
     int bucket = -1, row_lo = 0, row_hi = 0;
@@ -101,6 +140,60 @@ __global__ __launch_bounds__(GG_THREADS) void grouped_gemm_kernel(GroupedArgs g)
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    // ---- K extension first: acc = (A2 / rowscale) . B2_g^T, so that the epilogue's single
+    // rowscale * (acc + bias) yields rowscale * (A W^T + bias) + A2 B2^T ----
+    if (EXT) {
+        const int k = 4 * s_kq;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int r = s_row + 32 * u;
+            const int p = row_lo + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < row_hi && k < g.R) {
+                const int src = g.gather2 ? g.gather2[p] : p;
+                v = *reinterpret_cast<const float4 *>(g.a2 + (size_t)src * g.lda2 + k);
+                if (g.rowscale) {
+                    const float inv = 1.0f / g.rowscale[p];
+                    v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+                }
+            }
+            *reinterpret_cast<float2 *>(&As[r * GG_ROW + 2 * s_kq]) = make_float2(v.x, v.z);
+            *reinterpret_cast<float2 *>(&As[r * GG_ROW + GG_BK / 2 + 2 * s_kq]) = make_float2(v.y, v.w);
+            const int n = n0 + r;
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < g.N && k < g.R)
+                b = *reinterpret_cast<const float4 *>(g.b2 + (size_t)bucket * g.b2_gstride +
+                                                      (size_t)n * g.b2_ldn + k);
+            *reinterpret_cast<float2 *>(&Bs[r * GG_ROW + 2 * s_kq]) = make_float2(b.x, b.z);
+            *reinterpret_cast<float2 *>(&Bs[r * GG_ROW + GG_BK / 2 + 2 * s_kq]) = make_float2(b.y, b.w);
+        }
+        __syncthreads();
+        const int frow = lane & 31, fh = lane >> 5;
+        for (int q = 0; q < (g.R + 7) / 8; q++) {
+            float4 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+                af[i] = *reinterpret_cast<const float4 *>(
+                    &As[(wm + 32 * i + frow) * GG_ROW + fh * (GG_BK / 2) + 4 * q]);
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                bf[j] = *reinterpret_cast<const float4 *>(
+                    &Bs[(wn + 32 * j + frow) * GG_ROW + fh * (GG_BK / 2) + 4 * q]);
+            const float a0[4] = {af[0].x, af[0].y, af[0].z, af[0].w};
+            const float a1[4] = {af[1].x, af[1].y, af[1].z, af[1].w};
+            const float b0[4] = {bf[0].x, bf[0].y, bf[0].z, bf[0].w};
+            const float b1[4] = {bf[1].x, bf[1].y, bf[1].z, bf[1].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+            }
+        }
+        // the main loop's first __syncthreads orders these reads before its LDS writes
+    }
 
     // ---- software pipeline: the global loads of tile t+1 are in flight while the MFMAs
     // of tile t run; registers -> LDS happens at the top of the next iteration ----
@@ -205,25 +298,126 @@ __global__ __launch_bounds__(GG_THREADS) void grouped_gemm_kernel(GroupedArgs g)
         }
     }
 
-    // ---- epilogue: C[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31] ----
+    // ---- epilogue ----
+    // MFMA C layout: acc[i][j][r] = C[32 i + (r & 3) + 8 (r >> 2) + 4 (l >> 5)][32 j + (l & 31)]
+    // of the wave's 64 x 64 quadrant.  Each wave transposes its quadrant through LDS, 32 rows
+    // at a time, into a row layout -- 16 lanes x float4 = one 64-column row segment -- so
+    // that every global access of the epilogue (the stores, the h / s tiles of EPI_DACT,
+    // the bias) is 16 bytes per lane and 256 contiguous bytes per row, and a row dot is a
+    // 16-lane DPP reduction.
+    __syncthreads();   // all waves are done with the last k-step's tiles
+    constexpr int CS_ROW = 64 + 4;
+    float *cs = smem + wave * (32 * CS_ROW);
     const int ccol = lane & 31, chalf = lane >> 5;
+    const int rrow = lane >> 4, rcol = 4 * (lane & 15);
+    const int pslot = 2 * blockIdx.y + (wave & 1);   // this wave's half tile of columns
+    const float *sh = (EPI == EPI_DACT) ? (g.s_in ? g.s_in : g.h_in) : nullptr;
+    const int n = n0 + wn + rcol;
+    const bool vec = (g.N & 3) == 0;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias) {
+        const float *bp = g.bias + (size_t)bucket * g.N + n;
+        if (vec) {
+            if (n < g.N) bias4 = *reinterpret_cast<const float4 *>(bp);
+        } else {
+            bias4.x = n + 0 < g.N ? bp[0] : 0.f; bias4.y = n + 1 < g.N ? bp[1] : 0.f;
+            bias4.z = n + 2 < g.N ? bp[2] : 0.f; bias4.w = n + 3 < g.N ? bp[3] : 0.f;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 2; i++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int p = row_lo + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * chalf;
-            if (p >= row_hi) continue;
-            const float rs = g.rowscale ? g.rowscale[p] : 1.0f;
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * chalf;
+            cs[row * CS_ROW + ccol] = acc[i][0][r];
+            cs[row * CS_ROW + 32 + ccol] = acc[i][1][r];
+        }
+        // (a wave only reads what it wrote: no workgroup barrier)
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int n = n0 + wn + 32 * j + ccol;
-                if (n < g.N) {
-                    float v = acc[i][j][r];
-                    if (g.bias) v += g.bias[(size_t)bucket * g.N + n];
-                    g.out[(size_t)p * g.N + n] = rs * v;
+        for (int t = 0; t < 8; t++) {
+            const int row = rrow + 4 * t;
+            const int p = row_lo + wm + 32 * i + row;
+            const bool live = p < row_hi;
+            const float4 c4 = *reinterpret_cast<const float4 *>(&cs[row * CS_ROW + rcol]);
+            float c[4] = {c4.x, c4.y, c4.z, c4.w};
+            const float b[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+            const float rs = (live && g.rowscale) ? g.rowscale[p] : 1.0f;
+            const size_t at = (size_t)p * g.N + n;
+            float sv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (EPI == EPI_DACT && live) {
+                if (vec) {
+                    if (n < g.N) {
+                        const float4 t4 = *reinterpret_cast<const float4 *>(sh + at);
+                        sv[0] = t4.x; sv[1] = t4.y; sv[2] = t4.z; sv[3] = t4.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (n + e < g.N) sv[e] = sh[at + e];
+                }
+            }
+            float dot_h = 0.0f, dot_s = 0.0f;
+            float pre[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (EPI == EPI_DACT) {
+                    const float hv = g.s_in ? act_forward(g.act, sv[e]) : sv[e];
+                    dot_h = fmaf(c[e], hv, dot_h);
+                }
+                float v = rs * (c[e] + b[e]);
+                pre[e] = v;
+                if (EPI == EPI_ACT) v = act_forward(g.act, v);
+                if (EPI == EPI_DACT) {
+                    v *= act_derivative(g.act, sv[e]);
+                    dot_s = fmaf(v, sv[e], dot_s);
+                }
+                c[e] = v;
+            }
+            if (live) {
+                if (vec) {
+                    if (n < g.N) {
+                        *reinterpret_cast<float4 *>(g.out + at) = make_float4(c[0], c[1], c[2], c[3]);
+                        if (EPI == EPI_ACT && g.out2)
+                            *reinterpret_cast<float4 *>(g.out2 + at) =
+                                make_float4(pre[0], pre[1], pre[2], pre[3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (n + e < g.N) {
+                            g.out[at + e] = c[e];
+                            if (EPI == EPI_ACT && g.out2) g.out2[at + e] = pre[e];
+                        }
+                }
+            }
+            if (EPI == EPI_DACT) {
+                dot_h = group_sum<16>(dot_h);
+                dot_s = group_sum<16>(dot_s);
+                if (live && (lane & 15) == 0) {
+                    g.pdot_main[(size_t)p * g.pdot_ld + pslot] = dot_h;
+                    g.pdot_act[(size_t)p * g.pdot_ld + pslot] = dot_s;
                 }
             }
         }
+    }
+}
+
+// y[t, :] = bias + sum_{j < k} rows[pos[t * k + j], :]  -- the un-bucketing of the routed
+// FFN (reference: `y[mask] += ...` per block, lora_ffn.py:107-111): a gather in a fixed
+// order instead of a scatter-add, so the result is deterministic.
+__global__ __launch_bounds__(256) void rows_combine_kernel(
+    const float *__restrict__ rows, const int32_t *__restrict__ pos,
+    const float *__restrict__ bias, float *__restrict__ out, int n_tokens, int k, int d4) {
+    const int t = blockIdx.x;
+    for (int c = threadIdx.x; c < d4; c += 256) {
+        float4 acc = bias ? reinterpret_cast<const float4 *>(bias)[c]
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < k; j++) {
+            const int p = pos[(size_t)t * k + j];
+            const float4 v = reinterpret_cast<const float4 *>(rows + (size_t)p * d4 * 4)[c];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        reinterpret_cast<float4 *>(out + (size_t)t * d4 * 4)[c] = acc;
     }
 }
 
@@ -231,29 +425,87 @@ __global__ __launch_bounds__(GG_THREADS) void grouped_gemm_kernel(GroupedArgs g)
 
 using namespace spt;
 
+static int launch_grouped(const GroupedArgs &g, int epilogue, void *stream) {
+    if (!g.a || !g.w || !g.offsets || !g.out) return SPT_EINVAL;
+    if (g.P <= 0 || g.K <= 0 || g.N <= 0 || g.G <= 0 || g.lda < g.K) return SPT_EINVAL;
+    if (g.K % 4 != 0 || g.lda % 4 != 0) return SPT_ESHAPE;       // float4 rows of A
+    if (g.ldk != 1 && g.ldn != 1) return SPT_EUNSUP;
+    if (g.ldk == 1 && (g.ldn % 4 != 0 || g.gstride % 4 != 0)) return SPT_ESHAPE;
+    if (g.ldk != 1 && (g.ldk % 4 != 0 || g.N % 4 != 0 || g.gstride % 4 != 0)) return SPT_ESHAPE;
+    const bool ext = g.a2 != nullptr;
+    if (ext) {
+        if (!g.b2 || g.R <= 0 || g.R > GG_BK) return SPT_EINVAL;
+        if (g.R % 4 != 0 || g.lda2 % 4 != 0 || g.lda2 < g.R || g.b2_ldn % 4 != 0 ||
+            g.b2_gstride % 4 != 0)
+            return SPT_ESHAPE;
+    }
+    if (epilogue < EPI_PLAIN || epilogue > EPI_DACT) return SPT_EINVAL;
+    if (epilogue != EPI_PLAIN && (g.act < ACT_RELU || g.act > ACT_SILU)) return SPT_EUNSUP;
+    const unsigned row_tiles = (unsigned)((g.P + GG_BM - 1) / GG_BM + g.G);
+    const unsigned col_tiles = (unsigned)((g.N + GG_BN - 1) / GG_BN);
+    if (col_tiles > 65535) return SPT_EUNSUP;
+    if (epilogue == EPI_DACT) {
+        if ((!g.h_in && !g.s_in) || !g.pdot_main || !g.pdot_act) return SPT_EINVAL;
+        if (!g.s_in && g.act != ACT_RELU) return SPT_EINVAL;   // only ReLU is a function of h
+        if (g.pdot_ld < (int)(2 * col_tiles)) return SPT_ESHAPE;
+    }
+    dim3 grid(row_tiles, col_tiles);
+    hipStream_t s = (hipStream_t)stream;
+#define SPT_GG(BN, EPI, EXT)                                                                  \
+    hipLaunchKernelGGL((grouped_gemm_kernel<BN, EPI, EXT>), grid, dim3(GG_THREADS), 0, s, g)
+#define SPT_GG_EPI(BN, EXT)                                   \
+    do {                                                      \
+        if (epilogue == EPI_PLAIN) SPT_GG(BN, EPI_PLAIN, EXT); \
+        else if (epilogue == EPI_ACT) SPT_GG(BN, EPI_ACT, EXT); \
+        else SPT_GG(BN, EPI_DACT, EXT);                        \
+    } while (0)
+    if (g.ldk == 1) {
+        if (ext) SPT_GG_EPI(false, true); else SPT_GG_EPI(false, false);
+    } else {
+        if (ext) SPT_GG_EPI(true, true); else SPT_GG_EPI(true, false);
+    }
+#undef SPT_GG_EPI
+#undef SPT_GG
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
 extern "C" int spt_grouped_gemm(const float *a, const int32_t *gather, const float *w,
                                 const float *bias, const float *rowscale,
                                 const int32_t *offsets, float *out, int n_rows, int k, int n,
                                 int n_groups, int lda, long long w_group_stride, int w_ldn,
                                 int w_ldk, void *stream) {
-    if (!a || !w || !offsets || !out) return SPT_EINVAL;
-    if (n_rows <= 0 || k <= 0 || n <= 0 || n_groups <= 0 || lda < k) return SPT_EINVAL;
-    if (k % 4 != 0 || lda % 4 != 0) return SPT_ESHAPE;       // float4 rows of A
-    if (w_ldk != 1 && w_ldn != 1) return SPT_EUNSUP;
-    if (w_ldk == 1 && (w_ldn % 4 != 0 || w_group_stride % 4 != 0)) return SPT_ESHAPE;
-    if (w_ldk != 1 && (w_ldk % 4 != 0 || n % 4 != 0 || w_group_stride % 4 != 0)) return SPT_ESHAPE;
-    GroupedArgs g;
+    GroupedArgs g = {};
     g.a = a; g.gather = gather; g.w = w; g.bias = bias; g.rowscale = rowscale;
     g.offsets = offsets; g.out = out;
     g.P = n_rows; g.K = k; g.N = n; g.G = n_groups; g.lda = lda;
     g.gstride = w_group_stride; g.ldn = w_ldn; g.ldk = w_ldk;
-    const unsigned row_tiles = (unsigned)((n_rows + GG_BM - 1) / GG_BM + n_groups);
-    const unsigned col_tiles = (unsigned)((n + GG_BN - 1) / GG_BN);
-    if (col_tiles > 65535) return SPT_EUNSUP;
-    dim3 grid(row_tiles, col_tiles);
-    hipStream_t s = (hipStream_t)stream;
-    if (w_ldk == 1) hipLaunchKernelGGL((grouped_gemm_kernel<false>), grid, dim3(GG_THREADS), 0, s, g);
-    else hipLaunchKernelGGL((grouped_gemm_kernel<true>), grid, dim3(GG_THREADS), 0, s, g);
+    return launch_grouped(g, EPI_PLAIN, stream);
+}
+
+extern "C" int spt_grouped_gemm_pdot_width(int n) { return n > 0 ? 2 * ((n + GG_BN - 1) / GG_BN) : 0; }
+
+extern "C" int spt_grouped_gemm_fused(const SptGroupedGemm *d, void *stream) {
+    if (!d) return SPT_EINVAL;
+    GroupedArgs g = {};
+    g.a = d->a; g.gather = d->gather; g.w = d->w; g.bias = d->bias; g.rowscale = d->rowscale;
+    g.offsets = d->offsets; g.out = d->out;
+    g.P = d->n_rows; g.K = d->k; g.N = d->n; g.G = d->n_groups; g.lda = d->lda;
+    g.gstride = d->w_group_stride; g.ldn = d->w_ldn; g.ldk = d->w_ldk;
+    g.a2 = d->a2; g.gather2 = d->gather2; g.b2 = d->b2; g.lda2 = d->lda2; g.R = d->r;
+    g.b2_gstride = d->b2_group_stride; g.b2_ldn = d->b2_ldn;
+    g.act = d->activation; g.out2 = d->out2; g.h_in = d->h_in; g.s_in = d->s_in;
+    g.pdot_main = d->pdot_main; g.pdot_act = d->pdot_act; g.pdot_ld = d->pdot_ld;
+    return launch_grouped(g, d->epilogue, stream);
+}
+
+extern "C" int spt_rows_combine(const float *rows, const int32_t *pos, const float *bias,
+                                float *out, int n_tokens, int k, int d, void *stream) {
+    if (!rows || !pos || !out) return SPT_EINVAL;
+    if (n_tokens <= 0 || k <= 0 || d <= 0) return SPT_EINVAL;
+    if (d % 4 != 0) return SPT_ESHAPE;
+    hipLaunchKernelGGL(rows_combine_kernel, dim3((unsigned)n_tokens), dim3(256), 0,
+                       (hipStream_t)stream, rows, pos, bias, out, n_tokens, k, d / 4);
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }

@@ -45,12 +45,15 @@ _PROTOTYPES = {
     'spt_spmm_transposed': ([_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr], _c_int),
     'spt_grouped_gemm': ([_c_ptr] * 7 + [_c_int] * 5 + [ctypes.c_longlong, _c_int, _c_int, _c_ptr],
                          _c_int),
+    'spt_grouped_gemm_fused': ([_c_ptr, _c_ptr], _c_int),
+    'spt_grouped_gemm_pdot_width': ([_c_int], _c_int),
+    'spt_rows_combine': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_forward': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_backward': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 
@@ -550,6 +553,109 @@ def grouped_gemm(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Tensor,
         )
     if rc != 0:
         _raise(lib, rc, 'grouped_gemm')
+    return out
+
+
+class _GroupedDesc(ctypes.Structure):
+    """``SptGroupedGemm`` of include/spt_hip.h."""
+    _fields_ = [
+        ('a', _c_ptr), ('gather', _c_ptr), ('w', _c_ptr), ('bias', _c_ptr),
+        ('rowscale', _c_ptr), ('offsets', _c_ptr), ('out', _c_ptr),
+        ('n_rows', ctypes.c_int32), ('k', ctypes.c_int32), ('n', ctypes.c_int32),
+        ('n_groups', ctypes.c_int32), ('lda', ctypes.c_int32),
+        ('w_group_stride', ctypes.c_int64), ('w_ldn', ctypes.c_int32), ('w_ldk', ctypes.c_int32),
+        ('a2', _c_ptr), ('gather2', _c_ptr), ('b2', _c_ptr),
+        ('lda2', ctypes.c_int32), ('r', ctypes.c_int32),
+        ('b2_group_stride', ctypes.c_int64), ('b2_ldn', ctypes.c_int32),
+        ('epilogue', ctypes.c_int32), ('activation', ctypes.c_int32),
+        ('out2', _c_ptr), ('h_in', _c_ptr), ('s_in', _c_ptr),
+        ('pdot_main', _c_ptr), ('pdot_act', _c_ptr), ('pdot_ld', ctypes.c_int32),
+    ]
+
+
+EPI_PLAIN, EPI_ACT, EPI_DACT = 0, 1, 2
+ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Tensor,
+                       n_groups: int, n: int, k: int, w_group_stride: int, w_ldn: int,
+                       w_ldk: int, n_rows: int, gather=None, bias=None, rowscale=None,
+                       a2=None, gather2=None, b2=None, b2_group_stride: int = 0,
+                       epilogue: int = EPI_PLAIN, activation: int = ACT_RELU,
+                       keep_preact: bool = False, h_in=None, s_in=None):
+    """``spt_grouped_gemm_fused``: the block GEMM of a routed FFN with its LoRA side
+    product, rowscale / bias, and the activation (EPI_ACT) or its derivative plus the two
+    row dots of the coefficient gradient (EPI_DACT) folded in (include/spt_hip.h).
+
+    Returns ``out`` (EPI_PLAIN), ``(out, preact | None)`` (EPI_ACT) or
+    ``(out, dot_main [P], dot_act [P])`` (EPI_DACT)."""
+    for t, name in ((a, 'a'), (weight, 'weight')):
+        _check_type(t, torch.float32, name)
+    _check_type(offsets, torch.int32, 'offsets')
+    _require(a.dim() == 2 and a.stride(1) == 1, 'a must be [rows, k] with unit inner stride')
+    _require(weight.is_contiguous(), 'weight must be contiguous')
+    dev = _same_device(a, weight, offsets)
+    for t, name in ((gather, 'gather'), (gather2, 'gather2')):
+        if t is not None:
+            _check_type(t, torch.int32, name)
+    for t in (gather, bias, rowscale, a2, gather2, b2, h_in, s_in):
+        if t is not None:
+            _require(t.is_cuda and t.is_contiguous(), 'grouped_gemm_fused: contiguous CUDA operands')
+    lib = load_library()
+    with torch.cuda.device(dev):
+        out = torch.empty([n_rows, n], dtype=torch.float32, device=dev)
+        preact = dot_main = dot_act = None
+        if epilogue == EPI_ACT and keep_preact:
+            preact = torch.empty_like(out)
+        width = lib.spt_grouped_gemm_pdot_width(n)
+        if epilogue == EPI_DACT:
+            dot_main = torch.empty([n_rows, width], dtype=torch.float32, device=dev)
+            dot_act = torch.empty([n_rows, width], dtype=torch.float32, device=dev)
+        if n_rows > 0:
+            desc = _GroupedDesc(
+                a=_ptr(a), gather=_ptr(gather), w=_ptr(weight), bias=_ptr(bias),
+                rowscale=_ptr(rowscale), offsets=_ptr(offsets), out=_ptr(out),
+                n_rows=n_rows, k=k, n=n, n_groups=n_groups, lda=a.stride(0),
+                w_group_stride=w_group_stride, w_ldn=w_ldn, w_ldk=w_ldk,
+                a2=_ptr(a2), gather2=_ptr(gather2), b2=_ptr(b2),
+                lda2=a2.stride(0) if a2 is not None else 0,
+                r=a2.size(1) if a2 is not None else 0,
+                b2_group_stride=b2_group_stride,
+                b2_ldn=b2.stride(-2) if b2 is not None else 0,
+                epilogue=epilogue, activation=activation, out2=_ptr(preact),
+                h_in=_ptr(h_in), s_in=_ptr(s_in), pdot_main=_ptr(dot_main),
+                pdot_act=_ptr(dot_act), pdot_ld=width)
+            rc = lib.spt_grouped_gemm_fused(ctypes.byref(desc), _stream(dev))
+            if rc != 0:
+                _raise(lib, rc, 'grouped_gemm_fused')
+    if epilogue == EPI_ACT:
+        return out, preact
+    if epilogue == EPI_DACT:
+        return out, dot_main.sum(dim=-1), dot_act.sum(dim=-1)
+    return out
+
+
+def rows_combine(rows: torch.Tensor, pos: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
+    """out[t] = bias + sum_j rows[pos[t, j]] (``spt_rows_combine``); pos [T, k] int32."""
+    _check_type(rows, torch.float32, 'rows')
+    _check_type(pos, torch.int32, 'pos')
+    _require(rows.dim() == 2 and rows.is_contiguous() and pos.dim() == 2 and pos.is_contiguous(),
+             'rows [P, d], pos [T, k] contiguous')
+    dev = _same_device(rows, pos)
+    T, k = pos.shape
+    d = rows.size(1)
+    lib = load_library()
+    with torch.cuda.device(dev):
+        out = torch.empty([T, d], dtype=torch.float32, device=dev)
+        if T > 0:
+            rc = lib.spt_rows_combine(rows.data_ptr(), pos.data_ptr(), _ptr(bias), out.data_ptr(),
+                                      T, k, d, _stream(dev))
+            if rc != 0:
+                _raise(lib, rc, 'rows_combine')
     return out
 
 

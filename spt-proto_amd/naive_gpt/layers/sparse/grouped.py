@@ -25,6 +25,7 @@ class Buckets(NamedTuple):
     offsets: torch.Tensor   # [G + 1] int32, device
     coeff: torch.Tensor     # [P] router probability of (token, block), differentiable
     n_blocks: int
+    pos: torch.Tensor       # [T, k] int32: the rows of each token (inverse of `token`)
 
 
 def make_buckets(prob: torch.Tensor, k: int) -> Buckets:
@@ -39,8 +40,12 @@ def make_buckets(prob: torch.Tensor, k: int) -> Buckets:
     offsets = torch.zeros([n_blocks + 1], dtype=torch.int32, device=prob.device)
     offsets[1:] = torch.cumsum(counts, dim=0)
     coeff = prob.reshape(-1).index_select(0, token_long * n_blocks + block_sorted)
+    # row p holds the flat (token, choice) pair order[p]: invert the permutation
+    pos = torch.empty_like(order)
+    pos[order] = torch.arange(order.numel(), device=order.device)
     return Buckets(token=token_long.int(), token_long=token_long, block=block_sorted,
-                   offsets=offsets, coeff=coeff, n_blocks=n_blocks)
+                   offsets=offsets, coeff=coeff, n_blocks=n_blocks,
+                   pos=pos.view(n_tokens, k).int())
 
 
 class GroupedLinear(torch.autograd.Function):
@@ -100,3 +105,132 @@ def usable(x: torch.Tensor, *frozen_weights) -> bool:
         if w.requires_grad or not w.is_contiguous() or w.dtype != torch.float32:
             return False
     return True
+
+
+# ---------------------------------------------------------------- the fused LoRA routed FFN
+
+def activation_code(module):
+    """ext activation id of an nn activation module, or None when the fused epilogue does
+    not implement it (the caller then composes the layer from grouped_linear + torch)."""
+    from torch import nn
+    if isinstance(module, nn.ReLU):
+        return ext.ACT_RELU
+    if isinstance(module, nn.GELU) and getattr(module, 'approximate', 'none') == 'none':
+        return ext.ACT_GELU
+    if isinstance(module, nn.SiLU):
+        return ext.ACT_SILU
+    return None
+
+
+def _own_block(wide: torch.Tensor, block: torch.Tensor, n_blocks: int) -> torch.Tensor:
+    """[P, nb * r] -> [P, r]: row p keeps the r columns of its own block."""
+    rows, r = wide.size(0), wide.size(1) // n_blocks
+    index = block.view(rows, 1, 1).expand(rows, 1, r)
+    return wide.view(rows, n_blocks, r).gather(1, index).squeeze(1)
+
+
+def _in_own_block(narrow: torch.Tensor, block: torch.Tensor, n_blocks: int) -> torch.Tensor:
+    """[P, r] -> [P, nb * r], zero outside the row's own block (adjoint of _own_block)."""
+    rows, r = narrow.shape
+    wide = torch.zeros([rows, n_blocks, r], dtype=narrow.dtype, device=narrow.device)
+    wide.scatter_(1, block.view(rows, 1, 1).expand(rows, 1, r), narrow.unsqueeze(1))
+    return wide.view(rows, n_blocks * r)
+
+
+def _block_major(cat: torch.Tensor, n_blocks: int) -> torch.Tensor:
+    """[bs, nb * r] -> [nb * bs, r] (the layout of a LoRA table over d_feedforward)."""
+    bs = cat.size(0)
+    return cat.view(bs, n_blocks, -1).permute(1, 0, 2).reshape(n_blocks * bs, -1)
+
+
+def _block_cat(table: torch.Tensor, n_blocks: int) -> torch.Tensor:
+    """[nb * bs, r] -> [bs, nb * r]: all blocks' slices side by side."""
+    bs = table.size(0) // n_blocks
+    return table.view(n_blocks, bs, -1).permute(1, 0, 2).reshape(bs, -1)
+
+
+def _tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    from naive_gpt.layers.tuning.lora import tall_tn
+    return tall_tn(a, b)
+
+
+class RoutedLoRAFFN(torch.autograd.Function):
+    """y = LoRARoutedFFN(x) for frozen base weights (reference formula:
+    naive_gpt/layers/tuning/lora_ffn.py:87-111), as four fused block GEMMs:
+
+        h  = act(c (x W1_g^T + b1_g) + (x L1) R1_g^T)          spt_grouped_gemm_fused, EPI_ACT
+        ys = c (h W2_g) + (h L2_g) R2^T                        spt_grouped_gemm_fused
+        y  = b2 + sum over the token's rows of ys              spt_rows_combine
+      backward
+        ds = (c (dy W2_g^T) + (dy R2) L2_g^T) * act'(s)        EPI_DACT, + the two row dots
+        dx = sum over the token's rows of c (ds W1_g) + (ds R1_g) L1^T
+
+    Saved for backward: h (and the pre-activation only when act is not ReLU), the two
+    [*, r] LoRA intermediates -- against ~8 [P, d] tensors of the op-by-op composition.
+    The small [*, r] products and the LoRA table gradients stay torch matmuls.
+    """
+
+    @staticmethod
+    def forward(ctx, x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk: Buckets, act: int):
+        nb = bk.n_blocks
+        d_ff, d = w1.shape
+        bs, rank, rows = d_ff // nb, l1.size(1), bk.token.numel()
+        x, coeff = x.contiguous(), coeff.contiguous()
+        u = torch.matmul(x, l1)                                              # [T, r]
+        h, s = ext.grouped_gemm_fused(
+            x, w1, bk.offsets, nb, n=bs, k=d, w_group_stride=bs * d, w_ldn=d, w_ldk=1,
+            n_rows=rows, gather=bk.token, bias=b1, rowscale=coeff,
+            a2=u, gather2=bk.token, b2=r1, b2_group_stride=bs * rank,
+            epilogue=ext.EPI_ACT, activation=act, keep_preact=(act != ext.ACT_RELU))
+        z = _own_block(torch.matmul(h, _block_cat(l2, nb)), bk.block, nb).contiguous()   # [P, r]
+        ys = ext.grouped_gemm_fused(
+            h, w2, bk.offsets, nb, n=d, k=bs, w_group_stride=bs, w_ldn=d_ff, w_ldk=1,
+            n_rows=rows, rowscale=coeff, a2=z, b2=r2, b2_group_stride=0)
+        y = ext.rows_combine(ys, bk.pos, bias=b2)
+        ctx.bk, ctx.act = bk, act
+        ctx.save_for_backward(x, coeff, u, h, s, z, l1, r1, l2, r2, w1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, coeff, u, h, s, z, l1, r1, l2, r2, w1, w2 = ctx.saved_tensors
+        bk, act = ctx.bk, ctx.act
+        nb = bk.n_blocks
+        d_ff, d = w1.shape
+        bs, rank, rows = d_ff // nb, l1.size(1), bk.token.numel()
+        pos = bk.pos.long()
+        dy = dy.contiguous()
+        dzt = torch.matmul(dy, r2)                                           # [T, r]
+        ds, dot_main, dot_act = ext.grouped_gemm_fused(
+            dy, w2, bk.offsets, nb, n=bs, k=d, w_group_stride=bs, w_ldn=1, w_ldk=d_ff,
+            n_rows=rows, gather=bk.token, rowscale=coeff,
+            a2=dzt, gather2=bk.token, b2=l2, b2_group_stride=bs * rank,
+            epilogue=ext.EPI_DACT, activation=act, h_in=h, s_in=s)
+        du = _own_block(torch.matmul(ds, _block_cat(r1, nb)), bk.block, nb).contiguous()  # [P, r]
+        u_rows = u.index_select(0, bk.token_long)
+        # d/dc: <dy W2_g^T, h> + <ds, x W1_g^T + b1_g>, the second through
+        # s = c (x W1^T + b1) + u R1^T  =>  x W1^T + b1 = (s - u R1^T) / c
+        # (the kernel's dot_main still contains the LoRA term <dzt, h L2_g> / c = <dzt, z> / c)
+        dz_rows = dzt.index_select(0, bk.token_long)
+        grad_coeff = dot_main + (dot_act - (du * u_rows).sum(dim=-1)
+                                 - (dz_rows * z).sum(dim=-1)) / coeff
+        dxs = ext.grouped_gemm_fused(
+            ds, w1, bk.offsets, nb, n=d, k=bs, w_group_stride=bs * d, w_ldn=1, w_ldk=d,
+            n_rows=rows, rowscale=coeff, a2=du, b2=l1, b2_group_stride=0)
+        grad_x = ext.rows_combine(dxs, bk.pos)
+        # LoRA tables
+        du_tok = du[pos].sum(dim=1)                                          # [T, r]
+        grad_l1 = _tn(x, du_tok)
+        grad_r1 = _block_major(_tn(ds, _in_own_block(u_rows, bk.block, nb)), nb)
+        grad_l2 = _block_major(_tn(h, _in_own_block(dz_rows, bk.block, nb)), nb)
+        grad_r2 = _tn(dy, z[pos].sum(dim=1))
+        return (grad_x, grad_coeff, grad_l1, grad_r1, grad_l2, grad_r2,
+                None, None, None, None, None, None)
+
+
+def routed_lora_ffn(x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk: Buckets, act: int):
+    return RoutedLoRAFFN.apply(x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk, act)
+
+
+def fused_usable(rank: int) -> bool:
+    return rank % 4 == 0 and 0 < rank <= 32

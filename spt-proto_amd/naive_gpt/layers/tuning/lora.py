@@ -38,6 +38,52 @@ def _load_base(model: nn.Module, source: nn.Module):
     return model
 
 
+def tall_tn(a: torch.Tensor, b: torch.Tensor, chunk: int = 256) -> torch.Tensor:
+    """a^T @ b for tall a [R, m], b [R, n] with a small m or n -- the shape of every LoRA
+    table gradient (R = tokens, one side = rank).  As a single GEMM its [m, n] output is
+    a handful of workgroups on a 256-CU part (34 us for 1024 x 16 x 8192, 116 us for
+    1024 x 64 x 16384 measured); split over R into a batched product plus a sum it fills
+    the chip.  Falls back to one matmul for short or ragged R."""
+    rows = a.size(0)
+    if not a.is_cuda or rows % chunk != 0 or rows < 8 * chunk:
+        return torch.matmul(a.t(), b)
+    parts = rows // chunk
+    out = torch.bmm(a.reshape(parts, chunk, a.size(1)).transpose(1, 2),
+                    b.reshape(parts, chunk, b.size(1)))
+    return out.sum(dim=0)
+
+
+class _FrozenLoRALinear(torch.autograd.Function):
+    """y = x W^T + b + (x L) R^T with W, b frozen (the reference's forward,
+    lora.py:70-80, differentiated by hand): the side product is accumulated into the base
+    product by the GEMM epilogue (addmm, beta = 1) instead of a separate elementwise pass,
+    no weight gradient is formed, and the two table gradients use tall_tn."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, left, right):
+        x2 = x.reshape(-1, x.size(-1))
+        u = torch.matmul(x2, left)                                   # [T, r]
+        y = nn.functional.linear(x2, weight, bias)
+        y.addmm_(u, right.t())
+        ctx.save_for_backward(x2, u, weight, left, right)
+        ctx.x_shape = x.shape
+        return y.view(*x.shape[:-1], weight.size(0))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, u, weight, left, right = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.size(-1))
+        du = torch.matmul(dy2, right)                                # [T, r]
+        grad_x = None
+        if ctx.needs_input_grad[0]:
+            grad_x = torch.matmul(dy2, weight)
+            grad_x.addmm_(du, left.t())
+            grad_x = grad_x.view(ctx.x_shape)
+        grad_left = tall_tn(x2, du) if ctx.needs_input_grad[3] else None
+        grad_right = tall_tn(dy2, u) if ctx.needs_input_grad[4] else None
+        return grad_x, None, None, grad_left, grad_right
+
+
 class LoRALinear(nn.Linear):
     def __init__(self, d_lora: int, in_features: int, out_features: int,
                  bias: bool = True, *args, **kwargs):
@@ -55,6 +101,11 @@ class LoRALinear(nn.Linear):
         return _load_base(model, source)
 
     def forward(self, x: torch.Tensor):
+        frozen = not self.weight.requires_grad and (self.bias is None
+                                                    or not self.bias.requires_grad)
+        if frozen and x.is_cuda and x.dim() >= 2:
+            return _FrozenLoRALinear.apply(x, self.weight, self.bias,
+                                           self.lora.left.weight, self.lora.right.weight)
         y = nn.functional.linear(x, bias=self.bias, weight=self.weight)
         y += torch.matmul(torch.matmul(x, self.lora.left.weight),
                           self.lora.right.weight.T)

@@ -55,6 +55,14 @@ class LoRARoutedFFN(layers.RoutedFFN):
         prob = self.router(x)
         bk = grouped.make_buckets(prob, k=nb // 2)
         coeff = (2.0 * bk.coeff).contiguous()
+        act = grouped.activation_code(self.activation)
+        if act is not None and grouped.fused_usable(r) and self.fc2.bias is not None \
+                and not self.fc2.bias.requires_grad:
+            # four fused block GEMMs (layers/sparse/grouped.py: RoutedLoRAFFN)
+            return grouped.routed_lora_ffn(
+                x, coeff, self.fc1.lora.left.weight, self.fc1.lora.right.weight,
+                self.fc2.lora.left.weight, self.fc2.lora.right.weight,
+                self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, bk, act)
         rows = torch.arange(bk.block.numel(), device=x.device)
 
         g1 = grouped.grouped_linear(

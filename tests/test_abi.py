@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), name
     lib.spt_abi_version.restype = ctypes.c_int
-    assert lib.spt_abi_version() == 6
+    header_version = int(re.search(r'#define SPT_ABI_VERSION (\d+)', open(HEADER).read()).group(1))
+    assert lib.spt_abi_version() == header_version
     lib.spt_strerror.restype = ctypes.c_char_p
     lib.spt_strerror.argtypes = [ctypes.c_int]
     assert lib.spt_strerror(0) == b'ok'

@@ -130,3 +130,163 @@ def test_routed_ffn_grouped_path_equals_torch_path(kind):
     assert set(g1) == set(g2)
     for n in g1:
         assert torch.allclose(g1[n], g2[n], rtol=2e-3, atol=2e-4), n
+
+
+# ------------------------------------------------------------------ fused epilogues
+
+def _act(name):
+    return {'relu': torch.relu, 'gelu': lambda t: nn.functional.gelu(t),
+            'silu': nn.functional.silu}[name]
+
+
+def _act_code(name):
+    from naive_gpt import ext
+    return {'relu': ext.ACT_RELU, 'gelu': ext.ACT_GELU, 'silu': ext.ACT_SILU}[name]
+
+
+def _fused_case(P, K, N, G, R, layout, seed):
+    gen = torch.Generator().manual_seed(seed)
+    T = max(P // 2, 8)
+    a = torch.randn([T, K], generator=gen)
+    gather = torch.randint(0, T, [P], generator=gen, dtype=torch.int32)
+    cuts = sorted(torch.randint(0, P + 1, [G - 1], generator=gen).tolist())
+    if G > 2:
+        cuts[1] = cuts[0]
+    offsets = [0] + cuts + [P]
+    bias = torch.randn([G, N], generator=gen)
+    scale = torch.rand([P], generator=gen) + 0.5
+    if layout == 'bt':
+        w = torch.randn([G * N, K], generator=gen)
+        view = (N, K, N * K, K, 1)
+    else:
+        w = torch.randn([K, G * N], generator=gen)
+        view = (N, K, N, 1, G * N)
+    a2 = torch.randn([T, R], generator=gen)
+    b2 = torch.randn([G * N, R], generator=gen)          # block g = rows g*N .. (g+1)*N
+    base = ref_grouped(a, gather, w, view, bias, scale, offsets)
+    side = torch.zeros_like(base)
+    for g in range(G):
+        lo, hi = offsets[g], offsets[g + 1]
+        rows = gather[lo:hi].long()
+        side[lo:hi] = a2[rows].double() @ b2[g * N:(g + 1) * N].double().T
+    return dict(a=a, gather=gather, w=w, view=view, bias=bias, scale=scale, offsets=offsets,
+                a2=a2, b2=b2, base=base, side=side)
+
+
+def _call_fused(c, **kw):
+    from naive_gpt import ext
+    N, K, gs, ldn, ldk = c['view']
+    G = len(c['offsets']) - 1
+    dev = 'cuda'
+    return ext.grouped_gemm_fused(
+        c['a'].to(dev), c['w'].to(dev), torch.tensor(c['offsets'], dtype=torch.int32, device=dev),
+        G, n=N, k=K, w_group_stride=gs, w_ldn=ldn, w_ldk=ldk, n_rows=len(c['gather']),
+        gather=c['gather'].to(dev), bias=c['bias'].to(dev), rowscale=c['scale'].to(dev),
+        a2=c['a2'].to(dev), gather2=c['gather'].to(dev), b2=c['b2'].to(dev),
+        b2_group_stride=N * c['b2'].size(1), **kw)
+
+
+def _close64(got, want, what, rtol=1e-3):
+    got = got.detach().double().cpu()
+    scale = want.abs().max().item() + 1e-12
+    err = (got - want).abs().max().item()
+    assert err <= rtol * scale, '{}: max err {:.3e} vs scale {:.3e}'.format(what, err, scale)
+
+
+@pytest.mark.parametrize('P,K,N,G,R,layout', [
+    (1000, 64, 128, 4, 16, 'bt'), (1000, 64, 128, 4, 16, 'bn'),
+    (770, 36, 200, 3, 4, 'bt'), (770, 36, 200, 3, 4, 'bn'),      # tails in K, N; rank 4
+    (513, 128, 72, 4, 32, 'bt'),                                  # rank 32 = one full k-step
+])
+def test_fused_second_term_is_added_after_rowscale(P, K, N, G, R, layout):
+    from naive_gpt import ext
+    c = _fused_case(P, K, N, G, R, layout, seed=P + R)
+    out = _call_fused(c, epilogue=ext.EPI_PLAIN)
+    _close64(out, c['base'] + c['side'], 'out')
+
+
+@pytest.mark.parametrize('act', ['relu', 'gelu', 'silu'])
+@pytest.mark.parametrize('layout', ['bt', 'bn'])
+def test_fused_activation_epilogue(act, layout):
+    from naive_gpt import ext
+    c = _fused_case(900, 64, 200, 4, 8, layout, seed=11)
+    s_want = c['base'] + c['side']
+    out, pre = _call_fused(c, epilogue=ext.EPI_ACT, activation=_act_code(act), keep_preact=True)
+    _close64(pre, s_want, 'preact')
+    _close64(out, _act(act)(s_want), 'act')
+    out2, none = _call_fused(c, epilogue=ext.EPI_ACT, activation=_act_code(act))
+    assert none is None and torch.equal(out, out2)
+
+
+@pytest.mark.parametrize('act', ['relu', 'gelu', 'silu'])
+@pytest.mark.parametrize('layout', ['bt', 'bn'])
+def test_fused_activation_derivative_epilogue_and_row_dots(act, layout):
+    from naive_gpt import ext
+    c = _fused_case(900, 64, 200, 4, 8, layout, seed=12)
+    gen = torch.Generator().manual_seed(3)
+    s = torch.randn([900, 200], generator=gen)
+    h = _act(act)(s)
+    sd = s.double().requires_grad_(True)
+    deriv = torch.autograd.grad(_act(act)(sd).sum(), sd)[0]
+    want = (c['base'] + c['side']) * deriv
+    plain = ref_grouped(c['a'], c['gather'], c['w'], c['view'], None, None, c['offsets'])
+    kw = dict(h_in=h.cuda(), s_in=None if act == 'relu' else s.cuda())
+    out, dot_main, dot_act = _call_fused(c, epilogue=ext.EPI_DACT, activation=_act_code(act), **kw)
+    _close64(out, want, 'out')
+    # dot_main: t = v / rowscale - bias = k-sum + second term / rowscale
+    t = plain + c['side'] / c['scale'].double()[:, None]
+    _close64(dot_main, (t * h.double()).sum(-1), 'dot_main')
+    s_like = h.double() if act == 'relu' else s.double()
+    _close64(dot_act, (want * s_like).sum(-1), 'dot_act')
+
+
+def test_rows_combine_is_a_fixed_order_gather_sum():
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(9)
+    rows = torch.randn([600, 72], generator=gen).cuda()
+    pos = torch.randperm(600, generator=gen).view(200, 3).int().cuda()
+    bias = torch.randn([72], generator=gen).cuda()
+    want = rows[pos.long()].sum(1) + bias
+    got = ext.rows_combine(rows, pos, bias)
+    assert torch.allclose(got, want, atol=1e-5)
+    assert torch.equal(got, ext.rows_combine(rows, pos, bias))
+    assert torch.allclose(ext.rows_combine(rows, pos), rows[pos.long()].sum(1), atol=1e-5)
+
+
+@pytest.mark.parametrize('act', [nn.ReLU(), nn.GELU(), nn.SiLU()])
+def test_fused_lora_routed_ffn_equals_torch_loop(act):
+    """The layer through RoutedLoRAFFN (4 fused launches) against its own per-block torch
+    loop (the reference-shaped path that the CPU goldens pin), values and every gradient."""
+    from naive_gpt import layers
+    from naive_gpt.layers.sparse import grouped
+    torch.manual_seed(0)
+    ffn = layers.LoRARoutedFFN(d_lora=8, block_size=64, d_model=64, d_feedforward=256,
+                               activation=act).cuda()
+    gen = torch.Generator().manual_seed(1)
+    for name, p in ffn.named_parameters():
+        if name.endswith('lora.right.weight'):
+            p.data.copy_(0.1 * torch.randn(p.shape, generator=gen).cuda())
+    x = torch.randn([3, 50, 64], generator=gen).cuda()
+    w = torch.randn([3, 50, 64], generator=gen).cuda()
+
+    def run(fused):
+        ffn.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        saved = grouped.usable
+        if not fused:
+            grouped.usable = lambda *a, **k: False
+        try:
+            y = ffn(xi)
+        finally:
+            grouped.usable = saved
+        (y * w).sum().backward()
+        return y.detach(), xi.grad, {n: p.grad.clone() for n, p in ffn.named_parameters()
+                                     if p.grad is not None}
+
+    y0, gx0, g0 = run(False)
+    y1, gx1, g1 = run(True)
+    assert torch.allclose(y1, y0, rtol=1e-3, atol=1e-4)
+    assert torch.allclose(gx1, gx0, rtol=1e-3, atol=1e-4)
+    assert set(g0) == set(g1) and len(g0) >= 6
+    for n in g0:
+        assert torch.allclose(g1[n], g0[n], rtol=2e-3, atol=2e-4), n
