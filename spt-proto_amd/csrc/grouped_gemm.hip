@@ -17,13 +17,15 @@
 // (ceil(P/128) + G row tiles) and every workgroup finds its bucket from `offsets`.
 //
 // This is the one place of the hot path where the contraction is dense, so it runs on
-// the matrix cores: v_mfma_f32_32x32x2_f32, exact fp32 (a k-ordered fmaf chain), 157 TF
+// the matrix cores: v_mfma_f32_32x32x2_f32, exact fp32 (a fixed-order fmaf chain), 157 TF
 // peak (MI355X_MICROARCH "Matrix cores").  128 x 128 output tile per 256-thread
 // workgroup, each wave a 64 x 64 quadrant (2 x 2 MFMA tiles, 64 accumulator registers);
-// K is consumed in steps of 32 through LDS.  LDS image of an operand tile: [row][2][16]
-// floats -- the k's of one parity contiguous -- because lane l of the MFMA needs
-// k = k0 + (l >> 5): one ds_read_b128 then feeds four consecutive MFMAs.  Rows are
-// padded by 16 bytes, which makes the b128 reads of 32 consecutive rows conflict-free.
+// K is consumed in steps of 32 through LDS.  LDS image of an operand tile: [row][k] in
+// natural order; an MFMA contracts two k's, one from each half of the wave, and any
+// pairing is a valid summation order, so lane l takes k = 8 q + 4 (l >> 5) + e for step e
+// of group q: one ds_read_b128 feeds four consecutive MFMAs and the staging store is one
+// ds_write_b128 of the float4 that came from global memory (no register shuffling).  Rows
+// are padded by 16 bytes, which makes the b128 reads of 16 consecutive rows conflict-free.
 #include "spt_common.h"
 
 namespace spt {
@@ -31,7 +33,13 @@ namespace spt {
 constexpr int GG_THREADS = 256;
 constexpr int GG_BM = 128;
 constexpr int GG_BN = 128;
-constexpr int GG_BK = 32;
+#ifndef GG_BK_VALUE
+#define GG_BK_VALUE 32
+#endif
+constexpr int GG_BK = GG_BK_VALUE;
+constexpr int GG_KQ = GG_BK / 4;               // float4 per tile row
+constexpr int GG_RPP = GG_THREADS / GG_KQ;      // tile rows staged per pass
+constexpr int GG_NU = GG_BM / GG_RPP;           // passes (float4 loads per thread per operand)
 constexpr int GG_ROW = GG_BK + 4;    // floats per LDS row of a k-contiguous tile (16-byte pad)
 constexpr int GG_BNROW = GG_BN + 4;  // floats per LDS row of an n-contiguous weight tile
 
@@ -68,6 +76,7 @@ struct GroupedArgs {
     float *pdot_main;       // EPI_DACT: [P, pdot_ld]: sum_n (v / rowscale - bias)[p, n] * h[p, n]
     float *pdot_act;        // EPI_DACT: [P, pdot_ld]: sum_n out[p, n] * s[p, n] per half tile
     int pdot_ld;
+    int slots;              // workgroups resident at a time (CUs x occupancy)
 };
 
 __device__ __forceinline__ float act_forward(int act, float s) {
@@ -86,68 +95,94 @@ __device__ __forceinline__ float act_derivative(int act, float s) {
     return sg * (1.0f + s * (1.0f - sg));
 }
 
-template <bool BN_LAYOUT, int EPI, bool EXT>
-// two workgroups per CU (256 VGPRs); the EPI_DACT epilogue spills ~25 registers, outside
-// the k loop
-__global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_kernel(GroupedArgs g) {
-    // As | Bs; the epilogue reuses the whole buffer as four per-wave C staging areas
-    __shared__ __attribute__((aligned(16))) float smem[(GG_BM + GG_BN) * GG_ROW];
+// One output tile of BM x 128: BM = 128 (each wave a 64 x 64 quadrant) or BM = 64 (each
+// wave 32 x 64), same B tile, same LDS image, same epilogue.
+template <int BM, bool BN_LAYOUT, int EPI, bool EXT, bool KTAIL>
+__device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int bucket,
+                                          int row_lo, int row_hi, int col_tile) {
+    constexpr int NI = BM / 64;               // 32-row sub-blocks per wave
+    constexpr int NUA = BM / GG_RPP;          // float4 of A per thread per k-step
     float *As = smem;
     float *Bs = smem + GG_BM * GG_ROW;
-
-    // ---- which bucket / row tile is this workgroup? ----
-    int bucket = -1, row_lo = 0, row_hi = 0;
-    {
-        int tile = blockIdx.x;
-        for (int i = 0; i < g.G; i++) {
-            const int lo = g.offsets[i], hi = g.offsets[i + 1];
-            const int tiles = (hi - lo + GG_BM - 1) / GG_BM;
-            if (tile < tiles) {
-                bucket = i;
-                row_lo = lo + tile * GG_BM;
-                row_hi = min(hi, row_lo + GG_BM);
-                break;
-            }
-            tile -= tiles;
-        }
-    }
-    if (bucket < 0) return;  // uniform for the workgroup
-    const int n0 = blockIdx.y * GG_BN;
+    const int n0 = col_tile * GG_BN;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = (wave >> 1) * 64;  // quadrant origin inside the tile
+    const int wm = (wave >> 1) * (BM / 2);    // the wave's origin inside the tile
     const int wn = (wave & 1) * 64;
     const float *wg = g.w + (size_t)bucket * g.gstride;
 
-    // ---- staging assignment: tile = 128 rows x 8 float4 along k ----
-    // A (and BT weights): thread -> row (tid >> 3) + 32 u, k-quad tid & 7
-    const int s_row = tid >> 3, s_kq = tid & 7;
-    const float *a_src[4];
-    bool a_ok[4];
+    // ---- staging assignment: tile = rows x GG_KQ float4 along k ----
+    // thread -> row (tid / GG_KQ) + GG_RPP u, k-quad tid % GG_KQ
+    const int s_row = tid / GG_KQ, s_kq = tid % GG_KQ;
+    // Rows past the bucket end and columns past N are computed but never stored, so their
+    // operands only have to be readable: clamp them to the last valid row / column instead
+    // of predicating the loads.
+    const float *a_src[NUA];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int p = row_lo + s_row + 32 * u;
-        a_ok[u] = p < row_hi;
-        const int src = a_ok[u] ? (g.gather ? g.gather[p] : p) : 0;
+    for (int u = 0; u < NUA; u++) {
+        const int p = min(row_lo + s_row + GG_RPP * u, row_hi - 1);
+        const int src = g.gather ? g.gather[p] : p;
         a_src[u] = g.a + (size_t)src * g.lda;
     }
-
-    f32x16 acc[2][2];
+    const float *b_src[GG_NU];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int u = 0; u < GG_NU; u++)
+        b_src[u] = wg + (size_t)min(n0 + s_row + GG_RPP * u, g.N - 1) * g.ldn;
+    const float *bn_src = wg + min(n0 + 4 * (tid & 31), g.N - 4);
+
+    f32x16 acc[NI][2];
+#pragma unroll
+    for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    const int frow = lane & 31, fh = lane >> 5;
+    // MFMA step e of group q: lane l holds A[row = l & 31][k = 8 q + 4 (l >> 5) + e], B
+    // likewise (any pairing of the k's is a valid contraction order).  `bt_image`: B tile
+    // stored [n][k] (k-contiguous weights and the K extension), else [k][n].
+    auto mfma_group = [&](int q, bool bt_image) {
+        float4 af[NI];
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+            af[i] = *reinterpret_cast<const float4 *>(
+                &As[(wm + 32 * i + frow) * GG_ROW + 8 * q + 4 * fh]);
+        float b0[4], b1[4];
+        if (bt_image) {
+            const float4 bf0 = *reinterpret_cast<const float4 *>(
+                &Bs[(wn + frow) * GG_ROW + 8 * q + 4 * fh]);
+            const float4 bf1 = *reinterpret_cast<const float4 *>(
+                &Bs[(wn + 32 + frow) * GG_ROW + 8 * q + 4 * fh]);
+            b0[0] = bf0.x; b0[1] = bf0.y; b0[2] = bf0.z; b0[3] = bf0.w;
+            b1[0] = bf1.x; b1[1] = bf1.y; b1[2] = bf1.z; b1[3] = bf1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int kk = 8 * q + 4 * fh + e;
+                b0[e] = Bs[kk * GG_BNROW + wn + frow];
+                b1[e] = Bs[kk * GG_BNROW + wn + 32 + frow];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                const float a = e == 0 ? af[i].x : e == 1 ? af[i].y : e == 2 ? af[i].z : af[i].w;
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[e], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[e], acc[i][1], 0, 0, 0);
+            }
+        }
+    };
 
     // ---- K extension first: acc = (A2 / rowscale) . B2_g^T, so that the epilogue's single
     // rowscale * (acc + bias) yields rowscale * (A W^T + bias) + A2 B2^T ----
     if (EXT) {
         const int k = 4 * s_kq;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int r = s_row + 32 * u;
+        for (int u = 0; u < NUA; u++) {
+            const int r = s_row + GG_RPP * u;
             const int p = row_lo + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p < row_hi && k < g.R) {
@@ -158,159 +193,106 @@ __global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_kernel(GroupedArgs
                     v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
                 }
             }
-            *reinterpret_cast<float2 *>(&As[r * GG_ROW + 2 * s_kq]) = make_float2(v.x, v.z);
-            *reinterpret_cast<float2 *>(&As[r * GG_ROW + GG_BK / 2 + 2 * s_kq]) = make_float2(v.y, v.w);
+            *reinterpret_cast<float4 *>(&As[r * GG_ROW + 4 * s_kq]) = v;
+        }
+#pragma unroll
+        for (int u = 0; u < GG_NU; u++) {
+            const int r = s_row + GG_RPP * u;
             const int n = n0 + r;
             float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
             if (n < g.N && k < g.R)
                 b = *reinterpret_cast<const float4 *>(g.b2 + (size_t)bucket * g.b2_gstride +
                                                       (size_t)n * g.b2_ldn + k);
-            *reinterpret_cast<float2 *>(&Bs[r * GG_ROW + 2 * s_kq]) = make_float2(b.x, b.z);
-            *reinterpret_cast<float2 *>(&Bs[r * GG_ROW + GG_BK / 2 + 2 * s_kq]) = make_float2(b.y, b.w);
+            *reinterpret_cast<float4 *>(&Bs[r * GG_ROW + 4 * s_kq]) = b;
         }
         __syncthreads();
-        const int frow = lane & 31, fh = lane >> 5;
-        for (int q = 0; q < (g.R + 7) / 8; q++) {
-            float4 af[2], bf[2];
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-                af[i] = *reinterpret_cast<const float4 *>(
-                    &As[(wm + 32 * i + frow) * GG_ROW + fh * (GG_BK / 2) + 4 * q]);
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-                bf[j] = *reinterpret_cast<const float4 *>(
-                    &Bs[(wn + 32 * j + frow) * GG_ROW + fh * (GG_BK / 2) + 4 * q]);
-            const float a0[4] = {af[0].x, af[0].y, af[0].z, af[0].w};
-            const float a1[4] = {af[1].x, af[1].y, af[1].z, af[1].w};
-            const float b0[4] = {bf[0].x, bf[0].y, bf[0].z, bf[0].w};
-            const float b1[4] = {bf[1].x, bf[1].y, bf[1].z, bf[1].w};
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
-            }
-        }
+        for (int q = 0; q < (g.R + 7) / 8; q++) mfma_group(q, true);
         // the main loop's first __syncthreads orders these reads before its LDS writes
     }
 
-    // ---- software pipeline: the global loads of tile t+1 are in flight while the MFMAs
-    // of tile t run; registers -> LDS happens at the top of the next iteration ----
-    float4 av[4], bv[4];
-    auto load_tile = [&](int k0) {
+    // ---- software pipeline: the global loads of k-step t+1 are in flight while the MFMAs
+    // of step t run; registers -> LDS happens at the top of the next step.  (A second
+    // register set, two steps in flight, changed nothing for the half tiles of the last
+    // round: +-0 % measured.) ----
+    constexpr int PF = 1;
+    float4 av[PF][NUA], bv[PF][GG_NU];
+    // KTAIL == false (K % GG_BK == 0, every shape of the FFN): no predicate anywhere in the
+    // loads.  The predicated form compiles into branches around the loads, 8 per k-step.
+    auto load_tile = [&](float4 (&a)[NUA], float4 (&b)[GG_NU], int k0) {
         const int k = k0 + 4 * s_kq;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_ok[u] && k < g.K) av[u] = *reinterpret_cast<const float4 *>(a_src[u] + k);
+        for (int u = 0; u < NUA; u++) {
+            if constexpr (KTAIL)
+                a[u] = k < g.K ? *reinterpret_cast<const float4 *>(a_src[u] + k) : zero;
+            else
+                a[u] = *reinterpret_cast<const float4 *>(a_src[u] + k);
         }
-        if (!BN_LAYOUT) {
+        if constexpr (!BN_LAYOUT) {
             // W_g(n, k), k contiguous: same shape as A
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int n = n0 + s_row + 32 * u;
-                bv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n < g.N && k < g.K)
-                    bv[u] = *reinterpret_cast<const float4 *>(wg + (size_t)n * g.ldn + k);
+            for (int u = 0; u < GG_NU; u++) {
+                if constexpr (KTAIL)
+                    b[u] = k < g.K ? *reinterpret_cast<const float4 *>(b_src[u] + k) : zero;
+                else
+                    b[u] = *reinterpret_cast<const float4 *>(b_src[u] + k);
             }
         } else {
             // W_g(n, k), n contiguous: thread -> k row (tid >> 5) + 8 u, n-quad tid & 31
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < GG_NU; u++) {
                 const int kk = k0 + (tid >> 5) + 8 * u;
-                const int n = n0 + 4 * (tid & 31);
-                bv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kk < g.K && n < g.N)
-                    bv[u] = *reinterpret_cast<const float4 *>(wg + (size_t)kk * g.ldk + n);
+                if constexpr (KTAIL)
+                    b[u] = kk < g.K ? *reinterpret_cast<const float4 *>(bn_src + (size_t)kk * g.ldk)
+                                    : zero;
+                else
+                    b[u] = *reinterpret_cast<const float4 *>(bn_src + (size_t)kk * g.ldk);
             }
         }
     };
-    load_tile(0);
-
-    for (int k0 = 0; k0 < g.K; k0 += GG_BK) {
+    auto k_step = [&](float4 (&a)[NUA], float4 (&b)[GG_NU], int k_next) {
         __syncthreads();  // previous tile fully consumed
-        // ---- registers -> LDS (parity-split rows) ----
+        // ---- registers -> LDS ----
+        // (component-wise: a struct copy of a[u] keeps the whole array in scratch memory)
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int r = s_row + 32 * u;
-            // k = 4 kq .. 4 kq + 3  ->  parity 0: (x, z) at [2 kq, 2 kq + 1]; parity 1: (y, w)
-            *reinterpret_cast<float2 *>(&As[r * GG_ROW + 2 * s_kq]) = make_float2(av[u].x, av[u].z);
-            *reinterpret_cast<float2 *>(&As[r * GG_ROW + GG_BK / 2 + 2 * s_kq]) =
-                make_float2(av[u].y, av[u].w);
-        }
+        for (int u = 0; u < NUA; u++)
+            *reinterpret_cast<float4 *>(&As[(s_row + GG_RPP * u) * GG_ROW + 4 * s_kq]) =
+                make_float4(a[u].x, a[u].y, a[u].z, a[u].w);
         if (!BN_LAYOUT) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int r = s_row + 32 * u;
-                *reinterpret_cast<float2 *>(&Bs[r * GG_ROW + 2 * s_kq]) =
-                    make_float2(bv[u].x, bv[u].z);
-                *reinterpret_cast<float2 *>(&Bs[r * GG_ROW + GG_BK / 2 + 2 * s_kq]) =
-                    make_float2(bv[u].y, bv[u].w);
-            }
+            for (int u = 0; u < GG_NU; u++)
+                *reinterpret_cast<float4 *>(&Bs[(s_row + GG_RPP * u) * GG_ROW + 4 * s_kq]) =
+                    make_float4(b[u].x, b[u].y, b[u].z, b[u].w);
         } else {
-            // n-contiguous weights keep their orientation in LDS: Bs[k][n], rows of
-            // GG_BN + 4 floats (a parity-split image would need 4-byte writes 4 rows
-            // apart: 16-way bank conflicts)
+            // n-contiguous weights keep their orientation in LDS: Bs[k][n], rows of GG_BN + 4
+            // floats (transposing them into the [n][k] image needs 4-byte writes 4 rows apart:
+            // 16-way bank conflicts)
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int kk = (tid >> 5) + 8 * u;
-                *reinterpret_cast<float4 *>(&Bs[kk * GG_BNROW + 4 * (tid & 31)]) = bv[u];
-            }
+            for (int u = 0; u < GG_NU; u++)
+                *reinterpret_cast<float4 *>(&Bs[((tid >> 5) + 8 * u) * GG_BNROW + 4 * (tid & 31)]) =
+                    make_float4(b[u].x, b[u].y, b[u].z, b[u].w);
         }
         __syncthreads();
-        if (k0 + GG_BK < g.K) load_tile(k0 + GG_BK);
-
-        // ---- MFMA: lane l holds A[row = l & 31][k = kk + (l >> 5)], B likewise ----
-        const int frow = lane & 31, fh = lane >> 5;
+        if (k_next < g.K) load_tile(a, b, k_next);   // this register set is free again
 #pragma unroll
-        for (int q = 0; q < GG_BK / 8; q++) {   // 8 k's (4 per parity) per iteration
-            float4 af[2], bf[2];
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-                af[i] = *reinterpret_cast<const float4 *>(
-                    &As[(wm + 32 * i + frow) * GG_ROW + fh * (GG_BK / 2) + 4 * q]);
-            float b0[4], b1[4];
-            if (!BN_LAYOUT) {
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-                    bf[j] = *reinterpret_cast<const float4 *>(
-                        &Bs[(wn + 32 * j + frow) * GG_ROW + fh * (GG_BK / 2) + 4 * q]);
-                b0[0] = bf[0].x; b0[1] = bf[0].y; b0[2] = bf[0].z; b0[3] = bf[0].w;
-                b1[0] = bf[1].x; b1[1] = bf[1].y; b1[2] = bf[1].z; b1[3] = bf[1].w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int kk = 8 * q + 2 * e + fh;
-                    b0[e] = Bs[kk * GG_BNROW + wn + frow];
-                    b1[e] = Bs[kk * GG_BNROW + wn + 32 + frow];
-                }
-            }
-            const float a0[4] = {af[0].x, af[0].y, af[0].z, af[0].w};
-            const float a1[4] = {af[1].x, af[1].y, af[1].z, af[1].w};
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
-            }
-        }
-    }
+        for (int q = 0; q < GG_BK / 8; q++) mfma_group(q, !BN_LAYOUT);
+    };
+    load_tile(av[0], bv[0], 0);
+    for (int k0 = 0; k0 < g.K; k0 += GG_BK) k_step(av[0], bv[0], k0 + GG_BK);
 
     // ---- epilogue ----
     // MFMA C layout: acc[i][j][r] = C[32 i + (r & 3) + 8 (r >> 2) + 4 (l >> 5)][32 j + (l & 31)]
-    // of the wave's 64 x 64 quadrant.  Each wave transposes its quadrant through LDS, 32 rows
-    // at a time, into a row layout -- 16 lanes x float4 = one 64-column row segment -- so
-    // that every global access of the epilogue (the stores, the h / s tiles of EPI_DACT,
-    // the bias) is 16 bytes per lane and 256 contiguous bytes per row, and a row dot is a
+    // of the wave's (32 NI) x 64 part.  Each wave transposes it through LDS, 32 rows at a
+    // time, into a row layout -- 16 lanes x float4 = one 64-column row segment -- so that
+    // every global access of the epilogue (the stores, the h / s tiles of EPI_DACT, the
+    // bias) is 16 bytes per lane and 256 contiguous bytes per row, and a row dot is a
     // 16-lane DPP reduction.
     __syncthreads();   // all waves are done with the last k-step's tiles
     constexpr int CS_ROW = 64 + 4;
     float *cs = smem + wave * (32 * CS_ROW);
     const int ccol = lane & 31, chalf = lane >> 5;
     const int rrow = lane >> 4, rcol = 4 * (lane & 15);
-    const int pslot = 2 * blockIdx.y + (wave & 1);   // this wave's half tile of columns
+    const int pslot = 2 * col_tile + (wave & 1);   // this wave's half tile of columns
     const float *sh = (EPI == EPI_DACT) ? (g.s_in ? g.s_in : g.h_in) : nullptr;
     const int n = n0 + wn + rcol;
     const bool vec = (g.N & 3) == 0;
@@ -325,7 +307,7 @@ __global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_kernel(GroupedArgs
         }
     }
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < NI; i++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * chalf;
@@ -402,6 +384,87 @@ __global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_kernel(GroupedArgs
     }
 }
 
+// Work distribution.  A full tile costs ~200 us whatever it holds, and `slots` workgroups
+// run at a time (3 per CU), so a launch of T tiles takes ceil(T / slots) rounds.  Measured
+// with per-workgroup timestamps (tools/clock_gemm.py, P = 16384 rows ragged over 4 buckets,
+// K = N = 1024, 2.37 GHz in-kernel): 768 tiles start at t = 0 and end at 158-237 us (67 us
+// per tile and CU = 83 % MFMA-busy); the other 272 tiles then ran one per CU for another
+// 150-190 us, 363-381 us end to end against 253 us of work.  The last, partial round is
+// therefore cut into half-height tiles (64 x 128): twice as many workgroups (544, ~2 per
+// CU, 78 us each), 300-313 us end to end.  The split is decided on the device -- bucket
+// sizes never visit the host -- and workgroup ids are dispatched in order, so ids
+// [0, main) take the full rounds, ids [main, main + 2 R) the halves of the R remaining
+// tiles, and the rest of the (worst-case sized) grid exits at once.
+template <bool BN_LAYOUT, int EPI, bool EXT, bool KTAIL>
+__global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_kernel(GroupedArgs g) {
+    // As | Bs; the epilogue reuses the whole buffer as four per-wave C staging areas
+    __shared__ __attribute__((aligned(16))) float smem[(GG_BM + GG_BN) * GG_ROW];
+
+    const int n_col_tiles = (g.N + GG_BN - 1) / GG_BN;
+    int row_tiles = 0;
+    for (int i = 0; i < g.G; i++)
+        row_tiles += (g.offsets[i + 1] - g.offsets[i] + GG_BM - 1) / GG_BM;
+    const int total = row_tiles * n_col_tiles;
+    const int main_tiles = (total / g.slots) * g.slots;
+    const int rest = total - main_tiles;
+    int id = blockIdx.x;
+    int half = -1, logical;
+    // XCD-aware order inside each part: workgroups are dealt round-robin over the 8 XCDs
+    // (each with its own 4 MiB L2); xcd_remap gives every XCD a contiguous run of logical
+    // tiles, enumerated column-tile fastest, so the column tiles of one row tile (same
+    // 512 KiB A panel) run back to back on one L2.
+    if (id < main_tiles) {
+        logical = (int)xcd_remap((unsigned)id, (unsigned)main_tiles);
+    } else {
+        id -= main_tiles;
+        if (id >= 2 * rest) return;
+        const int h = (int)xcd_remap((unsigned)id, (unsigned)(2 * rest));
+        logical = main_tiles + (h >> 1);
+        half = h & 1;
+    }
+    const int col_tile = logical % n_col_tiles;
+    int bucket = -1, row_lo = 0, row_hi = 0;
+    {
+        int tile = logical / n_col_tiles;
+        for (int i = 0; i < g.G; i++) {
+            const int lo = g.offsets[i], hi = g.offsets[i + 1];
+            const int tiles = (hi - lo + GG_BM - 1) / GG_BM;
+            if (tile < tiles) {
+                bucket = i;
+                row_lo = lo + tile * GG_BM;
+                row_hi = min(hi, row_lo + GG_BM);
+                break;
+            }
+            tile -= tiles;
+        }
+    }
+    if (bucket < 0) return;  // uniform for the workgroup
+#ifdef GG_STAMP
+    // diagnostic build only (tools/clock_gemm.py): per-workgroup start / end on the 100 MHz
+    // wall clock and the shader clock, to a buffer nothing else reads
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (half < 0) {
+        gemm_tile<GG_BM, BN_LAYOUT, EPI, EXT, KTAIL>(g, smem, bucket, row_lo, row_hi, col_tile);
+    } else {
+        row_lo += (GG_BM / 2) * half;
+        row_hi = min(row_hi, row_lo + GG_BM / 2);
+        if (row_lo < row_hi)    // (a ragged tile may have no rows in its second half)
+            gemm_tile<GG_BM / 2, BN_LAYOUT, EPI, EXT, KTAIL>(g, smem, bucket, row_lo, row_hi,
+                                                             col_tile);
+    }
+#ifdef GG_STAMP
+    if (EPI == EPI_PLAIN && g.pdot_main && threadIdx.x == 0) {
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(g.pdot_main);
+        st[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - st_t0;
+        st[4 * blockIdx.x + 1] = st_r0;
+        st[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+        st[4 * blockIdx.x + 3] = (unsigned long long)(half + 1);
+    }
+#endif
+}
+
 // y[t, :] = bias + sum_{j < k} rows[pos[t * k + j], :]  -- the un-bucketing of the routed
 // FFN (reference: `y[mask] += ...` per block, lora_ffn.py:107-111): a gather in a fixed
 // order instead of a scatter-add, so the result is deterministic.
@@ -425,7 +488,20 @@ __global__ __launch_bounds__(256) void rows_combine_kernel(
 
 using namespace spt;
 
-static int launch_grouped(const GroupedArgs &g, int epilogue, void *stream) {
+// Workgroups resident at a time: 3 per CU (166 VGPRs -> 3 waves per SIMD; 36 KiB LDS).
+static int resident_slots() {
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return -1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return -1;
+        slots = 3 * cus;
+    }
+    return slots;
+}
+
+static int launch_grouped(GroupedArgs g, int epilogue, void *stream) {
     if (!g.a || !g.w || !g.offsets || !g.out) return SPT_EINVAL;
     if (g.P <= 0 || g.K <= 0 || g.N <= 0 || g.G <= 0 || g.lda < g.K) return SPT_EINVAL;
     if (g.K % 4 != 0 || g.lda % 4 != 0) return SPT_ESHAPE;       // float4 rows of A
@@ -443,22 +519,33 @@ static int launch_grouped(const GroupedArgs &g, int epilogue, void *stream) {
     if (epilogue != EPI_PLAIN && (g.act < ACT_RELU || g.act > ACT_SILU)) return SPT_EUNSUP;
     const unsigned row_tiles = (unsigned)((g.P + GG_BM - 1) / GG_BM + g.G);
     const unsigned col_tiles = (unsigned)((g.N + GG_BN - 1) / GG_BN);
-    if (col_tiles > 65535) return SPT_EUNSUP;
+    if ((unsigned long long)row_tiles * col_tiles > 0x3FFFFFFFull) return SPT_EUNSUP;
     if (epilogue == EPI_DACT) {
         if ((!g.h_in && !g.s_in) || !g.pdot_main || !g.pdot_act) return SPT_EINVAL;
         if (!g.s_in && g.act != ACT_RELU) return SPT_EINVAL;   // only ReLU is a function of h
         if (g.pdot_ld < (int)(2 * col_tiles)) return SPT_ESHAPE;
     }
-    dim3 grid(row_tiles, col_tiles);
+    // worst case: every tile in the halved last round
+    dim3 grid(2 * row_tiles * col_tiles);
     hipStream_t s = (hipStream_t)stream;
+    g.slots = resident_slots();
+    if (g.slots <= 0) return SPT_EINVAL;
 #define SPT_GG(BN, EPI, EXT)                                                                  \
-    hipLaunchKernelGGL((grouped_gemm_kernel<BN, EPI, EXT>), grid, dim3(GG_THREADS), 0, s, g)
+    do {                                                                                      \
+        if (k_tail)                                                                           \
+            hipLaunchKernelGGL((grouped_gemm_kernel<BN, EPI, EXT, true>), grid,               \
+                               dim3(GG_THREADS), 0, s, g);                                    \
+        else                                                                                  \
+            hipLaunchKernelGGL((grouped_gemm_kernel<BN, EPI, EXT, false>), grid,              \
+                               dim3(GG_THREADS), 0, s, g);                                    \
+    } while (0)
 #define SPT_GG_EPI(BN, EXT)                                   \
     do {                                                      \
         if (epilogue == EPI_PLAIN) SPT_GG(BN, EPI_PLAIN, EXT); \
         else if (epilogue == EPI_ACT) SPT_GG(BN, EPI_ACT, EXT); \
         else SPT_GG(BN, EPI_DACT, EXT);                        \
     } while (0)
+    const bool k_tail = (g.K % GG_BK) != 0;
     if (g.ldk == 1) {
         if (ext) SPT_GG_EPI(false, true); else SPT_GG_EPI(false, false);
     } else {

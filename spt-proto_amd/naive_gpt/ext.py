@@ -16,7 +16,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libspt_hip.so')
+# SPT_HIP_LIBRARY: another build of the same library (kernel A/B experiments, tools/)
+LIB_PATH = os.environ.get('SPT_HIP_LIBRARY') or os.path.join(os.path.dirname(_HERE), 'lib',
+                                                            'libspt_hip.so')
 
 _c_int = ctypes.c_int
 _c_f32 = ctypes.c_float
