@@ -117,24 +117,37 @@ class EventTimer:
         self.ext = ext
         self.events = {op: [] for op in self.OPS}
         self.enabled = False
+        self.only = None      # restrict the bracketing to one op (the timed region)
+        self.pool = []
         self.orig = {op: getattr(ext, op) for op in self.OPS}
         for op in self.OPS:
             setattr(ext, op, self._wrap(op))
+
+    def reserve(self, n_pairs: int):
+        """Create the events BEFORE the timed region: hipEventCreate costs ~10 us of host time,
+        40 times per step, which the step with the PQ loss (one host sync per step) cannot
+        hide behind GPU work."""
+        while len(self.pool) < 2 * n_pairs:
+            self.pool.append(torch.cuda.Event(enable_timing=True))
 
     def _wrap(self, op):
         fn = self.orig[op]
 
         def timed(*args, **kwargs):
-            if not self.enabled:
+            if not self.enabled or (self.only is not None and op != self.only):
                 return fn(*args, **kwargs)
-            a = torch.cuda.Event(enable_timing=True)
-            b = torch.cuda.Event(enable_timing=True)
+            if len(self.pool) < 2:
+                self.reserve(64)
+            a, b = self.pool.pop(), self.pool.pop()
             a.record()
             out = fn(*args, **kwargs)
             b.record()
             self.events[op].append((a, b))
             return out
         return timed
+
+    def reset(self):
+        self.events = {op: [] for op in self.OPS}
 
     def summary(self):
         out = {}
@@ -258,9 +271,21 @@ def main():
         allreduce_grads(params, world)
 
     torch.cuda.reset_peak_memory_stats()
-    # warm-up untimed and without events, then the timed region with events on
-    timed_loop(step, 0, args.warmup, world)
+    # Warm-up (untimed): after the first step every ext op is bracketed with HIP events,
+    # which gives the per-op table and names the dominant op.  Bracketing all ~17 launches
+    # of a step costs ~0.1 ms of host time per step (measured: 0.87 vs 0.74 ms/step), so in
+    # the timed region only the dominant op keeps its events: `value` is not perturbed and
+    # the roofline kernel is still measured live inside the K timed steps.
+    timed_loop(step, 0, 1, world)
+    timer.reserve(32 * max(args.warmup, 1) + 8 * args.steps)
     timer.enabled = True
+    timed_loop(step, 0, max(args.warmup - 1, 1), world)
+    timer.enabled = False
+    warm = timer.summary()
+    dominant = max(warm, key=lambda o: warm[o]['total_ms']) if warm else None
+    timer.reset()
+    timer.only = dominant
+    timer.enabled = dominant is not None
     dt = timed_loop(step, args.steps, 0, world)
     timer.enabled = False
     peak_gb = torch.cuda.max_memory_allocated() / 1e9
@@ -298,17 +323,20 @@ def main():
         result['with_pq_loss'] = recipe
 
     if rank == 0:
-        kernels = timer.summary()
+        kernels = warm                                  # every op, from the warm-up steps
+        warm_steps = max(args.warmup - 1, 1)
         B = N * H
+        live = timer.summary()                          # the dominant op, from the timed steps
+        kernels[dominant] = live[dominant]
         for op, st in kernels.items():
             st['algorithmic_GBps'] = algorithmic_bytes(op, B) / (st['avg_us'] * 1e-6) / 1e9
-        dominant = max(kernels, key=lambda o: kernels[o]['total_ms'])
+            st['per_step'] = st['calls'] / (args.steps if op == dominant else warm_steps)
         st = kernels[dominant]
         result['roofline'] = {
             'kernel': dominant, 'bound': 'hbm', 'achieved': st['algorithmic_GBps'],
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': st['algorithmic_GBps'] / HBM_PEAK_GBS,
             'traffic': measured_traffic(dominant), 'avg_us': st['avg_us'],
-            'calls_per_step': st['calls'] / args.steps,
+            'calls_per_step': st['per_step'],
             'bytes_per_launch': algorithmic_bytes(dominant, B),
             # an ext op can be more than one launch: spmm_transposed = permute_values_kernel
             # + spmm_t64_lds_kernel<1>; the HIP events bracket the op, so avg_us is the SUM
@@ -316,7 +344,7 @@ def main():
             'hip_kernels': OP_LAUNCHES.get(dominant, [OP_KERNEL.get(dominant)]),
         }
         result['kernels'] = {op: {'avg_us': round(s_['avg_us'], 2),
-                                  'calls_per_step': s_['calls'] / args.steps,
+                                  'calls_per_step': s_['per_step'],
                                   'GBps': round(s_['algorithmic_GBps'], 1),
                                   'frac': round(s_['algorithmic_GBps'] / HBM_PEAK_GBS, 4)}
                              for op, s_ in kernels.items()}

@@ -45,5 +45,11 @@ for _ in range(reps):
     if 'softmax' in ops:
         y = ext.softmax_forward_cuda(indptr, idx, vals)
         ext.softmax_backward_cuda(indptr, idx, y, vals)
+        ext.softmax_backward_clamped(indptr, idx, y, vals, vals, 0.125, 10.0)
+    if 'pq_loss' in ops:
+        zh = q.view(N, H, S, E)
+        ext.pq_encode_heads(zh, table)
+        ext.pq_loss_forward(q, table)
+        ext.pq_loss_backward(q, table, torch.ones([], device=dev))
 torch.cuda.synchronize()
 print('done')
