@@ -56,6 +56,8 @@ def algorithmic_bytes(op: str, B: int) -> int:
         'softmax_backward_cuda': 4 * S * Z * 4,
         'pq_loss_forward': S * E * 4,            # z read once
         'pq_loss_backward': 2 * S * E * 4,       # z read, grad_z written
+        # q, k, v read, y written, indices read, scores + probabilities written
+        'sparse_attention_forward': 4 * S * E * 4 + 3 * S * Z * 4,
     }
     return per[op] * B
 
@@ -75,6 +77,7 @@ OP_KERNEL = {
     'cdist_encode': 'spt::cdist_forward_kernel<8>',
     'pq_loss_forward': 'spt::pq_loss_forward_kernel<8>',
     'pq_loss_backward': 'spt::pq_loss_backward_kernel<8>',
+    'sparse_attention_forward': 'spt::sparse_attention_forward_kernel<true>',
 }
 
 
@@ -110,7 +113,7 @@ class EventTimer:
            'lookup_forward_cuda', 'sddmm_forward_cuda', 'spmm_forward_cuda',
            'spmm_transposed', 'csr_transpose',
            'softmax_forward_cuda', 'softmax_backward_cuda',
-           'pq_loss_forward', 'pq_loss_backward']
+           'pq_loss_forward', 'pq_loss_backward', 'sparse_attention_forward']
 
     def __init__(self):
         from naive_gpt import ext
@@ -276,18 +279,26 @@ def main():
     # of a step costs ~0.1 ms of host time per step (measured: 0.87 vs 0.74 ms/step), so in
     # the timed region only the dominant op keeps its events: `value` is not perturbed and
     # the roofline kernel is still measured live inside the K timed steps.
+    # (Live HIP events are not free either: with ~600 created-but-unused events every
+    # host synchronisation -- one per step when the PQ loss is armed -- took 2 ms longer, so
+    # the pool holds exactly what the next loop records and is dropped afterwards.)
+    warm_steps = max(args.warmup - 1, 1)
     timed_loop(step, 0, 1, world)
-    timer.reserve(32 * max(args.warmup, 1) + 8 * args.steps)
+    timer.reserve(32 * warm_steps)
     timer.enabled = True
-    timed_loop(step, 0, max(args.warmup - 1, 1), world)
+    timed_loop(step, 0, warm_steps, world)
     timer.enabled = False
     warm = timer.summary()
+    timer.pool.clear()
     dominant = max(warm, key=lambda o: warm[o]['total_ms']) if warm else None
     timer.reset()
     timer.only = dominant
     timer.enabled = dominant is not None
+    if dominant is not None:
+        timer.reserve(-(-warm[dominant]['calls'] // warm_steps) * args.steps)
     dt = timed_loop(step, args.steps, 0, world)
     timer.enabled = False
+    timer.pool.clear()
     peak_gb = torch.cuda.max_memory_allocated() / 1e9
     tokens = N * S * world * args.steps
 
@@ -324,7 +335,6 @@ def main():
 
     if rank == 0:
         kernels = warm                                  # every op, from the warm-up steps
-        warm_steps = max(args.warmup - 1, 1)
         B = N * H
         live = timer.summary()                          # the dominant op, from the timed steps
         kernels[dominant] = live[dominant]

@@ -42,7 +42,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 7
+#define SPT_ABI_VERSION 8
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -203,6 +203,27 @@ int spt_softmax_backward_clamped(const int32_t *indptr, const int32_t *indices,
                                  const float *clamped_scores, float scale, float clamp,
                                  float *grad_scores, int batch_size, int seq_length,
                                  int nnz, void *stream);
+
+/*
+ * The forward of the sparse attention core in one launch:
+ *   scores = clamp(scale * sddmm(q, k), -clamp, clamp)      attention.py:119-127
+ *   attn   = softmax(scores)  (masked, softmax.cu:7-47)      attention.py:128-130
+ *   y      = spmm(attn, v)                                   attention.py:140
+ * for UNIFORM CSR rows -- row r owns entries [r Z, (r+1) Z) of indices [B, nnz], Z = nnz / S,
+ * which is what spt_lookup_forward produces -- so there is no indptr argument.
+ * q, k, v: [batch, S, E] slices, or with heads > 0 the [N, S, heads, E] tensors themselves
+ * (batch = N * heads).  scores and attn [batch, nnz] are both outputs (the backward needs the
+ * clamp mask and the softmax VJP).  y is [batch, S, E], or with y_transposed != 0
+ * [batch, E, S]: the memory layout of the reference's `y.transpose(1, 2).contiguous()`
+ * (attention.py:141), saving that copy.
+ * Supported: d_head == 64, Z <= 64, Z % 4 == 0, S * 256 <= 128 KiB (SPT_EUNSUP otherwise:
+ * use the separate operators).  Same arithmetic as the separate operators.
+ */
+int spt_sparse_attention_forward(const int32_t *indices, const float *q, const float *k,
+                                 const float *v, float *scores, float *attn, float *y,
+                                 int batch_size, int seq_length, int d_head, int nnz,
+                                 float scale, float clamp, int heads, int y_transposed,
+                                 void *stream);
 
 /*
  * Routed FFN: token-bucketed grouped GEMM on the fp32 matrix cores.

@@ -47,6 +47,8 @@ _PROTOTYPES = {
     'spt_spmm_transposed': ([_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr], _c_int),
     'spt_grouped_gemm': ([_c_ptr] * 7 + [_c_int] * 5 + [ctypes.c_longlong, _c_int, _c_int, _c_ptr],
                          _c_int),
+    'spt_sparse_attention_forward': ([_c_ptr] * 7 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int,
+                                                                 _c_ptr], _c_int),
     'spt_grouped_gemm_fused': ([_c_ptr, _c_ptr], _c_int),
     'spt_grouped_gemm_pdot_width': ([_c_int], _c_int),
     'spt_rows_combine': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
@@ -55,7 +57,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 
@@ -382,6 +384,46 @@ def _alloc_dense(B, S, E, heads, dev):
     if heads > 0:
         return torch.empty([B // heads, S, heads, E], dtype=torch.float32, device=dev)
     return torch.empty([B, S, E], dtype=torch.float32, device=dev)
+
+
+def fused_attention_supported(S: int, E: int, B: int, nnz: int) -> bool:
+    """Shapes ``spt_sparse_attention_forward`` covers (fused_attention.hip)."""
+    if S <= 0 or nnz % S != 0:
+        return False
+    Z = nnz // S
+    return E == 64 and 0 < Z <= 64 and Z % 4 == 0 and S * E * 4 <= 128 * 1024 and B >= 32
+
+
+def sparse_attention_forward(indices: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
+                             v: torch.Tensor, scale: float, clamp: float,
+                             y_transposed: bool = False):
+    """One launch for sddmm -> scale, clamp -> softmax -> spmm on uniform CSR rows.
+
+    q, k, v: ``[N, S, H, E]`` (head layout); indices ``[N*H, nnz]``.  Returns
+    ``(scores, attn, y)``: the clamped scores and probabilities ``[N*H, nnz]`` and y as
+    ``[N*H, S, E]`` or, ``y_transposed``, ``[N*H, E, S]``."""
+    _check_dim(q, 4, 'q')
+    _check_type(q, torch.float32, 'q')
+    _check_type(indices, torch.int32, 'indices')
+    _require(q.shape == k.shape == v.shape, 'q, k, v: same shape')
+    _require(q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+             and indices.is_contiguous(), 'contiguous operands')
+    dev = _same_device(indices, q, k, v)
+    N, S, H, E = q.shape
+    B, nnz = N * H, indices.size(-1)
+    _require(indices.dim() == 2 and indices.size(0) == B, 'indices: [N * H, nnz]')
+    lib = load_library()
+    with torch.cuda.device(dev):
+        scores = torch.empty([B, nnz], dtype=torch.float32, device=dev)
+        attn = torch.empty([B, nnz], dtype=torch.float32, device=dev)
+        y = torch.empty([B, E, S] if y_transposed else [B, S, E], dtype=torch.float32, device=dev)
+        rc = lib.spt_sparse_attention_forward(
+            indices.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), scores.data_ptr(),
+            attn.data_ptr(), y.data_ptr(), B, S, E, nnz, float(scale), float(clamp), H,
+            int(bool(y_transposed)), _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'sparse_attention_forward')
+    return scores, attn, y
 
 
 def csr_transpose(indptr: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:

@@ -113,6 +113,41 @@ class _HeadSPMM(torch.autograd.Function):
         return None, None, grad_values, grad_v, None
 
 
+class _FusedAttention(torch.autograd.Function):
+    """y = spmm(softmax(clamp(scale * sddmm(q, k))), v) in ONE forward launch
+    (``spt_sparse_attention_forward``, fused_attention.hip), written straight into the
+    reference's output layout (the ``[N*H, E, S]`` memory its ``transpose(1, 2).contiguous()``
+    produces, see _sparse_apply).  The backward is the five launches of _HeadScores /
+    _HeadSPMM on the saved scores and probabilities."""
+
+    @staticmethod
+    def forward(ctx, indptr, indices, q, k, v, scale: float):
+        scores, attn, y = ext.sparse_attention_forward(indices, q, k, v, scale, CLAMP,
+                                                       y_transposed=True)
+        ctx.scale = scale
+        ctx.save_for_backward(indptr, indices, q, k, v, scores, attn)
+        return y.view(q.shape)
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        indptr, indices, q, k, v, scores, attn = ctx.saved_tensors
+        n, s, h, e = q.shape
+        # undo the layout: [N*H, E, S] memory -> grad_y [N*H, S, E]
+        grad_y = grad_out.contiguous().view(n * h, e, s).transpose(1, 2).contiguous()
+        transposed = ext.transposed_for(indptr, indices)
+        grad_attn = ext.sddmm_forward_cuda(False, True, indptr, indices, grad_y, v,
+                                           query_heads=0, key_heads=h)
+        grad_v = ext.spmm_transposed(transposed, indptr, indices, attn, grad_y,
+                                     x_heads=0, y_heads=h)
+        grad_raw = ext.softmax_backward_clamped(indptr, indices, attn, grad_attn, scores,
+                                                ctx.scale, CLAMP)
+        grad_q = ext.spmm_forward_cuda(False, False, indptr, indices, grad_raw, k,
+                                       x_heads=h, y_heads=h)
+        grad_k = ext.spmm_transposed(transposed, indptr, indices, grad_raw, q,
+                                     x_heads=h, y_heads=h)
+        return None, None, grad_q, grad_k, grad_v, None
+
+
 class _SparseCore:
     """Mixin with the CSR attention shared by the Vanilla and Rotary V2 layers."""
 
@@ -178,6 +213,10 @@ class _SparseCore:
         topk_indices = kernels.lookup(q_c, k_c, sparse_coeff=SPARSE_COEFF)
         csr_indices = topk_indices.flatten(start_dim=1)
         indptr = self._uniform_indptr(seq_length, q.device)
+        if ext.fused_attention_supported(seq_length, q.size(-1), q.size(0) * heads,
+                                         csr_indices.size(-1)):
+            # scores, softmax and the product with v run as one launch in _sparse_apply
+            return 'fused', indptr, csr_indices, q, k
         values = _HeadScores.apply(indptr, csr_indices, q, k, self.scaling, heads)
         return indptr, csr_indices, values, heads
 
@@ -206,6 +245,9 @@ class _SparseCore:
 
     def _sparse_apply(self, attn, v: torch.Tensor):
         v_size = v.size()
+        if len(attn) == 5:
+            _, indptr, indices, q, k = attn
+            return _FusedAttention.apply(indptr, indices, q, k, v.contiguous(), self.scaling)
         if len(attn) == 4:
             indptr, indices, values, heads = attn
             y = _HeadSPMM.apply(indptr, indices, values, v.contiguous(), heads)
