@@ -42,7 +42,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 8
+#define SPT_ABI_VERSION 9
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -216,6 +216,10 @@ int spt_softmax_backward_clamped(const int32_t *indptr, const int32_t *indices,
  * clamp mask and the softmax VJP).  y is [batch, S, E], or with y_transposed != 0
  * [batch, E, S]: the memory layout of the reference's `y.transpose(1, 2).contiguous()`
  * (attention.py:141), saving that copy.
+ * causal != 0 promises that every column id is <= its row (true for lookup's output): the
+ * K / V slices are then staged 64 rows at a time just ahead of the rows that need them,
+ * instead of whole before the first row; `scores` of entries with column > row are
+ * unspecified in that mode (their probability is 0 either way).
  * Supported: d_head == 64, Z <= 64, Z % 4 == 0, S * 256 <= 128 KiB (SPT_EUNSUP otherwise:
  * use the separate operators).  Same arithmetic as the separate operators.
  */
@@ -223,7 +227,7 @@ int spt_sparse_attention_forward(const int32_t *indices, const float *q, const f
                                  const float *v, float *scores, float *attn, float *y,
                                  int batch_size, int seq_length, int d_head, int nnz,
                                  float scale, float clamp, int heads, int y_transposed,
-                                 void *stream);
+                                 int causal, void *stream);
 
 /*
  * Routed FFN: token-bucketed grouped GEMM on the fp32 matrix cores.

@@ -48,7 +48,7 @@ _PROTOTYPES = {
     'spt_grouped_gemm': ([_c_ptr] * 7 + [_c_int] * 5 + [ctypes.c_longlong, _c_int, _c_int, _c_ptr],
                          _c_int),
     'spt_sparse_attention_forward': ([_c_ptr] * 7 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int,
-                                                                 _c_ptr], _c_int),
+                                                                 _c_int, _c_ptr], _c_int),
     'spt_grouped_gemm_fused': ([_c_ptr, _c_ptr], _c_int),
     'spt_grouped_gemm_pdot_width': ([_c_int], _c_int),
     'spt_rows_combine': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
@@ -57,7 +57,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 
@@ -396,12 +396,14 @@ def fused_attention_supported(S: int, E: int, B: int, nnz: int) -> bool:
 
 def sparse_attention_forward(indices: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
                              v: torch.Tensor, scale: float, clamp: float,
-                             y_transposed: bool = False):
+                             y_transposed: bool = False, causal: bool = False):
     """One launch for sddmm -> scale, clamp -> softmax -> spmm on uniform CSR rows.
 
     q, k, v: ``[N, S, H, E]`` (head layout); indices ``[N*H, nnz]``.  Returns
     ``(scores, attn, y)``: the clamped scores and probabilities ``[N*H, nnz]`` and y as
-    ``[N*H, S, E]`` or, ``y_transposed``, ``[N*H, E, S]``."""
+    ``[N*H, S, E]`` or, ``y_transposed``, ``[N*H, E, S]``.  ``causal`` promises column <= row
+    for every entry (lookup's output): K / V are then streamed into LDS just ahead of the rows
+    that use them."""
     _check_dim(q, 4, 'q')
     _check_type(q, torch.float32, 'q')
     _check_type(indices, torch.int32, 'indices')
@@ -420,7 +422,7 @@ def sparse_attention_forward(indices: torch.Tensor, q: torch.Tensor, k: torch.Te
         rc = lib.spt_sparse_attention_forward(
             indices.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), scores.data_ptr(),
             attn.data_ptr(), y.data_ptr(), B, S, E, nnz, float(scale), float(clamp), H,
-            int(bool(y_transposed)), _stream(dev))
+            int(bool(y_transposed)), int(bool(causal)), _stream(dev))
     if rc != 0:
         _raise(lib, rc, 'sparse_attention_forward')
     return scores, attn, y

@@ -122,8 +122,9 @@ class _FusedAttention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, indptr, indices, q, k, v, scale: float):
+        # causal: lookup only emits columns <= row (and column 0 as padding)
         scores, attn, y = ext.sparse_attention_forward(indices, q, k, v, scale, CLAMP,
-                                                       y_transposed=True)
+                                                       y_transposed=True, causal=True)
         ctx.scale = scale
         ctx.save_for_backward(indptr, indices, q, k, v, scores, attn)
         return y.view(q.shape)

@@ -34,6 +34,7 @@ def causal_indices(B, S, Z, gen):
     return idx.view(B, S * Z)
 
 
+@pytest.mark.parametrize('causal', [False, True])
 @pytest.mark.parametrize('N,H,S,Z,yt', [
     (2, 16, 512, 64, False), (2, 16, 512, 64, True),
     (1, 32, 256, 32, True),           # Z = 32: half of the entry lanes idle
@@ -41,7 +42,7 @@ def causal_indices(B, S, Z, gen):
     (2, 16, 80, 8, False),            # S not a multiple of 64 (ragged last write-out phase)
     (2, 16, 80, 8, True),
 ])
-def test_fused_forward_matches_oracle_chain(N, H, S, Z, yt):
+def test_fused_forward_matches_oracle_chain(N, H, S, Z, yt, causal):
     from naive_gpt import ext
     gen = torch.Generator().manual_seed(N * S + Z)
     q, k, v = [torch.randn([N, S, H, 64], generator=gen) for _ in range(3)]
@@ -50,7 +51,7 @@ def test_fused_forward_matches_oracle_chain(N, H, S, Z, yt):
     scale = 64 ** -0.5
     want_scores, want_attn, want_y = oracle_chain(indices, q, k, v, scale)
     scores, attn, y = ext.sparse_attention_forward(indices.cuda(), q.cuda(), k.cuda(), v.cuda(),
-                                                   scale, CLAMP, y_transposed=yt)
+                                                   scale, CLAMP, y_transposed=yt, causal=causal)
     assert (want_scores.abs() == CLAMP).any()
     assert torch.allclose(scores.cpu(), want_scores, rtol=1e-4, atol=1e-4)
     assert torch.allclose(attn.cpu(), want_attn, rtol=1e-3, atol=1e-6)
@@ -71,7 +72,7 @@ def test_masked_entries_get_zero_probability():
     indices = torch.randint(0, S, [N * H, S * Z], generator=gen, dtype=torch.int32)
     indices.view(N * H, S, Z)[:, :, 0] = 0         # every row keeps one live entry
     want_scores, want_attn, want_y = oracle_chain(indices, q, k, v, 0.125)
-    # the fused kernel assumes col <= row only for ... nothing: K and V are staged whole
+    # causal=False: K and V are staged whole, so even masked entries get their true score
     scores, attn, y = ext.sparse_attention_forward(indices.cuda(), q.cuda(), k.cuda(), v.cuda(),
                                                    0.125, CLAMP)
     rows = torch.arange(S).view(1, S, 1)

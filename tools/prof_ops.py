@@ -46,6 +46,10 @@ for _ in range(reps):
         y = ext.softmax_forward_cuda(indptr, idx, vals)
         ext.softmax_backward_cuda(indptr, idx, y, vals)
         ext.softmax_backward_clamped(indptr, idx, y, vals, vals, 0.125, 10.0)
+    if 'fused' in ops:
+        q4 = q.view(N, H, S, E).transpose(1, 2).contiguous()
+        ext.sparse_attention_forward(idx, q4, q4, q4, 0.125, 10.0, y_transposed=True, causal=True)
+        ext.sparse_attention_forward(idx, q4, q4, q4, 0.125, 10.0, y_transposed=False, causal=True)
     if 'pq_loss' in ops:
         zh = q.view(N, H, S, E)
         ext.pq_encode_heads(zh, table)
