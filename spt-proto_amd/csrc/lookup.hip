@@ -47,14 +47,25 @@ __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
 
 // wave-wide inclusive prefix sum (GCN sequence: 4 shifts inside each row of 16 lanes,
 // then lane 15 -> next row, lane 31 -> upper half).  Fields packed in v must not carry.
+// LANES = 64: over the wave; LANES = 32: independently over each half of the wave.
+template <int LANES>
 __device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v) {
     v += dpp_u32<0x111, 0xF>(v);  // row_shr:1
     v += dpp_u32<0x112, 0xF>(v);  // row_shr:2
     v += dpp_u32<0x114, 0xF>(v);  // row_shr:4
     v += dpp_u32<0x118, 0xF>(v);  // row_shr:8
     v += dpp_u32<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
-    v += dpp_u32<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+    if (LANES == 64) v += dpp_u32<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
     return v;
+}
+
+// value of the last lane of this lane's segment (LANES = 64: wave-uniform)
+template <int LANES>
+__device__ __forceinline__ unsigned segment_last(unsigned v) {
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+    if (LANES == 64) return hi;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)v, 31);
+    return (lane_id() & 32) ? hi : lo;
 }
 
 // ---- code representations -------------------------------------------------------
@@ -125,16 +136,24 @@ __device__ __forceinline__ Code<W> pack_codes(const int32_t *__restrict__ src, i
 // fields, two per register, exactly as the wave scan leaves them.  Output words are
 // written with plain LDS stores: the only word with two writers is the one behind the
 // reference's cursor-saturation quirk, fixed up after the loop by one lane.
-template <int W, bool NIB>
+//
+// LANES lanes per query row: 64 (one row per wave) or 32 (two rows per wave, rows gy and
+// gy + 1 in the lower / upper half).  The work per row is mostly fixed cost (scans, list
+// offsets, fix-up, row store: ~600 instructions whatever the row length), so at S <= 1024,
+// where 32 lanes still hold a row in <= 5 groups each, two rows per wave nearly halve it.
+// `gy`, `qsrc`, `myrow`, `dst` are per-lane values (uniform inside a segment).
+template <int W, bool NIB, int LANES>
 __device__ __forceinline__ void lookup_row(const uint32_t *__restrict__ kcodes,
                                            const int32_t *__restrict__ qsrc,
                                            int32_t *__restrict__ myrow,
-                                           int32_t *__restrict__ dst, int gy, int M, int Z) {
-    const int lane = lane_id();
+                                           int32_t *__restrict__ dst, int gy, int gy_max, int M,
+                                           int Z) {
+    const int lane = lane_id() & (LANES - 1);       // lane inside the row's segment
     const int Q = Z >> 2;
     const int limit = min(gy + 1, Z);
     const int ngroups = (gy + 4) >> 2;              // 4-column groups holding a candidate
-    const int gpl = (ngroups + SPT_WAVE - 1) >> 6;  // groups per lane
+    // groups per lane: from the longest row of the wave, so that the loops stay uniform
+    const int gpl = (((gy_max + 4) >> 2) + LANES - 1) / LANES;
     const int g0 = lane * gpl;
     const int g1 = min(ngroups, g0 + gpl);
     const bool keep_slots = gpl <= 5;               // 20 columns x 3 bits
@@ -143,9 +162,9 @@ __device__ __forceinline__ void lookup_row(const uint32_t *__restrict__ kcodes,
     const int div = M >> 2;
     const unsigned magic = (32u + div - 1) / div;
 
-    const Code<W> qc = pack_codes<W, NIB>(qsrc, M, false);  // wave-uniform
+    const Code<W> qc = pack_codes<W, NIB>(qsrc, M, false);  // uniform inside the segment
 
-    for (int i = lane; i < Z; i += SPT_WAVE) myrow[i] = 0;
+    for (int i = lane; i < Z; i += LANES) myrow[i] = 0;
 
     // slots of the 4 columns of group g (4 = not a candidate).  The group's codes are
     // 4*W consecutive LDS words, 16-byte aligned: W ds_read_b128.
@@ -193,19 +212,19 @@ __device__ __forceinline__ void lookup_row(const uint32_t *__restrict__ kcodes,
         }
     }
 
-    // ---- exclusive scan over lanes; totals are wave-uniform ----------------------------
+    // ---- exclusive scan over the lanes of the row; totals are uniform per row -----------
     unsigned posA[4], posB[4];   // worker tx: ranks of slots (0,1) and (2,3), 16 bits each
     int n[4][4];                 // list sizes
 #pragma unroll
     for (int tx = 0; tx < 4; tx++) {
         const unsigned ownA = (cnt8[tx] & 0xFFu) | ((cnt8[tx] & 0xFF00u) << 8);
         const unsigned ownB = ((cnt8[tx] >> 16) & 0xFFu) | ((cnt8[tx] >> 24) << 16);
-        const unsigned incA = wave_inclusive_scan(ownA);
-        const unsigned incB = wave_inclusive_scan(ownB);
+        const unsigned incA = wave_inclusive_scan<LANES>(ownA);
+        const unsigned incB = wave_inclusive_scan<LANES>(ownB);
         posA[tx] = incA - ownA;
         posB[tx] = incB - ownB;
-        const unsigned totA = (unsigned)__builtin_amdgcn_readlane((int)incA, 63);
-        const unsigned totB = (unsigned)__builtin_amdgcn_readlane((int)incB, 63);
+        const unsigned totA = segment_last<LANES>(incA);
+        const unsigned totB = segment_last<LANES>(incB);
         n[tx][0] = totA & 0xFFFF;
         n[tx][1] = totA >> 16;
         n[tx][2] = totB & 0xFFFF;
@@ -252,20 +271,22 @@ __device__ __forceinline__ void lookup_row(const uint32_t *__restrict__ kcodes,
 
     // ---- reference quirk: the cursor of worker 2 (3) saturates on the word that holds
     // entry Q-1 of worker 1 (0); its LAST candidate of the slot survives there if larger.
-    // Wave-uniform and rare (both lists need >= Q entries).
+    // Rare (both lists need >= Q entries): the reduction runs only when some row of the
+    // wave needs it.
 #pragma unroll
     for (int sl = 0; sl < 4; sl++) {
 #pragma unroll
         for (int tx = 2; tx < 4; tx++) {
             const int ptx = 3 - tx;
-            if (n[tx][sl] >= Q && n[ptx][sl] >= Q) {      // uniform
+            const bool need = n[tx][sl] >= Q && n[ptx][sl] >= Q;     // uniform per row
+            if (__builtin_amdgcn_ballot_w64(need) != 0ull) {          // uniform per wave
                 int lastcol = (tx == 2) ? last2[sl] : last3[sl];
 #pragma unroll
-                for (int d = 1; d < SPT_WAVE; d <<= 1)
+                for (int d = 1; d < LANES; d <<= 1)
                     lastcol = max(lastcol, __shfl_xor(lastcol, d, SPT_WAVE));
                 const int p = ptx + 4 * (off[ptx][sl] + Q - 1);
                 __builtin_amdgcn_wave_barrier();
-                if (lane == 0 && p < limit) myrow[p] = max(myrow[p], lastcol);
+                if (need && lane == 0 && p < limit) myrow[p] = max(myrow[p], lastcol);
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -273,20 +294,22 @@ __device__ __forceinline__ void lookup_row(const uint32_t *__restrict__ kcodes,
 
     // ---- coalesced store of the row (zeros included) -----------------------------------
     __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < Z; i += SPT_WAVE) dst[i] = myrow[i];
+    for (int i = lane; i < Z; i += LANES) dst[i] = myrow[i];
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int WN, int WU>  // words per token: nibble form, uint16 form
+template <int WN, int WU, int LANES>  // words per token (nibble, uint16 form); lanes per row
 __global__ __launch_bounds__(LK_THREADS) void lookup_forward_kernel(
     const int32_t *__restrict__ query, const int32_t *__restrict__ key,
     int32_t *__restrict__ out, int B, int S, int M, int Z, int tiles_per_batch) {
+    constexpr int RPW = SPT_WAVE / LANES;   // rows per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *kcodes = reinterpret_cast<uint32_t *>(smem);                 // [cols][W]
-    int32_t *rowbuf = reinterpret_cast<int32_t *>(smem) + (size_t)S * WU;  // [LK_WAVES][Z]
+    int32_t *rowbuf = reinterpret_cast<int32_t *>(smem) + (size_t)S * WU;  // [LK_WAVES * RPW][Z]
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int seg = (tid & 63) / LANES;     // which of the wave's rows this lane works on
     // heavy (late) row tiles first: they take longest, so they should start earliest
     const int b = blockIdx.x % B;
     const int tile = tiles_per_batch - 1 - (blockIdx.x / B);
@@ -301,7 +324,7 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_forward_kernel(
     for (int i = tid; i < LK_ROWS * M; i += LK_THREADS) wide |= qsrc[i];
     const bool use_u16 = __syncthreads_or((wide & ~0xF) != 0);
 
-    int32_t *myrow = rowbuf + wave * Z;
+    int32_t *myrow = rowbuf + (wave * RPW + seg) * Z;
     if (!use_u16) {
         for (int col = tid; col < ncols; col += LK_THREADS) {
             const Code<WN> c = pack_codes<WN, true>(ksrc + (size_t)col * M, M, true);
@@ -309,10 +332,11 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_forward_kernel(
             for (int d = 0; d < WN; d++) kcodes[col * WN + d] = c.w[d];
         }
         __syncthreads();
-        for (int r = wave; r < LK_ROWS; r += LK_WAVES) {
-            const int gy = row0 + r;
-            lookup_row<WN, true>(kcodes, qsrc + (size_t)r * M, myrow,
-                                 out + ((size_t)b * S + gy) * Z, gy, M, Z);
+        for (int r = wave * RPW; r < LK_ROWS; r += LK_WAVES * RPW) {
+            const int gy = row0 + r + seg;
+            lookup_row<WN, true, LANES>(kcodes, qsrc + (size_t)(r + seg) * M, myrow,
+                                        out + ((size_t)b * S + gy) * Z, gy, row0 + r + RPW - 1,
+                                        M, Z);
         }
     } else {
         for (int col = tid; col < ncols; col += LK_THREADS) {
@@ -321,10 +345,11 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_forward_kernel(
             for (int d = 0; d < WU; d++) kcodes[col * WU + d] = c.w[d];
         }
         __syncthreads();
-        for (int r = wave; r < LK_ROWS; r += LK_WAVES) {
-            const int gy = row0 + r;
-            lookup_row<WU, false>(kcodes, qsrc + (size_t)r * M, myrow,
-                                  out + ((size_t)b * S + gy) * Z, gy, M, Z);
+        for (int r = wave * RPW; r < LK_ROWS; r += LK_WAVES * RPW) {
+            const int gy = row0 + r + seg;
+            lookup_row<WU, false, LANES>(kcodes, qsrc + (size_t)(r + seg) * M, myrow,
+                                         out + ((size_t)b * S + gy) * Z, gy, row0 + r + RPW - 1,
+                                         M, Z);
         }
     }
 }
@@ -346,21 +371,28 @@ extern "C" int spt_lookup_forward(const int32_t *query, const int32_t *key, int3
     if (M < 4 || M > 16) return SPT_EUNSUP;                    // lookup.cu:167-169
     if (S > 32768) return SPT_EUNSUP;                          // 8-bit per-lane counters (ref: uint16 columns, lookup.cu:32)
     const int WU = (M + 1) / 2;
-    const size_t lds = (size_t)S * WU * 4 + (size_t)LK_WAVES * Z * 4;
+    // two rows per wave while 32 lanes hold a row in <= 5 groups of 4 columns each
+    const int lanes = (S <= 640) ? 32 : 64;
+    const size_t lds = (size_t)S * WU * 4 + (size_t)LK_WAVES * (SPT_WAVE / lanes) * Z * 4;
     if (lds > 160 * 1024) return SPT_EUNSUP;
     const int tiles = S / LK_ROWS;
     const long long nblk = (long long)batch_size * tiles;
     if (nblk > 0x7FFFFFFFLL) return SPT_EUNSUP;
     dim3 grid((unsigned)nblk);
     hipStream_t s = (hipStream_t)stream;
-#define SPT_LK(WN_, WU_)                                                                      \
+#define SPT_LK2(WN_, WU_, LN_)                                                                \
     do {                                                                                      \
         if (lds > 64 * 1024)                                                                  \
             SPT_HIP_TRY(hipFuncSetAttribute(                                                  \
-                reinterpret_cast<const void *>(&lookup_forward_kernel<WN_, WU_>),             \
+                reinterpret_cast<const void *>(&lookup_forward_kernel<WN_, WU_, LN_>),        \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
-        hipLaunchKernelGGL((lookup_forward_kernel<WN_, WU_>), grid, dim3(LK_THREADS), lds, s, \
-                           query, key, out, batch_size, S, M, Z, tiles);                      \
+        hipLaunchKernelGGL((lookup_forward_kernel<WN_, WU_, LN_>), grid, dim3(LK_THREADS),    \
+                           lds, s, query, key, out, batch_size, S, M, Z, tiles);              \
+    } while (0)
+#define SPT_LK(WN_, WU_)                                    \
+    do {                                                    \
+        if (lanes == 32) SPT_LK2(WN_, WU_, 32);             \
+        else SPT_LK2(WN_, WU_, 64);                         \
     } while (0)
     switch (WU) {
         case 2: SPT_LK(1, 2); break;
@@ -372,6 +404,7 @@ extern "C" int spt_lookup_forward(const int32_t *query, const int32_t *key, int3
         case 8: SPT_LK(2, 8); break;
         default: return SPT_EUNSUP;
     }
+#undef SPT_LK2
 #undef SPT_LK
     SPT_LAUNCH_CHECK();
     return SPT_OK;
