@@ -69,7 +69,7 @@ OP_KERNEL = {
     'spmm_forward_cuda': 'spt::spmm_g4_lds_kernel<4, 1>',
     'spmm_transposed': 'spt::spmm_t64_lds_kernel<1>',
     'csr_transpose': 'spt::csr_transpose_bitmap_kernel',
-    'lookup_forward_cuda': 'spt::lookup_forward_kernel<1, 4>',
+    'lookup_forward_cuda': 'spt::lookup_forward_kernel<1, 4, 32>',
     'softmax_forward_cuda': 'spt::softmax_kernel<16, 0>',
     'softmax_backward_cuda': 'spt::softmax_kernel<16, 1>',
     'softmax_backward_clamped': 'spt::softmax_kernel<16, 2>',
@@ -77,7 +77,7 @@ OP_KERNEL = {
     'cdist_encode': 'spt::cdist_forward_kernel<8>',
     'pq_loss_forward': 'spt::pq_loss_forward_kernel<8>',
     'pq_loss_backward': 'spt::pq_loss_backward_kernel<8>',
-    'sparse_attention_forward': 'spt::sparse_attention_forward_kernel<true>',
+    'sparse_attention_forward': 'spt::sparse_attention_forward_kernel<true, true>',
 }
 
 

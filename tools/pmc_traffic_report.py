@@ -12,7 +12,8 @@ for d, name in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
     if not files:
         continue
     vals = collections.defaultdict(list)
-    for r in csv.DictReader(open(files[0])):
+    files.sort(key=os.path.getmtime)          # gpurun merges: keep the newest pass
+    for r in csv.DictReader(open(files[-1])):
         if r['Counter_Name'] == name and 'spt::' in r['Kernel_Name']:
             vals[r['Kernel_Name'].split('(')[0].replace('void ', '')].append(float(r['Counter_Value']))
     for k, v in vals.items():
