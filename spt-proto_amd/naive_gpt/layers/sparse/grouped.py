@@ -234,3 +234,91 @@ def routed_lora_ffn(x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk: Buckets, act: 
 
 def fused_usable(rank: int) -> bool:
     return rank % 4 == 0 and 0 < rank <= 32
+
+
+class RoutedLoRALLaMAFFN(torch.autograd.Function):
+    """y = LoRARoutedLLaMaFFN(x) for frozen base weights (reference formula:
+    naive_gpt/layers/tuning/lora_ffn.py:196-222), with c the router coefficient of a row:
+
+        g  = c (x G_g^T) + (x Lg) Rg_g^T,   sd = c (x S_g^T) + (x Ls) Rs_g^T     two fused GEMMs
+        h  = act(g) * sd                                                        (torch)
+        ys = c (h D_g) + (h Ld_g) Rd^T;   y = sum over the token's rows of ys   fused GEMM + combine
+
+    Same building blocks as RoutedLoRAFFN (LoRA side products as the GEMMs' K extension, token
+    gather and rowscale inside the kernel, rows_combine instead of index_add); the gating product
+    and the activation derivative stay elementwise torch ops.  The coefficient gradient uses
+    <A, h> = (<c A + E, h> - <E, h>) / c with <E, h> = <dy Rd, h Ld_g> (both [*, r]), and the same
+    identity for the two up projections."""
+
+    @staticmethod
+    def forward(ctx, x, coeff, lg, rg, ls, rs, ld, rd, wg, ws, wd, bk: Buckets, activation):
+        nb = bk.n_blocks
+        d_ff, d = wg.shape
+        bs, rank, rows = d_ff // nb, lg.size(1), bk.token.numel()
+        x, coeff = x.contiguous(), coeff.contiguous()
+        ug, us = torch.matmul(x, lg), torch.matmul(x, ls)                      # [T, r]
+
+        def up(w, u, r_table):
+            return ext.grouped_gemm_fused(
+                x, w, bk.offsets, nb, n=bs, k=d, w_group_stride=bs * d, w_ldn=d, w_ldk=1,
+                n_rows=rows, gather=bk.token, rowscale=coeff, a2=u, gather2=bk.token,
+                b2=r_table, b2_group_stride=bs * rank)
+
+        g, sd = up(wg, ug, rg), up(ws, us, rs)
+        h = activation(g) * sd
+        z = _own_block(torch.matmul(h, _block_cat(ld, nb)), bk.block, nb).contiguous()
+        ys = ext.grouped_gemm_fused(
+            h, wd, bk.offsets, nb, n=d, k=bs, w_group_stride=bs, w_ldn=d_ff, w_ldk=1,
+            n_rows=rows, rowscale=coeff, a2=z, b2=rd, b2_group_stride=0)
+        y = ext.rows_combine(ys, bk.pos)
+        ctx.bk, ctx.activation = bk, activation
+        ctx.save_for_backward(x, coeff, ug, us, g, sd, h, z, lg, rg, ls, rs, ld, rd, wg, ws, wd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, coeff, ug, us, g, sd, h, z, lg, rg, ls, rs, ld, rd, wg, ws, wd = ctx.saved_tensors
+        bk, activation = ctx.bk, ctx.activation
+        nb = bk.n_blocks
+        d_ff, d = wg.shape
+        bs, rank, rows = d_ff // nb, lg.size(1), bk.token.numel()
+        pos = bk.pos.long()
+        dy = dy.contiguous()
+        dzt = torch.matmul(dy, rd)                                            # [T, r]
+        dz_rows = dzt.index_select(0, bk.token_long)
+        dh = ext.grouped_gemm_fused(
+            dy, wd, bk.offsets, nb, n=bs, k=d, w_group_stride=bs, w_ldn=1, w_ldk=d_ff,
+            n_rows=rows, gather=bk.token, rowscale=coeff, a2=dzt, gather2=bk.token, b2=ld,
+            b2_group_stride=bs * rank)
+        grad_coeff = ((dh * h).sum(dim=-1) - (dz_rows * z).sum(dim=-1)) / coeff
+        # through h = act(g) * sd
+        with torch.enable_grad():
+            g_ = g.detach().requires_grad_(True)
+            ag = activation(g_)
+            dg, = torch.autograd.grad(ag, g_, dh * sd)
+        dsd = dh * ag.detach()
+
+        def down(dpre, pre, w, u, l_table, r_table):
+            """-> (dx rows [P, d], d coefficient [P], grad of the two LoRA tables)"""
+            du = _own_block(torch.matmul(dpre, _block_cat(r_table, nb)), bk.block, nb).contiguous()
+            u_rows = u.index_select(0, bk.token_long)
+            dc = ((dpre * pre).sum(dim=-1) - (du * u_rows).sum(dim=-1)) / coeff
+            dxs = ext.grouped_gemm_fused(
+                dpre, w, bk.offsets, nb, n=d, k=bs, w_group_stride=bs * d, w_ldn=1, w_ldk=d,
+                n_rows=rows, rowscale=coeff, a2=du, b2=l_table, b2_group_stride=0)
+            grad_l = _tn(x, du[pos].sum(dim=1))
+            grad_r = _block_major(_tn(dpre, _in_own_block(u_rows, bk.block, nb)), nb)
+            return dxs, dc, grad_l, grad_r
+
+        dxs_g, dc_g, grad_lg, grad_rg = down(dg, g, wg, ug, lg, rg)
+        dxs_s, dc_s, grad_ls, grad_rs = down(dsd, sd, ws, us, ls, rs)
+        grad_x = ext.rows_combine(dxs_g.add_(dxs_s), bk.pos)
+        grad_coeff = grad_coeff + dc_g + dc_s
+        grad_ld = _block_major(_tn(h, _in_own_block(dz_rows, bk.block, nb)), nb)
+        grad_rd = _tn(dy, z[pos].sum(dim=1))
+        return (grad_x, grad_coeff, grad_lg, grad_rg, grad_ls, grad_rs, grad_ld, grad_rd,
+                None, None, None, None, None)
+
+
+def routed_lora_llama_ffn(x, coeff, lg, rg, ls, rs, ld, rd, wg, ws, wd, bk: Buckets, activation):
+    return RoutedLoRALLaMAFFN.apply(x, coeff, lg, rg, ls, rs, ld, rd, wg, ws, wd, bk, activation)

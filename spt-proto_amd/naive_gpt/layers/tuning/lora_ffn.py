@@ -140,6 +140,13 @@ class LoRARoutedLLaMaFFN(layers.RoutedLLaMaFFN):
         prob = self.router(x)
         bk = grouped.make_buckets(prob, k=nb // 2)
         coeff = (2.0 * bk.coeff).contiguous()
+        if grouped.fused_usable(r):
+            # three fused block GEMMs forward (layers/sparse/grouped.py: RoutedLoRALLaMAFFN)
+            return grouped.routed_lora_llama_ffn(
+                x, coeff, self.gate.lora.left.weight, self.gate.lora.right.weight,
+                self.side.lora.left.weight, self.side.lora.right.weight,
+                self.down.lora.left.weight, self.down.lora.right.weight,
+                self.gate.weight, self.side.weight, self.down.weight, bk, self.activation)
         rows = torch.arange(bk.block.numel(), device=x.device)
 
         def up(linear):

@@ -68,4 +68,18 @@ ms3 = timeit(lambda: torch.matmul(b, wd.T), 20, 5)
 res['torch_matmul_same_flops_ms'] = ms3
 res['torch_matmul_TFLOPs'] = flops / ms3 / 1e9
 res['tokens_per_s_routed_grouped'] = T / res['routed_grouped_ms'] * 1e3
+# the gated (LLaMA) variant at the same dimensions
+routed_l = layers.LoRARoutedLLaMaFFN(d_lora=r, block_size=dff // 4, d_model=d, d_feedforward=dff,
+                                     activation=nn.SiLU()).to(dev)
+for n_, p in routed_l.named_parameters():
+    if n_.endswith('lora.right.weight'):
+        p.data.normal_(0, 0.02)
+dense_l = layers.LLaMaFeedforward(d_model=d, d_feedforward=dff, activation=nn.SiLU()).to(dev)
+for p in dense_l.parameters():
+    p.requires_grad = False
+res['llama_routed_grouped_ms'] = timeit(step(routed_l))
+grouped.usable = lambda *a, **k: False
+res['llama_routed_torch_loop_ms'] = timeit(step(routed_l))
+grouped.usable = orig
+res['llama_dense_frozen_ms'] = timeit(step(dense_l))
 print(json.dumps(res))
