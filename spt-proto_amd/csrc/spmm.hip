@@ -173,6 +173,14 @@ __global__ __launch_bounds__(SP_THREADS_LDS) void permute_values_kernel(
 // transposed product, E = 64, one workgroup per batch: dynamic, wide-row aware
 // (gather_rows_dynamic).  The ticket word lives behind the tile in the dynamic region.
 // MODE G_SPMM: `values` are already in transposed order (permute_values_kernel).
+//
+// Measured and dropped (MI355X, lookup-shaped patterns: row lengths of A^T are 0 .. ~480,
+// one outlier of ~2400 = column 0 with lookup's padding, mean 64): processing the rows in
+// length order with one QUAD per row and 16 entries per round (no cross-lane reduction,
+// 172 rounds per slice instead of 252) -- 76 us against 74: a long row then is 20-30
+// sequential, latency-bound rounds on one wave, and sending rows over 256 entries to the
+// whole-wave mode leaves 32 of them to be processed one by one.  Length-sorting alone
+// (same 4 x 64 mapping): +-0.
 template <int MODE>
 __global__ __launch_bounds__(SP_THREADS_LDS) void spmm_t64_lds_kernel(
     const int32_t *__restrict__ t_ptr, const int32_t *__restrict__ t_row,
