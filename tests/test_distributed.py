@@ -148,3 +148,36 @@ def test_tuner_replicas_stay_identical_and_match_the_global_batch(tmp_path):
     for k, p in model.named_parameters():
         if p.requires_grad:
             assert torch.allclose(p, r0[k], rtol=1e-5, atol=1e-7), k
+
+
+@pytest.mark.gpu
+def test_rccl_path_on_one_gpu():
+    """The N > 1 code path of bench.py / SparseTuner with the real backend: a one-rank RCCL
+    group on cuda:0 (the pool gives this session a single GPU; the 2..8-rank runs are the
+    driver's).  Broadcast of parameters and buffers (bool `trigger` included) and the flat
+    gradient all-reduce must run on device tensors and leave the values unchanged."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        from naive_gpt import layers, utils
+        attn = layers.SparseVanillaAttentionV2(d_head=64, d_codeword=8, n_codewords=16,
+                                               p_dropout=0.0).cuda()
+        attn.trigger.fill_(True)
+        before = attn.quantizer.weight.detach().clone()
+        utils.broadcast_parameters(attn, src=0)
+        assert torch.equal(attn.quantizer.weight, before) and bool(attn.trigger)
+        params = utils.trainable_parameters(attn)
+        for p in params:
+            p.grad = torch.randn_like(p)
+        want = [p.grad.clone() for p in params]
+        n = utils.allreduce_gradients(params, world_size=1, force=True)
+        assert n == sum(p.numel() for p in params)
+        for p, w in zip(params, want):
+            assert torch.allclose(p.grad, w)
+        t = torch.tensor([1.5], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        assert t.item() == 1.5
+    finally:
+        dist.destroy_process_group()
