@@ -58,6 +58,8 @@ def algorithmic_bytes(op: str, B: int) -> int:
         'pq_loss_backward': 2 * S * E * 4,       # z read, grad_z written
         # q, k, v read, y written, indices read, scores + probabilities written
         'sparse_attention_forward': 4 * S * E * 4 + 3 * S * Z * 4,
+        # dY, v, k read, grad_q + dY rows written; indices, scores, attn read, dS written
+        'sparse_attention_backward_rows': 5 * S * E * 4 + 4 * S * Z * 4,
     }
     return per[op] * B
 
@@ -78,6 +80,7 @@ OP_KERNEL = {
     'pq_loss_forward': 'spt::pq_loss_forward_kernel<8>',
     'pq_loss_backward': 'spt::pq_loss_backward_kernel<8>',
     'sparse_attention_forward': 'spt::sparse_attention_forward_kernel<true, true>',
+    'sparse_attention_backward_rows': 'spt::sparse_attention_backward_rows_kernel<true, true>',
 }
 
 
@@ -113,7 +116,8 @@ class EventTimer:
            'lookup_forward_cuda', 'sddmm_forward_cuda', 'spmm_forward_cuda',
            'spmm_transposed', 'csr_transpose',
            'softmax_forward_cuda', 'softmax_backward_cuda',
-           'pq_loss_forward', 'pq_loss_backward', 'sparse_attention_forward']
+           'pq_loss_forward', 'pq_loss_backward', 'sparse_attention_forward',
+           'sparse_attention_backward_rows']
 
     def __init__(self):
         from naive_gpt import ext

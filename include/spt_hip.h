@@ -42,7 +42,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 9
+#define SPT_ABI_VERSION 10
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -228,6 +228,26 @@ int spt_sparse_attention_forward(const int32_t *indices, const float *q, const f
                                  int batch_size, int seq_length, int d_head, int nnz,
                                  float scale, float clamp, int heads, int y_transposed,
                                  int causal, void *stream);
+
+/*
+ * The row-wise half of the backward of spt_sparse_attention_forward in one launch:
+ *   dP       = sddmm(grad_y, v)                          (kernels/spmm.py:25-40)
+ *   grad_raw = clamp-mask(scale * softmax_backward(attn, dP))   -- wrt the RAW sddmm scores
+ *              (softmax.cu:49-81 with its 1e-9 clamp, then attention.py:125-127)
+ *   grad_q   = spmm(grad_raw, k)                         (kernels/sddmm.py:25-41)
+ * grad_y is [batch, S, E], or with grad_y_transposed != 0 the [batch, E, S] memory that the
+ * transposed forward output hands back; in that case the kernel also writes grad_y_rows
+ * [batch, S, E] (may be NULL), the operand the grad_v product wants.  v, k, grad_q follow
+ * `heads` as in the forward; scores / attn are the forward's outputs.  grad_k and grad_v are
+ * the two spt_spmm_transposed calls on (grad_raw, q) and (attn, grad_y_rows).
+ * Same shape limits and `causal` contract as the forward.
+ */
+int spt_sparse_attention_backward_rows(const int32_t *indices, const float *grad_y,
+                                       const float *v, const float *k, const float *scores,
+                                       const float *attn, float *grad_raw, float *grad_q,
+                                       float *grad_y_rows, int batch_size, int seq_length,
+                                       int d_head, int nnz, float scale, float clamp, int heads,
+                                       int grad_y_transposed, int causal, void *stream);
 
 /*
  * Routed FFN: token-bucketed grouped GEMM on the fp32 matrix cores.

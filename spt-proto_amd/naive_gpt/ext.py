@@ -49,6 +49,8 @@ _PROTOTYPES = {
                          _c_int),
     'spt_sparse_attention_forward': ([_c_ptr] * 7 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int,
                                                                  _c_int, _c_ptr], _c_int),
+    'spt_sparse_attention_backward_rows': ([_c_ptr] * 9 + [_c_int] * 4 + [_c_f32, _c_f32] +
+                                           [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_grouped_gemm_fused': ([_c_ptr, _c_ptr], _c_int),
     'spt_grouped_gemm_pdot_width': ([_c_int], _c_int),
     'spt_rows_combine': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
@@ -57,7 +59,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib = None
 
@@ -426,6 +428,42 @@ def sparse_attention_forward(indices: torch.Tensor, q: torch.Tensor, k: torch.Te
     if rc != 0:
         _raise(lib, rc, 'sparse_attention_forward')
     return scores, attn, y
+
+
+def sparse_attention_backward_rows(indices: torch.Tensor, grad_y: torch.Tensor, v: torch.Tensor,
+                                   k: torch.Tensor, scores: torch.Tensor, attn: torch.Tensor,
+                                   scale: float, clamp: float, grad_y_transposed: bool = False,
+                                   causal: bool = False):
+    """Row-wise half of the fused attention backward (``spt_sparse_attention_backward_rows``).
+
+    v, k: ``[N, S, H, E]``; grad_y: ``[N*H, S, E]`` or (``grad_y_transposed``) ``[N*H, E, S]``.
+    Returns ``(grad_raw [N*H, nnz], grad_q [N, S, H, E], grad_y_rows [N*H, S, E])`` -- the
+    last is ``grad_y`` itself when it was not transposed."""
+    _check_dim(v, 4, 'v')
+    _check_type(v, torch.float32, 'v')
+    _check_type(indices, torch.int32, 'indices')
+    _require(v.shape == k.shape, 'v, k: same shape')
+    for t in (indices, grad_y, v, k, scores, attn):
+        _require(t.is_contiguous(), 'contiguous operands')
+    dev = _same_device(indices, grad_y, v, k, scores, attn)
+    N, S, H, E = v.shape
+    B, nnz = N * H, indices.size(-1)
+    _require(grad_y.numel() == B * S * E, 'grad_y: N * H * S * E elements')
+    _require(scores.shape == attn.shape == indices.shape, 'scores, attn: the shape of indices')
+    lib = load_library()
+    with torch.cuda.device(dev):
+        grad_raw = torch.empty([B, nnz], dtype=torch.float32, device=dev)
+        grad_q = torch.empty_like(v)
+        rows = torch.empty([B, S, E], dtype=torch.float32, device=dev) if grad_y_transposed \
+            else grad_y.view(B, S, E)
+        rc = lib.spt_sparse_attention_backward_rows(
+            indices.data_ptr(), grad_y.data_ptr(), v.data_ptr(), k.data_ptr(),
+            scores.data_ptr(), attn.data_ptr(), grad_raw.data_ptr(), grad_q.data_ptr(),
+            rows.data_ptr() if grad_y_transposed else None, B, S, E, nnz, float(scale),
+            float(clamp), H, int(bool(grad_y_transposed)), int(bool(causal)), _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'sparse_attention_backward_rows')
+    return grad_raw, grad_q, rows
 
 
 def csr_transpose(indptr: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:

@@ -117,8 +117,8 @@ class _FusedAttention(torch.autograd.Function):
     """y = spmm(softmax(clamp(scale * sddmm(q, k))), v) in ONE forward launch
     (``spt_sparse_attention_forward``, fused_attention.hip), written straight into the
     reference's output layout (the ``[N*H, E, S]`` memory its ``transpose(1, 2).contiguous()``
-    produces, see _sparse_apply).  The backward is the five launches of _HeadScores /
-    _HeadSPMM on the saved scores and probabilities."""
+    produces, see _sparse_apply).  The backward is ``spt_sparse_attention_backward_rows``
+    (grad_q and the score gradients) plus the two transposed products (grad_k, grad_v)."""
 
     @staticmethod
     def forward(ctx, indptr, indices, q, k, v, scale: float):
@@ -132,18 +132,16 @@ class _FusedAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out: torch.Tensor):
         indptr, indices, q, k, v, scores, attn = ctx.saved_tensors
-        n, s, h, e = q.shape
-        # undo the layout: [N*H, E, S] memory -> grad_y [N*H, S, E]
-        grad_y = grad_out.contiguous().view(n * h, e, s).transpose(1, 2).contiguous()
+        h = q.size(2)
+        # one launch: dP = dY V^T, softmax VJP through the clamp, grad_q = dS K; it reads
+        # grad_out in the [N*H, E, S] layout it arrives in and leaves the [N*H, S, E] rows
+        # behind for the grad_v product
+        grad_raw, grad_q, grad_y = ext.sparse_attention_backward_rows(
+            indices, grad_out.contiguous(), v, k, scores, attn, ctx.scale, CLAMP,
+            grad_y_transposed=True, causal=True)
         transposed = ext.transposed_for(indptr, indices)
-        grad_attn = ext.sddmm_forward_cuda(False, True, indptr, indices, grad_y, v,
-                                           query_heads=0, key_heads=h)
         grad_v = ext.spmm_transposed(transposed, indptr, indices, attn, grad_y,
                                      x_heads=0, y_heads=h)
-        grad_raw = ext.softmax_backward_clamped(indptr, indices, attn, grad_attn, scores,
-                                                ctx.scale, CLAMP)
-        grad_q = ext.spmm_forward_cuda(False, False, indptr, indices, grad_raw, k,
-                                       x_heads=h, y_heads=h)
         grad_k = ext.spmm_transposed(transposed, indptr, indices, grad_raw, q,
                                      x_heads=h, y_heads=h)
         return None, None, grad_q, grad_k, grad_v, None

@@ -115,3 +115,38 @@ def test_layer_through_fused_kernel_equals_separate_operators(kind, monkeypatch)
     fused, separate = run(True), run(False)
     for a, b, name in zip(fused, separate, ['y', 'grad_q', 'grad_k', 'grad_v']):
         assert torch.allclose(a, b, rtol=1e-3, atol=1e-4), name
+
+
+@pytest.mark.parametrize('causal', [False, True])
+@pytest.mark.parametrize('N,H,S,Z,gt', [
+    (2, 16, 512, 64, True), (2, 16, 512, 64, False),
+    (1, 32, 256, 32, True), (2, 16, 80, 8, True), (2, 16, 80, 8, False),
+])
+def test_backward_rows_matches_oracle_chain(N, H, S, Z, gt, causal):
+    """dP = sddmm(dY, V); dS = clamp-mask(scale * softmax_backward(P, dP)); dQ = spmm(dS, K)."""
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(7 * N + S + Z)
+    B, E = N * H, 64
+    q, k, v = [torch.randn([N, S, H, E], generator=gen) for _ in range(3)]
+    q = q * 3.0
+    gy = torch.randn([B, S, E], generator=gen)
+    indices = causal_indices(B, S, Z, gen)
+    scale = E ** -0.5
+    scores, attn, _ = oracle_chain(indices, q, k, v, scale)
+    flat = lambda t: t.transpose(1, 2).contiguous().view(B, S, E)       # noqa: E731
+    indptr = torch.arange(0, S * Z + 1, Z, dtype=torch.int32)
+    f, t = torch.scalar_tensor(False), torch.scalar_tensor(True)
+    dp = ext_stub.sddmm_forward_cuda(f, t, indptr, indices, gy, flat(v))
+    ds = ext_stub.softmax_backward_cuda(indptr, indices, attn, dp)
+    want_raw = torch.where(scores.abs() < CLAMP, ds * np.float32(scale), torch.zeros_like(ds))
+    want_q = ext_stub.spmm_forward_cuda(f, f, indptr, indices, want_raw, flat(k))
+    want_q = want_q.view(N, H, S, E).transpose(1, 2)                      # -> [N, S, H, E]
+
+    gy_in = gy.transpose(1, 2).contiguous() if gt else gy
+    raw, gq, rows = ext.sparse_attention_backward_rows(
+        indices.cuda(), gy_in.cuda(), v.cuda(), k.cuda(), scores.cuda(), attn.cuda(),
+        scale, CLAMP, grad_y_transposed=gt, causal=causal)
+    assert (scores.abs() == CLAMP).any() and (want_raw == 0).any()
+    assert torch.allclose(raw.cpu(), want_raw, rtol=1e-3, atol=1e-5)
+    assert torch.allclose(gq.cpu(), want_q, rtol=1e-3, atol=1e-4)
+    assert torch.equal(rows.cpu(), gy)                                    # a pure re-layout

@@ -50,6 +50,9 @@ for _ in range(reps):
         q4 = q.view(N, H, S, E).transpose(1, 2).contiguous()
         ext.sparse_attention_forward(idx, q4, q4, q4, 0.125, 10.0, y_transposed=True, causal=True)
         ext.sparse_attention_forward(idx, q4, q4, q4, 0.125, 10.0, y_transposed=False, causal=True)
+        sc, at, yt = ext.sparse_attention_forward(idx, q4, q4, q4, 0.125, 10.0, y_transposed=True, causal=True)
+        ext.sparse_attention_backward_rows(idx, yt, q4, q4, sc, at, 0.125, 10.0, grad_y_transposed=True, causal=True)
+        ext.sparse_attention_backward_rows(idx, yt.view(B, S, E), q4, q4, sc, at, 0.125, 10.0, grad_y_transposed=False, causal=True)
     if 'pq_loss' in ops:
         zh = q.view(N, H, S, E)
         ext.pq_encode_heads(zh, table)
