@@ -42,7 +42,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 10
+#define SPT_ABI_VERSION 11
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -319,6 +319,19 @@ typedef struct SptGroupedGemm {
 } SptGroupedGemm;
 int spt_grouped_gemm_fused(const SptGroupedGemm *desc, void *stream);
 int spt_grouped_gemm_pdot_width(int n);
+
+/*
+ * Bucketing for the routed FFN: the k largest of the n_blocks router probabilities of every
+ * token (feedforward.py:56-64: `topk(prob, k)`), as (token, block) pairs sorted by block and,
+ * inside a block, by token -- the order of the reference's `x[mask]` (lora_ffn.py:93-95):
+ *   token[p], block[p]   the p-th pair;           offsets[g]  first pair of block g
+ *   pos[t * k + j]       the row of token t's j-th selected block (ascending block id)
+ * prob [n_tokens, n_blocks] fp32; token / block [n_tokens * k], offsets [n_blocks + 1],
+ * pos [n_tokens * k] int32.  Ties go to the lower block index.  One workgroup:
+ * n_blocks <= 8 and n_tokens <= 65536 (SPT_EUNSUP otherwise).
+ */
+int spt_route_topk(const float *prob, int32_t *token, int32_t *block, int32_t *offsets,
+                   int32_t *pos, int n_tokens, int n_blocks, int k, void *stream);
 
 /*
  * Un-bucketing: out[t, :] = bias + sum_{j < k} rows[pos[t * k + j], :] (bias may be NULL).

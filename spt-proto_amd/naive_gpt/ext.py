@@ -54,12 +54,13 @@ _PROTOTYPES = {
     'spt_grouped_gemm_fused': ([_c_ptr, _c_ptr], _c_int),
     'spt_grouped_gemm_pdot_width': ([_c_int], _c_int),
     'spt_rows_combine': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_route_topk': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_forward': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_backward': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _lib = None
 
@@ -721,6 +722,31 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
     if epilogue == EPI_DACT:
         return out, dot_main.sum(dim=-1), dot_act.sum(dim=-1)
     return out
+
+
+def route_topk_supported(n_tokens: int, n_blocks: int) -> bool:
+    return 0 < n_blocks <= 8 and 0 < n_tokens <= 65536
+
+
+def route_topk(prob: torch.Tensor, k: int):
+    """``spt_route_topk``: prob [T, G] fp32 -> (token [P], block [P], offsets [G + 1],
+    pos [T, k]) int32, the (token, block) pairs of the per-token top-k sorted by block."""
+    _check_dim(prob, 2, 'prob')
+    _check_type(prob, torch.float32, 'prob')
+    T, G = prob.shape
+    _require(0 < k <= G, 'route_topk: 0 < k <= n_blocks')
+    dev = prob.device
+    lib = load_library()
+    with torch.cuda.device(dev):
+        token = torch.empty([T * k], dtype=torch.int32, device=dev)
+        block = torch.empty([T * k], dtype=torch.int32, device=dev)
+        offsets = torch.empty([G + 1], dtype=torch.int32, device=dev)
+        pos = torch.empty([T, k], dtype=torch.int32, device=dev)
+        rc = lib.spt_route_topk(prob.data_ptr(), token.data_ptr(), block.data_ptr(),
+                                offsets.data_ptr(), pos.data_ptr(), T, G, k, _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'route_topk')
+    return token, block, offsets, pos
 
 
 def rows_combine(rows: torch.Tensor, pos: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:

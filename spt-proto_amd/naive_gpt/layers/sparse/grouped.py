@@ -31,6 +31,14 @@ class Buckets(NamedTuple):
 def make_buckets(prob: torch.Tensor, k: int) -> Buckets:
     """prob [T, G] router probabilities -> block-sorted (token, block) rows."""
     n_tokens, n_blocks = prob.shape
+    if prob.is_cuda and prob.dtype == torch.float32 \
+            and ext.route_topk_supported(n_tokens, n_blocks):
+        # one launch (routing.hip) instead of topk + argsort + bincount + cumsum + gathers
+        token, block, offsets, pos = ext.route_topk(prob.detach().contiguous(), k)
+        token_long, block_long = token.long(), block.long()
+        coeff = prob.reshape(-1).index_select(0, token_long * n_blocks + block_long)
+        return Buckets(token=token, token_long=token_long, block=block_long, offsets=offsets,
+                       coeff=coeff, n_blocks=n_blocks, pos=pos)
     indices = torch.topk(prob, k=k, dim=-1, sorted=False).indices       # [T, k]
     block = indices.reshape(-1)
     order = torch.argsort(block, stable=True)

@@ -290,3 +290,31 @@ def test_fused_lora_routed_ffn_equals_torch_loop(act):
     assert set(g0) == set(g1) and len(g0) >= 6
     for n in g0:
         assert torch.allclose(g1[n], g0[n], rtol=2e-3, atol=2e-4), n
+
+
+@pytest.mark.parametrize('T,G,k', [(8192, 4, 2), (1000, 8, 4), (77, 4, 2), (5, 2, 1), (40000, 4, 2)])
+def test_route_topk_is_the_stable_block_sort_of_topk(T, G, k):
+    """spt_route_topk against the torch composition it replaces (topk -> stable argsort by
+    block): same pairs in the same order, offsets = bucket boundaries, pos = the rows of a token."""
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(T + G)
+    prob = torch.rand([T, G], generator=gen).cuda()
+    token, block, offsets, pos = ext.route_topk(prob, k)
+    sel = torch.topk(prob, k=k, dim=-1).indices.sort(dim=-1).values           # [T, k] ascending
+    flat_block = sel.reshape(-1)
+    order = torch.argsort(flat_block, stable=True)
+    assert torch.equal(block.long(), flat_block[order])
+    assert torch.equal(token.long(), order // k)
+    counts = torch.bincount(flat_block, minlength=G)
+    assert torch.equal(offsets.long(), torch.cat([counts.new_zeros(1), counts.cumsum(0)]))
+    # pos[t, j] is the row that holds (t, j-th selected block)
+    assert torch.equal(token.long()[pos.long()], torch.arange(T, device='cuda').view(T, 1).expand(T, k))
+    assert torch.equal(block.long()[pos.long()], sel)
+
+
+def test_route_topk_ties_go_to_the_lower_block():
+    from naive_gpt import ext
+    prob = torch.tensor([[0.5, 0.5, 0.5, 0.5], [0.1, 0.9, 0.9, 0.1], [1.0, 0.0, 1.0, 1.0]]).cuda()
+    token, block, offsets, pos = ext.route_topk(prob, 2)
+    picked = [sorted(block[pos[t].long()].tolist()) for t in range(3)]
+    assert picked == [[0, 1], [1, 2], [0, 2]]
