@@ -22,10 +22,7 @@ namespace spt {
 constexpr int RT_THREADS = 1024;
 constexpr int RT_MAXG = 8;
 
-__device__ __forceinline__ unsigned select_topk(const float *__restrict__ p, int G, int k) {
-    float v[RT_MAXG];
-#pragma unroll
-    for (int j = 0; j < RT_MAXG; j++) v[j] = j < G ? p[j] : 0.0f;
+__device__ __forceinline__ unsigned select_topk(const float (&v)[RT_MAXG], int G, int k) {
     unsigned mask = 0u;
 #pragma unroll
     for (int j = 0; j < RT_MAXG; j++) {
@@ -41,6 +38,8 @@ __device__ __forceinline__ unsigned select_topk(const float *__restrict__ p, int
 __global__ __launch_bounds__(RT_THREADS) void route_topk_kernel(
     const float *__restrict__ prob, int32_t *__restrict__ token, int32_t *__restrict__ block,
     int32_t *__restrict__ offsets, int32_t *__restrict__ pos, int T, int G, int k) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint8_t *sel = reinterpret_cast<uint8_t *>(smem);          // [T] selection masks
     __shared__ int wave_tot[RT_THREADS / 64][RT_MAXG];
     __shared__ int base[RT_MAXG + 1];
     const int tid = threadIdx.x;
@@ -48,13 +47,36 @@ __global__ __launch_bounds__(RT_THREADS) void route_topk_kernel(
     const int tpt = (T + RT_THREADS - 1) / RT_THREADS;
     const int t0 = min(T, tid * tpt), t1 = min(T, t0 + tpt);
 
+    // pass 1: selections (kept in LDS for pass 2) and per-thread counts.  The probabilities
+    // of 8 tokens are requested before the first is used: a single workgroup has nothing
+    // else to hide the load latency behind.
     int cnt[RT_MAXG];
 #pragma unroll
     for (int g = 0; g < RT_MAXG; g++) cnt[g] = 0;
-    for (int t = t0; t < t1; t++) {
-        const unsigned m = select_topk(prob + (size_t)t * G, G, k);
+    for (int tb = t0; tb < t1; tb += 8) {
+        float v[8][RT_MAXG];
 #pragma unroll
-        for (int g = 0; g < RT_MAXG; g++) cnt[g] += (m >> g) & 1u;
+        for (int u = 0; u < 8; u++) {
+            const int t = min(tb + u, t1 - 1);
+            if (G == 4) {
+                const float4 q = *reinterpret_cast<const float4 *>(prob + (size_t)t * 4);
+                v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
+#pragma unroll
+                for (int j = 4; j < RT_MAXG; j++) v[u][j] = 0.0f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < RT_MAXG; j++) v[u][j] = j < G ? prob[(size_t)t * G + j] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (tb + u < t1) {
+                const unsigned m = select_topk(v[u], G, k);
+                sel[tb + u] = (uint8_t)m;
+#pragma unroll
+                for (int g = 0; g < RT_MAXG; g++) cnt[g] += (m >> g) & 1u;
+            }
+        }
     }
     // exclusive prefix over threads, per block
     int pre[RT_MAXG];
@@ -86,8 +108,9 @@ __global__ __launch_bounds__(RT_THREADS) void route_topk_kernel(
         for (int w = 0; w < wave; w++) before += wave_tot[w][g];
         pre[g] += before;
     }
+    // pass 2: placement (a thread only reads the selections it wrote)
     for (int t = t0; t < t1; t++) {
-        const unsigned m = select_topk(prob + (size_t)t * G, G, k);
+        const unsigned m = sel[t];
         int j = 0;
 #pragma unroll
         for (int g = 0; g < RT_MAXG; g++) {
@@ -112,8 +135,12 @@ extern "C" int spt_route_topk(const float *prob, int32_t *token, int32_t *block,
     if (!prob || !token || !block || !offsets || !pos) return SPT_EINVAL;
     if (n_tokens <= 0 || n_blocks <= 0 || k <= 0 || k > n_blocks) return SPT_EINVAL;
     if (n_blocks > RT_MAXG || n_tokens > 64 * RT_THREADS) return SPT_EUNSUP;
-    hipLaunchKernelGGL(route_topk_kernel, dim3(1), dim3(RT_THREADS), 0, (hipStream_t)stream, prob,
-                       token, block, offsets, pos, n_tokens, n_blocks, k);
+    const size_t lds = ((size_t)n_tokens + 15) & ~(size_t)15;
+    if (lds > 64 * 1024)
+        SPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&route_topk_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(route_topk_kernel, dim3(1), dim3(RT_THREADS), lds, (hipStream_t)stream,
+                       prob, token, block, offsets, pos, n_tokens, n_blocks, k);
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }
