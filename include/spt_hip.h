@@ -42,7 +42,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 11
+#define SPT_ABI_VERSION 12
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -145,7 +145,8 @@ int spt_sddmm_forward(const int32_t *indptr, const int32_t *indices,
  * which is built into `workspace` (spt_spmm_workspace_bytes() bytes, uninitialised;
  * may be NULL when trans_lhs == 0).
  */
-int64_t spt_spmm_workspace_bytes(int trans_lhs, int batch_size, int seq_length, int nnz);
+int64_t spt_spmm_workspace_bytes(int trans_lhs, int batch_size, int seq_length, int d_head,
+                                 int nnz);
 int spt_spmm_forward(int trans_lhs, const int32_t *indptr,
                      const int32_t *indices, const float *values,
                      const float *x, float *y, void *workspace, int batch_size,
@@ -159,16 +160,22 @@ int spt_spmm_forward(int trans_lhs, const int32_t *indptr,
  *   spt_csr_transpose   builds the transposed structure of (indptr, indices) into
  *                       `transposed` (spt_csr_transpose_workspace_bytes() bytes);
  *   spt_spmm_transposed y = A^T . x using that structure and the CSR-ordered `values`;
- *                       `workspace` (spt_spmm_transposed_workspace_bytes() bytes, may be
- *                       NULL) receives the values in transposed order: with it the product
- *                       streams them instead of gathering through the permutation.
+ *                       `workspace`: spt_spmm_transposed_workspace_bytes() bytes.
+ * The structure is laid out for the product kernel of a given head size, so d_head is an
+ * argument of all four and must be the same in the calls that share a buffer:
+ *   flat form     (S * d_head * 4 <= 128 KiB, or d_head != 64): one transposed CSR per slice;
+ *                 the workspace receives the values in transposed order (may be NULL: the
+ *                 product then gathers them through the permutation);
+ *   chunked form  (d_head == 64, S a multiple of 512 above 512): one transposed CSR per
+ *                 512-row chunk of A, A^T x = sum_j A_j^T x_j with x_j in LDS; the workspace
+ *                 holds the per-chunk partial outputs and is required.
  */
-int64_t spt_csr_transpose_workspace_bytes(int batch_size, int seq_length, int nnz);
+int64_t spt_csr_transpose_workspace_bytes(int batch_size, int seq_length, int nnz, int d_head);
 int spt_csr_transpose(const int32_t *indptr, const int32_t *indices,
-                      void *transposed, int batch_size, int seq_length, int nnz,
+                      void *transposed, int batch_size, int seq_length, int nnz, int d_head,
                       void *stream);
-int64_t spt_spmm_transposed_workspace_bytes(int batch_size, int nnz);
-int spt_spmm_transposed(const void *transposed, const float *values,
+int64_t spt_spmm_transposed_workspace_bytes(int batch_size, int seq_length, int d_head, int nnz);
+int spt_spmm_transposed(const int32_t *indptr, const void *transposed, const float *values,
                         const float *x, float *y, void *workspace, int batch_size,
                         int seq_length, int d_head, int nnz, int x_heads,
                         int y_heads, void *stream);

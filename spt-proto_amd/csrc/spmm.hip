@@ -514,27 +514,202 @@ __global__ __launch_bounds__(TR_THREADS) void csr_transpose_bitmap_kernel(
     }
 }
 
+// ------------------------------------------------------------------ long sequences: chunked form
+//
+// S > 512 at E = 64: a slice of x (S x 256 bytes) no longer fits LDS, and the gather over
+// the whole transposed structure reads 256-byte rows at random from a 512 KiB..2 MiB window per
+// slice (33.5 M row reads per launch at S = 2048, B = 64: they miss L2; 2.3 ms measured), while the
+// LDS counting sort above runs B workgroups on 256 CUs (2.2 ms).  The transposed structure is
+// therefore built per ROW CHUNK of 512 rows: A = [A_0; A_1; ...], A^T x = sum_j A_j^T x_j, and
+// each A_j^T x_j is the S = 512 problem again -- x_j (128 KiB) in LDS, one workgroup per
+// (slice, chunk), 4 x as many workgroups -- producing S output rows that a last pass adds up
+// (only chunks j >= c / 512 reach column c: the pattern is causal in practice, but nothing here
+// relies on it).  The transposition is a three-launch counting sort over (slice, chunk,
+// 128-row quarter) workgroups: count per column, prefix over quarters and columns, place.
+// Entries of one (column, quarter) are placed through an LDS cursor: their order depends on
+// wave timing (as the reference's atomic cuSPARSE path), the order across quarters is by row.
+constexpr int CH_ROWS = 512;      // rows of x per chunk = one LDS tile at E = 64
+constexpr int CH_QUARTERS = 4;    // counting-sort workgroups per chunk
+constexpr int CH_QROWS = CH_ROWS / CH_QUARTERS;
+
+__global__ __launch_bounds__(TR_THREADS) void chunk_count_kernel(
+    const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+    int32_t *__restrict__ counts, int S, int nnz, int nchunks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *hist = reinterpret_cast<int *>(smem);            // [S]
+    const int q = blockIdx.x % CH_QUARTERS;
+    const int bj = blockIdx.x / CH_QUARTERS;              // b * nchunks + j
+    const int b = bj / nchunks, j = bj - b * nchunks;
+    const int r0 = j * CH_ROWS + q * CH_QROWS;
+    for (int i = threadIdx.x; i < S; i += TR_THREADS) hist[i] = 0;
+    __syncthreads();
+    const int e0 = indptr[r0], e1 = indptr[min(S, r0 + CH_QROWS)];
+    const int32_t *idx_b = indices + (size_t)b * nnz;
+    for (int e = e0 + threadIdx.x; e < e1; e += TR_THREADS) atomicAdd(&hist[idx_b[e]], 1);
+    __syncthreads();
+    int32_t *dst = counts + (size_t)blockIdx.x * S;
+    for (int i = threadIdx.x; i < S; i += TR_THREADS) dst[i] = hist[i];
+}
+
+// counts[bj][q][c] -> first position of (c, q) inside the chunk's transposed arrays; t_ptr
+__global__ __launch_bounds__(TR_THREADS) void chunk_scan_kernel(int32_t *__restrict__ counts,
+                                                                int32_t *__restrict__ t_ptr,
+                                                                int S) {
+    __shared__ int wave_tot[TR_WAVES];
+    const int bj = blockIdx.x;
+    int32_t *cq = counts + (size_t)bj * CH_QUARTERS * S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cpt = (S + TR_THREADS - 1) / TR_THREADS;    // columns per thread
+    const int c0 = min(S, tid * cpt), c1 = min(S, c0 + cpt);
+    int mine = 0;
+    for (int c = c0; c < c1; c++)
+#pragma unroll
+        for (int q = 0; q < CH_QUARTERS; q++) mine += cq[(size_t)q * S + c];
+    int inc = mine;
+#pragma unroll
+    for (int d = 1; d < SPT_WAVE; d <<= 1) {
+        const int o = __shfl_up(inc, d, SPT_WAVE);
+        if (lane >= d) inc += o;
+    }
+    if (lane == SPT_WAVE - 1) wave_tot[wave] = inc;
+    __syncthreads();
+    int run = inc - mine;
+    for (int w = 0; w < wave; w++) run += wave_tot[w];
+    int32_t *tp = t_ptr + (size_t)bj * (S + 1);
+    for (int c = c0; c < c1; c++) {
+        tp[c] = run;
+#pragma unroll
+        for (int q = 0; q < CH_QUARTERS; q++) {
+            const int n = cq[(size_t)q * S + c];
+            cq[(size_t)q * S + c] = run;
+            run += n;
+        }
+    }
+    if (tid == TR_THREADS - 1) tp[S] = run;
+}
+
+__global__ __launch_bounds__(TR_THREADS) void chunk_place_kernel(
+    const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const int32_t *__restrict__ base, int32_t *__restrict__ t_row, int32_t *__restrict__ t_perm,
+    int S, int nnz, int nchunks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *cursor = reinterpret_cast<int *>(smem);          // [S]
+    const int q = blockIdx.x % CH_QUARTERS;
+    const int bj = blockIdx.x / CH_QUARTERS;
+    const int b = bj / nchunks, j = bj - b * nchunks;
+    const int r0 = j * CH_ROWS + q * CH_QROWS;
+    const int32_t *mybase = base + (size_t)blockIdx.x * S;
+    for (int i = threadIdx.x; i < S; i += TR_THREADS) cursor[i] = mybase[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t *idx_b = indices + (size_t)b * nnz;
+    const size_t out0 = (size_t)b * nnz + indptr[j * CH_ROWS];     // the chunk's entry range
+    for (int r = r0 + wave; r < min(S, r0 + CH_QROWS); r += TR_WAVES) {
+        const int st = indptr[r], en = indptr[r + 1];
+        for (int e = st + lane; e < en; e += SPT_WAVE) {
+            const int pos = atomicAdd(&cursor[idx_b[e]], 1);
+            t_row[out0 + pos] = r - j * CH_ROWS;           // row inside the chunk's x tile
+            t_perm[out0 + pos] = e;                        // position in the slice's values
+        }
+    }
+}
+
+// One (slice, chunk): partial[j][b] = A_j^T x_j, all S rows (zeros where the chunk has nothing).
+__global__ __launch_bounds__(SP_THREADS_LDS) void spmm_t64_chunk_kernel(
+    const int32_t *__restrict__ indptr, const int32_t *__restrict__ t_ptr,
+    const int32_t *__restrict__ t_row, const int32_t *__restrict__ t_perm,
+    const float *__restrict__ values, const float *__restrict__ x, float *__restrict__ partial,
+    int B, int S, int nnz, int nchunks, int x_heads) {
+    constexpr int E = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xtile = reinterpret_cast<float *>(smem);       // [CH_ROWS][E]
+    int *ticket = reinterpret_cast<int *>(smem + (size_t)CH_ROWS * E * sizeof(float));
+    const int bj = blockIdx.x;
+    const int b = bj / nchunks, j = bj - b * nchunks;
+    const int tid = threadIdx.x;
+    if (tid == 0) *ticket = 0;
+    const DenseView xv = dense_view(b, S, E, x_heads);
+    stage_rows(xtile, x + xv.base + (size_t)j * CH_ROWS * xv.ld, xv.ld, CH_ROWS, E, tid,
+               SP_THREADS_LDS);
+    __syncthreads();
+    const size_t e0 = (size_t)b * nnz + indptr[j * CH_ROWS];
+    gather_rows_dynamic<G_SPMM_PERM>(t_ptr + (size_t)bj * (S + 1), t_row + e0, t_perm + e0,
+                                     values + (size_t)b * nnz, xtile,
+                                     partial + ((size_t)j * B + b) * S * E, ticket, S, E);
+}
+
+// y[b][c] = sum over chunks of partial[j][b][c]
+__global__ __launch_bounds__(256) void chunk_reduce_kernel(const float *__restrict__ partial,
+                                                           float *__restrict__ y, int B, int S,
+                                                           int nchunks, int y_heads) {
+    constexpr int E = 64;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;     // float4 index
+    const long long total = (long long)B * S * (E / 4);
+    if (i >= total) return;
+    const int c4 = (int)(i % (E / 4));
+    const long long row = i / (E / 4);
+    const int b = (int)(row / S), c = (int)(row - (long long)b * S);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < nchunks; j++) {
+        const float4 v = *reinterpret_cast<const float4 *>(
+            partial + (((size_t)j * B + b) * S + c) * E + 4 * c4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const DenseView yv = dense_view(b, S, E, y_heads);
+    *reinterpret_cast<float4 *>(y + yv.base + (size_t)c * yv.ld + 4 * c4) = acc;
+}
+
 // ------------------------------------------------------------------ host side
 
 struct TransposedCsr {
-    int32_t *t_ptr, *t_row, *t_perm;
+    int32_t *t_ptr, *t_row, *t_perm, *counts;
 };
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static int64_t transpose_bytes(int B, int S, int nnz) {
+// Which form does the product kernel for this head size want?
+static bool chunked_layout(int S, int E) {
+    return E == 64 && S > CH_ROWS && S % CH_ROWS == 0 && S <= 16384;
+}
+
+static int64_t transpose_bytes(int B, int S, int nnz, int E) {
+    if (chunked_layout(S, E)) {
+        const size_t nch = (size_t)S / CH_ROWS;
+        return (int64_t)(align256((size_t)B * nch * (S + 1) * 4) + 2 * align256((size_t)B * nnz * 4) +
+                         align256((size_t)B * nch * CH_QUARTERS * S * 4));
+    }
     return (int64_t)(align256((size_t)B * (S + 1) * 4) + 2 * align256((size_t)B * nnz * 4));
 }
 
-static TransposedCsr carve(void *workspace, int B, int S, int nnz) {
+static TransposedCsr carve(void *workspace, int B, int S, int nnz, int E = 0) {
     char *p = reinterpret_cast<char *>(workspace);
+    const size_t nch = chunked_layout(S, E) ? (size_t)S / CH_ROWS : 1;
     TransposedCsr t;
     t.t_ptr = reinterpret_cast<int32_t *>(p);
-    p += align256((size_t)B * (S + 1) * 4);
+    p += align256((size_t)B * nch * (S + 1) * 4);
     t.t_row = reinterpret_cast<int32_t *>(p);
     p += align256((size_t)B * nnz * 4);
     t.t_perm = reinterpret_cast<int32_t *>(p);
+    p += align256((size_t)B * nnz * 4);
+    t.counts = reinterpret_cast<int32_t *>(p);      // chunked form only
     return t;
+}
+
+static int launch_transpose_chunked(const int32_t *indptr, const int32_t *indices,
+                                    TransposedCsr t, int B, int S, int nnz, hipStream_t s) {
+    const int nch = S / CH_ROWS;
+    const size_t lds = (size_t)S * sizeof(int);
+    const unsigned nq = (unsigned)((size_t)B * nch * CH_QUARTERS);
+    hipLaunchKernelGGL(chunk_count_kernel, dim3(nq), dim3(TR_THREADS), lds, s, indptr, indices,
+                       t.counts, S, nnz, nch);
+    SPT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chunk_scan_kernel, dim3((unsigned)(B * nch)), dim3(TR_THREADS), 0, s,
+                       t.counts, t.t_ptr, S);
+    SPT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chunk_place_kernel, dim3(nq), dim3(TR_THREADS), lds, s, indptr, indices,
+                       t.counts, t.t_row, t.t_perm, S, nnz, nch);
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
 }
 
 static int launch_transpose(const int32_t *indptr, const int32_t *indices, TransposedCsr t,
@@ -679,46 +854,87 @@ static int check_spmm_args(const void *a, const void *b, const void *c, const vo
     return SPT_OK;
 }
 
+// A^T x on the chunked form: (slice, chunk) products into `partial`, then the sum over chunks
+static int launch_gather_chunked(const int32_t *indptr, const TransposedCsr &t,
+                                 const float *values, const float *x, float *y, float *partial,
+                                 int B, int S, int nnz, int x_heads, int y_heads, hipStream_t s) {
+    if (x_heads < 0 || y_heads < 0) return SPT_EINVAL;
+    if ((x_heads > 0 && B % x_heads != 0) || (y_heads > 0 && B % y_heads != 0)) return SPT_ESHAPE;
+    if (!partial) return SPT_EINVAL;
+    const int nch = S / CH_ROWS;
+    const size_t lds = (size_t)CH_ROWS * 64 * sizeof(float) + 16;
+    SPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_t64_chunk_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(spmm_t64_chunk_kernel, dim3((unsigned)(B * nch)), dim3(SP_THREADS_LDS), lds,
+                       s, indptr, t.t_ptr, t.t_row, t.t_perm, values, x, partial, B, S, nnz, nch,
+                       x_heads);
+    SPT_LAUNCH_CHECK();
+    const long long total4 = (long long)B * S * 16;
+    hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+                       s, partial, y, B, S, nch, y_heads);
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
+static int64_t product_scratch_bytes(int B, int S, int E, int nnz) {
+    if (chunked_layout(S, E))                                        // per-chunk partial outputs
+        return (int64_t)(S / CH_ROWS) * B * S * E * (int64_t)sizeof(float);
+    return (int64_t)B * nnz * (int64_t)sizeof(float);                 // permuted values
+}
+
 }  // namespace spt
 
 using namespace spt;
 
-extern "C" int64_t spt_csr_transpose_workspace_bytes(int batch_size, int seq_length, int nnz) {
+extern "C" int64_t spt_csr_transpose_workspace_bytes(int batch_size, int seq_length, int nnz,
+                                                     int d_head) {
     if (batch_size <= 0 || seq_length <= 0 || nnz < 0) return 0;
-    return transpose_bytes(batch_size, seq_length, nnz);
+    return transpose_bytes(batch_size, seq_length, nnz, d_head);
 }
 
 extern "C" int spt_csr_transpose(const int32_t *indptr, const int32_t *indices, void *transposed,
-                                 int batch_size, int seq_length, int nnz, void *stream) {
+                                 int batch_size, int seq_length, int nnz, int d_head,
+                                 void *stream) {
     if (!indptr || !indices || !transposed) return SPT_EINVAL;
     if (batch_size <= 0 || seq_length <= 0 || nnz <= 0) return SPT_EINVAL;
-    return launch_transpose(indptr, indices, carve(transposed, batch_size, seq_length, nnz),
-                            batch_size, seq_length, nnz, (hipStream_t)stream);
+    const TransposedCsr t = carve(transposed, batch_size, seq_length, nnz, d_head);
+    if (chunked_layout(seq_length, d_head))
+        return launch_transpose_chunked(indptr, indices, t, batch_size, seq_length, nnz,
+                                        (hipStream_t)stream);
+    return launch_transpose(indptr, indices, t, batch_size, seq_length, nnz, (hipStream_t)stream);
 }
 
-extern "C" int64_t spt_spmm_transposed_workspace_bytes(int batch_size, int nnz) {
-    if (batch_size <= 0 || nnz <= 0) return 0;
-    return (int64_t)batch_size * nnz * (int64_t)sizeof(float);
+extern "C" int64_t spt_spmm_transposed_workspace_bytes(int batch_size, int seq_length, int d_head,
+                                                       int nnz) {
+    if (batch_size <= 0 || seq_length <= 0 || d_head <= 0 || nnz <= 0) return 0;
+    return product_scratch_bytes(batch_size, seq_length, d_head, nnz);
 }
 
-extern "C" int spt_spmm_transposed(const void *transposed, const float *values, const float *x,
-                                   float *y, void *workspace, int batch_size, int seq_length,
-                                   int d_head, int nnz, int x_heads, int y_heads, void *stream) {
+extern "C" int spt_spmm_transposed(const int32_t *indptr, const void *transposed,
+                                   const float *values, const float *x, float *y, void *workspace,
+                                   int batch_size, int seq_length, int d_head, int nnz,
+                                   int x_heads, int y_heads, void *stream) {
     const int rc =
-        check_spmm_args(transposed, values, x, y, y, batch_size, seq_length, d_head, nnz);
+        check_spmm_args(transposed, values, x, y, indptr, batch_size, seq_length, d_head, nnz);
     if (rc != SPT_OK) return rc;
     if (nnz == 0) return SPT_EINVAL;
-    const TransposedCsr t = carve(const_cast<void *>(transposed), batch_size, seq_length, nnz);
+    const TransposedCsr t =
+        carve(const_cast<void *>(transposed), batch_size, seq_length, nnz, d_head);
+    if (chunked_layout(seq_length, d_head))
+        return launch_gather_chunked(indptr, t, values, x, y, reinterpret_cast<float *>(workspace),
+                                     batch_size, seq_length, nnz, x_heads, y_heads,
+                                     (hipStream_t)stream);
     return launch_gather<true>(t.t_ptr, seq_length + 1, t.t_row, t.t_perm, values, x, y,
                                batch_size, seq_length, d_head, nnz, x_heads, y_heads,
                                (hipStream_t)stream, reinterpret_cast<float *>(workspace));
 }
 
 extern "C" int64_t spt_spmm_workspace_bytes(int trans_lhs, int batch_size, int seq_length,
-                                            int nnz) {
+                                            int d_head, int nnz) {
     if (!trans_lhs) return 0;
-    return (int64_t)align256((size_t)spt_csr_transpose_workspace_bytes(batch_size, seq_length, nnz)) +
-           spt_spmm_transposed_workspace_bytes(batch_size, nnz);
+    return (int64_t)align256(
+               (size_t)spt_csr_transpose_workspace_bytes(batch_size, seq_length, nnz, d_head)) +
+           spt_spmm_transposed_workspace_bytes(batch_size, seq_length, d_head, nnz);
 }
 
 extern "C" int spt_spmm_forward(int trans_lhs, const int32_t *indptr, const int32_t *indices,
@@ -738,12 +954,18 @@ extern "C" int spt_spmm_forward(int trans_lhs, const int32_t *indptr, const int3
         return launch_gather<false>(indptr, 0, indices, nullptr, values, x, y, B, S, E, nnz,
                                     x_heads, y_heads, s);
     if (!workspace) return SPT_EINVAL;
-    const TransposedCsr t = carve(workspace, B, S, nnz);
+    const TransposedCsr t = carve(workspace, B, S, nnz, E);
+    float *scratch = reinterpret_cast<float *>(
+        reinterpret_cast<char *>(workspace) +
+        align256((size_t)spt_csr_transpose_workspace_bytes(B, S, nnz, E)));
+    if (chunked_layout(S, E)) {
+        const int rc2 = launch_transpose_chunked(indptr, indices, t, B, S, nnz, s);
+        if (rc2 != SPT_OK) return rc2;
+        return launch_gather_chunked(indptr, t, values, x, y, scratch, B, S, nnz, x_heads, y_heads,
+                                     s);
+    }
     const int rc2 = launch_transpose(indptr, indices, t, B, S, nnz, s);
     if (rc2 != SPT_OK) return rc2;
-    float *vt = reinterpret_cast<float *>(
-        reinterpret_cast<char *>(workspace) +
-        align256((size_t)spt_csr_transpose_workspace_bytes(B, S, nnz)));
     return launch_gather<true>(t.t_ptr, S + 1, t.t_row, t.t_perm, values, x, y, B, S, E, nnz,
-                               x_heads, y_heads, s, vt);
+                               x_heads, y_heads, s, scratch);
 }

@@ -39,12 +39,12 @@ _PROTOTYPES = {
     'spt_sddmm_forward': (
         [_c_ptr] * 5 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int
     ),
-    'spt_spmm_workspace_bytes': ([_c_int] * 4, ctypes.c_int64),
+    'spt_spmm_workspace_bytes': ([_c_int] * 5, ctypes.c_int64),
     'spt_spmm_forward': ([_c_int] + [_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr], _c_int),
-    'spt_csr_transpose_workspace_bytes': ([_c_int] * 3, ctypes.c_int64),
-    'spt_csr_transpose': ([_c_ptr] * 3 + [_c_int] * 3 + [_c_ptr], _c_int),
-    'spt_spmm_transposed_workspace_bytes': ([_c_int] * 2, ctypes.c_int64),
-    'spt_spmm_transposed': ([_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr], _c_int),
+    'spt_csr_transpose_workspace_bytes': ([_c_int] * 4, ctypes.c_int64),
+    'spt_csr_transpose': ([_c_ptr] * 3 + [_c_int] * 4 + [_c_ptr], _c_int),
+    'spt_spmm_transposed_workspace_bytes': ([_c_int] * 4, ctypes.c_int64),
+    'spt_spmm_transposed': ([_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr], _c_int),
     'spt_grouped_gemm': ([_c_ptr] * 7 + [_c_int] * 5 + [ctypes.c_longlong, _c_int, _c_int, _c_ptr],
                          _c_int),
     'spt_sparse_attention_forward': ([_c_ptr] * 7 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int,
@@ -60,7 +60,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _lib = None
 
@@ -467,36 +467,37 @@ def sparse_attention_backward_rows(indices: torch.Tensor, grad_y: torch.Tensor, 
     return grad_raw, grad_q, rows
 
 
-def csr_transpose(indptr: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
+def csr_transpose(indptr: torch.Tensor, indices: torch.Tensor, d_head: int = 64) -> torch.Tensor:
     """Transposed structure of a batched CSR pattern, as an opaque uint8 buffer for
-    ``spmm_transposed``.  Depends on (indptr, indices) only, so one build serves every
-    A^T product of a backward pass."""
+    ``spmm_transposed``.  Depends on (indptr, indices) and on the head size of the products
+    that will use it (it selects the flat or the chunked form, include/spt_hip.h), so one
+    build serves every A^T product of a backward pass."""
     _check_csr(indptr, indices)
     dev = _same_device(indptr, indices)
     B, nnz = indices.shape
     S = indptr.size(-1) - 1
     lib = load_library()
     with torch.cuda.device(dev):
-        nbytes = lib.spt_csr_transpose_workspace_bytes(B, S, nnz)
+        nbytes = lib.spt_csr_transpose_workspace_bytes(B, S, nnz, int(d_head))
         buf = torch.empty([max(int(nbytes), 16)], dtype=torch.uint8, device=dev)
         if nnz > 0:
             rc = lib.spt_csr_transpose(indptr.data_ptr(), indices.data_ptr(),
-                                       buf.data_ptr(), B, S, nnz, _stream(dev))
+                                       buf.data_ptr(), B, S, nnz, int(d_head), _stream(dev))
             if rc != 0:
                 _raise(lib, rc, 'csr_transpose')
     return buf
 
 
-def transposed_for(indptr: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
+def transposed_for(indptr: torch.Tensor, indices: torch.Tensor, d_head: int = 64) -> torch.Tensor:
     """``csr_transpose`` memoised on the ``indices`` tensor object itself (keyed by the
-    tensors' in-place version counters), so the A^T products of one backward pass --
-    grad_K in sddmm's backward, grad_V in spmm's -- share one build.  The cache dies
-    with the tensor."""
-    key = (indices._version, indptr.data_ptr(), indptr._version)
+    tensors' in-place version counters and the head size), so the A^T products of one
+    backward pass -- grad_K in sddmm's backward, grad_V in spmm's -- share one build.  The
+    cache dies with the tensor."""
+    key = (indices._version, indptr.data_ptr(), indptr._version, int(d_head))
     cached = getattr(indices, '_spt_transposed', None)
     if cached is not None and cached[0] == key:
         return cached[1]
-    buf = csr_transpose(indptr, indices)
+    buf = csr_transpose(indptr, indices, d_head)
     indices._spt_transposed = (key, buf)
     return buf
 
@@ -504,8 +505,8 @@ def transposed_for(indptr: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
 def spmm_transposed(transposed: torch.Tensor, indptr: torch.Tensor,
                     indices: torch.Tensor, values: torch.Tensor,
                     x: torch.Tensor, x_heads: int = 0, y_heads: int = 0) -> torch.Tensor:
-    """y = A^T . x with a structure from ``csr_transpose`` (same result as
-    ``spmm_forward_cuda(True, False, ...)``)."""
+    """y = A^T . x with a structure from ``csr_transpose`` built for this head size (same
+    result as ``spmm_forward_cuda(True, False, ...)``)."""
     dev, B, S, E = _check_spmm(indptr, indices, values, x, x_heads)
     nnz = indices.size(-1)
     lib = load_library()
@@ -513,9 +514,11 @@ def spmm_transposed(transposed: torch.Tensor, indptr: torch.Tensor,
         output = _alloc_dense(B, S, E, y_heads, dev)
         if nnz == 0:
             return output.zero_()
-        nbytes = lib.spt_spmm_transposed_workspace_bytes(B, nnz)
+        _require(transposed.numel() >= lib.spt_csr_transpose_workspace_bytes(B, S, nnz, E),
+                 'spmm_transposed: the structure was built for another head size')
+        nbytes = lib.spt_spmm_transposed_workspace_bytes(B, S, E, nnz)
         scratch = torch.empty([max(int(nbytes), 16)], dtype=torch.uint8, device=dev)
-        rc = lib.spt_spmm_transposed(transposed.data_ptr(), values.data_ptr(),
+        rc = lib.spt_spmm_transposed(indptr.data_ptr(), transposed.data_ptr(), values.data_ptr(),
                                      x.data_ptr(), output.data_ptr(), scratch.data_ptr(),
                                      B, S, E, nnz, int(x_heads), int(y_heads), _stream(dev))
     if rc != 0:
@@ -538,7 +541,7 @@ def spmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,
             return output.zero_()
         workspace = None
         if trans:
-            nbytes = lib.spt_spmm_workspace_bytes(trans, B, S, nnz)
+            nbytes = lib.spt_spmm_workspace_bytes(trans, B, S, E, nnz)
             workspace = torch.empty([max(int(nbytes), 16)], dtype=torch.uint8, device=dev)
         rc = lib.spt_spmm_forward(
             trans, indptr.data_ptr(), indices.data_ptr(), values.data_ptr(),

@@ -32,7 +32,7 @@ class SDDMM(torch.autograd.Function):
             )
         if ctx.needs_input_grad[3]:
             grad_key = ext.spmm_transposed(
-                ext.transposed_for(indptr, indices),
+                ext.transposed_for(indptr, indices, query.size(-1)),
                 indptr, indices, grad_output, query
             )
         return None, None, grad_query, grad_key

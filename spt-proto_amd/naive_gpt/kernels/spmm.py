@@ -26,7 +26,7 @@ class SPMM(torch.autograd.Function):
             )
         if ctx.needs_input_grad[3]:
             grad_x = ext.spmm_transposed(
-                ext.transposed_for(indptr, indices),
+                ext.transposed_for(indptr, indices, grad_output.size(-1)),
                 indptr, indices, values, grad_output
             )
         return None, None, grad_values, grad_x

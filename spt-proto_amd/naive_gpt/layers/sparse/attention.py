@@ -53,7 +53,7 @@ class _ScaledClampedSDDMM(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             grad_query = ext.spmm_forward_cuda(False, False, indptr, indices, grad_raw, key)
         if ctx.needs_input_grad[3]:
-            grad_key = ext.spmm_transposed(ext.transposed_for(indptr, indices),
+            grad_key = ext.spmm_transposed(ext.transposed_for(indptr, indices, query.size(-1)),
                                            indptr, indices, grad_raw, query)
         return None, None, grad_query, grad_key, None
 
@@ -83,7 +83,7 @@ class _HeadScores(torch.autograd.Function):
             grad_q = ext.spmm_forward_cuda(False, False, indptr, indices, grad_raw, k,
                                            x_heads=h, y_heads=h)
         if ctx.needs_input_grad[3]:
-            grad_k = ext.spmm_transposed(ext.transposed_for(indptr, indices), indptr, indices,
+            grad_k = ext.spmm_transposed(ext.transposed_for(indptr, indices, q.size(-1)), indptr, indices,
                                          grad_raw, q, x_heads=h, y_heads=h)
         return None, None, grad_q, grad_k, None, None
 
@@ -108,7 +108,7 @@ class _HeadSPMM(torch.autograd.Function):
             grad_values = ext.sddmm_forward_cuda(False, True, indptr, indices, grad_y, v,
                                                  query_heads=0, key_heads=h)
         if ctx.needs_input_grad[3]:
-            grad_v = ext.spmm_transposed(ext.transposed_for(indptr, indices), indptr, indices,
+            grad_v = ext.spmm_transposed(ext.transposed_for(indptr, indices, v.size(-1)), indptr, indices,
                                          values, grad_y, x_heads=0, y_heads=h)
         return None, None, grad_values, grad_v, None
 
@@ -139,7 +139,7 @@ class _FusedAttention(torch.autograd.Function):
         grad_raw, grad_q, grad_y = ext.sparse_attention_backward_rows(
             indices, grad_out.contiguous(), v, k, scores, attn, ctx.scale, CLAMP,
             grad_y_transposed=True, causal=True)
-        transposed = ext.transposed_for(indptr, indices)
+        transposed = ext.transposed_for(indptr, indices, q.size(-1))
         grad_v = ext.spmm_transposed(transposed, indptr, indices, attn, grad_y,
                                      x_heads=0, y_heads=h)
         grad_k = ext.spmm_transposed(transposed, indptr, indices, grad_raw, q,

@@ -54,7 +54,7 @@ def oracle_ext(monkeypatch):
         monkeypatch.setattr(ext, name, getattr(ext_stub, name))
     monkeypatch.setattr(ext, 'sddmm_forward_cuda', sddmm)
     monkeypatch.setattr(ext, 'spmm_forward_cuda', spmm)
-    monkeypatch.setattr(ext, 'transposed_for', lambda indptr, indices: None)
+    monkeypatch.setattr(ext, 'transposed_for', lambda indptr, indices, d_head=64: None)
     monkeypatch.setattr(ext, 'spmm_transposed',
                         lambda t, indptr, indices, values, x: spmm(True, False, indptr, indices,
                                                                    values, x))

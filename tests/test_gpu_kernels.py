@@ -162,7 +162,9 @@ SPARSE_SHAPES = [
     (32, 512, 64, 64, True),     # config 2 slice -> LDS-resident kernels
     (48, 256, 64, 32, True),     # LDS-resident, rows split over blocks
     (3, 512, 64, 64, True),      # few batches -> gather-from-global kernels
-    (2, 2048, 64, 256, True),    # config 4: tile does not fit LDS
+    (2, 2048, 64, 256, True),    # config 4: tile does not fit LDS -> chunked transposed form
+    (3, 1024, 64, 128, True),    # two 512-row chunks
+    (2, 1536, 64, 48, False),    # three chunks, non-causal pattern (every chunk reaches every column)
     (2, 512, 128, 64, True),     # config 5 head dim
     (5, 16 * 7, 48, 14, False),  # reference test distribution (test_sddmm.py:49-53)
     (4, 16, 16, 2, False), (2, 256, 32, 32, False), (40, 128, 16, 16, False),
@@ -435,3 +437,27 @@ def test_layer_head_layout_path_equals_copying_path():
         for a, b in zip(fast, slow):
             if a is not None:
                 assert torch.allclose(a, b, rtol=1e-3, atol=2e-4)
+
+
+def test_chunked_transposed_product_head_layout_and_reuse():
+    """S = 1024 at E = 64: one chunked build serves both products of a backward, with the
+    head-layout operands of the attention layer; equal to the plain-layout result."""
+    from naive_gpt import ext
+    rng = np.random.default_rng(5)
+    N, H, S, E, Z = 2, 4, 1024, 64, 128
+    B = N * H
+    indptr, idx = uniform_csr(rng, B, S, Z, True)
+    vals = rng.standard_normal([B, S * Z]).astype(np.float32)
+    x4 = torch.from_numpy(rng.standard_normal([N, S, H, E]).astype(np.float32)).cuda()
+    flat = lambda t: t.transpose(1, 2).contiguous().view(B, S, E)       # noqa: E731
+    d_indptr, d_idx, d_vals = dev(indptr), dev(idx), dev(vals)
+    t = ext.transposed_for(d_indptr, d_idx, E)
+    assert ext.transposed_for(d_indptr, d_idx, E) is t
+    y_flat = ext.spmm_transposed(t, d_indptr, d_idx, d_vals, flat(x4))
+    close(y_flat, O.spmm_forward(True, indptr, idx, vals, flat(x4).cpu().numpy()), atol=5e-3)
+    y_heads = ext.spmm_transposed(t, d_indptr, d_idx, d_vals, x4, x_heads=H, y_heads=H)
+    assert y_heads.shape == (N, S, H, E)
+    assert torch.allclose(flat(y_heads), y_flat, rtol=1e-5, atol=1e-4)
+    # a structure built for another head size is refused, not misread
+    with pytest.raises(RuntimeError):
+        ext.spmm_transposed(ext.csr_transpose(d_indptr, d_idx, 128), d_indptr, d_idx, d_vals, flat(x4))
