@@ -42,7 +42,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 12
+#define SPT_ABI_VERSION 13
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -255,6 +255,51 @@ int spt_sparse_attention_backward_rows(const int32_t *indices, const float *grad
                                        float *grad_y_rows, int batch_size, int seq_length,
                                        int d_head, int nnz, float scale, float clamp, int heads,
                                        int grad_y_transposed, int causal, void *stream);
+
+/*
+ * The same attention core on the matrix cores (mfma_attention.hip): the CSR rows select the
+ * live cells of dense 32 x 32 score tiles computed with v_mfma_f32_32x32x16_bf16 on fp32
+ * operands split into two bf16 halves (three MFMAs per product, fp32 accumulation, relative
+ * error <= 2^-16 per product).  Nothing of size nnz is written: the backward recomputes the
+ * tiles from q, k, v and the [batch, S] row sums.
+ *   y[i]       = sum_p exp(s_p) v[col_p] / max(1e-9, row_sum[i]),
+ *   s_p        = clamp(scale * q[i].k[col_p]),  entries with col_p > i take no part
+ *   row_sum[i] = sum_p exp(s_p)                 (softmax.cu:17-30)
+ * Any uniform-row CSR with Z = nnz / S <= 64, Z % 4 == 0, d_head == 64, S <= 2048
+ * (repeated columns count with their multiplicity); SPT_EUNSUP otherwise.
+ * Layouts of q, k, v (heads) and y (y_transposed) as in spt_sparse_attention_forward.
+ */
+int spt_attention_mfma_supported(int seq_length, int d_head, int nnz);
+/*
+ * spt_attention_mfma_prepare buckets the CSR entries of every 32-row tile by 32-key tile (one
+ * pass over `indices` [batch, nnz]) into `tiles`, an opaque device buffer of
+ * spt_attention_mfma_tiles_bytes(...) bytes that the forward and the backward of the same
+ * layer step share (it depends on `indices` only).
+ */
+int64_t spt_attention_mfma_tiles_bytes(int batch_size, int seq_length, int nnz);
+int spt_attention_mfma_prepare(const int32_t *indices, void *tiles, int batch_size,
+                               int seq_length, int nnz, void *stream);
+int spt_attention_mfma_forward(const void *tiles, const float *q, const float *k,
+                               const float *v, float *y, float *row_sum, int batch_size,
+                               int seq_length, int d_head, int nnz, float scale, float clamp,
+                               int heads, int y_transposed, void *stream);
+
+/*
+ * The whole backward of spt_attention_mfma_forward: two launches, nothing of size nnz.
+ *   delta[i]  = max(1e-9, grad_y[i] . y[i])            (= sum_p P_p dP_p, softmax.cu:69)
+ *   dS_p      = scale * P_p * (dP_p - delta[i]) where |s_p| < clamp, else 0
+ *   grad_q[i] = sum_p dS_p k[col_p];  grad_k[j] = sum_{p: col_p = j} dS_p q[row_p];
+ *   grad_v[j] = sum_{p: col_p = j} P_p grad_y[row_p]
+ * y, grad_y: [batch, S, E], or with transposed != 0 both [batch, E, S] (S % 4 == 0).
+ * q, k, v and the three gradients follow `heads` as in the forward.  row_sum is the forward's
+ * output; delta [batch, S] is scratch that the first launch fills for the second.
+ */
+int spt_attention_mfma_backward(const void *tiles, const float *q, const float *k,
+                                const float *v, const float *y, const float *grad_y,
+                                const float *row_sum, float *delta, float *grad_q,
+                                float *grad_k, float *grad_v, int batch_size, int seq_length,
+                                int d_head, int nnz, float scale, float clamp, int heads,
+                                int transposed, void *stream);
 
 /*
  * Routed FFN: token-bucketed grouped GEMM on the fp32 matrix cores.

@@ -1,0 +1,989 @@
+// mfma_attention.hip -- the sparse attention core on the matrix cores (gfx950).
+//
+// Reference: SparseVanillaAttentionV2._get_attn / _apply_attn
+// (naive_gpt/layers/sparse/attention.py:106-142) and its backward through kernels/sddmm.py,
+// kernels/spmm.py, extension/softmax.cu.  Same mathematics as fused_attention.hip, different
+// machine mapping.  At the densities lookup produces (Z / S = 1/8 at S = 512) a gather kernel
+// moves a 256-byte K or V row through LDS per CSR entry and is LDS-bandwidth bound at ~1/5 of
+// the HBM roofline.  Here the CSR rows only decide WHICH cells of a dense
+// 32 x 32 score tile are alive:
+//
+//   tile      D[j, i] = sum_e K[j, e] Q[i, e]       v_mfma_f32_32x32x16_bf16, fp32 accumulate
+//   cells     p[j, i] = m[i, j] * exp(clamp(scale * D[j, i]))   m = multiplicity of column j in
+//             CSR row i (0 for most cells; > 1 only for lookup's zero padding), col <= row only
+//   product   Y[i, :] += sum_j p[j, i] V[j, :]      the accumulator tile is the next A operand
+//   row       y = Y / max(1e-9, sum_j p)            (softmax.cu:30; no max-subtraction, as there)
+//
+// fp32 operands are split into two bf16 halves x = hi + lo (hi = RNE(x), lo = RNE(x - hi)) and
+// every product is three MFMAs (lo*hi + hi*lo + hi*hi): relative error <= 2^-16 per product,
+// 50x inside the 1e-3 parity bar, at 1/5 of the fp32-MFMA cost.
+//
+// A workgroup of 8 waves owns 256 rows of one (sample, head) slice, a wave 32 rows.  K and V
+// stream through LDS 32 keys at a time as bf16 images (K row-major for the A operand, V
+// transposed for the B operand, double-buffered, one barrier per tile); a wave skips the
+// tiles its rows have no entries in, which includes everything right of the diagonal
+// (softmax.cu:19-31 masks col > row).  The multiplicities m come from a one-off pass over the
+// CSR (spt_attention_mfma_prepare) that stores, per (32-row tile, 32-key tile), the 1 KiB of
+// cell counts already permuted into the accumulator layout: a consumer lane loads its 16
+// bytes with one global_load_dwordx4 a tile ahead and touches no LDS for them.
+#include "spt_common.h"
+
+namespace spt {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int MA_THREADS = 512;
+constexpr int MA_WAVES = MA_THREADS / SPT_WAVE;   // 8
+constexpr int MA_WROWS = 32;                       // rows per wave = one MFMA tile
+constexpr int MA_ROWS = MA_WAVES * MA_WROWS;       // 256 rows per workgroup
+constexpr int MA_KT = 32;                          // keys per tile
+constexpr int MA_E = 64;
+constexpr int MA_MAXZ = 64;                        // entries per row the per-wave list holds
+constexpr int MA_MAXNT = 64;                       // key tiles: S <= 2048
+
+// LDS images of one key tile, bf16: rows padded so that the operand reads are conflict-free
+constexpr int MA_KLD = 144;                        // bytes per key row: 64 bf16 + 16
+constexpr int MA_VLD = 72;                         // bytes per e row of V^T: 32 bf16 + 8
+constexpr int MA_KH = 0, MA_KL = MA_KT * MA_KLD, MA_VH = 2 * MA_KT * MA_KLD,
+              MA_VL = MA_VH + MA_E * MA_VLD, MA_IMG = MA_VL + MA_E * MA_VLD;   // 18432 B
+constexpr int MA_CLD = 9;                          // words per row of the multiplicity tile
+constexpr int MA_LIST = MA_WROWS * MA_MAXZ * 2;    // prepare: the bucketed entries of a row tile
+constexpr int MA_CNT = MA_WROWS * MA_CLD * 4;      // prepare: one tile of counts, 1152 B
+constexpr int MA_CELLS = MA_WROWS * MA_KT;         // bytes of one stored cell tile
+
+struct Split { unsigned hi, lo; };
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// two floats -> packed bf16 pairs (first value in the low half): hi = RNE, lo = RNE(x - hi).
+// Whole-vector conversions: element-wise (__bf16) casts compile to one v_cvt_pk_bf16_f32 per
+// ELEMENT plus re-packing (81 conversions per tile instead of 24).
+__device__ __forceinline__ Split split2(float a, float b) {
+    const f32x2 x = {a, b};
+    Split s;
+    s.hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+    const f32x2 hf = {__builtin_bit_cast(float, s.hi << 16),
+                      __builtin_bit_cast(float, s.hi & 0xffff0000u)};
+    s.lo = __builtin_bit_cast(unsigned, __builtin_convertvector(x - hf, bf16x2));
+    return s;
+}
+struct Frag { uint4 hi, lo; };      // 8 bf16 each: one MFMA operand fragment, split
+__device__ __forceinline__ Frag split8(float a0, float a1, float a2, float a3, float a4,
+                                       float a5, float a6, float a7) {
+    const Split s0 = split2(a0, a1), s1 = split2(a2, a3), s2 = split2(a4, a5),
+                s3 = split2(a6, a7);
+    Frag f;
+    f.hi = make_uint4(s0.hi, s1.hi, s2.hi, s3.hi);
+    f.lo = make_uint4(s0.lo, s1.lo, s2.lo, s3.lo);
+    return f;
+}
+__device__ __forceinline__ f32x16 mma(const uint4 &a, const uint4 &b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// (a.hi + a.lo)(b.hi + b.lo) without the lo*lo term, small terms first
+__device__ __forceinline__ f32x16 mma3(const Frag &a, const Frag &b, f32x16 c) {
+    c = mma(a.lo, b.hi, c);
+    c = mma(a.hi, b.lo, c);
+    return mma(a.hi, b.hi, c);
+}
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS executes one wave's instructions in order; this only stops the compiler from
+    // moving accesses of different lanes' data across the point
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// accumulator register r of lane half h holds tile row  (r & 3) + 8 (r >> 2) + 4 h
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- 32-row tiles of a dense operand: global fp32 -> registers -> bf16 LDS images ----
+// "rows" image [r][e] (144-byte rows): A-operand fragments by read_rows;
+// "cols" image [e][r] (72-byte rows):  B-operand fragments in accumulator k order by read_cols.
+constexpr int MA_RIMG = MA_KT * MA_KLD;            // one rows image (hi or lo): 4608 B
+constexpr int MA_CIMG = MA_E * MA_VLD;             // one cols image (hi or lo): 4608 B
+// four values of row r at e4 .. e4 + 3
+template <bool ROWS, bool COLS>
+__device__ __forceinline__ void put4_along_e(char *rows, char *cols, int r, int e4,
+                                             const float4 &x) {
+    const Split a = split2(x.x, x.y), b = split2(x.z, x.w);
+    if (ROWS) {
+        *reinterpret_cast<uint2 *>(rows + r * MA_KLD + e4 * 2) = make_uint2(a.hi, b.hi);
+        *reinterpret_cast<uint2 *>(rows + MA_RIMG + r * MA_KLD + e4 * 2) = make_uint2(a.lo, b.lo);
+    }
+    if (COLS) {
+        auto st = [&](char *img, int e, unsigned v16) {
+            *reinterpret_cast<unsigned short *>(img + e * MA_VLD + r * 2) = (unsigned short)v16;
+        };
+        st(cols, e4 + 0, a.hi & 0xffffu); st(cols, e4 + 1, a.hi >> 16);
+        st(cols, e4 + 2, b.hi & 0xffffu); st(cols, e4 + 3, b.hi >> 16);
+        st(cols + MA_CIMG, e4 + 0, a.lo & 0xffffu); st(cols + MA_CIMG, e4 + 1, a.lo >> 16);
+        st(cols + MA_CIMG, e4 + 2, b.lo & 0xffffu); st(cols + MA_CIMG, e4 + 3, b.lo >> 16);
+    }
+}
+// four values of column e at rows r4 .. r4 + 3 (an operand stored [E][S])
+template <bool ROWS, bool COLS>
+__device__ __forceinline__ void put4_along_r(char *rows, char *cols, int e, int r4,
+                                             const float4 &x) {
+    const Split a = split2(x.x, x.y), b = split2(x.z, x.w);
+    if (COLS) {
+        *reinterpret_cast<uint2 *>(cols + e * MA_VLD + r4 * 2) = make_uint2(a.hi, b.hi);
+        *reinterpret_cast<uint2 *>(cols + MA_CIMG + e * MA_VLD + r4 * 2) = make_uint2(a.lo, b.lo);
+    }
+    if (ROWS) {
+        auto st = [&](char *img, int r, unsigned v16) {
+            *reinterpret_cast<unsigned short *>(img + r * MA_KLD + e * 2) = (unsigned short)v16;
+        };
+        st(rows, r4 + 0, a.hi & 0xffffu); st(rows, r4 + 1, a.hi >> 16);
+        st(rows, r4 + 2, b.hi & 0xffffu); st(rows, r4 + 3, b.hi >> 16);
+        st(rows + MA_RIMG, r4 + 0, a.lo & 0xffffu); st(rows + MA_RIMG, r4 + 1, a.lo >> 16);
+        st(rows + MA_RIMG, r4 + 2, b.lo & 0xffffu); st(rows + MA_RIMG, r4 + 3, b.lo >> 16);
+    }
+}
+
+// The forward's key tiles: K as a rows image, V as a cols image.
+struct TileRegs { float4 kf, vf; };
+struct TileStager {
+    const float *k_b, *v_b;
+    int ld, S, jl, e4;
+    __device__ __forceinline__ TileStager(const float *k, const float *v, int ld_, int S_, int tid)
+        : k_b(k), v_b(v), ld(ld_), S(S_), jl(tid >> 4), e4((tid & 15) * 4) {}
+    __device__ __forceinline__ TileRegs load(int t) const {
+        TileRegs r;
+        r.kf = r.vf = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int j = t * MA_KT + jl;
+        if (j < S) {
+            r.kf = *reinterpret_cast<const float4 *>(k_b + (size_t)j * ld + e4);
+            r.vf = *reinterpret_cast<const float4 *>(v_b + (size_t)j * ld + e4);
+        }
+        return r;
+    }
+    __device__ __forceinline__ void store(char *buf, const TileRegs &r) const {
+        put4_along_e<true, false>(buf + MA_KH, nullptr, jl, e4, r.kf);
+        put4_along_e<false, true>(nullptr, buf + MA_VH, jl, e4, r.vf);
+    }
+};
+
+// A-operand fragment of k-step ks from a row-major image: lane (r, h) reads row r, elements
+// 8h + 16ks .. + 8 (16 bytes)
+__device__ __forceinline__ Frag read_rows(const char *hi, const char *lo, int lane, int ks) {
+    const int off = (lane & 31) * MA_KLD + 16 * (lane >> 5) + 32 * ks;
+    Frag f;
+    f.hi = *reinterpret_cast<const uint4 *>(hi + off);
+    f.lo = *reinterpret_cast<const uint4 *>(lo + off);
+    return f;
+}
+// B-operand fragment whose k order matches an accumulator tile used as the A operand
+// (k-step s, element jj of lane half h <-> tile row 16s + 8(jj>>2) + 4h + (jj&3)):
+// lane (c, h) reads row c of the transposed image at 16s + 4h .. +4 and 16s + 8 + 4h .. +4
+__device__ __forceinline__ Frag read_cols(const char *hi, const char *lo, int row, int h, int s) {
+    const int off = row * MA_VLD + 32 * s + 8 * h;
+    const uint2 a = *reinterpret_cast<const uint2 *>(hi + off),
+                b = *reinterpret_cast<const uint2 *>(hi + off + 16),
+                c = *reinterpret_cast<const uint2 *>(lo + off),
+                d = *reinterpret_cast<const uint2 *>(lo + off + 16);
+    Frag f;
+    f.hi = make_uint4(a.x, a.y, b.x, b.y);
+    f.lo = make_uint4(c.x, c.y, d.x, d.y);
+    return f;
+}
+
+// B-operand fragments of a wave's own 32 rows of a dense operand: lane (r, h) holds row
+// i0 + r, elements 8h + 16ks .. + 8.  TR == false: x[row * ld + e]; TR: x[e * S + row].
+template <bool TR>
+__device__ __forceinline__ void load_own_rows_raw(float (&x)[32], const float *x_b, int ld, int S,
+                                                  int i0, int lane) {
+    const int row = i0 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[8 * ks + j] = 0.f;
+        if (row < S) {
+            if (!TR) {
+                const float *p = x_b + (size_t)row * ld + 8 * h + 16 * ks;
+                const float4 a = *reinterpret_cast<const float4 *>(p);
+                const float4 b = *reinterpret_cast<const float4 *>(p + 4);
+                x[8 * ks + 0] = a.x; x[8 * ks + 1] = a.y; x[8 * ks + 2] = a.z; x[8 * ks + 3] = a.w;
+                x[8 * ks + 4] = b.x; x[8 * ks + 5] = b.y; x[8 * ks + 6] = b.z; x[8 * ks + 7] = b.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    x[8 * ks + j] = x_b[(size_t)(8 * h + 16 * ks + j) * S + row];
+            }
+        }
+    }
+}
+__device__ __forceinline__ void split_own_rows(Frag (&f)[4], const float (&x)[32]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++)
+        f[ks] = split8(x[8 * ks], x[8 * ks + 1], x[8 * ks + 2], x[8 * ks + 3], x[8 * ks + 4],
+                       x[8 * ks + 5], x[8 * ks + 6], x[8 * ks + 7]);
+}
+__device__ __forceinline__ void load_own_rows(Frag (&f)[4], const float *x_b, int ld, int S,
+                                              int i0, int lane) {
+    float x[32];
+    load_own_rows_raw<false>(x, x_b, ld, S, i0, lane);
+    split_own_rows(f, x);
+}
+
+// ---- cell tiles: multiplicity of every (row, key) cell, per 32 x 32 tile ----
+//   masks [batch][RT] uint64: bit t set <=> key tile t has a live entry in row tile rt
+//   cells [batch][RT (RT + 1) / 2][64 lanes][16] uint8: tile (rt, t <= rt) at rt (rt + 1) / 2 + t;
+//     byte 4 g + u of lane (c, h) = multiplicity of key 32 t + 8 g + 4 h + u in row 32 rt + c --
+//     accumulator register 4 g + u of that lane when the tile is computed as D[key, row]
+//   cells_t, same indexing: byte 4 g + u of lane (c, h) = multiplicity of key 32 t + c in row
+//     32 rt + 8 g + 4 h + u -- the tile computed as D[row, key] (the key-owned backward)
+//   live = col <= row (softmax.cu:19-31 masks the others) and 0 <= col < S.
+// A wave owns a row tile: counting sort of its 32 Z entries by key tile (lane-private uint16
+// histograms: wave-wide atomics on <= 16 bucket counters ran at under one lane per clock),
+// then per bucket the counts are accumulated in an LDS tile and stored permuted.
+constexpr int MB_WAVES = 4;
+__host__ __device__ __forceinline__ size_t tri(size_t n) { return n * (n + 1) / 2; }
+__host__ __device__ __forceinline__ size_t prepare_lds_per_wave(int NT) {
+    return (size_t)NT * SPT_WAVE * 2 + MA_LIST + 2 * MA_CNT + (MA_MAXNT + 4) * 4;
+}
+__global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kernel(
+    const int32_t *__restrict__ indices, unsigned long long *__restrict__ masks,
+    unsigned char *__restrict__ cells, unsigned char *__restrict__ cells_t, int S, int Z, int NT,
+    int RT, int n_tiles_total) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gw = blockIdx.x * MB_WAVES + wave;
+    if (gw >= n_tiles_total) return;                    // no workgroup barrier below
+    const int b = gw / RT, rt = gw - b * RT, i0 = rt * MA_WROWS;
+    const size_t per_wave = prepare_lds_per_wave(NT);
+    unsigned short *hist = reinterpret_cast<unsigned short *>(smem + wave * per_wave);
+    unsigned short *stage = hist + (size_t)NT * SPT_WAVE;
+    unsigned *cnt = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(stage) + MA_LIST);
+    unsigned *cnt_t = cnt + MA_CNT / 4;                 // the same counts, [key][row]
+    int *boff = reinterpret_cast<int *>(reinterpret_cast<char *>(cnt) + 2 * MA_CNT);
+
+    // the tile's rows are one contiguous run of 32 * Z ints (Z % 4 == 0)
+    const int nrows = min(MA_WROWS, S - i0);
+    const int n4 = nrows * Z / 4;
+    const int4 *src = reinterpret_cast<const int4 *>(indices + ((size_t)b * S + i0) * Z);
+    constexpr int PER = MA_WROWS * MA_MAXZ / 4 / SPT_WAVE;   // 8 int4 per lane
+    int4 ent[PER];
+    int rowl[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int x = u * SPT_WAVE + lane;
+        ent[u] = make_int4(-1, -1, -1, -1);
+        if (x < n4) ent[u] = src[x];
+        rowl[u] = 4 * x / Z;          // an int4 never straddles rows
+    }
+    for (int x = lane; x < NT * SPT_WAVE / 2; x += SPT_WAVE)
+        reinterpret_cast<unsigned *>(hist)[x] = 0;
+    wave_lds_fence();
+    auto alive = [&](int c, int rl) { return c >= 0 && c <= i0 + rl && c < S; };
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int c[4] = {ent[u].x, ent[u].y, ent[u].z, ent[u].w};
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (alive(c[q], rowl[u])) hist[(c[q] >> 5) * SPT_WAVE + lane] += 1;
+    }
+    wave_lds_fence();
+    // bucket-major, lane-minor exclusive scan: hist[t][lane] becomes the lane's first slot
+    int running = 0;
+    unsigned long long mask = 0;
+    const int nbuckets = min(NT, rt + 1);               // live entries have col <= row
+    for (int t = 0; t < nbuckets; t++) {
+        const int v = hist[t * SPT_WAVE + lane];
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < SPT_WAVE; d <<= 1) {
+            const int up = __shfl_up(incl, d, SPT_WAVE);
+            if (lane >= d) incl += up;
+        }
+        hist[t * SPT_WAVE + lane] = (unsigned short)(running + incl - v);
+        if (lane == 0) boff[t] = running;
+        const int tot = __shfl(incl, SPT_WAVE - 1, SPT_WAVE);
+        if (tot > 0) mask |= 1ull << t;
+        running += tot;
+    }
+    if (lane == 0) {
+        boff[nbuckets] = running;
+        masks[gw] = mask;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int c[4] = {ent[u].x, ent[u].y, ent[u].z, ent[u].w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (alive(c[q], rowl[u])) {
+                const int at = (c[q] >> 5) * SPT_WAVE + lane;
+                const int pos = hist[at];
+                hist[at] = (unsigned short)(pos + 1);
+                stage[pos] = (unsigned short)((rowl[u] << 5) | (c[q] & 31));
+            }
+        }
+    }
+    wave_lds_fence();
+    // per bucket: counts in an LDS tile (row-major, 4 keys per word), stored permuted
+    unsigned char *out = cells + ((size_t)b * tri(RT) + tri(rt)) * MA_CELLS;
+    unsigned char *out_t = cells_t + ((size_t)b * tri(RT) + tri(rt)) * MA_CELLS;
+    const int c32 = lane & 31, h = lane >> 5;
+    for (int t = 0; t < nbuckets; t++) {
+        if (!((mask >> t) & 1ull)) continue;
+        const int lo = boff[t], n = boff[t + 1] - lo;
+        uint4 *c4 = reinterpret_cast<uint4 *>(cnt);     // both tiles: 2 x 72 x 16 bytes
+        c4[lane] = make_uint4(0u, 0u, 0u, 0u);
+        c4[SPT_WAVE + lane] = make_uint4(0u, 0u, 0u, 0u);
+        if (lane < 16) c4[2 * SPT_WAVE + lane] = make_uint4(0u, 0u, 0u, 0u);
+        wave_lds_fence();
+        for (int x = lane; x < n; x += SPT_WAVE) {
+            const unsigned e = stage[lo + x];
+            const unsigned r = e >> 5, jl = e & 31;
+            atomicAdd(&cnt[r * MA_CLD + (jl >> 2)], 1u << (8 * (jl & 3)));
+            atomicAdd(&cnt_t[jl * MA_CLD + (r >> 2)], 1u << (8 * (r & 3)));
+        }
+        wave_lds_fence();
+        // word 2 g + h of row c holds keys 8 g + 4 h .. + 3: exactly this lane's bytes 4 g ..
+        const unsigned *row = cnt + c32 * MA_CLD + h, *col = cnt_t + c32 * MA_CLD + h;
+        reinterpret_cast<uint4 *>(out + (size_t)t * MA_CELLS)[lane] =
+            make_uint4(row[0], row[2], row[4], row[6]);
+        reinterpret_cast<uint4 *>(out_t + (size_t)t * MA_CELLS)[lane] =
+            make_uint4(col[0], col[2], col[4], col[6]);
+        wave_lds_fence();
+    }
+}
+
+// a consumer wave's view of its row tile's cell tiles
+struct CellTiles {
+    unsigned long long mask;
+    const uint4 *base;        // tile t of this row tile: base[t * 64 + lane]
+    __device__ __forceinline__ CellTiles(const unsigned long long *masks,
+                                         const unsigned char *cells, int b, int RT, int rt,
+                                         bool have) {
+        mask = have ? masks[(size_t)b * RT + rt] : 0ull;
+        base = reinterpret_cast<const uint4 *>(
+            cells + ((size_t)b * tri(RT) + tri(have ? rt : 0)) * MA_CELLS);
+    }
+    __device__ __forceinline__ bool live(int t) const { return (mask >> t) & 1ull; }
+    __device__ __forceinline__ uint4 load(int t, int lane) const { return base[t * 64 + lane]; }
+};
+
+// Row tile rt costs rt + 1 key tiles, so contiguous 256-row blocks would give the workgroups
+// of a slice 36 : 100 of the work at S = 512 and, two to a CU, idle CUs at the end.  Folded
+// instead: workgroup g of a slice takes row tiles 4g .. 4g+3 (waves 0-3) and the mirror
+// images RTpad-4g-4 .. RTpad-4g-1 (waves 4-7; one short and one long wave per SIMD).
+__device__ __forceinline__ int folded_row_tile(int g, int blocks_per_batch, int wave) {
+    return wave < 4 ? 4 * g + wave : MA_WAVES * blocks_per_batch - 4 * (g + 1) + (wave - 4);
+}
+
+// ===================================== forward =============================================
+// grid: batch * ceil(S / 256) workgroups.
+#ifdef MA_STAMP
+// diagnostic build only (tools/time_mfma.py, MA_STAMPS=1): shader-clock cycles per phase of
+// the last wave of workgroup 0, written over row_sum[0 .. 11]
+#define MA_T(i)                                                         \
+    do {                                                                \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
+        st_acc[i] += (float)(now__ - st_prev);                          \
+        st_prev = now__;                                                \
+    } while (0)
+#else
+#define MA_T(i)
+#endif
+
+// exp(clamp(scale d)) = exp2(med3(d * scale log2e, -+clamp log2e)); without a clamp the
+// exponent is bounded at 2^127 so that dead cells (m = 0) stay 0 and not 0 * inf
+struct ScoreMap {
+    float sl2, bound;
+    __device__ __forceinline__ ScoreMap(float scale, float clampv) {
+        const float log2e = 1.4426950408889634f;
+        sl2 = scale * log2e;
+        bound = clampv > 0.0f ? clampv * log2e : 127.0f;
+    }
+    __device__ __forceinline__ float exp_of(float d) const {
+        return __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(d * sl2, -bound, bound));
+    }
+    // the clamp passes gradient strictly inside (-clamp, clamp) (attention.py:125-127 through
+    // spt_softmax_backward_clamped: |clamped| < clamp)
+    __device__ __forceinline__ bool inside(float d) const { return fabsf(d * sl2) < bound; }
+};
+// byte u of a cell word as float (v_cvt_f32_ubyte<u>)
+template <int U>
+__device__ __forceinline__ float cell_count(unsigned word) {
+    return (float)((word >> (8 * U)) & 0xffu);
+}
+
+// two workgroups per CU (4 waves per SIMD, 128 VGPRs): the barrier keeps the waves of one
+// workgroup in the same phase, a second workgroup fills the other pipes meanwhile
+#ifndef MA_WAVES_PER_EU
+#define MA_WAVES_PER_EU 4
+#endif
+#ifndef MA_ROWS_WAVES_PER_EU
+#define MA_ROWS_WAVES_PER_EU 2
+#endif
+template <bool YT>
+__global__ __launch_bounds__(MA_THREADS)
+__attribute__((amdgpu_waves_per_eu(MA_WAVES_PER_EU, MA_WAVES_PER_EU)))
+void attention_mfma_forward_kernel(
+    const unsigned long long *__restrict__ masks, const unsigned char *__restrict__ cells,
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    float *__restrict__ y, float *__restrict__ row_sum, int S, float scale, float clampv,
+    int heads, int blocks_per_batch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *img = smem;                                   // [2][MA_IMG]
+    float *stat = reinterpret_cast<float *>(smem + 2 * MA_IMG);   // [waves][32]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, c32 = lane & 31;
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = bid / blocks_per_batch;
+    const int i0 = MA_WROWS * folded_row_tile(bid % blocks_per_batch, blocks_per_batch, wave);
+    const DenseView dv = dense_view(b, S, MA_E, heads);
+    const int RT = (S + MA_WROWS - 1) / MA_WROWS;
+    const float *k_b = k + dv.base, *v_b = v + dv.base;
+
+#ifdef MA_STAMP
+    float st_acc[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_t0 = st_prev, st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const CellTiles ct(masks, cells, b, RT, i0 / MA_WROWS, i0 < S);
+    Frag qf[4];
+    load_own_rows(qf, q + dv.base, dv.ld, S, i0, lane);
+
+    // tiles any row of this workgroup can see: keys <= its last row (that of wave 7)
+    const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch, MA_WAVES - 1);
+    const int T = min(RT, last_tile + 1);
+    const TileStager stager(k_b, v_b, dv.ld, S, tid);
+    stager.store(img, stager.load(0));
+    uint4 mcur = make_uint4(0u, 0u, 0u, 0u);
+    if (ct.live(0)) mcur = ct.load(0, lane);
+    __syncthreads();
+
+    f32x16 yacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; r++) yacc[0][r] = yacc[1][r] = 0.f;
+    float rs = 0.f;
+    const ScoreMap sm(scale, clampv);
+    MA_T(0);
+
+    for (int t = 0; t < T; t++) {
+        const char *buf = img + (t & 1) * MA_IMG;
+        // tile t+1 (K, V and this wave's cell counts) is in flight while tile t is computed
+#ifndef MA_EXP_NOSTAGE
+        const TileRegs nxt = stager.load(t + 1);
+#endif
+        uint4 mnxt = make_uint4(0u, 0u, 0u, 0u);
+#ifndef MA_EXP_NOCELLS
+        if (ct.live(t + 1)) mnxt = ct.load(t + 1, lane);
+#else
+        mnxt = make_uint4(t, 1u, 0x01010101u, 0u);
+#endif
+        MA_T(1);
+        if (ct.live(t)) {
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; r++) d[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+                d = mma3(read_rows(buf + MA_KH, buf + MA_KL, lane, ks), qf[ks], d);
+            MA_T(2);
+            // cells: this lane holds row i0 + c32, keys 32t + acc_row(r, h); byte 4g + u of
+            // mcur is the multiplicity of register 4g + u
+            const unsigned mw[4] = {mcur.x, mcur.y, mcur.z, mcur.w};
+            float p[16];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                p[4 * g + 0] = cell_count<0>(mw[g]) * sm.exp_of(d[4 * g + 0]);
+                p[4 * g + 1] = cell_count<1>(mw[g]) * sm.exp_of(d[4 * g + 1]);
+                p[4 * g + 2] = cell_count<2>(mw[g]) * sm.exp_of(d[4 * g + 2]);
+                p[4 * g + 3] = cell_count<3>(mw[g]) * sm.exp_of(d[4 * g + 3]);
+                rs += (p[4 * g] + p[4 * g + 1]) + (p[4 * g + 2] + p[4 * g + 3]);
+            }
+            MA_T(3);
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const Frag pf = split8(p[8 * s], p[8 * s + 1], p[8 * s + 2], p[8 * s + 3],
+                                       p[8 * s + 4], p[8 * s + 5], p[8 * s + 6], p[8 * s + 7]);
+#pragma unroll
+                for (int eh = 0; eh < 2; eh++)
+                    yacc[eh] = mma3(pf, read_cols(buf + MA_VH, buf + MA_VL, c32 + 32 * eh, h, s),
+                                    yacc[eh]);
+            }
+            MA_T(4);
+        }
+#ifndef MA_EXP_NOSTAGE
+        if (t + 1 < T) stager.store(img + ((t + 1) & 1) * MA_IMG, nxt);
+#endif
+        mcur = mnxt;
+        MA_T(5);
+#ifndef MA_EXP_NOBAR
+        __syncthreads();
+#endif
+        MA_T(6);
+    }
+
+    // ---- rows: 1 / max(1e-9, sum); the two lane halves hold disjoint keys of the same row ----
+    rs += __shfl_xor(rs, 32, SPT_WAVE);
+    const float inv = 1.0f / fmaxf(1e-9f, rs);
+    float *wstat = stat + wave * MA_WROWS;
+    if (h == 0) {
+        wstat[c32] = inv;
+        if (i0 + c32 < S) row_sum[(size_t)b * S + i0 + c32] = rs;
+    }
+    wave_lds_fence();
+    float *y_b = y + (size_t)b * S * MA_E;
+    if (i0 < S) {
+        if (!YT) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int il = acc_row(r, h);
+                const float sc = wstat[il];
+                if (i0 + il < S) {
+                    y_b[(size_t)(i0 + il) * MA_E + c32] = yacc[0][r] * sc;
+                    y_b[(size_t)(i0 + il) * MA_E + 32 + c32] = yacc[1][r] * sc;
+                }
+            }
+        } else {
+            // [batch, E, S]: registers r = 4g .. 4g+3 are four consecutive rows of one e
+#pragma unroll
+            for (int eh = 0; eh < 2; eh++) {
+                float *col = y_b + (size_t)(c32 + 32 * eh) * S + i0;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int il = 8 * g + 4 * h;
+                    const float4 o = make_float4(
+                        yacc[eh][4 * g] * wstat[il], yacc[eh][4 * g + 1] * wstat[il + 1],
+                        yacc[eh][4 * g + 2] * wstat[il + 2], yacc[eh][4 * g + 3] * wstat[il + 3]);
+                    if (i0 + il + 3 < S && (S & 3) == 0) {
+                        *reinterpret_cast<float4 *>(col + il) = o;
+                    } else {
+                        const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (i0 + il + u < S) col[il + u] = ov[u];
+                    }
+                }
+            }
+        }
+    }
+#ifdef MA_STAMP
+    MA_T(7);
+    if (bid == 0 && wave == MA_WAVES - 1 && lane == 0) {
+        for (int i = 0; i < 8; i++) row_sum[i] = st_acc[i];
+        row_sum[9] = (float)(__builtin_amdgcn_s_memtime() - st_t0);
+        row_sum[10] = (float)(__builtin_amdgcn_s_memrealtime() - st_r0);
+        row_sum[11] = (float)T;
+    }
+#endif
+}
+
+// ===================================== backward ============================================
+// Nothing of size nnz was saved: both kernels recompute the score tiles from q, k and the
+// probabilities from the forward's row sums.  With P = m exp(s) / row_sum and
+//   delta_i = max(1e-9, sum_p P_p dP_p) = max(1e-9, dY_i . Y_i)        (softmax.cu:69; P dP
+//             summed over a row is dY_i . (P V)_i = dY_i . Y_i)
+//   dS      = scale * P * (dP - delta) inside the clamp, 0 outside      (softmax.cu:75-78)
+// the row-owned kernel produces grad_q (+ delta for its sibling), the key-owned one grad_k
+// and grad_v:
+//   grad_q[i] = sum_j dS[i, j] k[j]     grad_k[j] = sum_i dS[i, j] q[i]     (kernels/sddmm.py)
+//   grad_v[j] = sum_i P[i, j] dY[i]     dP[i, j]  = dY[i] . v[j]            (kernels/spmm.py)
+
+// ---- row-owned: same skeleton as the forward; images K rows | V rows | K cols ----
+constexpr int MR_KR = 0, MR_VR = 2 * MA_RIMG, MR_KC = 4 * MA_RIMG,
+              MR_IMG = 4 * MA_RIMG + 2 * MA_CIMG;                           // 27648 B
+struct RowsStager : TileStager {
+    using TileStager::TileStager;
+    __device__ __forceinline__ void store(char *buf, const TileRegs &r) const {
+        put4_along_e<true, true>(buf + MR_KR, buf + MR_KC, jl, e4, r.kf);
+        put4_along_e<true, false>(buf + MR_VR, nullptr, jl, e4, r.vf);
+    }
+};
+
+// GT: grad_y and y arrive as [batch, E, S] (the transposed forward output and its gradient)
+template <bool GT>
+__global__ __launch_bounds__(MA_THREADS)
+__attribute__((amdgpu_waves_per_eu(MA_ROWS_WAVES_PER_EU, MA_ROWS_WAVES_PER_EU)))
+void attention_mfma_backward_rows_kernel(
+    const unsigned long long *__restrict__ masks, const unsigned char *__restrict__ cells,
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    const float *__restrict__ gy, const float *__restrict__ y,
+    const float *__restrict__ row_sum, float *__restrict__ grad_q, float *__restrict__ delta,
+    int S, float scale, float clampv, int heads, int blocks_per_batch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *img = smem;                                   // [2][MR_IMG]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, c32 = lane & 31;
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = bid / blocks_per_batch;
+    const int i0 = MA_WROWS * folded_row_tile(bid % blocks_per_batch, blocks_per_batch, wave);
+    const DenseView dv = dense_view(b, S, MA_E, heads);
+    const int RT = (S + MA_WROWS - 1) / MA_WROWS;
+
+    const CellTiles ct(masks, cells, b, RT, i0 / MA_WROWS, i0 < S);
+    // own rows: dY (B operand of dP = V dY^T), delta = max(1e-9, dY . Y), Q (B operand of D)
+    Frag gf[4], qf[4];
+    float delta_i;
+    {
+        float xr[32], yr[32];
+        const size_t ob = (size_t)b * S * MA_E;
+        load_own_rows_raw<GT>(xr, gy + ob, MA_E, S, i0, lane);
+        load_own_rows_raw<GT>(yr, y + ob, MA_E, S, i0, lane);
+        float dl = 0.f;
+#pragma unroll
+        for (int x = 0; x < 32; x++) dl = fmaf(xr[x], yr[x], dl);
+        dl += __shfl_xor(dl, 32, SPT_WAVE);
+        delta_i = fmaxf(1e-9f, dl);
+        split_own_rows(gf, xr);
+    }
+    load_own_rows(qf, q + dv.base, dv.ld, S, i0, lane);
+    const int row = i0 + c32;
+    const float rsum = row < S ? row_sum[(size_t)b * S + row] : 1.0f;
+    const float pscale = scale / fmaxf(1e-9f, rsum);
+    if (h == 0 && row < S) delta[(size_t)b * S + row] = delta_i;
+
+    const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch, MA_WAVES - 1);
+    const int T = min(RT, last_tile + 1);
+    const RowsStager stager(k + dv.base, v + dv.base, dv.ld, S, tid);
+    stager.store(img, stager.load(0));
+    uint4 mcur = make_uint4(0u, 0u, 0u, 0u);
+    if (ct.live(0)) mcur = ct.load(0, lane);
+    __syncthreads();
+
+    f32x16 qacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; r++) qacc[0][r] = qacc[1][r] = 0.f;
+    const ScoreMap sm(scale, clampv);
+
+    for (int t = 0; t < T; t++) {
+        const char *buf = img + (t & 1) * MR_IMG;
+        const TileRegs nxt = stager.load(t + 1);
+        uint4 mnxt = make_uint4(0u, 0u, 0u, 0u);
+        if (ct.live(t + 1)) mnxt = ct.load(t + 1, lane);
+        if (ct.live(t)) {
+            f32x16 d, dp;
+#pragma unroll
+            for (int r = 0; r < 16; r++) d[r] = dp[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                d = mma3(read_rows(buf + MR_KR, buf + MR_KR + MA_RIMG, lane, ks), qf[ks], d);
+                dp = mma3(read_rows(buf + MR_VR, buf + MR_VR + MA_RIMG, lane, ks), gf[ks], dp);
+            }
+            const unsigned mw[4] = {mcur.x, mcur.y, mcur.z, mcur.w};
+            float ds[16];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const float m4[4] = {cell_count<0>(mw[g]), cell_count<1>(mw[g]),
+                                     cell_count<2>(mw[g]), cell_count<3>(mw[g])};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int r = 4 * g + u;
+                    const float pw = m4[u] * sm.exp_of(d[r]) * pscale;
+                    ds[r] = sm.inside(d[r]) ? pw * (dp[r] - delta_i) : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                const Frag sf = split8(ds[8 * s2], ds[8 * s2 + 1], ds[8 * s2 + 2], ds[8 * s2 + 3],
+                                       ds[8 * s2 + 4], ds[8 * s2 + 5], ds[8 * s2 + 6], ds[8 * s2 + 7]);
+#pragma unroll
+                for (int eh = 0; eh < 2; eh++)
+                    qacc[eh] = mma3(sf, read_cols(buf + MR_KC, buf + MR_KC + MA_CIMG,
+                                                  c32 + 32 * eh, h, s2), qacc[eh]);
+            }
+        }
+        if (t + 1 < T) stager.store(img + ((t + 1) & 1) * MR_IMG, nxt);
+        mcur = mnxt;
+        __syncthreads();
+    }
+    if (i0 < S) {
+        float *gq_b = grad_q + dv.base;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int il = acc_row(r, h);
+            if (i0 + il < S) {
+                gq_b[(size_t)(i0 + il) * dv.ld + c32] = qacc[0][r];
+                gq_b[(size_t)(i0 + il) * dv.ld + 32 + c32] = qacc[1][r];
+            }
+        }
+    }
+}
+
+// ---- key-owned: a wave owns 32 keys (K, V fragments and the grad_k, grad_v accumulators in
+// registers) and walks the row tiles at or below the diagonal; 32 rows of Q and dY stream
+// through LDS as images Q rows | dY rows | Q cols | dY cols, plus the rows' 1 / row_sum and
+// delta.  Tiles are computed as D[row, key], so the sums over rows take the accumulator tile
+// as the A operand.  Folded like the rows: waves 0-3 own key tiles 4g .. 4g+3 (many row
+// tiles), waves 4-7 their mirror images (few).
+constexpr int MK_QR = 0, MK_GR = 2 * MA_RIMG, MK_QC = 4 * MA_RIMG,
+              MK_GC = 4 * MA_RIMG + 2 * MA_CIMG, MK_ST = 4 * MA_RIMG + 4 * MA_CIMG,
+              MK_IMG = MK_ST + 2 * MA_WROWS * 4;                            // 37120 B
+template <bool GT>
+struct KeysStager {
+    const float *q_b, *gy_b, *rs_b, *dl_b;
+    int ld, S, tid;
+    struct Regs { float4 qf, gf; float st; };
+    __device__ __forceinline__ Regs load(int rt) const {
+        Regs r;
+        r.qf = r.gf = make_float4(0.f, 0.f, 0.f, 0.f);
+        r.st = 0.f;
+        const int i0 = rt * MA_WROWS;
+        if (i0 >= S) return r;
+        const int il = tid >> 4, e4 = (tid & 15) * 4;
+        if (i0 + il < S) {
+            r.qf = *reinterpret_cast<const float4 *>(q_b + (size_t)(i0 + il) * ld + e4);
+            if (!GT) r.gf = *reinterpret_cast<const float4 *>(gy_b + (size_t)(i0 + il) * MA_E + e4);
+        }
+        if (GT) {       // [E][S]: four consecutive rows of one e (S % 4 == 0)
+            const int e = tid >> 3, i4 = (tid & 7) * 4;
+            if (i0 + i4 < S) r.gf = *reinterpret_cast<const float4 *>(gy_b + (size_t)e * S + i0 + i4);
+        }
+        if (tid < MA_WROWS) {
+            if (i0 + tid < S) r.st = 1.0f / fmaxf(1e-9f, rs_b[i0 + tid]);
+        } else if (tid < 2 * MA_WROWS) {
+            if (i0 + tid - MA_WROWS < S) r.st = dl_b[i0 + tid - MA_WROWS];
+        }
+        return r;
+    }
+    __device__ __forceinline__ void store(char *buf, const Regs &r) const {
+        const int il = tid >> 4, e4 = (tid & 15) * 4;
+        put4_along_e<true, true>(buf + MK_QR, buf + MK_QC, il, e4, r.qf);
+        if (!GT) put4_along_e<true, true>(buf + MK_GR, buf + MK_GC, il, e4, r.gf);
+        else put4_along_r<true, true>(buf + MK_GR, buf + MK_GC, tid >> 3, (tid & 7) * 4, r.gf);
+        if (tid < 2 * MA_WROWS) reinterpret_cast<float *>(buf + MK_ST)[tid] = r.st;
+    }
+};
+
+template <bool GT>
+__global__ __launch_bounds__(MA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void attention_mfma_backward_keys_kernel(
+    const unsigned long long *__restrict__ masks, const unsigned char *__restrict__ cells_t,
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    const float *__restrict__ gy, const float *__restrict__ row_sum,
+    const float *__restrict__ delta, float *__restrict__ grad_k, float *__restrict__ grad_v,
+    int S, float scale, float clampv, int heads, int blocks_per_batch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *img = smem;                                   // [2][MK_IMG]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, c32 = lane & 31;
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = bid / blocks_per_batch, g = bid % blocks_per_batch;
+    const int kt = folded_row_tile(g, blocks_per_batch, wave);
+    const int j0 = kt * MA_KT;
+    const DenseView dv = dense_view(b, S, MA_E, heads);
+    const int RT = (S + MA_WROWS - 1) / MA_WROWS;
+    const bool have = j0 < S;
+
+    Frag kf[4], vf[4];
+    load_own_rows(kf, k + dv.base, dv.ld, S, j0, lane);
+    load_own_rows(vf, v + dv.base, dv.ld, S, j0, lane);
+    const unsigned long long *mask_b = masks + (size_t)b * RT;
+    const uint4 *cell_b = reinterpret_cast<const uint4 *>(cells_t + (size_t)b * tri(RT) * MA_CELLS);
+    auto live = [&](unsigned long long m, int rt) {
+        return have && rt >= kt && rt < RT && ((m >> kt) & 1ull);
+    };
+    auto cell_load = [&](int rt) { return cell_b[(tri(rt) + kt) * 64 + lane]; };
+
+    const int rt0 = 4 * g;                              // the first row tile any wave needs
+    const KeysStager<GT> stager{q + dv.base, gy + (size_t)b * S * MA_E, row_sum + (size_t)b * S,
+                                delta + (size_t)b * S, dv.ld, S, tid};
+    stager.store(img, stager.load(rt0));
+    unsigned long long mcur_mask = rt0 < RT ? mask_b[rt0] : 0ull;
+    uint4 mcur = make_uint4(0u, 0u, 0u, 0u);
+    if (live(mcur_mask, rt0)) mcur = cell_load(rt0);
+    __syncthreads();
+
+    f32x16 kacc[2], vacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; r++) kacc[0][r] = kacc[1][r] = vacc[0][r] = vacc[1][r] = 0.f;
+    const ScoreMap sm(scale, clampv);
+
+    for (int rt = rt0; rt < RT; rt++) {
+        const char *buf = img + ((rt - rt0) & 1) * MK_IMG;
+        const typename KeysStager<GT>::Regs nxt = stager.load(rt + 1);
+        const unsigned long long mnxt_mask = rt + 1 < RT ? mask_b[rt + 1] : 0ull;
+        uint4 mnxt = make_uint4(0u, 0u, 0u, 0u);
+        if (live(mnxt_mask, rt + 1)) mnxt = cell_load(rt + 1);
+        if (live(mcur_mask, rt)) {
+            f32x16 d, dp;
+#pragma unroll
+            for (int r = 0; r < 16; r++) d[r] = dp[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                d = mma3(read_rows(buf + MK_QR, buf + MK_QR + MA_RIMG, lane, ks), kf[ks], d);
+                dp = mma3(read_rows(buf + MK_GR, buf + MK_GR + MA_RIMG, lane, ks), vf[ks], dp);
+            }
+            // this lane: key j0 + c32, rows 8g + 4h + u of the tile in register 4g + u
+            const float *st = reinterpret_cast<const float *>(buf + MK_ST);
+            const unsigned mw[4] = {mcur.x, mcur.y, mcur.z, mcur.w};
+            float p[16], ds[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const float4 inv4 = *reinterpret_cast<const float4 *>(st + 8 * g4 + 4 * h);
+                const float4 del4 = *reinterpret_cast<const float4 *>(st + MA_WROWS + 8 * g4 + 4 * h);
+                const float inv[4] = {inv4.x, inv4.y, inv4.z, inv4.w};
+                const float del[4] = {del4.x, del4.y, del4.z, del4.w};
+                const float m4[4] = {cell_count<0>(mw[g4]), cell_count<1>(mw[g4]),
+                                     cell_count<2>(mw[g4]), cell_count<3>(mw[g4])};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int r = 4 * g4 + u;
+                    p[r] = m4[u] * sm.exp_of(d[r]) * inv[u];
+                    ds[r] = sm.inside(d[r]) ? scale * p[r] * (dp[r] - del[u]) : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                const Frag pf = split8(p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3],
+                                       p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]);
+                const Frag sf = split8(ds[8 * s2], ds[8 * s2 + 1], ds[8 * s2 + 2], ds[8 * s2 + 3],
+                                       ds[8 * s2 + 4], ds[8 * s2 + 5], ds[8 * s2 + 6], ds[8 * s2 + 7]);
+#pragma unroll
+                for (int eh = 0; eh < 2; eh++) {
+                    vacc[eh] = mma3(pf, read_cols(buf + MK_GC, buf + MK_GC + MA_CIMG,
+                                                  c32 + 32 * eh, h, s2), vacc[eh]);
+                    kacc[eh] = mma3(sf, read_cols(buf + MK_QC, buf + MK_QC + MA_CIMG,
+                                                  c32 + 32 * eh, h, s2), kacc[eh]);
+                }
+            }
+        }
+        if (rt + 1 < RT) stager.store(img + ((rt + 1 - rt0) & 1) * MK_IMG, nxt);
+        mcur = mnxt;
+        mcur_mask = mnxt_mask;
+        __syncthreads();
+    }
+    if (have) {
+        float *gk_b = grad_k + dv.base, *gv_b = grad_v + dv.base;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int jl = acc_row(r, h);
+            if (j0 + jl < S) {
+                const size_t at = (size_t)(j0 + jl) * dv.ld + c32;
+                gk_b[at] = kacc[0][r];
+                gk_b[at + 32] = kacc[1][r];
+                gv_b[at] = vacc[0][r];
+                gv_b[at + 32] = vacc[1][r];
+            }
+        }
+    }
+}
+
+static bool mfma_shape_ok(int S, int E, int nnz) {
+    if (E != MA_E || S <= 0 || nnz <= 0 || nnz % S != 0) return false;
+    const int Z = nnz / S;
+    return Z <= MA_MAXZ && Z % 4 == 0 && S <= MA_MAXNT * MA_KT;
+}
+static size_t mfma_forward_lds() { return 2 * MA_IMG + (size_t)MA_WAVES * MA_WROWS * sizeof(float); }
+struct TileSet {
+    unsigned long long *masks;
+    unsigned char *cells, *cells_t;
+};
+static size_t tile_cells_bytes(int B, int S) {
+    const size_t RT = (S + MA_WROWS - 1) / MA_WROWS;
+    return (size_t)B * tri(RT) * MA_CELLS;
+}
+static size_t tile_mask_bytes(int B, int S) {
+    const size_t RT = (S + MA_WROWS - 1) / MA_WROWS;
+    return (((size_t)B * RT * sizeof(unsigned long long)) + 255) & ~(size_t)255;
+}
+static TileSet carve_tiles(void *ws, int B, int S) {
+    TileSet t;
+    t.masks = static_cast<unsigned long long *>(ws);
+    t.cells = reinterpret_cast<unsigned char *>(static_cast<char *>(ws) + tile_mask_bytes(B, S));
+    t.cells_t = t.cells + tile_cells_bytes(B, S);
+    return t;
+}
+
+}  // namespace spt
+
+extern "C" int spt_attention_mfma_supported(int seq_length, int d_head, int nnz) {
+    return spt::mfma_shape_ok(seq_length, d_head, nnz) ? 1 : 0;
+}
+
+extern "C" int64_t spt_attention_mfma_tiles_bytes(int batch_size, int seq_length, int nnz) {
+    using namespace spt;
+    if (batch_size <= 0 || !mfma_shape_ok(seq_length, MA_E, nnz)) return 0;
+    return (int64_t)(tile_mask_bytes(batch_size, seq_length) +
+                     2 * tile_cells_bytes(batch_size, seq_length));
+}
+
+extern "C" int spt_attention_mfma_prepare(const int32_t *indices, void *tiles, int batch_size,
+                                          int seq_length, int nnz, void *stream) {
+    using namespace spt;
+    if (!indices || !tiles || batch_size <= 0) return SPT_EINVAL;
+    if (!mfma_shape_ok(seq_length, MA_E, nnz)) return SPT_EUNSUP;
+    const int S = seq_length, Z = nnz / S, NT = (S + MA_KT - 1) / MA_KT;
+    const int RT = (S + MA_WROWS - 1) / MA_WROWS, total = batch_size * RT;
+    const TileSet ts = carve_tiles(tiles, batch_size, S);
+    const size_t lds = (size_t)MB_WAVES * prepare_lds_per_wave(NT);
+    hipLaunchKernelGGL(attention_cell_tiles_kernel, dim3((total + MB_WAVES - 1) / MB_WAVES),
+                       dim3(MB_WAVES * SPT_WAVE), lds, static_cast<hipStream_t>(stream), indices,
+                       ts.masks, ts.cells, ts.cells_t, S, Z, NT, RT, total);
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
+extern "C" int spt_attention_mfma_forward(const void *tiles, const float *q, const float *k,
+                                          const float *v, float *y, float *row_sum,
+                                          int batch_size, int seq_length, int d_head, int nnz,
+                                          float scale, float clamp, int heads, int y_transposed,
+                                          void *stream) {
+    using namespace spt;
+    if (!tiles || !q || !k || !v || !y || !row_sum) return SPT_EINVAL;
+    if (batch_size <= 0 || heads < 0) return SPT_EINVAL;
+    if (!mfma_shape_ok(seq_length, d_head, nnz)) return SPT_EUNSUP;
+    if (heads > 0 && batch_size % heads != 0) return SPT_ESHAPE;
+    const int S = seq_length;
+    const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
+    const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, S);
+    const size_t lds = mfma_forward_lds();
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
+    if (y_transposed)
+        hipLaunchKernelGGL(attention_mfma_forward_kernel<true>, grid, block, lds, s, ts.masks,
+                           ts.cells, q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
+    else
+        hipLaunchKernelGGL(attention_mfma_forward_kernel<false>, grid, block, lds, s, ts.masks,
+                           ts.cells, q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
+extern "C" int spt_attention_mfma_backward(const void *tiles, const float *q, const float *k,
+                                           const float *v, const float *y, const float *grad_y,
+                                           const float *row_sum, float *delta, float *grad_q,
+                                           float *grad_k, float *grad_v, int batch_size,
+                                           int seq_length, int d_head, int nnz, float scale,
+                                           float clamp, int heads, int transposed, void *stream) {
+    using namespace spt;
+    if (!tiles || !q || !k || !v || !y || !grad_y || !row_sum || !delta || !grad_q || !grad_k ||
+        !grad_v)
+        return SPT_EINVAL;
+    if (batch_size <= 0 || heads < 0) return SPT_EINVAL;
+    if (!mfma_shape_ok(seq_length, d_head, nnz)) return SPT_EUNSUP;
+    if (heads > 0 && batch_size % heads != 0) return SPT_ESHAPE;
+    const int S = seq_length;
+    if (transposed && (S & 3)) return SPT_EUNSUP;
+    const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
+    const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, S);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
+    const size_t lds_r = 2 * MR_IMG, lds_k = 2 * MK_IMG;
+#define SPT_MB(GT)                                                                              \
+    do {                                                                                        \
+        hipLaunchKernelGGL(attention_mfma_backward_rows_kernel<GT>, grid, block, lds_r, s,      \
+                           ts.masks, ts.cells, q, k, v, grad_y, y, row_sum, grad_q, delta, S,   \
+                           scale, clamp, heads, bpb);                                           \
+        SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
+            (const void *)attention_mfma_backward_keys_kernel<GT>,                              \
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));                           \
+        hipLaunchKernelGGL(attention_mfma_backward_keys_kernel<GT>, grid, block, lds_k, s,      \
+                           ts.masks, ts.cells_t, q, k, v, grad_y, row_sum, delta, grad_k,       \
+                           grad_v, S, scale, clamp, heads, bpb);                                \
+    } while (0)
+    if (transposed) SPT_MB(true);
+    else SPT_MB(false);
+#undef SPT_MB
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}

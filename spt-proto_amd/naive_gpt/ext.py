@@ -51,6 +51,13 @@ _PROTOTYPES = {
                                                                  _c_int, _c_ptr], _c_int),
     'spt_sparse_attention_backward_rows': ([_c_ptr] * 9 + [_c_int] * 4 + [_c_f32, _c_f32] +
                                            [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_attention_mfma_supported': ([_c_int] * 3, _c_int),
+    'spt_attention_mfma_tiles_bytes': ([_c_int] * 3, ctypes.c_int64),
+    'spt_attention_mfma_prepare': ([_c_ptr] * 2 + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_attention_mfma_forward': ([_c_ptr] * 6 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int,
+                                                               _c_ptr], _c_int),
+    'spt_attention_mfma_backward': ([_c_ptr] * 11 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int,
+                                                                 _c_ptr], _c_int),
     'spt_grouped_gemm_fused': ([_c_ptr, _c_ptr], _c_int),
     'spt_grouped_gemm_pdot_width': ([_c_int], _c_int),
     'spt_rows_combine': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
@@ -60,7 +67,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _lib = None
 
@@ -429,6 +436,103 @@ def sparse_attention_forward(indices: torch.Tensor, q: torch.Tensor, k: torch.Te
     if rc != 0:
         _raise(lib, rc, 'sparse_attention_forward')
     return scores, attn, y
+
+
+def attention_mfma_supported(S: int, E: int, nnz: int) -> bool:
+    """Shapes the matrix-core attention kernels cover (mfma_attention.hip)."""
+    return bool(load_library().spt_attention_mfma_supported(int(S), int(E), int(nnz)))
+
+
+class MfmaTiles:
+    """The CSR entries bucketed by (32-row tile, 32-key tile): ``spt_attention_mfma_prepare``.
+    Depends on ``indices`` only; shared by the forward and the backward of a layer step."""
+
+    __slots__ = ('buffer', 'batch', 'seq', 'nnz')
+
+    def __init__(self, buffer, batch, seq, nnz):
+        self.buffer, self.batch, self.seq, self.nnz = buffer, batch, seq, nnz
+
+
+def attention_mfma_prepare(indices: torch.Tensor, seq_length: int) -> MfmaTiles:
+    _check_dim(indices, 2, 'indices')
+    _check_type(indices, torch.int32, 'indices')
+    _require(indices.is_contiguous(), 'contiguous indices')
+    dev = _same_device(indices)
+    B, nnz = indices.shape
+    lib = load_library()
+    size = lib.spt_attention_mfma_tiles_bytes(B, int(seq_length), nnz)
+    _require(size > 0, 'attention_mfma: unsupported shape (d_head 64, Z <= 64, Z % 4 == 0, S <= 2048)')
+    with torch.cuda.device(dev):
+        buf = torch.empty([size], dtype=torch.uint8, device=dev)
+        rc = lib.spt_attention_mfma_prepare(indices.data_ptr(), buf.data_ptr(), B, int(seq_length),
+                                            nnz, _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'attention_mfma_prepare')
+    return MfmaTiles(buf, B, int(seq_length), nnz)
+
+
+def attention_mfma_forward(tiles, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                           scale: float, clamp: float, y_transposed: bool = False):
+    """The attention core on the matrix cores (``spt_attention_mfma_forward``).
+
+    q, k, v: ``[N, S, H, E]``; ``tiles``: :func:`attention_mfma_prepare` of the ``[N*H, nnz]``
+    indices (or the indices themselves).  Returns ``(y, row_sum)``: y ``[N*H, S, E]`` or
+    (``y_transposed``) ``[N*H, E, S]`` and the softmax denominators ``[N*H, S]`` the backward
+    needs; no ``[N*H, nnz]`` array is produced."""
+    _check_dim(q, 4, 'q')
+    _check_type(q, torch.float32, 'q')
+    _require(q.shape == k.shape == v.shape, 'q, k, v: same shape')
+    _require(q.is_contiguous() and k.is_contiguous() and v.is_contiguous(), 'contiguous operands')
+    N, S, H, E = q.shape
+    B = N * H
+    if isinstance(tiles, torch.Tensor):
+        _require(E == 64, 'attention_mfma: d_head == 64')
+        tiles = attention_mfma_prepare(tiles, S)
+    _require(tiles.batch == B and tiles.seq == S, 'tiles: prepared for [N * H, nnz] indices at S')
+    dev = _same_device(tiles.buffer, q, k, v)
+    lib = load_library()
+    with torch.cuda.device(dev):
+        y = torch.empty([B, E, S] if y_transposed else [B, S, E], dtype=torch.float32, device=dev)
+        row_sum = torch.empty([B, S], dtype=torch.float32, device=dev)
+        rc = lib.spt_attention_mfma_forward(
+            tiles.buffer.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(),
+            row_sum.data_ptr(), B, S, E, tiles.nnz, float(scale), float(clamp), H,
+            int(bool(y_transposed)), _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'attention_mfma_forward')
+    return y, row_sum
+
+
+def attention_mfma_backward(tiles: MfmaTiles, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                            y: torch.Tensor, grad_y: torch.Tensor, row_sum: torch.Tensor,
+                            scale: float, clamp: float, transposed: bool = False):
+    """Backward of :func:`attention_mfma_forward` (``spt_attention_mfma_backward``).
+
+    y, grad_y: the forward's output and its gradient, ``[N*H, S, E]`` or (``transposed``)
+    ``[N*H, E, S]``.  Returns ``(grad_q, grad_k, grad_v)``, each ``[N, S, H, E]``."""
+    _check_dim(q, 4, 'q')
+    _check_type(q, torch.float32, 'q')
+    _require(q.shape == k.shape == v.shape, 'q, k, v: same shape')
+    for t in (q, k, v, y, grad_y, row_sum):
+        _require(t.is_contiguous(), 'contiguous operands')
+    N, S, H, E = q.shape
+    B = N * H
+    _require(tiles.batch == B and tiles.seq == S, 'tiles: prepared for [N * H, nnz] indices at S')
+    _require(y.numel() == B * S * E and grad_y.numel() == B * S * E, 'y, grad_y: N * H * S * E elements')
+    _require(row_sum.numel() == B * S, 'row_sum: [N * H, S]')
+    dev = _same_device(tiles.buffer, q, k, v, y, grad_y, row_sum)
+    lib = load_library()
+    with torch.cuda.device(dev):
+        grad_q, grad_k, grad_v = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty([B, S], dtype=torch.float32, device=dev)
+        rc = lib.spt_attention_mfma_backward(
+            tiles.buffer.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(),
+            grad_y.data_ptr(), row_sum.data_ptr(), delta.data_ptr(), grad_q.data_ptr(),
+            grad_k.data_ptr(), grad_v.data_ptr(), B, S, E, tiles.nnz, float(scale), float(clamp),
+            H, int(bool(transposed)), _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'attention_mfma_backward')
+    return grad_q, grad_k, grad_v
 
 
 def sparse_attention_backward_rows(indices: torch.Tensor, grad_y: torch.Tensor, v: torch.Tensor,

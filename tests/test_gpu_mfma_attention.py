@@ -1,0 +1,143 @@
+"""spt_attention_mfma_* (mfma_attention.hip: dense score tiles on the bf16 matrix cores, fp32
+operands split in two) against the oracle chain sddmm -> scale, clamp -> softmax -> spmm."""
+import pytest
+import torch
+
+from test_gpu_fused_attention import CLAMP, causal_indices, oracle_chain
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    (2, 16, 512, 64), (1, 32, 256, 32), (4, 8, 128, 16),
+    (2, 16, 80, 8),                    # S not a multiple of the 32-row tile
+    (1, 4, 1024, 64),                  # four row blocks per slice
+    (1, 2, 2048, 64),                  # the longest supported sequence
+    (1, 4, 96, 64),                    # Z close to S: many repeated columns
+]
+
+
+@pytest.mark.parametrize('yt', [False, True])
+@pytest.mark.parametrize('N,H,S,Z', SHAPES)
+def test_mfma_forward_matches_oracle_chain(N, H, S, Z, yt):
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(N * S + Z)
+    q, k, v = [torch.randn([N, S, H, 64], generator=gen) for _ in range(3)]
+    q = q * 3.0                                    # some scores beyond the clamp
+    indices = causal_indices(N * H, S, Z, gen)     # random with repeats: multiplicities matter
+    scale = 64 ** -0.5
+    assert ext.attention_mfma_supported(S, 64, S * Z)
+    want_scores, want_attn, want_y = oracle_chain(indices, q, k, v, scale)
+    y, row_sum = ext.attention_mfma_forward(indices.cuda(), q.cuda(), k.cuda(), v.cuda(),
+                                            scale, CLAMP, y_transposed=yt)
+    if yt:
+        assert y.shape == (N * H, 64, S)
+        y = y.transpose(1, 2)
+    rows = torch.arange(S).view(1, S, 1)
+    live = (indices.view(N * H, S, Z) <= rows).float()
+    want_sum = (want_scores.view(N * H, S, Z).exp() * live).sum(-1)
+    assert torch.allclose(row_sum.cpu(), want_sum, rtol=1e-4)
+    assert torch.allclose(y.cpu(), want_y, rtol=1e-3, atol=1e-4)
+    # the split-bf16 products are far inside the bar: report-level check of the actual error
+    assert (y.cpu() - want_y).abs().max() < 2e-4 * want_y.abs().max()
+
+
+@pytest.mark.parametrize('gt', [False, True])
+@pytest.mark.parametrize('N,H,S,Z', SHAPES)
+def test_mfma_backward_matches_oracle_chain(N, H, S, Z, gt):
+    """grad_q, grad_k, grad_v against the oracle operators chained as the reference's autograd
+    does: dP = sddmm(dY, V); dS = clamp-mask(scale * softmax_backward(P, dP));
+    dQ = spmm(dS, K); dK = spmm(dS^T, Q); dV = spmm(P^T, dY)."""
+    import numpy as np
+    from oracle import ext_stub
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(7 * N + S + Z)
+    B, E = N * H, 64
+    q, k, v = [torch.randn([N, S, H, E], generator=gen) for _ in range(3)]
+    q = q * 3.0
+    gy = torch.randn([B, S, E], generator=gen)
+    indices = causal_indices(B, S, Z, gen)
+    scale = E ** -0.5
+    scores, attn, want_y = oracle_chain(indices, q, k, v, scale)
+    flat = lambda t: t.transpose(1, 2).contiguous().view(B, S, E)       # noqa: E731
+    heads = lambda t: t.view(N, H, S, E).transpose(1, 2)                  # noqa: E731
+    indptr = torch.arange(0, S * Z + 1, Z, dtype=torch.int32)
+    f, t = torch.scalar_tensor(False), torch.scalar_tensor(True)
+    dp = ext_stub.sddmm_forward_cuda(f, t, indptr, indices, gy, flat(v))
+    ds = ext_stub.softmax_backward_cuda(indptr, indices, attn, dp)
+    raw = torch.where(scores.abs() < CLAMP, ds * np.float32(scale), torch.zeros_like(ds))
+    want_q = heads(ext_stub.spmm_forward_cuda(f, f, indptr, indices, raw, flat(k)))
+    want_k = heads(ext_stub.spmm_forward_cuda(t, f, indptr, indices, raw, flat(q)))
+    want_v = heads(ext_stub.spmm_forward_cuda(t, f, indptr, indices, attn, gy))
+
+    tiles = ext.attention_mfma_prepare(indices.cuda(), S)
+    y, row_sum = ext.attention_mfma_forward(tiles, q.cuda(), k.cuda(), v.cuda(), scale, CLAMP,
+                                            y_transposed=gt)
+    gy_in = gy.transpose(1, 2).contiguous() if gt else gy
+    gq, gk, gv = ext.attention_mfma_backward(tiles, q.cuda(), k.cuda(), v.cuda(), y, gy_in.cuda(),
+                                             row_sum, scale, CLAMP, transposed=gt)
+    assert (scores.abs() == CLAMP).any() and (raw == 0).any()
+    for got, want, name in ((gq, want_q, 'grad_q'), (gk, want_k, 'grad_k'), (gv, want_v, 'grad_v')):
+        err = (got.cpu() - want).abs().max().item()
+        assert torch.allclose(got.cpu(), want, rtol=1e-3, atol=2e-4 * want.abs().max().item()), \
+            (name, err, want.abs().max().item())
+
+
+def test_mfma_forward_masks_columns_beyond_the_row():
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(4)
+    N, H, S, Z = 2, 16, 128, 16
+    q, k, v = [torch.randn([N, S, H, 64], generator=gen) for _ in range(3)]
+    indices = torch.randint(0, S, [N * H, S * Z], generator=gen, dtype=torch.int32)
+    indices.view(N * H, S, Z)[:, :, 0] = 0         # every row keeps one live entry
+    _, _, want_y = oracle_chain(indices, q, k, v, 0.125)
+    y, _ = ext.attention_mfma_forward(indices.cuda(), q.cuda(), k.cuda(), v.cuda(), 0.125, CLAMP)
+    assert torch.allclose(y.cpu(), want_y, rtol=1e-3, atol=1e-4)
+
+
+def test_mfma_unsupported_shapes_are_refused():
+    from naive_gpt import ext
+    assert not ext.attention_mfma_supported(128, 32, 128 * 16)        # d_head 32
+    assert not ext.attention_mfma_supported(4096, 64, 4096 * 64)      # S > 2048
+    assert not ext.attention_mfma_supported(512, 64, 512 * 128)       # Z > 64
+    q = torch.randn([1, 4096, 2, 64], device='cuda')
+    idx = torch.zeros([2, 4096 * 64], dtype=torch.int32, device='cuda')
+    with pytest.raises(RuntimeError):
+        ext.attention_mfma_forward(idx, q, q, q, 1.0, CLAMP)
+
+
+def test_cell_tiles_hold_the_multiplicity_of_every_live_cell():
+    """spt_attention_mfma_prepare: per (32-row, 32-key) tile the count of each (row, col) cell,
+    stored in the accumulator permutation documented in include/spt_hip.h."""
+    import numpy as np
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(9)
+    B, S, Z = 6, 160, 16
+    indices = torch.randint(0, S, [B, S * Z], generator=gen, dtype=torch.int32)
+    indices.view(B, S, Z)[:, :, :3] = 0                      # repeated column 0, as lookup pads
+    tiles = ext.attention_mfma_prepare(indices.cuda(), S)
+    RT = S // 32
+    raw = tiles.buffer.cpu().numpy()
+    mask_bytes = (B * RT * 8 + 255) // 256 * 256
+    masks = raw[:B * RT * 8].view('uint64').reshape(B, RT)
+    ntile = RT * (RT + 1) // 2
+    cells, cells_t = raw[mask_bytes:mask_bytes + 2 * B * ntile * 1024].reshape(2, B, ntile, 64, 16)
+    idx = indices.view(B, S, Z).numpy()
+    for b in range(B):
+        for rt in range(RT):
+            want = np.zeros([RT, 32, 32], dtype=np.int64)       # [key tile][row][key]
+            for r in range(32):
+                for c in idx[b, rt * 32 + r]:
+                    if c <= rt * 32 + r:
+                        want[c // 32, r, c % 32] += 1
+            for t in range(rt + 1):
+                live = bool((int(masks[b, rt]) >> t) & 1)
+                assert live == bool(want[t].any())
+                if not live:
+                    continue
+                tile, tile_t = cells[b, rt * (rt + 1) // 2 + t], cells_t[b, rt * (rt + 1) // 2 + t]
+                for lane in range(64):
+                    c, h = lane % 32, lane // 32
+                    for g in range(4):
+                        for u in range(4):
+                            assert tile[lane, 4 * g + u] == want[t, c, 8 * g + 4 * h + u]
+                            assert tile_t[lane, 4 * g + u] == want[t, 8 * g + 4 * h + u, c]

@@ -22,6 +22,6 @@ def step(m, mk):
         m(q, k, v, attn_mask=mk).sum().backward()
     return f
 ms_s, gb_s = timeit(step(sparse, None))
-ms_d, gb_d = timeit(step(dense, mask))
+ms_d, gb_d = timeit(step(dense, mask)) if os.environ.get('SPARSE_ONLY') != '1' else (float('nan'), float('nan'))
 print(json.dumps({'N': N, 'S': S, 'H': H, 'sparse_ms': ms_s, 'dense_ms': ms_d, 'speedup': ms_d / ms_s,
                   'sparse_gb': gb_s, 'dense_gb': gb_d, 'tokens_per_s_sparse': N * S / ms_s * 1e3}))
