@@ -147,6 +147,29 @@ class _FusedAttention(torch.autograd.Function):
         return None, None, grad_q, grad_k, grad_v, None
 
 
+class _MfmaAttention(torch.autograd.Function):
+    """The same function as _FusedAttention on the matrix cores (mfma_attention.hip): dense
+    32 x 32 score tiles from split-bf16 MFMAs, the CSR only selecting the live cells.  Saves
+    q, k, v, y and the [N*H, S] row sums -- nothing of size nnz; the backward recomputes the
+    tiles in two launches (grad_q; grad_k and grad_v)."""
+
+    @staticmethod
+    def forward(ctx, indices, q, k, v, scale: float):
+        tiles = ext.attention_mfma_prepare(indices, q.size(1))
+        y, row_sum = ext.attention_mfma_forward(tiles, q, k, v, scale, CLAMP, y_transposed=True)
+        ctx.scale, ctx.tiles = scale, tiles
+        ctx.save_for_backward(q, k, v, y, row_sum)
+        return y.view(q.shape)
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        q, k, v, y, row_sum = ctx.saved_tensors
+        grad_q, grad_k, grad_v = ext.attention_mfma_backward(
+            ctx.tiles, q, k, v, y, grad_out.contiguous(), row_sum, ctx.scale, CLAMP,
+            transposed=True)
+        return None, grad_q, grad_k, grad_v, None
+
+
 class _SparseCore:
     """Mixin with the CSR attention shared by the Vanilla and Rotary V2 layers."""
 
@@ -212,6 +235,9 @@ class _SparseCore:
         topk_indices = kernels.lookup(q_c, k_c, sparse_coeff=SPARSE_COEFF)
         csr_indices = topk_indices.flatten(start_dim=1)
         indptr = self._uniform_indptr(seq_length, q.device)
+        if seq_length % 4 == 0 and ext.attention_mfma_supported(seq_length, q.size(-1),
+                                                                csr_indices.size(-1)):
+            return 'mfma', indptr, csr_indices, q, k
         if ext.fused_attention_supported(seq_length, q.size(-1), q.size(0) * heads,
                                          csr_indices.size(-1)):
             # scores, softmax and the product with v run as one launch in _sparse_apply
@@ -245,7 +271,9 @@ class _SparseCore:
     def _sparse_apply(self, attn, v: torch.Tensor):
         v_size = v.size()
         if len(attn) == 5:
-            _, indptr, indices, q, k = attn
+            kind, indptr, indices, q, k = attn
+            if kind == 'mfma':
+                return _MfmaAttention.apply(indices, q, k, v.contiguous(), self.scaling)
             return _FusedAttention.apply(indptr, indices, q, k, v.contiguous(), self.scaling)
         if len(attn) == 4:
             indptr, indices, values, heads = attn

@@ -141,3 +141,27 @@ def test_cell_tiles_hold_the_multiplicity_of_every_live_cell():
                         for u in range(4):
                             assert tile[lane, 4 * g + u] == want[t, c, 8 * g + 4 * h + u]
                             assert tile_t[lane, 4 * g + u] == want[t, 8 * g + 4 * h + u, c]
+
+
+@pytest.mark.parametrize('kind', ['vanilla', 'rotary'])
+def test_layer_through_mfma_kernels_equals_separate_operators(kind, monkeypatch):
+    from naive_gpt import ext, layers
+    torch.manual_seed(0)
+    cls = layers.SparseVanillaAttentionV2 if kind == 'vanilla' else layers.SparseRotaryAttentionV2
+    attn = cls(d_head=64, d_codeword=8, n_codewords=16, p_dropout=0.0).cuda()
+    N, S, H = 2, 256, 16
+    q, k, v, w = [torch.randn([N, S, H, 64], device='cuda') for _ in range(4)]
+
+    def run(mfma):
+        if not mfma:
+            monkeypatch.setattr(ext, 'attention_mfma_supported', lambda *a: False)
+            monkeypatch.setattr(ext, 'fused_attention_supported', lambda *a: False)
+        qi, ki, vi = [t.clone().requires_grad_(True) for t in (q, k, v)]
+        y = attn(qi, ki, vi, attn_mask=None)
+        (y * w).sum().backward()
+        monkeypatch.undo()
+        return y.detach(), qi.grad, ki.grad, vi.grad
+
+    fast, separate = run(True), run(False)
+    for a, b, name in zip(fast, separate, ['y', 'grad_q', 'grad_k', 'grad_v']):
+        assert torch.allclose(a, b, rtol=1e-3, atol=2e-4 * b.abs().max().item()), name
