@@ -33,6 +33,11 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
+MFMA_BF16_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+# v_mfma_f32_32x32x16_bf16 per 32 x 32 tile (mfma_attention.hip): forward D + PV; backward
+# rows kernel D + dP + dQ, keys kernel D + dP + dV + dK
+MFMA_PER_TILE = {'attention_mfma_forward': 24, 'attention_mfma_backward': 36 + 48}
+
 
 S, H, E = 512, 16, 64   # BERT-large: d_model 1024 = 16 heads x 64
 M, C, D = E // 8, 16, 8
@@ -60,6 +65,12 @@ def algorithmic_bytes(op: str, B: int) -> int:
         'sparse_attention_forward': 4 * S * E * 4 + 3 * S * Z * 4,
         # dY, v, k read, grad_q + dY rows written; indices, scores, attn read, dS written
         'sparse_attention_backward_rows': 5 * S * E * 4 + 4 * S * Z * 4,
+        # matrix-core path (mfma_attention.hip): every dense operand once + the CSR information.
+        # prepare: indices read, the two sets of 1 KiB cell tiles (lower triangle) written
+        'attention_mfma_prepare': S * Z * 4 + 2 * (S // 32) * (S // 32 + 1) // 2 * 1024,
+        'attention_mfma_forward': 4 * S * E * 4 + S * Z * 4,       # q k v -> y (+ the pattern)
+        # q k v dY y read, three gradients written (+ the pattern); two launches
+        'attention_mfma_backward': 8 * S * E * 4 + S * Z * 4,
     }
     return per[op] * B
 
@@ -81,6 +92,9 @@ OP_KERNEL = {
     'pq_loss_backward': 'spt::pq_loss_backward_kernel<8>',
     'sparse_attention_forward': 'spt::sparse_attention_forward_kernel<true, true>',
     'sparse_attention_backward_rows': 'spt::sparse_attention_backward_rows_kernel<true, true>',
+    'attention_mfma_prepare': 'spt::attention_cell_tiles_kernel',
+    'attention_mfma_forward': 'spt::attention_mfma_forward_kernel<true>',
+    'attention_mfma_backward': 'spt::attention_mfma_backward_keys_kernel<true>',
 }
 
 
@@ -88,6 +102,8 @@ OP_LAUNCHES = {
     'spmm_transposed': ['spt::permute_values_kernel', 'spt::spmm_t64_lds_kernel<1>'],
     'pq_loss_forward': ['spt::pq_loss_forward_kernel<8>', 'spt::pq_loss_finish_kernel'],
     'pq_loss_backward': ['spt::pq_loss_backward_kernel<8>', 'spt::pq_loss_table_reduce_kernel'],
+    'attention_mfma_backward': ['spt::attention_mfma_backward_rows_kernel<true>',
+                                'spt::attention_mfma_backward_keys_kernel<true>'],
 }
 
 
@@ -117,7 +133,8 @@ class EventTimer:
            'spmm_transposed', 'csr_transpose',
            'softmax_forward_cuda', 'softmax_backward_cuda',
            'pq_loss_forward', 'pq_loss_backward', 'sparse_attention_forward',
-           'sparse_attention_backward_rows']
+           'sparse_attention_backward_rows', 'attention_mfma_prepare', 'attention_mfma_forward',
+           'attention_mfma_backward']
 
     def __init__(self):
         from naive_gpt import ext
@@ -361,6 +378,16 @@ def main():
             # of those rows in profiles/*_kernel_stats.csv
             'hip_kernels': OP_LAUNCHES.get(dominant, [OP_KERNEL.get(dominant)]),
         }
+        if dominant in MFMA_PER_TILE:
+            # the matrix-core kernels are issue-bound, not HBM-bound: also price the MFMAs they
+            # execute (dense 32 x 32 tiles on and below the diagonal, three bf16 MFMAs per fp32
+            # product) against the dense bf16 peak
+            tiles = (S // 32) * (S // 32 + 1) // 2
+            flops = B * tiles * MFMA_PER_TILE[dominant] * 2 * 32 * 32 * 16
+            tf = flops / (st['avg_us'] * 1e-6) / 1e12
+            result['roofline']['mfma'] = {'executed_TFLOPs': tf, 'peak': MFMA_BF16_PEAK_TF,
+                                          'frac': tf / MFMA_BF16_PEAK_TF,
+                                          'mfma_per_tile': MFMA_PER_TILE[dominant]}
         result['kernels'] = {op: {'avg_us': round(s_['avg_us'], 2),
                                   'calls_per_step': s_['per_step'],
                                   'GBps': round(s_['algorithmic_GBps'], 1),

@@ -148,14 +148,15 @@ struct TileStager {
     int ld, S, jl, e4;
     __device__ __forceinline__ TileStager(const float *k, const float *v, int ld_, int S_, int tid)
         : k_b(k), v_b(v), ld(ld_), S(S_), jl(tid >> 4), e4((tid & 15) * 4) {}
+    // Unconditional loads with clamped rows: a load under a branch makes the compiler wait
+    // with vmcnt(0) for OLDER loads too (it cannot count what the branch issued), which
+    // exposed the full memory latency in every iteration.  Keys >= S read row S - 1: finite
+    // data whose cells have multiplicity 0.
     __device__ __forceinline__ TileRegs load(int t) const {
         TileRegs r;
-        r.kf = r.vf = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int j = t * MA_KT + jl;
-        if (j < S) {
-            r.kf = *reinterpret_cast<const float4 *>(k_b + (size_t)j * ld + e4);
-            r.vf = *reinterpret_cast<const float4 *>(v_b + (size_t)j * ld + e4);
-        }
+        const int j = min(t * MA_KT + jl, S - 1);
+        r.kf = *reinterpret_cast<const float4 *>(k_b + (size_t)j * ld + e4);
+        r.vf = *reinterpret_cast<const float4 *>(v_b + (size_t)j * ld + e4);
         return r;
     }
     __device__ __forceinline__ void store(char *buf, const TileRegs &r) const {
@@ -169,6 +170,11 @@ struct TileStager {
 __device__ __forceinline__ Frag read_rows(const char *hi, const char *lo, int lane, int ks) {
     const int off = (lane & 31) * MA_KLD + 16 * (lane >> 5) + 32 * ks;
     Frag f;
+#ifdef MA_EXP_NOLDSREAD
+    f.hi = make_uint4(off, lane, ks, 0x3f803f80u);
+    f.lo = make_uint4(lane, off, 0x3c003c00u, ks);
+    return f;
+#endif
     f.hi = *reinterpret_cast<const uint4 *>(hi + off);
     f.lo = *reinterpret_cast<const uint4 *>(lo + off);
     return f;
@@ -178,6 +184,14 @@ __device__ __forceinline__ Frag read_rows(const char *hi, const char *lo, int la
 // lane (c, h) reads row c of the transposed image at 16s + 4h .. +4 and 16s + 8 + 4h .. +4
 __device__ __forceinline__ Frag read_cols(const char *hi, const char *lo, int row, int h, int s) {
     const int off = row * MA_VLD + 32 * s + 8 * h;
+#ifdef MA_EXP_NOLDSREAD
+    {
+        Frag f;
+        f.hi = make_uint4(off, row, s, 0x3f803f80u);
+        f.lo = make_uint4(row, off, 0x3c003c00u, s);
+        return f;
+    }
+#endif
     const uint2 a = *reinterpret_cast<const uint2 *>(hi + off),
                 b = *reinterpret_cast<const uint2 *>(hi + off + 16),
                 c = *reinterpret_cast<const uint2 *>(lo + off),
@@ -193,37 +207,32 @@ __device__ __forceinline__ Frag read_cols(const char *hi, const char *lo, int ro
 template <bool TR>
 __device__ __forceinline__ void load_own_rows_raw(float (&x)[32], const float *x_b, int ld, int S,
                                                   int i0, int lane) {
-    const int row = i0 + (lane & 31), h = lane >> 5;
+    // rows >= S read row S - 1 (unconditional loads; such rows are never stored)
+    const int row = min(i0 + (lane & 31), S - 1), h = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
+        if (!TR) {
+            const float *p = x_b + (size_t)row * ld + 8 * h + 16 * ks;
+            const float4 a = *reinterpret_cast<const float4 *>(p);
+            const float4 b = *reinterpret_cast<const float4 *>(p + 4);
+            x[8 * ks + 0] = a.x; x[8 * ks + 1] = a.y; x[8 * ks + 2] = a.z; x[8 * ks + 3] = a.w;
+            x[8 * ks + 4] = b.x; x[8 * ks + 5] = b.y; x[8 * ks + 6] = b.z; x[8 * ks + 7] = b.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[8 * ks + j] = 0.f;
-        if (row < S) {
-            if (!TR) {
-                const float *p = x_b + (size_t)row * ld + 8 * h + 16 * ks;
-                const float4 a = *reinterpret_cast<const float4 *>(p);
-                const float4 b = *reinterpret_cast<const float4 *>(p + 4);
-                x[8 * ks + 0] = a.x; x[8 * ks + 1] = a.y; x[8 * ks + 2] = a.z; x[8 * ks + 3] = a.w;
-                x[8 * ks + 4] = b.x; x[8 * ks + 5] = b.y; x[8 * ks + 6] = b.z; x[8 * ks + 7] = b.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    x[8 * ks + j] = x_b[(size_t)(8 * h + 16 * ks + j) * S + row];
-            }
+            for (int j = 0; j < 8; j++)
+                x[8 * ks + j] = x_b[(size_t)(8 * h + 16 * ks + j) * S + row];
         }
     }
 }
-__device__ __forceinline__ void split_own_rows(Frag (&f)[4], const float (&x)[32]) {
+// split into the four k-step fragments, optionally pre-multiplied (the score scale folded
+// into the operand: one multiply per element here instead of one per cell per tile)
+__device__ __forceinline__ void split_own_rows(Frag (&f)[4], const float (&x)[32],
+                                               float mult = 1.0f) {
 #pragma unroll
     for (int ks = 0; ks < 4; ks++)
-        f[ks] = split8(x[8 * ks], x[8 * ks + 1], x[8 * ks + 2], x[8 * ks + 3], x[8 * ks + 4],
-                       x[8 * ks + 5], x[8 * ks + 6], x[8 * ks + 7]);
-}
-__device__ __forceinline__ void load_own_rows(Frag (&f)[4], const float *x_b, int ld, int S,
-                                              int i0, int lane) {
-    float x[32];
-    load_own_rows_raw<false>(x, x_b, ld, S, i0, lane);
-    split_own_rows(f, x);
+        f[ks] = split8(x[8 * ks] * mult, x[8 * ks + 1] * mult, x[8 * ks + 2] * mult,
+                       x[8 * ks + 3] * mult, x[8 * ks + 4] * mult, x[8 * ks + 5] * mult,
+                       x[8 * ks + 6] * mult, x[8 * ks + 7] * mult);
 }
 
 // ---- cell tiles: multiplicity of every (row, key) cell, per 32 x 32 tile ----
@@ -354,16 +363,21 @@ __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kern
 // a consumer wave's view of its row tile's cell tiles
 struct CellTiles {
     unsigned long long mask;
+    int last;                 // the row tile's own index = its last stored key tile
     const uint4 *base;        // tile t of this row tile: base[t * 64 + lane]
     __device__ __forceinline__ CellTiles(const unsigned long long *masks,
                                          const unsigned char *cells, int b, int RT, int rt,
                                          bool have) {
         mask = have ? masks[(size_t)b * RT + rt] : 0ull;
+        last = have ? rt : 0;
         base = reinterpret_cast<const uint4 *>(
             cells + ((size_t)b * tri(RT) + tri(have ? rt : 0)) * MA_CELLS);
     }
     __device__ __forceinline__ bool live(int t) const { return (mask >> t) & 1ull; }
-    __device__ __forceinline__ uint4 load(int t, int lane) const { return base[t * 64 + lane]; }
+    // always in bounds (t clamped), so the caller can load unconditionally
+    __device__ __forceinline__ uint4 load(int t, int lane) const {
+        return base[min(t, last) * 64 + lane];
+    }
 };
 
 // Row tile rt costs rt + 1 key tiles, so contiguous 256-row blocks would give the workgroups
@@ -398,12 +412,13 @@ struct ScoreMap {
         sl2 = scale * log2e;
         bound = clampv > 0.0f ? clampv * log2e : 127.0f;
     }
+    // d: the tile value with sl2 already folded into one operand (q or k pre-multiplied)
     __device__ __forceinline__ float exp_of(float d) const {
-        return __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(d * sl2, -bound, bound));
+        return __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(d, -bound, bound));
     }
     // the clamp passes gradient strictly inside (-clamp, clamp) (attention.py:125-127 through
     // spt_softmax_backward_clamped: |clamped| < clamp)
-    __device__ __forceinline__ bool inside(float d) const { return fabsf(d * sl2) < bound; }
+    __device__ __forceinline__ bool inside(float d) const { return fabsf(d) < bound; }
 };
 // byte u of a cell word as float (v_cvt_f32_ubyte<u>)
 template <int U>
@@ -441,43 +456,39 @@ void attention_mfma_forward_kernel(
     const float *k_b = k + dv.base, *v_b = v + dv.base;
 
 #ifdef MA_STAMP
-    float st_acc[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
-    const unsigned long long st_t0 = st_prev, st_r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+    float st_it[20];
+#pragma unroll
+    for (int i = 0; i < 20; i++) st_it[i] = 0.f;
 #endif
     const CellTiles ct(masks, cells, b, RT, i0 / MA_WROWS, i0 < S);
-    Frag qf[4];
-    load_own_rows(qf, q + dv.base, dv.ld, S, i0, lane);
-
     // tiles any row of this workgroup can see: keys <= its last row (that of wave 7)
     const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch, MA_WAVES - 1);
     const int T = min(RT, last_tile + 1);
+    const ScoreMap sm(scale, clampv);
+    // every prologue load is issued before the first result is needed
     const TileStager stager(k_b, v_b, dv.ld, S, tid);
-    stager.store(img, stager.load(0));
-    uint4 mcur = make_uint4(0u, 0u, 0u, 0u);
-    if (ct.live(0)) mcur = ct.load(0, lane);
+    const TileRegs first = stager.load(0);
+    uint4 mcur = ct.load(0, lane);
+    Frag qf[4];
+    {
+        float xq[32];
+        load_own_rows_raw<false>(xq, q + dv.base, dv.ld, S, i0, lane);
+        stager.store(img, first);
+        split_own_rows(qf, xq, sm.sl2);
+    }
     __syncthreads();
 
     f32x16 yacc[2];
 #pragma unroll
     for (int r = 0; r < 16; r++) yacc[0][r] = yacc[1][r] = 0.f;
     float rs = 0.f;
-    const ScoreMap sm(scale, clampv);
-    MA_T(0);
 
     for (int t = 0; t < T; t++) {
         const char *buf = img + (t & 1) * MA_IMG;
         // tile t+1 (K, V and this wave's cell counts) is in flight while tile t is computed
-#ifndef MA_EXP_NOSTAGE
-        const TileRegs nxt = stager.load(t + 1);
-#endif
-        uint4 mnxt = make_uint4(0u, 0u, 0u, 0u);
-#ifndef MA_EXP_NOCELLS
-        if (ct.live(t + 1)) mnxt = ct.load(t + 1, lane);
-#else
-        mnxt = make_uint4(t, 1u, 0x01010101u, 0u);
-#endif
-        MA_T(1);
+        const TileRegs nxt = stager.load(min(t + 1, T - 1));
+        const uint4 mnxt = ct.load(t + 1, lane);
         if (ct.live(t)) {
             f32x16 d;
 #pragma unroll
@@ -485,7 +496,6 @@ void attention_mfma_forward_kernel(
 #pragma unroll
             for (int ks = 0; ks < 4; ks++)
                 d = mma3(read_rows(buf + MA_KH, buf + MA_KL, lane, ks), qf[ks], d);
-            MA_T(2);
             // cells: this lane holds row i0 + c32, keys 32t + acc_row(r, h); byte 4g + u of
             // mcur is the multiplicity of register 4g + u
             const unsigned mw[4] = {mcur.x, mcur.y, mcur.z, mcur.w};
@@ -498,7 +508,6 @@ void attention_mfma_forward_kernel(
                 p[4 * g + 3] = cell_count<3>(mw[g]) * sm.exp_of(d[4 * g + 3]);
                 rs += (p[4 * g] + p[4 * g + 1]) + (p[4 * g + 2] + p[4 * g + 3]);
             }
-            MA_T(3);
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 const Frag pf = split8(p[8 * s], p[8 * s + 1], p[8 * s + 2], p[8 * s + 3],
@@ -508,18 +517,21 @@ void attention_mfma_forward_kernel(
                     yacc[eh] = mma3(pf, read_cols(buf + MA_VH, buf + MA_VL, c32 + 32 * eh, h, s),
                                     yacc[eh]);
             }
-            MA_T(4);
         }
-#ifndef MA_EXP_NOSTAGE
         if (t + 1 < T) stager.store(img + ((t + 1) & 1) * MA_IMG, nxt);
-#endif
         mcur = mnxt;
-        MA_T(5);
-#ifndef MA_EXP_NOBAR
-        __syncthreads();
+#ifdef MA_STAMP
+        {
+            const float now = (float)(__builtin_amdgcn_s_memtime() - st_t0);
+#pragma unroll
+            for (int i = 0; i < 16; i++) st_it[i] = (i == t) ? now : st_it[i];
+        }
 #endif
-        MA_T(6);
+        __syncthreads();
     }
+#ifdef MA_STAMP
+    st_it[16] = (float)(__builtin_amdgcn_s_memtime() - st_t0);
+#endif
 
     // ---- rows: 1 / max(1e-9, sum); the two lane halves hold disjoint keys of the same row ----
     rs += __shfl_xor(rs, 32, SPT_WAVE);
@@ -566,12 +578,14 @@ void attention_mfma_forward_kernel(
         }
     }
 #ifdef MA_STAMP
-    MA_T(7);
-    if (bid == 0 && wave == MA_WAVES - 1 && lane == 0) {
-        for (int i = 0; i < 8; i++) row_sum[i] = st_acc[i];
-        row_sum[9] = (float)(__builtin_amdgcn_s_memtime() - st_t0);
-        row_sum[10] = (float)(__builtin_amdgcn_s_memrealtime() - st_r0);
-        row_sum[11] = (float)T;
+    // (after everything else: the stamps overwrite row sums of batch slices 0 and 1)
+    __syncthreads();
+    if (bid < 2 && lane == 0) {
+        float *out = row_sum + (size_t)bid * 160 + wave * 20;
+        for (int i = 0; i < 17; i++) out[i] = st_it[i];
+        out[17] = (float)(__builtin_amdgcn_s_memtime() - st_t0);
+        out[18] = (float)T;
+        out[19] = (float)(i0 / 32);
     }
 #endif
 }
@@ -620,45 +634,44 @@ void attention_mfma_backward_rows_kernel(
     const int RT = (S + MA_WROWS - 1) / MA_WROWS;
 
     const CellTiles ct(masks, cells, b, RT, i0 / MA_WROWS, i0 < S);
+    const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch, MA_WAVES - 1);
+    const int T = min(RT, last_tile + 1);
+    const ScoreMap sm(scale, clampv);
+    const RowsStager stager(k + dv.base, v + dv.base, dv.ld, S, tid);
+    const TileRegs first = stager.load(0);
+    uint4 mcur = ct.load(0, lane);
     // own rows: dY (B operand of dP = V dY^T), delta = max(1e-9, dY . Y), Q (B operand of D)
     Frag gf[4], qf[4];
     float delta_i;
+    const int row = i0 + c32;
+    const float rsum = row_sum[(size_t)b * S + min(row, S - 1)];
     {
-        float xr[32], yr[32];
+        float xr[32], yr[32], xq[32];
         const size_t ob = (size_t)b * S * MA_E;
         load_own_rows_raw<GT>(xr, gy + ob, MA_E, S, i0, lane);
         load_own_rows_raw<GT>(yr, y + ob, MA_E, S, i0, lane);
+        load_own_rows_raw<false>(xq, q + dv.base, dv.ld, S, i0, lane);
+        stager.store(img, first);
         float dl = 0.f;
 #pragma unroll
         for (int x = 0; x < 32; x++) dl = fmaf(xr[x], yr[x], dl);
         dl += __shfl_xor(dl, 32, SPT_WAVE);
         delta_i = fmaxf(1e-9f, dl);
         split_own_rows(gf, xr);
+        split_own_rows(qf, xq, sm.sl2);
     }
-    load_own_rows(qf, q + dv.base, dv.ld, S, i0, lane);
-    const int row = i0 + c32;
-    const float rsum = row < S ? row_sum[(size_t)b * S + row] : 1.0f;
     const float pscale = scale / fmaxf(1e-9f, rsum);
     if (h == 0 && row < S) delta[(size_t)b * S + row] = delta_i;
-
-    const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch, MA_WAVES - 1);
-    const int T = min(RT, last_tile + 1);
-    const RowsStager stager(k + dv.base, v + dv.base, dv.ld, S, tid);
-    stager.store(img, stager.load(0));
-    uint4 mcur = make_uint4(0u, 0u, 0u, 0u);
-    if (ct.live(0)) mcur = ct.load(0, lane);
     __syncthreads();
 
     f32x16 qacc[2];
 #pragma unroll
     for (int r = 0; r < 16; r++) qacc[0][r] = qacc[1][r] = 0.f;
-    const ScoreMap sm(scale, clampv);
 
     for (int t = 0; t < T; t++) {
         const char *buf = img + (t & 1) * MR_IMG;
-        const TileRegs nxt = stager.load(t + 1);
-        uint4 mnxt = make_uint4(0u, 0u, 0u, 0u);
-        if (ct.live(t + 1)) mnxt = ct.load(t + 1, lane);
+        const TileRegs nxt = stager.load(min(t + 1, T - 1));
+        const uint4 mnxt = ct.load(t + 1, lane);
         if (ct.live(t)) {
             f32x16 d, dp;
 #pragma unroll
@@ -722,34 +735,36 @@ struct KeysStager {
     const float *q_b, *gy_b, *rs_b, *dl_b;
     int ld, S, tid;
     struct Regs { float4 qf, gf; float st; };
+    // unconditional, clamped loads (see TileStager::load); rows >= S are given weight 0 by
+    // store(), so whatever finite data the clamped rows hold never counts
     __device__ __forceinline__ Regs load(int rt) const {
         Regs r;
-        r.qf = r.gf = make_float4(0.f, 0.f, 0.f, 0.f);
-        r.st = 0.f;
         const int i0 = rt * MA_WROWS;
-        if (i0 >= S) return r;
         const int il = tid >> 4, e4 = (tid & 15) * 4;
-        if (i0 + il < S) {
-            r.qf = *reinterpret_cast<const float4 *>(q_b + (size_t)(i0 + il) * ld + e4);
-            if (!GT) r.gf = *reinterpret_cast<const float4 *>(gy_b + (size_t)(i0 + il) * MA_E + e4);
+        const int row = min(i0 + il, S - 1);
+        r.qf = *reinterpret_cast<const float4 *>(q_b + (size_t)row * ld + e4);
+        if (!GT) {
+            r.gf = *reinterpret_cast<const float4 *>(gy_b + (size_t)row * MA_E + e4);
+        } else {        // [E][S]: four consecutive rows of one e (S % 4 == 0)
+            const int e = tid >> 3, i4 = min(i0 + (tid & 7) * 4, S - 4);
+            r.gf = *reinterpret_cast<const float4 *>(gy_b + (size_t)e * S + i4);
         }
-        if (GT) {       // [E][S]: four consecutive rows of one e (S % 4 == 0)
-            const int e = tid >> 3, i4 = (tid & 7) * 4;
-            if (i0 + i4 < S) r.gf = *reinterpret_cast<const float4 *>(gy_b + (size_t)e * S + i0 + i4);
-        }
-        if (tid < MA_WROWS) {
-            if (i0 + tid < S) r.st = 1.0f / fmaxf(1e-9f, rs_b[i0 + tid]);
-        } else if (tid < 2 * MA_WROWS) {
-            if (i0 + tid - MA_WROWS < S) r.st = dl_b[i0 + tid - MA_WROWS];
-        }
+        // (raw values here: arithmetic on them would wait for the loads at the top of the
+        // iteration)
+        const int sr = min(i0 + (tid & (MA_WROWS - 1)), S - 1);
+        r.st = (tid & MA_WROWS) ? dl_b[sr] : rs_b[sr];
         return r;
     }
-    __device__ __forceinline__ void store(char *buf, const Regs &r) const {
+    __device__ __forceinline__ void store(char *buf, const Regs &r, int rt) const {
         const int il = tid >> 4, e4 = (tid & 15) * 4;
         put4_along_e<true, true>(buf + MK_QR, buf + MK_QC, il, e4, r.qf);
         if (!GT) put4_along_e<true, true>(buf + MK_GR, buf + MK_GC, il, e4, r.gf);
         else put4_along_r<true, true>(buf + MK_GR, buf + MK_GC, tid >> 3, (tid & 7) * 4, r.gf);
-        if (tid < 2 * MA_WROWS) reinterpret_cast<float *>(buf + MK_ST)[tid] = r.st;
+        if (tid < 2 * MA_WROWS) {
+            const bool in = rt * MA_WROWS + (tid & (MA_WROWS - 1)) < S;
+            const float inv = 1.0f / fmaxf(1e-9f, r.st);
+            reinterpret_cast<float *>(buf + MK_ST)[tid] = !in ? 0.0f : (tid < MA_WROWS ? inv : r.st);
+        }
     }
 };
 
@@ -774,36 +789,51 @@ void attention_mfma_backward_keys_kernel(
     const int RT = (S + MA_WROWS - 1) / MA_WROWS;
     const bool have = j0 < S;
 
+    const ScoreMap sm(scale, clampv);
     Frag kf[4], vf[4];
-    load_own_rows(kf, k + dv.base, dv.ld, S, j0, lane);
-    load_own_rows(vf, v + dv.base, dv.ld, S, j0, lane);
-    const unsigned long long *mask_b = masks + (size_t)b * RT;
+    {
+        float xk[32], xv[32];
+        load_own_rows_raw<false>(xk, k + dv.base, dv.ld, S, j0, lane);
+        load_own_rows_raw<false>(xv, v + dv.base, dv.ld, S, j0, lane);
+        split_own_rows(kf, xk, sm.sl2);     // the score scale (log2 domain) folded into K
+        split_own_rows(vf, xv);
+    }
+    // the slice's row-tile masks live in registers (lane rt: mask of row tile rt), so that the
+    // loop body has no load whose result it needs at once
+    const unsigned long long mask_reg = lane < RT ? masks[(size_t)b * RT + lane] : 0ull;
+    auto mask_of = [&](int rt) -> unsigned long long {
+        if (rt >= RT) return 0ull;
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)mask_reg, rt);
+        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(mask_reg >> 32), rt);
+        return ((unsigned long long)hi << 32) | lo;
+    };
     const uint4 *cell_b = reinterpret_cast<const uint4 *>(cells_t + (size_t)b * tri(RT) * MA_CELLS);
     auto live = [&](unsigned long long m, int rt) {
         return have && rt >= kt && rt < RT && ((m >> kt) & 1ull);
     };
-    auto cell_load = [&](int rt) { return cell_b[(tri(rt) + kt) * 64 + lane]; };
+    // always in bounds: the row tile clamped to the last one, the key tile to the diagonal
+    auto cell_load = [&](int rt) {
+        const int rc = min(rt, RT - 1);
+        return cell_b[(tri(rc) + min(kt, rc)) * 64 + lane];
+    };
 
     const int rt0 = 4 * g;                              // the first row tile any wave needs
     const KeysStager<GT> stager{q + dv.base, gy + (size_t)b * S * MA_E, row_sum + (size_t)b * S,
                                 delta + (size_t)b * S, dv.ld, S, tid};
-    stager.store(img, stager.load(rt0));
-    unsigned long long mcur_mask = rt0 < RT ? mask_b[rt0] : 0ull;
-    uint4 mcur = make_uint4(0u, 0u, 0u, 0u);
-    if (live(mcur_mask, rt0)) mcur = cell_load(rt0);
+    stager.store(img, stager.load(min(rt0, RT - 1)), rt0);
+    unsigned long long mcur_mask = mask_of(rt0);
+    uint4 mcur = cell_load(rt0);
     __syncthreads();
 
     f32x16 kacc[2], vacc[2];
 #pragma unroll
     for (int r = 0; r < 16; r++) kacc[0][r] = kacc[1][r] = vacc[0][r] = vacc[1][r] = 0.f;
-    const ScoreMap sm(scale, clampv);
 
     for (int rt = rt0; rt < RT; rt++) {
         const char *buf = img + ((rt - rt0) & 1) * MK_IMG;
-        const typename KeysStager<GT>::Regs nxt = stager.load(rt + 1);
-        const unsigned long long mnxt_mask = rt + 1 < RT ? mask_b[rt + 1] : 0ull;
-        uint4 mnxt = make_uint4(0u, 0u, 0u, 0u);
-        if (live(mnxt_mask, rt + 1)) mnxt = cell_load(rt + 1);
+        const typename KeysStager<GT>::Regs nxt = stager.load(min(rt + 1, RT - 1));
+        const unsigned long long mnxt_mask = mask_of(rt + 1);
+        const uint4 mnxt = cell_load(rt + 1);
         if (live(mcur_mask, rt)) {
             f32x16 d, dp;
 #pragma unroll
@@ -847,7 +877,7 @@ void attention_mfma_backward_keys_kernel(
                 }
             }
         }
-        if (rt + 1 < RT) stager.store(img + ((rt + 1 - rt0) & 1) * MK_IMG, nxt);
+        if (rt + 1 < RT) stager.store(img + ((rt + 1 - rt0) & 1) * MK_IMG, nxt, rt + 1);
         mcur = mnxt;
         mcur_mask = mnxt_mask;
         __syncthreads();

@@ -45,7 +45,10 @@ if hasattr(ext, 'attention_mfma_backward'):
     res['mfma_bwd_us'] = timeit(lambda: ext.attention_mfma_backward(tiles, q, k, v, y1, gy, rs, 0.125, 10.0, transposed=True))
 if os.environ.get('MA_STAMPS') == '1':
     _, rs = ext.attention_mfma_forward(tiles, q, k, v, 0.125, 10.0, y_transposed=True)
-    names = ['prologue', 'issue_loads', 'D', 'cells', 'PV', 'store', 'barrier', 'epilogue', '-', 'total_cyc',
-             'total_100MHz', 'T']
-    res['stamps'] = {n: float(x) for n, x in zip(names, rs[0, :12].cpu())}
+    st = rs.flatten()[:320].cpu().view(2, 8, 20)
+    for wg in range(2):
+        for w in range(8):
+            row = st[wg, w]
+            print('wg', wg, 'wave', w, 'rt', int(row[19]), 'T', int(row[18]), 'end', int(row[17]),
+                  'iter ends', [int(x) for x in row[:17]])
 print(res)
