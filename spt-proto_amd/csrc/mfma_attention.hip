@@ -40,7 +40,7 @@ constexpr int MA_WROWS = 32;                       // rows per wave = one MFMA t
 constexpr int MA_ROWS = MA_WAVES * MA_WROWS;       // 256 rows per workgroup
 constexpr int MA_KT = 32;                          // keys per tile
 constexpr int MA_E = 64;
-constexpr int MA_MAXZ = 64;                        // entries per row the per-wave list holds
+constexpr int MA_MAXZ = 256;                       // entries per row (cell counts are bytes)
 constexpr int MA_MAXNT = 64;                       // key tiles: S <= 2048
 
 // LDS images of one key tile, bf16: rows padded so that the operand reads are conflict-free
@@ -49,7 +49,6 @@ constexpr int MA_VLD = 72;                         // bytes per e row of V^T: 32
 constexpr int MA_KH = 0, MA_KL = MA_KT * MA_KLD, MA_VH = 2 * MA_KT * MA_KLD,
               MA_VL = MA_VH + MA_E * MA_VLD, MA_IMG = MA_VL + MA_E * MA_VLD;   // 18432 B
 constexpr int MA_CLD = 9;                          // words per row of the multiplicity tile
-constexpr int MA_LIST = MA_WROWS * MA_MAXZ * 2;    // prepare: the bucketed entries of a row tile
 constexpr int MA_CNT = MA_WROWS * MA_CLD * 4;      // prepare: one tile of counts, 1152 B
 constexpr int MA_CELLS = MA_WROWS * MA_KT;         // bytes of one stored cell tile
 
@@ -243,14 +242,24 @@ __device__ __forceinline__ void split_own_rows(Frag (&f)[4], const float (&x)[32
 //   cells_t, same indexing: byte 4 g + u of lane (c, h) = multiplicity of key 32 t + c in row
 //     32 rt + 8 g + 4 h + u -- the tile computed as D[row, key] (the key-owned backward)
 //   live = col <= row (softmax.cu:19-31 masks the others) and 0 <= col < S.
-// A wave owns a row tile: counting sort of its 32 Z entries by key tile (lane-private uint16
-// histograms: wave-wide atomics on <= 16 bucket counters ran at under one lane per clock),
-// then per bucket the counts are accumulated in an LDS tile and stored permuted.
+// A wave owns a row tile and walks its key tiles in chunks of MB_CHUNK: the chunk's counts
+// live in LDS as [tile][row][key] bytes (4 keys per word); every entry whose column falls into
+// the chunk does one ds_add_u32 (LDS atomics run at about one lane per clock per CU, so they
+// are the kernel's cost: the transposed tiles are gathered bytewise from the same counts
+// rather than counted a second time).  (A first
+// version bucketed the entries by key tile with a counting sort before counting: 33 us at
+// the bench shape, latency-bound on its LDS read-modify-write chains and wave scans.)
+// A byte saturates at 255: only Z >= 256 can reach it (row 0 of a lookup pattern, whose Z
+// entries are all column 0, and there any multiplicity >= 1 gives the same result); then the
+// add that would carry into the neighbouring key is taken back.
 constexpr int MB_WAVES = 4;
+constexpr int MB_CHUNK = 8;                          // key tiles per pass over the entries
+constexpr int MB_CNT_WORDS = MB_CHUNK * MA_WROWS * MA_CLD;     // one orientation: 2304 words
 __host__ __device__ __forceinline__ size_t tri(size_t n) { return n * (n + 1) / 2; }
-__host__ __device__ __forceinline__ size_t prepare_lds_per_wave(int NT) {
-    return (size_t)NT * SPT_WAVE * 2 + MA_LIST + 2 * MA_CNT + (MA_MAXNT + 4) * 4;
+__host__ __device__ __forceinline__ size_t prepare_lds_per_wave() {
+    return (size_t)MB_CNT_WORDS * 4;                 // 9216 B
 }
+template <bool SATURATE>
 __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kernel(
     const int32_t *__restrict__ indices, unsigned long long *__restrict__ masks,
     unsigned char *__restrict__ cells, unsigned char *__restrict__ cells_t, int S, int Z, int NT,
@@ -261,103 +270,70 @@ __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kern
     const int gw = blockIdx.x * MB_WAVES + wave;
     if (gw >= n_tiles_total) return;                    // no workgroup barrier below
     const int b = gw / RT, rt = gw - b * RT, i0 = rt * MA_WROWS;
-    const size_t per_wave = prepare_lds_per_wave(NT);
-    unsigned short *hist = reinterpret_cast<unsigned short *>(smem + wave * per_wave);
-    unsigned short *stage = hist + (size_t)NT * SPT_WAVE;
-    unsigned *cnt = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(stage) + MA_LIST);
-    unsigned *cnt_t = cnt + MA_CNT / 4;                 // the same counts, [key][row]
-    int *boff = reinterpret_cast<int *>(reinterpret_cast<char *>(cnt) + 2 * MA_CNT);
+    unsigned *cnt = reinterpret_cast<unsigned *>(smem + wave * prepare_lds_per_wave());
 
     // the tile's rows are one contiguous run of 32 * Z ints (Z % 4 == 0)
     const int nrows = min(MA_WROWS, S - i0);
     const int n4 = nrows * Z / 4;
     const int4 *src = reinterpret_cast<const int4 *>(indices + ((size_t)b * S + i0) * Z);
-    constexpr int PER = MA_WROWS * MA_MAXZ / 4 / SPT_WAVE;   // 8 int4 per lane
-    int4 ent[PER];
-    int rowl[PER];
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-        const int x = u * SPT_WAVE + lane;
-        ent[u] = make_int4(-1, -1, -1, -1);
-        if (x < n4) ent[u] = src[x];
-        rowl[u] = 4 * x / Z;          // an int4 never straddles rows
-    }
-    for (int x = lane; x < NT * SPT_WAVE / 2; x += SPT_WAVE)
-        reinterpret_cast<unsigned *>(hist)[x] = 0;
-    wave_lds_fence();
-    auto alive = [&](int c, int rl) { return c >= 0 && c <= i0 + rl && c < S; };
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-        const int c[4] = {ent[u].x, ent[u].y, ent[u].z, ent[u].w};
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (alive(c[q], rowl[u])) hist[(c[q] >> 5) * SPT_WAVE + lane] += 1;
-    }
-    wave_lds_fence();
-    // bucket-major, lane-minor exclusive scan: hist[t][lane] becomes the lane's first slot
-    int running = 0;
-    unsigned long long mask = 0;
-    const int nbuckets = min(NT, rt + 1);               // live entries have col <= row
-    for (int t = 0; t < nbuckets; t++) {
-        const int v = hist[t * SPT_WAVE + lane];
-        int incl = v;
-#pragma unroll
-        for (int d = 1; d < SPT_WAVE; d <<= 1) {
-            const int up = __shfl_up(incl, d, SPT_WAVE);
-            if (lane >= d) incl += up;
-        }
-        hist[t * SPT_WAVE + lane] = (unsigned short)(running + incl - v);
-        if (lane == 0) boff[t] = running;
-        const int tot = __shfl(incl, SPT_WAVE - 1, SPT_WAVE);
-        if (tot > 0) mask |= 1ull << t;
-        running += tot;
-    }
-    if (lane == 0) {
-        boff[nbuckets] = running;
-        masks[gw] = mask;
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-        const int c[4] = {ent[u].x, ent[u].y, ent[u].z, ent[u].w};
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (alive(c[q], rowl[u])) {
-                const int at = (c[q] >> 5) * SPT_WAVE + lane;
-                const int pos = hist[at];
-                hist[at] = (unsigned short)(pos + 1);
-                stage[pos] = (unsigned short)((rowl[u] << 5) | (c[q] & 31));
-            }
-        }
-    }
-    wave_lds_fence();
-    // per bucket: counts in an LDS tile (row-major, 4 keys per word), stored permuted
     unsigned char *out = cells + ((size_t)b * tri(RT) + tri(rt)) * MA_CELLS;
     unsigned char *out_t = cells_t + ((size_t)b * tri(RT) + tri(rt)) * MA_CELLS;
     const int c32 = lane & 31, h = lane >> 5;
-    for (int t = 0; t < nbuckets; t++) {
-        if (!((mask >> t) & 1ull)) continue;
-        const int lo = boff[t], n = boff[t + 1] - lo;
-        uint4 *c4 = reinterpret_cast<uint4 *>(cnt);     // both tiles: 2 x 72 x 16 bytes
-        c4[lane] = make_uint4(0u, 0u, 0u, 0u);
-        c4[SPT_WAVE + lane] = make_uint4(0u, 0u, 0u, 0u);
-        if (lane < 16) c4[2 * SPT_WAVE + lane] = make_uint4(0u, 0u, 0u, 0u);
+    const int nbuckets = min(NT, rt + 1);               // live entries have col <= row
+    unsigned long long mask = 0;
+
+    auto count = [&](unsigned *word, unsigned sh) {
+        if (!SATURATE) {
+            atomicAdd(word, 1u << sh);
+        } else {
+            const unsigned old = atomicAdd(word, 1u << sh);
+            if (((old >> sh) & 0xffu) == 0xffu) atomicSub(word, 1u << sh);
+        }
+    };
+    for (int t0 = 0; t0 < nbuckets; t0 += MB_CHUNK) {
+        uint4 *c4 = reinterpret_cast<uint4 *>(cnt);     // 9 x 64 x 16 bytes
+#pragma unroll
+        for (int x = 0; x < MB_CNT_WORDS / 4 / SPT_WAVE; x++)
+            c4[x * SPT_WAVE + lane] = make_uint4(0u, 0u, 0u, 0u);
         wave_lds_fence();
-        for (int x = lane; x < n; x += SPT_WAVE) {
-            const unsigned e = stage[lo + x];
-            const unsigned r = e >> 5, jl = e & 31;
-            atomicAdd(&cnt[r * MA_CLD + (jl >> 2)], 1u << (8 * (jl & 3)));
-            atomicAdd(&cnt_t[jl * MA_CLD + (r >> 2)], 1u << (8 * (r & 3)));
+        for (int x = lane; x < n4; x += SPT_WAVE) {
+            const int4 e4 = src[x];
+            const int rl = 4 * x / Z;                   // an int4 never straddles rows
+            const int c[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int tl = (c[q] >> 5) - t0;
+                if (c[q] >= 0 && c[q] <= i0 + rl && c[q] < S && tl >= 0 && tl < MB_CHUNK) {
+                    const unsigned jl = c[q] & 31;
+                    count(&cnt[(tl * MA_WROWS + rl) * MA_CLD + (jl >> 2)], 8 * (jl & 3));
+                }
+            }
         }
         wave_lds_fence();
-        // word 2 g + h of row c holds keys 8 g + 4 h .. + 3: exactly this lane's bytes 4 g ..
-        const unsigned *row = cnt + c32 * MA_CLD + h, *col = cnt_t + c32 * MA_CLD + h;
-        reinterpret_cast<uint4 *>(out + (size_t)t * MA_CELLS)[lane] =
-            make_uint4(row[0], row[2], row[4], row[6]);
-        reinterpret_cast<uint4 *>(out_t + (size_t)t * MA_CELLS)[lane] =
-            make_uint4(col[0], col[2], col[4], col[6]);
+        const int tend = min(MB_CHUNK, nbuckets - t0);
+        for (int tl = 0; tl < tend; tl++) {
+            // word 2 g + h of row c holds keys 8 g + 4 h .. + 3: exactly this lane's bytes 4 g ..
+            const unsigned *row = cnt + (tl * MA_WROWS + c32) * MA_CLD + h;
+            const uint4 mine = make_uint4(row[0], row[2], row[4], row[6]);
+            if (__ballot((mine.x | mine.y | mine.z | mine.w) != 0u) == 0ull) continue;
+            mask |= 1ull << (t0 + tl);
+            reinterpret_cast<uint4 *>(out + (size_t)(t0 + tl) * MA_CELLS)[lane] = mine;
+            // transposed: byte 4 g + u of lane (c, h) = count of key c in row 8 g + 4 h + u
+            const unsigned char *bytes = reinterpret_cast<const unsigned char *>(cnt) +
+                                         (size_t)tl * MA_WROWS * MA_CLD * 4 + c32;
+            unsigned w[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const unsigned char *p0 = bytes + (8 * g + 4 * h) * MA_CLD * 4;
+                w[g] = (unsigned)p0[0] | ((unsigned)p0[MA_CLD * 4] << 8) |
+                       ((unsigned)p0[2 * MA_CLD * 4] << 16) | ((unsigned)p0[3 * MA_CLD * 4] << 24);
+            }
+            reinterpret_cast<uint4 *>(out_t + (size_t)(t0 + tl) * MA_CELLS)[lane] =
+                make_uint4(w[0], w[1], w[2], w[3]);
+        }
         wave_lds_fence();
     }
+    if (lane == 0) masks[gw] = mask;
 }
 
 // a consumer wave's view of its row tile's cell tiles
@@ -431,6 +407,9 @@ __device__ __forceinline__ float cell_count(unsigned word) {
 #ifndef MA_WAVES_PER_EU
 #define MA_WAVES_PER_EU 4
 #endif
+#ifndef MA_SUB
+#define MA_SUB 1            // key tiles per forward iteration (2: 48 -> 58-71 us at the bench shape)
+#endif
 #ifndef MA_ROWS_WAVES_PER_EU
 #define MA_ROWS_WAVES_PER_EU 2
 #endif
@@ -443,8 +422,8 @@ void attention_mfma_forward_kernel(
     float *__restrict__ y, float *__restrict__ row_sum, int S, float scale, float clampv,
     int heads, int blocks_per_batch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *img = smem;                                   // [2][MA_IMG]
-    float *stat = reinterpret_cast<float *>(smem + 2 * MA_IMG);   // [waves][32]
+    char *img = smem;                                   // [2][MA_SUB][MA_IMG]
+    float *stat = reinterpret_cast<float *>(smem + 2 * MA_SUB * MA_IMG);   // [waves][32]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c32 = lane & 31;
@@ -466,15 +445,25 @@ void attention_mfma_forward_kernel(
     const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch, MA_WAVES - 1);
     const int T = min(RT, last_tile + 1);
     const ScoreMap sm(scale, clampv);
+    // An iteration = MA_SUB key tiles: the per-iteration latencies (barrier, LDS round trips,
+    // the MFMA chain's tail) are paid once per MA_SUB tiles, and the tiles of one iteration
+    // are independent instruction chains (one's MFMAs beside the other's cell arithmetic).
+    constexpr int SUB = MA_SUB;
     // every prologue load is issued before the first result is needed
     const TileStager stager(k_b, v_b, dv.ld, S, tid);
-    const TileRegs first = stager.load(0);
-    uint4 mcur = ct.load(0, lane);
+    TileRegs nxt[SUB];
+    uint4 mcur[SUB], mnxt[SUB];
+#pragma unroll
+    for (int u = 0; u < SUB; u++) {
+        nxt[u] = stager.load(min(u, T - 1));
+        mcur[u] = ct.load(u, lane);
+    }
     Frag qf[4];
     {
         float xq[32];
         load_own_rows_raw<false>(xq, q + dv.base, dv.ld, S, i0, lane);
-        stager.store(img, first);
+#pragma unroll
+        for (int u = 0; u < SUB; u++) stager.store(img + u * MA_IMG, nxt[u]);
         split_own_rows(qf, xq, sm.sl2);
     }
     __syncthreads();
@@ -484,47 +473,72 @@ void attention_mfma_forward_kernel(
     for (int r = 0; r < 16; r++) yacc[0][r] = yacc[1][r] = 0.f;
     float rs = 0.f;
 
-    for (int t = 0; t < T; t++) {
-        const char *buf = img + (t & 1) * MA_IMG;
-        // tile t+1 (K, V and this wave's cell counts) is in flight while tile t is computed
-        const TileRegs nxt = stager.load(min(t + 1, T - 1));
-        const uint4 mnxt = ct.load(t + 1, lane);
-        if (ct.live(t)) {
-            f32x16 d;
+    const int NIT = (T + SUB - 1) / SUB;
+    for (int it = 0; it < NIT; it++) {
+        const int t0 = it * SUB;
+        const char *buf = img + (it & 1) * SUB * MA_IMG;
+        // the next iteration's tiles (K, V and this wave's cell counts) are in flight meanwhile
+        bool lv[SUB], any = false;
 #pragma unroll
-            for (int r = 0; r < 16; r++) d[r] = 0.f;
+        for (int u = 0; u < SUB; u++) {
+            nxt[u] = stager.load(min(t0 + SUB + u, T - 1));
+            mnxt[u] = ct.load(t0 + SUB + u, lane);
+            lv[u] = t0 + u < T && ct.live(t0 + u);
+            any |= lv[u];
+        }
+        if (any) {
+            // a dead tile of a live iteration is computed with all multiplicities 0
+            f32x16 d[SUB];
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++)
-                d = mma3(read_rows(buf + MA_KH, buf + MA_KL, lane, ks), qf[ks], d);
-            // cells: this lane holds row i0 + c32, keys 32t + acc_row(r, h); byte 4g + u of
-            // mcur is the multiplicity of register 4g + u
-            const unsigned mw[4] = {mcur.x, mcur.y, mcur.z, mcur.w};
-            float p[16];
+            for (int u = 0; u < SUB; u++) {
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                p[4 * g + 0] = cell_count<0>(mw[g]) * sm.exp_of(d[4 * g + 0]);
-                p[4 * g + 1] = cell_count<1>(mw[g]) * sm.exp_of(d[4 * g + 1]);
-                p[4 * g + 2] = cell_count<2>(mw[g]) * sm.exp_of(d[4 * g + 2]);
-                p[4 * g + 3] = cell_count<3>(mw[g]) * sm.exp_of(d[4 * g + 3]);
-                rs += (p[4 * g] + p[4 * g + 1]) + (p[4 * g + 2] + p[4 * g + 3]);
+                for (int r = 0; r < 16; r++) d[u][r] = 0.f;
             }
 #pragma unroll
-            for (int s = 0; s < 2; s++) {
-                const Frag pf = split8(p[8 * s], p[8 * s + 1], p[8 * s + 2], p[8 * s + 3],
-                                       p[8 * s + 4], p[8 * s + 5], p[8 * s + 6], p[8 * s + 7]);
+            for (int ks = 0; ks < 4; ks++) {
 #pragma unroll
-                for (int eh = 0; eh < 2; eh++)
-                    yacc[eh] = mma3(pf, read_cols(buf + MA_VH, buf + MA_VL, c32 + 32 * eh, h, s),
-                                    yacc[eh]);
+                for (int u = 0; u < SUB; u++)
+                    d[u] = mma3(read_rows(buf + u * MA_IMG + MA_KH, buf + u * MA_IMG + MA_KL, lane, ks),
+                                qf[ks], d[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < SUB; u++) {
+                // cells: this lane holds row i0 + c32, keys 32t + acc_row(r, h); byte 4g + u of
+                // the cell word is the multiplicity of register 4g + u
+                const unsigned mw[4] = {lv[u] ? mcur[u].x : 0u, lv[u] ? mcur[u].y : 0u,
+                                        lv[u] ? mcur[u].z : 0u, lv[u] ? mcur[u].w : 0u};
+                float p[16];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    p[4 * g + 0] = cell_count<0>(mw[g]) * sm.exp_of(d[u][4 * g + 0]);
+                    p[4 * g + 1] = cell_count<1>(mw[g]) * sm.exp_of(d[u][4 * g + 1]);
+                    p[4 * g + 2] = cell_count<2>(mw[g]) * sm.exp_of(d[u][4 * g + 2]);
+                    p[4 * g + 3] = cell_count<3>(mw[g]) * sm.exp_of(d[u][4 * g + 3]);
+                    rs += (p[4 * g] + p[4 * g + 1]) + (p[4 * g + 2] + p[4 * g + 3]);
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    const Frag pf = split8(p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3],
+                                           p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]);
+#pragma unroll
+                    for (int eh = 0; eh < 2; eh++)
+                        yacc[eh] = mma3(pf, read_cols(buf + u * MA_IMG + MA_VH, buf + u * MA_IMG + MA_VL,
+                                                      c32 + 32 * eh, h, s2), yacc[eh]);
+                }
             }
         }
-        if (t + 1 < T) stager.store(img + ((t + 1) & 1) * MA_IMG, nxt);
-        mcur = mnxt;
+        if (it + 1 < NIT) {
+#pragma unroll
+            for (int u = 0; u < SUB; u++)
+                stager.store(img + (((it + 1) & 1) * SUB + u) * MA_IMG, nxt[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < SUB; u++) mcur[u] = mnxt[u];
 #ifdef MA_STAMP
         {
             const float now = (float)(__builtin_amdgcn_s_memtime() - st_t0);
 #pragma unroll
-            for (int i = 0; i < 16; i++) st_it[i] = (i == t) ? now : st_it[i];
+            for (int i = 0; i < 16; i++) st_it[i] = (i == it) ? now : st_it[i];
         }
 #endif
         __syncthreads();
@@ -657,11 +671,14 @@ void attention_mfma_backward_rows_kernel(
         for (int x = 0; x < 32; x++) dl = fmaf(xr[x], yr[x], dl);
         dl += __shfl_xor(dl, 32, SPT_WAVE);
         delta_i = fmaxf(1e-9f, dl);
-        split_own_rows(gf, xr);
+        // scale / row_sum is a per-row factor of dS: folded into dY (and delta) once here
+        // instead of into every cell: dS = m e (dP' - delta') with dP' = pscale dP
+        const float pscale = scale / fmaxf(1e-9f, rsum);
+        split_own_rows(gf, xr, pscale);
         split_own_rows(qf, xq, sm.sl2);
+        if (h == 0 && row < S) delta[(size_t)b * S + row] = delta_i;
+        delta_i *= pscale;
     }
-    const float pscale = scale / fmaxf(1e-9f, rsum);
-    if (h == 0 && row < S) delta[(size_t)b * S + row] = delta_i;
     __syncthreads();
 
     f32x16 qacc[2];
@@ -690,7 +707,7 @@ void attention_mfma_backward_rows_kernel(
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int r = 4 * g + u;
-                    const float pw = m4[u] * sm.exp_of(d[r]) * pscale;
+                    const float pw = m4[u] * sm.exp_of(d[r]);
                     ds[r] = sm.inside(d[r]) ? pw * (dp[r] - delta_i) : 0.0f;
                 }
             }
@@ -729,14 +746,15 @@ void attention_mfma_backward_rows_kernel(
 // tiles), waves 4-7 their mirror images (few).
 constexpr int MK_QR = 0, MK_GR = 2 * MA_RIMG, MK_QC = 4 * MA_RIMG,
               MK_GC = 4 * MA_RIMG + 2 * MA_CIMG, MK_ST = 4 * MA_RIMG + 4 * MA_CIMG,
-              MK_IMG = MK_ST + 2 * MA_WROWS * 4;                            // 37120 B
+              MK_IMG = MK_ST + MA_WROWS * 4;                                // 36992 B
 template <bool GT>
 struct KeysStager {
     const float *q_b, *gy_b, *rs_b, *dl_b;
     int ld, S, tid;
-    struct Regs { float4 qf, gf; float st; };
+    struct Regs { float4 qf, gf, rs; float st_rs, st_dl; };
     // unconditional, clamped loads (see TileStager::load); rows >= S are given weight 0 by
-    // store(), so whatever finite data the clamped rows hold never counts
+    // store(), so whatever finite data the clamped rows hold never counts.  Raw values only:
+    // arithmetic on them here would wait for the loads at the top of the iteration.
     __device__ __forceinline__ Regs load(int rt) const {
         Regs r;
         const int i0 = rt * MA_WROWS;
@@ -745,26 +763,40 @@ struct KeysStager {
         r.qf = *reinterpret_cast<const float4 *>(q_b + (size_t)row * ld + e4);
         if (!GT) {
             r.gf = *reinterpret_cast<const float4 *>(gy_b + (size_t)row * MA_E + e4);
+            r.rs = make_float4(rs_b[row], 0.f, 0.f, 0.f);
         } else {        // [E][S]: four consecutive rows of one e (S % 4 == 0)
             const int e = tid >> 3, i4 = min(i0 + (tid & 7) * 4, S - 4);
             r.gf = *reinterpret_cast<const float4 *>(gy_b + (size_t)e * S + i4);
+            r.rs = *reinterpret_cast<const float4 *>(rs_b + i4);
         }
-        // (raw values here: arithmetic on them would wait for the loads at the top of the
-        // iteration)
         const int sr = min(i0 + (tid & (MA_WROWS - 1)), S - 1);
-        r.st = (tid & MA_WROWS) ? dl_b[sr] : rs_b[sr];
+        r.st_rs = rs_b[sr];
+        r.st_dl = dl_b[sr];
         return r;
     }
+    // 1 / row_sum is a per-row factor of both P (grad_v) and dS (grad_k): dY is staged
+    // pre-multiplied by it, rows >= S by 0, and the rows' delta likewise
     __device__ __forceinline__ void store(char *buf, const Regs &r, int rt) const {
+        const int i0 = rt * MA_WROWS;
         const int il = tid >> 4, e4 = (tid & 15) * 4;
+        auto weight = [&](float rs, int row) {
+            return row < S ? 1.0f / fmaxf(1e-9f, rs) : 0.0f;
+        };
         put4_along_e<true, true>(buf + MK_QR, buf + MK_QC, il, e4, r.qf);
-        if (!GT) put4_along_e<true, true>(buf + MK_GR, buf + MK_GC, il, e4, r.gf);
-        else put4_along_r<true, true>(buf + MK_GR, buf + MK_GC, tid >> 3, (tid & 7) * 4, r.gf);
-        if (tid < 2 * MA_WROWS) {
-            const bool in = rt * MA_WROWS + (tid & (MA_WROWS - 1)) < S;
-            const float inv = 1.0f / fmaxf(1e-9f, r.st);
-            reinterpret_cast<float *>(buf + MK_ST)[tid] = !in ? 0.0f : (tid < MA_WROWS ? inv : r.st);
+        if (!GT) {
+            const float w = weight(r.rs.x, i0 + il);
+            put4_along_e<true, true>(buf + MK_GR, buf + MK_GC, il, e4,
+                                     make_float4(w * r.gf.x, w * r.gf.y, w * r.gf.z, w * r.gf.w));
+        } else {
+            const int i4 = (tid & 7) * 4;
+            put4_along_r<true, true>(
+                buf + MK_GR, buf + MK_GC, tid >> 3, i4,
+                make_float4(weight(r.rs.x, i0 + i4) * r.gf.x, weight(r.rs.y, i0 + i4 + 1) * r.gf.y,
+                            weight(r.rs.z, i0 + i4 + 2) * r.gf.z,
+                            weight(r.rs.w, i0 + i4 + 3) * r.gf.w));
         }
+        if (tid < MA_WROWS)
+            reinterpret_cast<float *>(buf + MK_ST)[tid] = weight(r.st_rs, i0 + tid) * r.st_dl;
     }
 };
 
@@ -849,17 +881,15 @@ void attention_mfma_backward_keys_kernel(
             float p[16], ds[16];
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
-                const float4 inv4 = *reinterpret_cast<const float4 *>(st + 8 * g4 + 4 * h);
-                const float4 del4 = *reinterpret_cast<const float4 *>(st + MA_WROWS + 8 * g4 + 4 * h);
-                const float inv[4] = {inv4.x, inv4.y, inv4.z, inv4.w};
+                const float4 del4 = *reinterpret_cast<const float4 *>(st + 8 * g4 + 4 * h);
                 const float del[4] = {del4.x, del4.y, del4.z, del4.w};
                 const float m4[4] = {cell_count<0>(mw[g4]), cell_count<1>(mw[g4]),
                                      cell_count<2>(mw[g4]), cell_count<3>(mw[g4])};
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int r = 4 * g4 + u;
-                    p[r] = m4[u] * sm.exp_of(d[r]) * inv[u];
-                    ds[r] = sm.inside(d[r]) ? scale * p[r] * (dp[r] - del[u]) : 0.0f;
+                    p[r] = m4[u] * sm.exp_of(d[r]);          // x 1 / row_sum: in the dY images
+                    ds[r] = sm.inside(d[r]) ? p[r] * (dp[r] - del[u]) : 0.0f;   // x scale: epilogue
                 }
             }
 #pragma unroll
@@ -889,8 +919,8 @@ void attention_mfma_backward_keys_kernel(
             const int jl = acc_row(r, h);
             if (j0 + jl < S) {
                 const size_t at = (size_t)(j0 + jl) * dv.ld + c32;
-                gk_b[at] = kacc[0][r];
-                gk_b[at + 32] = kacc[1][r];
+                gk_b[at] = scale * kacc[0][r];
+                gk_b[at + 32] = scale * kacc[1][r];
                 gv_b[at] = vacc[0][r];
                 gv_b[at + 32] = vacc[1][r];
             }
@@ -903,7 +933,9 @@ static bool mfma_shape_ok(int S, int E, int nnz) {
     const int Z = nnz / S;
     return Z <= MA_MAXZ && Z % 4 == 0 && S <= MA_MAXNT * MA_KT;
 }
-static size_t mfma_forward_lds() { return 2 * MA_IMG + (size_t)MA_WAVES * MA_WROWS * sizeof(float); }
+static size_t mfma_forward_lds() {
+    return 2 * MA_SUB * MA_IMG + (size_t)MA_WAVES * MA_WROWS * sizeof(float);
+}
 struct TileSet {
     unsigned long long *masks;
     unsigned char *cells, *cells_t;
@@ -945,10 +977,20 @@ extern "C" int spt_attention_mfma_prepare(const int32_t *indices, void *tiles, i
     const int S = seq_length, Z = nnz / S, NT = (S + MA_KT - 1) / MA_KT;
     const int RT = (S + MA_WROWS - 1) / MA_WROWS, total = batch_size * RT;
     const TileSet ts = carve_tiles(tiles, batch_size, S);
-    const size_t lds = (size_t)MB_WAVES * prepare_lds_per_wave(NT);
-    hipLaunchKernelGGL(attention_cell_tiles_kernel, dim3((total + MB_WAVES - 1) / MB_WAVES),
-                       dim3(MB_WAVES * SPT_WAVE), lds, static_cast<hipStream_t>(stream), indices,
-                       ts.masks, ts.cells, ts.cells_t, S, Z, NT, RT, total);
+    const size_t lds = (size_t)MB_WAVES * prepare_lds_per_wave();
+    const dim3 grid((total + MB_WAVES - 1) / MB_WAVES), block(MB_WAVES * SPT_WAVE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (Z > 255) {
+        SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_cell_tiles_kernel<true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(attention_cell_tiles_kernel<true>, grid, block, lds, s, indices,
+                           ts.masks, ts.cells, ts.cells_t, S, Z, NT, RT, total);
+    } else {
+        SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_cell_tiles_kernel<false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(attention_cell_tiles_kernel<false>, grid, block, lds, s, indices,
+                           ts.masks, ts.cells, ts.cells_t, S, Z, NT, RT, total);
+    }
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }
@@ -969,6 +1011,10 @@ extern "C" int spt_attention_mfma_forward(const void *tiles, const float *q, con
     const size_t lds = mfma_forward_lds();
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
+    SPT_HIP_TRY(hipFuncSetAttribute(
+        y_transposed ? (const void *)attention_mfma_forward_kernel<true>
+                     : (const void *)attention_mfma_forward_kernel<false>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (y_transposed)
         hipLaunchKernelGGL(attention_mfma_forward_kernel<true>, grid, block, lds, s, ts.masks,
                            ts.cells, q, k, v, y, row_sum, S, scale, clamp, heads, bpb);

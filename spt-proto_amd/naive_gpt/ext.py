@@ -461,7 +461,7 @@ def attention_mfma_prepare(indices: torch.Tensor, seq_length: int) -> MfmaTiles:
     B, nnz = indices.shape
     lib = load_library()
     size = lib.spt_attention_mfma_tiles_bytes(B, int(seq_length), nnz)
-    _require(size > 0, 'attention_mfma: unsupported shape (d_head 64, Z <= 64, Z % 4 == 0, S <= 2048)')
+    _require(size > 0, 'attention_mfma: unsupported shape (d_head 64, Z <= 256, Z % 4 == 0, S <= 2048)')
     with torch.cuda.device(dev):
         buf = torch.empty([size], dtype=torch.uint8, device=dev)
         rc = lib.spt_attention_mfma_prepare(indices.data_ptr(), buf.data_ptr(), B, int(seq_length),

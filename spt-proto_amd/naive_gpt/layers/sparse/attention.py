@@ -215,8 +215,16 @@ class _SparseCore:
             self.register_buffer('loss', loss_q + loss_k, persistent=False)
 
     @staticmethod
+    def _mfma_ok(t: torch.Tensor) -> bool:
+        n, s, h, e = t.shape
+        return (t.is_cuda and t.dtype == torch.float32 and s % 4 == 0 and s % SPARSE_COEFF == 0
+                and ext.attention_mfma_supported(s, e, s * (s // SPARSE_COEFF)))
+
+    @staticmethod
     def _head_layout_ok(t: torch.Tensor) -> bool:
         n, s, h, e = t.shape
+        if _SparseCore._mfma_ok(t):        # the matrix-core kernels take [N, S, H, E] at any S
+            return True
         return (t.is_cuda and t.dtype == torch.float32
                 and ext.head_layout_supported(s, e, n * h))
 
