@@ -217,8 +217,10 @@ class _SparseCore:
     @staticmethod
     def _mfma_ok(t: torch.Tensor) -> bool:
         n, s, h, e = t.shape
+        # (n * h >= 32 as for the other head-layout kernels: below that the launch cannot fill
+        # the GPU, and small direct calls of _get_attn keep returning the reference's triple)
         return (t.is_cuda and t.dtype == torch.float32 and s % 4 == 0 and s % SPARSE_COEFF == 0
-                and ext.attention_mfma_supported(s, e, s * (s // SPARSE_COEFF)))
+                and n * h >= 32 and ext.attention_mfma_supported(s, e, s * (s // SPARSE_COEFF)))
 
     @staticmethod
     def _head_layout_ok(t: torch.Tensor) -> bool:
