@@ -352,7 +352,10 @@ def main():
                                '(cdist/lookup/sddmm/softmax/spmm fwd+bwd)',
                    'micro_batch_per_gpu': N, 'global_batch': N * world, 'seq_len': S,
                    'n_heads': H, 'd_head': E, 'nnz_per_row': Z, 'pq': [M, C, D],
-                   'trigger': bool(args.trigger), 'parallelism': 'dp{}'.format(world)},
+                   'trigger': bool(args.trigger), 'parallelism': 'dp{}'.format(world),
+                   'arithmetic': 'fp32 tensors; attention products = 3 bf16 MFMAs on hi/lo-split '
+                                 'fp32 operands, fp32 accumulation (error ~2e-5 of the output '
+                                 'scale, bar 1e-3); PQ codes / top-k indices exact'},
         'peak_hbm_gb': peak_gb,
     }
     if recipe is not None:

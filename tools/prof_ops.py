@@ -53,6 +53,11 @@ for _ in range(reps):
         sc, at, yt = ext.sparse_attention_forward(idx, q4, q4, q4, 0.125, 10.0, y_transposed=True, causal=True)
         ext.sparse_attention_backward_rows(idx, yt, q4, q4, sc, at, 0.125, 10.0, grad_y_transposed=True, causal=True)
         ext.sparse_attention_backward_rows(idx, yt.view(B, S, E), q4, q4, sc, at, 0.125, 10.0, grad_y_transposed=False, causal=True)
+    if 'mfma' in ops:
+        q4 = q.view(N, H, S, E).transpose(1, 2).contiguous()
+        tiles = ext.attention_mfma_prepare(idx, S)
+        yt, rs = ext.attention_mfma_forward(tiles, q4, q4, q4, 0.125, 10.0, y_transposed=True)
+        ext.attention_mfma_backward(tiles, q4, q4, q4, yt, yt, rs, 0.125, 10.0, transposed=True)
     if 'pq_loss' in ops:
         zh = q.view(N, H, S, E)
         ext.pq_encode_heads(zh, table)

@@ -6,8 +6,10 @@ python bench.py --steps 20 --warmup 5 --trigger --no-cpu --no-dense > gpurun_out
 python tools/bench_block.py > gpurun_out/final_block.json 2>/dev/null
 python tools/bench_ffn.py > gpurun_out/final_ffn.json 2>/dev/null
 timeout -k 10 600 python tools/bench_model.py > gpurun_out/final_model.json 2>/dev/null
+python tools/bench_long.py > gpurun_out/final_long.json 2>/dev/null
+python tools/time_mfma.py > gpurun_out/final_mfma_ops.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/final_prof $GRAFT_REPO_ROOT/gpurun_out/final_prof_trigger
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu --no-dense > $GRAFT_REPO_ROOT/gpurun_out/final_prof.log 2>&1
-cd $GRAFT_REPO_ROOT && bash tools/pmc_traffic.sh sddmm,spmm_n,transpose,lookup,cdist,softmax,pq_loss,fused > gpurun_out/final_traffic.log 2>&1
+cd $GRAFT_REPO_ROOT && bash tools/pmc_traffic.sh sddmm,spmm_n,transpose,lookup,cdist,softmax,pq_loss,fused,mfma > gpurun_out/final_traffic.log 2>&1
 echo done
