@@ -82,7 +82,7 @@ OP_KERNEL = {
     'spmm_forward_cuda': 'spt::spmm_g4_lds_kernel<4, 1>',
     'spmm_transposed': 'spt::spmm_t64_lds_kernel<1>',
     'csr_transpose': 'spt::csr_transpose_bitmap_kernel',
-    'lookup_forward_cuda': 'spt::lookup_forward_kernel<1, 4, 32>',
+    'lookup_forward_cuda': 'spt::lookup_rows_kernel<1>',
     'softmax_forward_cuda': 'spt::softmax_kernel<16, 0>',
     'softmax_backward_cuda': 'spt::softmax_kernel<16, 1>',
     'softmax_backward_clamped': 'spt::softmax_kernel<16, 2>',

@@ -26,6 +26,8 @@
 // to the exact uint16 comparison of the reference (lookup.cu:22,43).  The output
 // row is assembled in LDS with ds_max (the two writers of a saturated word resolve
 // to the larger column, as in the reference) and stored coalesced, zeros included.
+#include <type_traits>
+
 #include "spt_common.h"
 
 namespace spt {
@@ -354,6 +356,234 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_forward_kernel(
     }
 }
 
+// ---- rows-on-lanes form (S <= 512) ---------------------------------------------------------
+// The kernel above gives a wave one (or two) query rows and pays ~600 instructions of fixed cost
+// per row (wave scans for the list ranks, offsets, fix-up, row store): 107 us at the bench shape,
+// a quarter of the fine-tune step once attention moved to the matrix cores.  Here a wave takes
+// 64 consecutive rows, one per LANE, and walks the key columns in ascending order, so the rank
+// of a column inside its (slot, worker) list is simply the lane's running counter: no
+// cross-lane work at all, the key codes are wave-uniform (one broadcast LDS read per 4
+// columns).  Kept candidates are parked per list as one byte (column / 4: the worker is the
+// list's) in a lane-private LDS region; when the row is complete the lane knows its list sizes,
+// hence the reference's output positions, and assembles its row in LDS for a coalesced store.
+// Same closed form as lookup_row (see the file header), same quirks, bit-identical output.
+template <int W, bool NIB>
+__device__ __forceinline__ int rows_match(const uint32_t *__restrict__ kc, const Code<W> &qc,
+                                          const int32_t *__restrict__ kraw,
+                                          const int32_t (&qraw)[16], int M) {
+    if (NIB) {
+        Code<W> k;
+#pragma unroll
+        for (int d = 0; d < W; d++) k.w[d] = kc[d];
+        return match_count<W, true>(k, qc);
+    }
+    int cnt = 0;                       // exact uint16 comparison (lookup.cu:22,43)
+    for (int m = 0; m < M; m++) cnt += ((kraw[m] ^ qraw[m]) & 0xFFFF) == 0;
+    return cnt;
+}
+
+template <int W>
+__global__ __launch_bounds__(SPT_WAVE) void lookup_rows_kernel(
+    const int32_t *__restrict__ query, const int32_t *__restrict__ key,
+    int32_t *__restrict__ out, int B, int S, int M, int Z, int blocks_per_batch, int list_pitch,
+    int out_pitch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x % B;
+    const int blk = blocks_per_batch - 1 - (blockIdx.x / B);     // heavy row blocks first
+    const int r0 = blk * SPT_WAVE, gy = r0 + lane;
+    const int ncols = min(S, r0 + SPT_WAVE);
+    const int ngroups = (ncols + 3) >> 2;
+    const int Q = Z >> 2;
+    uint32_t *kcodes = reinterpret_cast<uint32_t *>(smem);                    // [4 ngroups][W]
+    const size_t kbytes = (size_t)(((S + 3) & ~3) + 4) * W * 4;     // + one group: the prefetch
+    unsigned char *lists = reinterpret_cast<unsigned char *>(smem) + kbytes +
+                           (size_t)lane * list_pitch;    // [16 lists][Q] bytes + 8 last-group bytes
+    unsigned short *orow = reinterpret_cast<unsigned short *>(
+        smem + kbytes + (size_t)SPT_WAVE * list_pitch);   // [64][out_pitch]
+    const int32_t *ksrc = key + (size_t)b * S * M;
+    const int32_t *qsrc = query + ((size_t)b * S + min(gy, S - 1)) * M;
+
+    // 4-bit form unless some code this block touches is outside [0, 16).  One pass: every lane
+    // loads the codes of its (<= 8) key columns with unconditional 16-byte loads (clamped
+    // column: a load per code with a wait each, as a first version had, cost more than the
+    // walk), checks them and packs them as nibbles; the packed words are only used if the
+    // whole block passed the check.
+    int wide = 0;
+    int32_t qraw[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) qraw[m] = 0;
+    if ((M & 3) == 0) {
+#pragma unroll
+        for (int m4 = 0; m4 < 4; m4++) {
+            if (4 * m4 < M) {
+                const int4 t = reinterpret_cast<const int4 *>(qsrc)[m4];
+                qraw[4 * m4] = t.x; qraw[4 * m4 + 1] = t.y; qraw[4 * m4 + 2] = t.z; qraw[4 * m4 + 3] = t.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 16; m++)
+            if (m < M) qraw[m] = qsrc[m];
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) wide |= qraw[m];
+    Code<W> qc;
+#pragma unroll
+    for (int d = 0; d < W; d++) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) word |= ((uint32_t)qraw[8 * d + j] & 0xFu) << (4 * j);   // pad: 0
+        qc.w[d] = word;
+    }
+    constexpr int KPL = 512 / SPT_WAVE;                 // key columns per lane at S <= 512
+    int32_t kraw[KPL][16];
+#pragma unroll
+    for (int i = 0; i < KPL; i++) {
+        const int col = min(lane + SPT_WAVE * i, ncols - 1);
+        const int32_t *src = ksrc + (size_t)col * M;
+#pragma unroll
+        for (int m = 0; m < 16; m++) kraw[i][m] = 0;
+        if ((M & 3) == 0) {
+#pragma unroll
+            for (int m4 = 0; m4 < 4; m4++) {
+                if (4 * m4 < M) {
+                    const int4 t = reinterpret_cast<const int4 *>(src)[m4];
+                    kraw[i][4 * m4] = t.x; kraw[i][4 * m4 + 1] = t.y;
+                    kraw[i][4 * m4 + 2] = t.z; kraw[i][4 * m4 + 3] = t.w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; m++)
+                if (m < M) kraw[i][m] = src[m];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < KPL; i++) {
+        const int col = lane + SPT_WAVE * i;
+#pragma unroll
+        for (int m = 0; m < 16; m++) wide |= kraw[i][m];
+        if (col < 4 * ngroups) {
+#pragma unroll
+            for (int d = 0; d < W; d++) {
+                uint32_t word = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int m = 8 * d + j;
+                    // pad nibbles are 0xF in keys (0 in queries): they never match
+                    const uint32_t nibv = (m < M && col < ncols) ? ((uint32_t)kraw[i][m] & 0xFu) : 0xFu;
+                    word |= nibv << (4 * j);
+                }
+                kcodes[col * W + d] = word;
+            }
+        }
+    }
+    const bool nib = __builtin_amdgcn_ballot_w64((wide & ~0xF) != 0) == 0ull;
+    unsigned char *lastg = lists + 16 * Q;            // [2 workers][4 slots]: last column / 4
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // slot = min(3, matches / (M / 4)) (lookup.cu:61-63) as a multiply-shift, as in lookup_row
+    const int div = M >> 2;
+    const unsigned magic = (32u + div - 1) / div;
+    // list sizes: worker tx, four 8-bit fields (slot 0..3): a list holds at most S / 4 <= 128
+    // columns at S <= 512
+    unsigned n8[4] = {0u, 0u, 0u, 0u};
+
+    // the group's four codes are read together, one group ahead: read one by one they sat
+    // behind the byte stores (same LDS, no alias information) with a full LDS latency each
+    auto group_codes = [&](int g, uint32_t (&raw)[4 * W]) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(kcodes + (size_t)g * 4 * W);
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            const uint4 t = src[i];
+            raw[4 * i + 0] = t.x; raw[4 * i + 1] = t.y; raw[4 * i + 2] = t.z; raw[4 * i + 3] = t.w;
+        }
+    };
+    const unsigned Q4 = 4u * Q;
+    auto walk = [&](auto nib_tag) {
+        constexpr bool NIBF = decltype(nib_tag)::value;
+        uint32_t nxt[4 * W];
+        if (NIBF) group_codes(0, nxt);
+        for (int g = 0; g < ngroups; g++) {
+            uint32_t cur[4 * W];
+#pragma unroll
+            for (int i = 0; i < 4 * W; i++) cur[i] = nxt[i];
+            if (NIBF) group_codes(g + 1, nxt);
+#pragma unroll
+            for (int tx = 0; tx < 4; tx++) {
+                const int c = 4 * g + tx;
+                const int cs = min(c, S - 1);
+                const unsigned cnt = (unsigned)rows_match<W, NIBF>(cur + tx * W, qc,
+                                                                   ksrc + (size_t)cs * M, qraw, M);
+                const unsigned sl = min(3u, __umul24(cnt, magic) >> 5);
+                const bool active = c <= gy;          // (c < ncols <= S follows for real rows)
+                const unsigned sh = sl << 3;
+                const unsigned rank = (n8[tx] >> sh) & 0xFFu;
+                n8[tx] += (active ? 1u : 0u) << sh;
+                const unsigned cap = (tx < 2) ? Q : Q - 1;
+                if (active && rank < cap) lists[__umul24(sl, Q4) + tx * Q + rank] = (unsigned char)g;
+                if (tx >= 2 && active) lastg[(tx - 2) * 4 + sl] = (unsigned char)g;
+            }
+        }
+    };
+    if (nib) walk(std::true_type{});
+    else walk(std::false_type{});
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- the row is complete: sizes -> kept counts -> output positions ----
+    const int limit = min(gy + 1, Z);
+    unsigned short *mine = orow + (size_t)lane * out_pitch;
+    int n[4][4], off[4][4];
+#pragma unroll
+    for (int tx = 0; tx < 4; tx++) {
+        n[tx][0] = n8[tx] & 0xFF; n[tx][1] = (n8[tx] >> 8) & 0xFF;
+        n[tx][2] = (n8[tx] >> 16) & 0xFF; n[tx][3] = n8[tx] >> 24;
+        const int cap = (tx < 2) ? Q : Q - 1;
+        const int k3 = min(n[tx][3], cap), k2 = min(n[tx][2], cap), k1 = min(n[tx][1], cap),
+                  k0 = min(n[tx][0], cap);
+        off[tx][3] = 0;
+        off[tx][2] = k3;
+        off[tx][1] = k3 + k2;
+        off[tx][0] = k3 + k2 + k1;
+        const int total = k3 + k2 + k1 + k0;
+        // position index i of worker tx: the slot whose kept range holds it (slot 3 first)
+        for (int i = 0; i < Q; i++) {
+            const int p = tx + 4 * i;
+            const int sl = i < off[tx][2] ? 3 : (i < off[tx][1] ? 2 : (i < off[tx][0] ? 1 : 0));
+            const int r = i - sel4(off[tx][0], off[tx][1], off[tx][2], off[tx][3], sl);
+            unsigned short v = 0;
+            if (i < total && p < limit) v = (unsigned short)(4 * lists[(sl * 4 + tx) * Q + r] + tx);
+            mine[p] = v;
+        }
+    }
+    // reference quirk: the cursor of worker 2 (3) saturates on the word that holds entry Q-1
+    // of worker 1 (0); its LAST candidate of the slot survives there if larger
+#pragma unroll
+    for (int sl = 0; sl < 4; sl++) {
+#pragma unroll
+        for (int tx = 2; tx < 4; tx++) {
+            const int ptx = 3 - tx;
+            if (n[tx][sl] >= Q && n[ptx][sl] >= Q) {
+                const int p = ptx + 4 * (off[ptx][sl] + Q - 1);
+                const int lastcol = 4 * lastg[(tx - 2) * 4 + sl] + tx;
+                if (p < limit) mine[p] = (unsigned short)max((int)mine[p], lastcol);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- coalesced store, zeros included ----
+    const int nrows = min(SPT_WAVE, S - r0);
+    for (int r = 0; r < nrows; r++) {
+        int32_t *dst = out + ((size_t)b * S + r0 + r) * Z;
+        const unsigned short *src = orow + (size_t)r * out_pitch;
+        for (int i = lane; i < Z; i += SPT_WAVE) dst[i] = src[i];
+    }
+}
+
 }  // namespace spt
 
 using namespace spt;
@@ -371,6 +601,30 @@ extern "C" int spt_lookup_forward(const int32_t *query, const int32_t *key, int3
     if (M < 4 || M > 16) return SPT_EUNSUP;                    // lookup.cu:167-169
     if (S > 32768) return SPT_EUNSUP;                          // 8-bit per-lane counters (ref: uint16 columns, lookup.cu:32)
     const int WU = (M + 1) / 2;
+    hipStream_t s = (hipStream_t)stream;
+    if (S <= 512) {
+        // rows-on-lanes form: column / 4 and the list sizes (<= S / 4) fit in bytes
+        const int WN = (M + 7) / 8;
+        const int Q = Z / 4;
+        const int list_pitch = ((16 * Q + 8 + 3) & ~3) | 4;      // odd number of words
+        const int out_pitch = Z + 2;                              // uint16: odd number of words
+        const size_t lds = (size_t)(((S + 3) & ~3) + 4) * WN * 4 + (size_t)SPT_WAVE * list_pitch +
+                           (size_t)SPT_WAVE * out_pitch * 2;
+        const int nb = (S + SPT_WAVE - 1) / SPT_WAVE;
+        const long long nblk = (long long)batch_size * nb;
+        if (lds <= 64 * 1024 && nblk <= 0x7FFFFFFFLL) {
+            if (WN == 1)
+                hipLaunchKernelGGL(lookup_rows_kernel<1>, dim3((unsigned)nblk), dim3(SPT_WAVE), lds,
+                                   s, query, key, out, batch_size, S, M, Z, nb, list_pitch,
+                                   out_pitch);
+            else
+                hipLaunchKernelGGL(lookup_rows_kernel<2>, dim3((unsigned)nblk), dim3(SPT_WAVE), lds,
+                                   s, query, key, out, batch_size, S, M, Z, nb, list_pitch,
+                                   out_pitch);
+            SPT_LAUNCH_CHECK();
+            return SPT_OK;
+        }
+    }
     // two rows per wave while 32 lanes hold a row in <= 5 groups of 4 columns each
     const int lanes = (S <= 640) ? 32 : 64;
     const size_t lds = (size_t)S * WU * 4 + (size_t)LK_WAVES * (SPT_WAVE / lanes) * Z * 4;
@@ -379,7 +633,6 @@ extern "C" int spt_lookup_forward(const int32_t *query, const int32_t *key, int3
     const long long nblk = (long long)batch_size * tiles;
     if (nblk > 0x7FFFFFFFLL) return SPT_EUNSUP;
     dim3 grid((unsigned)nblk);
-    hipStream_t s = (hipStream_t)stream;
 #define SPT_LK2(WN_, WU_, LN_)                                                                \
     do {                                                                                      \
         if (lds > 64 * 1024)                                                                  \

@@ -169,11 +169,7 @@ struct TileStager {
 __device__ __forceinline__ Frag read_rows(const char *hi, const char *lo, int lane, int ks) {
     const int off = (lane & 31) * MA_KLD + 16 * (lane >> 5) + 32 * ks;
     Frag f;
-#ifdef MA_EXP_NOLDSREAD
-    f.hi = make_uint4(off, lane, ks, 0x3f803f80u);
-    f.lo = make_uint4(lane, off, 0x3c003c00u, ks);
-    return f;
-#endif
+
     f.hi = *reinterpret_cast<const uint4 *>(hi + off);
     f.lo = *reinterpret_cast<const uint4 *>(lo + off);
     return f;
@@ -183,14 +179,7 @@ __device__ __forceinline__ Frag read_rows(const char *hi, const char *lo, int la
 // lane (c, h) reads row c of the transposed image at 16s + 4h .. +4 and 16s + 8 + 4h .. +4
 __device__ __forceinline__ Frag read_cols(const char *hi, const char *lo, int row, int h, int s) {
     const int off = row * MA_VLD + 32 * s + 8 * h;
-#ifdef MA_EXP_NOLDSREAD
-    {
-        Frag f;
-        f.hi = make_uint4(off, row, s, 0x3f803f80u);
-        f.lo = make_uint4(row, off, 0x3c003c00u, s);
-        return f;
-    }
-#endif
+
     const uint2 a = *reinterpret_cast<const uint2 *>(hi + off),
                 b = *reinterpret_cast<const uint2 *>(hi + off + 16),
                 c = *reinterpret_cast<const uint2 *>(lo + off),
@@ -366,18 +355,9 @@ __device__ __forceinline__ int folded_row_tile(int g, int blocks_per_batch, int 
 
 // ===================================== forward =============================================
 // grid: batch * ceil(S / 256) workgroups.
-#ifdef MA_STAMP
-// diagnostic build only (tools/time_mfma.py, MA_STAMPS=1): shader-clock cycles per phase of
-// the last wave of workgroup 0, written over row_sum[0 .. 11]
-#define MA_T(i)                                                         \
-    do {                                                                \
-        const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
-        st_acc[i] += (float)(now__ - st_prev);                          \
-        st_prev = now__;                                                \
-    } while (0)
-#else
-#define MA_T(i)
-#endif
+// -DMA_STAMP (diagnostic build only; tools/time_mfma.py with MA_STAMPS=1 and SPT_HIP_LIBRARY):
+// every wave of workgroups 0 and 1 records the shader clock at the end of each of its forward
+// iterations, written over the first row sums.
 
 // exp(clamp(scale d)) = exp2(med3(d * scale log2e, -+clamp log2e)); without a clamp the
 // exponent is bounded at 2^127 so that dead cells (m = 0) stay 0 and not 0 * inf
