@@ -34,8 +34,12 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int MA_THREADS = 512;
-constexpr int MA_WAVES = MA_THREADS / SPT_WAVE;   // 8
+#ifndef MA_THREADS_VALUE
+#define MA_THREADS_VALUE 512
+#endif
+constexpr int MA_THREADS = MA_THREADS_VALUE;       // 512 or 256
+constexpr int MA_WAVES = MA_THREADS / SPT_WAVE;    // 8 or 4
+constexpr int MA_RPT = 512 / MA_THREADS;           // 32 x 64 tile: float4s per thread to stage
 constexpr int MA_WROWS = 32;                       // rows per wave = one MFMA tile
 constexpr int MA_ROWS = MA_WAVES * MA_WROWS;       // 256 rows per workgroup
 constexpr int MA_KT = 32;                          // keys per tile
@@ -140,8 +144,9 @@ __device__ __forceinline__ void put4_along_r(char *rows, char *cols, int e, int 
     }
 }
 
-// The forward's key tiles: K as a rows image, V as a cols image.
-struct TileRegs { float4 kf, vf; };
+// The forward's key tiles: K as a rows image, V as a cols image.  Thread t stages the
+// float4 (row (t >> 4) + (MA_THREADS / 16) u, columns 4 (t & 15) ..) for u < MA_RPT.
+struct TileRegs { float4 kf[MA_RPT], vf[MA_RPT]; };
 struct TileStager {
     const float *k_b, *v_b;
     int ld, S, jl, e4;
@@ -153,14 +158,20 @@ struct TileStager {
     // data whose cells have multiplicity 0.
     __device__ __forceinline__ TileRegs load(int t) const {
         TileRegs r;
-        const int j = min(t * MA_KT + jl, S - 1);
-        r.kf = *reinterpret_cast<const float4 *>(k_b + (size_t)j * ld + e4);
-        r.vf = *reinterpret_cast<const float4 *>(v_b + (size_t)j * ld + e4);
+#pragma unroll
+        for (int u = 0; u < MA_RPT; u++) {
+            const int j = min(t * MA_KT + jl + (MA_THREADS / 16) * u, S - 1);
+            r.kf[u] = *reinterpret_cast<const float4 *>(k_b + (size_t)j * ld + e4);
+            r.vf[u] = *reinterpret_cast<const float4 *>(v_b + (size_t)j * ld + e4);
+        }
         return r;
     }
     __device__ __forceinline__ void store(char *buf, const TileRegs &r) const {
-        put4_along_e<true, false>(buf + MA_KH, nullptr, jl, e4, r.kf);
-        put4_along_e<false, true>(nullptr, buf + MA_VH, jl, e4, r.vf);
+#pragma unroll
+        for (int u = 0; u < MA_RPT; u++) {
+            put4_along_e<true, false>(buf + MA_KH, nullptr, jl + (MA_THREADS / 16) * u, e4, r.kf[u]);
+            put4_along_e<false, true>(nullptr, buf + MA_VH, jl + (MA_THREADS / 16) * u, e4, r.vf[u]);
+        }
     }
 };
 
@@ -350,7 +361,9 @@ struct CellTiles {
 // instead: workgroup g of a slice takes row tiles 4g .. 4g+3 (waves 0-3) and the mirror
 // images RTpad-4g-4 .. RTpad-4g-1 (waves 4-7; one short and one long wave per SIMD).
 __device__ __forceinline__ int folded_row_tile(int g, int blocks_per_batch, int wave) {
-    return wave < 4 ? 4 * g + wave : MA_WAVES * blocks_per_batch - 4 * (g + 1) + (wave - 4);
+    constexpr int HALF = MA_WAVES / 2;
+    return wave < HALF ? HALF * g + wave
+                       : MA_WAVES * blocks_per_batch - HALF * (g + 1) + (wave - HALF);
 }
 
 // ===================================== forward =============================================
@@ -392,6 +405,9 @@ __device__ __forceinline__ float cell_count(unsigned word) {
 #endif
 #ifndef MA_ROWS_WAVES_PER_EU
 #define MA_ROWS_WAVES_PER_EU 2
+#endif
+#ifndef MA_KEYS_WAVES_PER_EU
+#define MA_KEYS_WAVES_PER_EU 2
 #endif
 template <bool YT>
 __global__ __launch_bounds__(MA_THREADS)
@@ -601,8 +617,12 @@ constexpr int MR_KR = 0, MR_VR = 2 * MA_RIMG, MR_KC = 4 * MA_RIMG,
 struct RowsStager : TileStager {
     using TileStager::TileStager;
     __device__ __forceinline__ void store(char *buf, const TileRegs &r) const {
-        put4_along_e<true, true>(buf + MR_KR, buf + MR_KC, jl, e4, r.kf);
-        put4_along_e<true, false>(buf + MR_VR, nullptr, jl, e4, r.vf);
+#pragma unroll
+        for (int u = 0; u < MA_RPT; u++) {
+            const int row = jl + (MA_THREADS / 16) * u;
+            put4_along_e<true, true>(buf + MR_KR, buf + MR_KC, row, e4, r.kf[u]);
+            put4_along_e<true, false>(buf + MR_VR, nullptr, row, e4, r.vf[u]);
+        }
     }
 };
 
@@ -731,23 +751,28 @@ template <bool GT>
 struct KeysStager {
     const float *q_b, *gy_b, *rs_b, *dl_b;
     int ld, S, tid;
-    struct Regs { float4 qf, gf, rs; float st_rs, st_dl; };
+    struct Regs { float4 qf[MA_RPT], gf[MA_RPT], rs[MA_RPT]; float st_rs, st_dl; };
     // unconditional, clamped loads (see TileStager::load); rows >= S are given weight 0 by
     // store(), so whatever finite data the clamped rows hold never counts.  Raw values only:
     // arithmetic on them here would wait for the loads at the top of the iteration.
     __device__ __forceinline__ Regs load(int rt) const {
         Regs r;
         const int i0 = rt * MA_WROWS;
-        const int il = tid >> 4, e4 = (tid & 15) * 4;
-        const int row = min(i0 + il, S - 1);
-        r.qf = *reinterpret_cast<const float4 *>(q_b + (size_t)row * ld + e4);
-        if (!GT) {
-            r.gf = *reinterpret_cast<const float4 *>(gy_b + (size_t)row * MA_E + e4);
-            r.rs = make_float4(rs_b[row], 0.f, 0.f, 0.f);
-        } else {        // [E][S]: four consecutive rows of one e (S % 4 == 0)
-            const int e = tid >> 3, i4 = min(i0 + (tid & 7) * 4, S - 4);
-            r.gf = *reinterpret_cast<const float4 *>(gy_b + (size_t)e * S + i4);
-            r.rs = *reinterpret_cast<const float4 *>(rs_b + i4);
+        const int e4 = (tid & 15) * 4;
+#pragma unroll
+        for (int u = 0; u < MA_RPT; u++) {
+            const int il = (tid >> 4) + (MA_THREADS / 16) * u;
+            const int row = min(i0 + il, S - 1);
+            r.qf[u] = *reinterpret_cast<const float4 *>(q_b + (size_t)row * ld + e4);
+            if (!GT) {
+                r.gf[u] = *reinterpret_cast<const float4 *>(gy_b + (size_t)row * MA_E + e4);
+                r.rs[u] = make_float4(rs_b[row], 0.f, 0.f, 0.f);
+            } else {        // [E][S]: four consecutive rows of one e (S % 4 == 0)
+                const int e = (tid >> 3) + (MA_THREADS / 8) * u;
+                const int i4 = min(i0 + (tid & 7) * 4, S - 4);
+                r.gf[u] = *reinterpret_cast<const float4 *>(gy_b + (size_t)e * S + i4);
+                r.rs[u] = *reinterpret_cast<const float4 *>(rs_b + i4);
+            }
         }
         const int sr = min(i0 + (tid & (MA_WROWS - 1)), S - 1);
         r.st_rs = rs_b[sr];
@@ -758,22 +783,28 @@ struct KeysStager {
     // pre-multiplied by it, rows >= S by 0, and the rows' delta likewise
     __device__ __forceinline__ void store(char *buf, const Regs &r, int rt) const {
         const int i0 = rt * MA_WROWS;
-        const int il = tid >> 4, e4 = (tid & 15) * 4;
+        const int e4 = (tid & 15) * 4;
         auto weight = [&](float rs, int row) {
             return row < S ? 1.0f / fmaxf(1e-9f, rs) : 0.0f;
         };
-        put4_along_e<true, true>(buf + MK_QR, buf + MK_QC, il, e4, r.qf);
-        if (!GT) {
-            const float w = weight(r.rs.x, i0 + il);
-            put4_along_e<true, true>(buf + MK_GR, buf + MK_GC, il, e4,
-                                     make_float4(w * r.gf.x, w * r.gf.y, w * r.gf.z, w * r.gf.w));
-        } else {
-            const int i4 = (tid & 7) * 4;
-            put4_along_r<true, true>(
-                buf + MK_GR, buf + MK_GC, tid >> 3, i4,
-                make_float4(weight(r.rs.x, i0 + i4) * r.gf.x, weight(r.rs.y, i0 + i4 + 1) * r.gf.y,
-                            weight(r.rs.z, i0 + i4 + 2) * r.gf.z,
-                            weight(r.rs.w, i0 + i4 + 3) * r.gf.w));
+#pragma unroll
+        for (int u = 0; u < MA_RPT; u++) {
+            const int il = (tid >> 4) + (MA_THREADS / 16) * u;
+            put4_along_e<true, true>(buf + MK_QR, buf + MK_QC, il, e4, r.qf[u]);
+            if (!GT) {
+                const float w = weight(r.rs[u].x, i0 + il);
+                put4_along_e<true, true>(
+                    buf + MK_GR, buf + MK_GC, il, e4,
+                    make_float4(w * r.gf[u].x, w * r.gf[u].y, w * r.gf[u].z, w * r.gf[u].w));
+            } else {
+                const int i4 = (tid & 7) * 4;
+                put4_along_r<true, true>(
+                    buf + MK_GR, buf + MK_GC, (tid >> 3) + (MA_THREADS / 8) * u, i4,
+                    make_float4(weight(r.rs[u].x, i0 + i4) * r.gf[u].x,
+                                weight(r.rs[u].y, i0 + i4 + 1) * r.gf[u].y,
+                                weight(r.rs[u].z, i0 + i4 + 2) * r.gf[u].z,
+                                weight(r.rs[u].w, i0 + i4 + 3) * r.gf[u].w));
+            }
         }
         if (tid < MA_WROWS)
             reinterpret_cast<float *>(buf + MK_ST)[tid] = weight(r.st_rs, i0 + tid) * r.st_dl;
@@ -781,7 +812,8 @@ struct KeysStager {
 };
 
 template <bool GT>
-__global__ __launch_bounds__(MA_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(MA_THREADS)
+__attribute__((amdgpu_waves_per_eu(MA_KEYS_WAVES_PER_EU, MA_KEYS_WAVES_PER_EU)))
 void attention_mfma_backward_keys_kernel(
     const unsigned long long *__restrict__ masks, const unsigned char *__restrict__ cells_t,
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
@@ -829,7 +861,7 @@ void attention_mfma_backward_keys_kernel(
         return cell_b[(tri(rc) + min(kt, rc)) * 64 + lane];
     };
 
-    const int rt0 = 4 * g;                              // the first row tile any wave needs
+    const int rt0 = (MA_WAVES / 2) * g;                 // the first row tile any wave needs
     const KeysStager<GT> stager{q + dv.base, gy + (size_t)b * S * MA_E, row_sum + (size_t)b * S,
                                 delta + (size_t)b * S, dv.ld, S, tid};
     stager.store(img, stager.load(min(rt0, RT - 1)), rt0);
