@@ -50,11 +50,13 @@ constexpr int MA_MAXNT = 64;                       // key tiles: S <= 2048
 // LDS images of one key tile, bf16: rows padded so that the operand reads are conflict-free
 constexpr int MA_KLD = 144;                        // bytes per key row: 64 bf16 + 16
 constexpr int MA_VLD = 72;                         // bytes per e row of V^T: 32 bf16 + 8
+// the forward's tile: K rows image (hi, lo) | V rows image (hi, lo)
 constexpr int MA_KH = 0, MA_KL = MA_KT * MA_KLD, MA_VH = 2 * MA_KT * MA_KLD,
-              MA_VL = MA_VH + MA_E * MA_VLD, MA_IMG = MA_VL + MA_E * MA_VLD;   // 18432 B
+              MA_VL = 3 * MA_KT * MA_KLD, MA_IMG = 4 * MA_KT * MA_KLD;         // 18432 B
 constexpr int MA_CLD = 9;                          // words per row of the multiplicity tile
 constexpr int MA_CNT = MA_WROWS * MA_CLD * 4;      // prepare: one tile of counts, 1152 B
 constexpr int MA_CELLS = MA_WROWS * MA_KT;         // bytes of one stored cell tile
+constexpr int MA_TLD = 36;                         // floats per row of the epilogue's [e][row] tile
 
 struct Split { unsigned hi, lo; };
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -170,7 +172,7 @@ struct TileStager {
 #pragma unroll
         for (int u = 0; u < MA_RPT; u++) {
             put4_along_e<true, false>(buf + MA_KH, nullptr, jl + (MA_THREADS / 16) * u, e4, r.kf[u]);
-            put4_along_e<false, true>(nullptr, buf + MA_VH, jl + (MA_THREADS / 16) * u, e4, r.vf[u]);
+            put4_along_e<true, false>(buf + MA_VH, nullptr, jl + (MA_THREADS / 16) * u, e4, r.vf[u]);
         }
     }
 };
@@ -195,6 +197,45 @@ __device__ __forceinline__ Frag read_cols(const char *hi, const char *lo, int ro
                 b = *reinterpret_cast<const uint2 *>(hi + off + 16),
                 c = *reinterpret_cast<const uint2 *>(lo + off),
                 d = *reinterpret_cast<const uint2 *>(lo + off + 16);
+    Frag f;
+    f.hi = make_uint4(a.x, a.y, b.x, b.y);
+    f.lo = make_uint4(c.x, c.y, d.x, d.y);
+    return f;
+}
+
+// The same B-operand fragment from a ROWS image through gfx950's transposing LDS read:
+// ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4-row x 16-column block of
+// 16-bit elements, rows in its elements 0..3; lane 4q + p of the group supplies the address of
+// row q, columns 4p .. 4p + 3.  Two blocks (tile rows 16s + 4h .. and 16s + 8 + 4h ..) give
+// elements 0..3 and 4..7; the group's columns are 16 (lane >> 4 & 1) .. + 15 of the 32-column
+// half `col0`.  No transposed copy of the tile and none of its 2-byte scattered stores.
+// (All 64 lanes must be active: the gather crosses lanes.)
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_tr_b64(const char *p) {
+    const v4s16 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) v4s16 *)(p));
+    return __builtin_bit_cast(uint2, r);
+}
+__device__ __forceinline__ Frag read_cols_tr(const char *hi, const char *lo, int col0, int lane,
+                                             int s) {
+    const int gl = lane & 15, q = gl >> 2, p = gl & 3, h = lane >> 5;
+    const int off = (16 * s + 4 * h + q) * MA_KLD + (col0 + 16 * ((lane >> 4) & 1) + 4 * p) * 2;
+    const uint2 a = lds_tr_b64(hi + off), b = lds_tr_b64(hi + off + 8 * MA_KLD),
+                c = lds_tr_b64(lo + off), d = lds_tr_b64(lo + off + 8 * MA_KLD);
+    Frag f;
+    f.hi = make_uint4(a.x, a.y, b.x, b.y);
+    f.lo = make_uint4(c.x, c.y, d.x, d.y);
+    return f;
+}
+
+// A-operand fragment of k-step ks from a COLS image [e][row] (an operand that arrives as
+// [E][S]): lane (r, h) wants row r, elements 8h + 16ks .. + 8 -- columns of the image, again the
+// transposing read: blocks of image rows e0 .. e0+3 and e0+4 .. e0+7, image columns = tile rows
+__device__ __forceinline__ Frag read_rows_tr(const char *hi, const char *lo, int lane, int ks) {
+    const int gl = lane & 15, q = gl >> 2, p = gl & 3, h = lane >> 5;
+    const int off = (8 * h + 16 * ks + q) * MA_VLD + (16 * ((lane >> 4) & 1) + 4 * p) * 2;
+    const uint2 a = lds_tr_b64(hi + off), b = lds_tr_b64(hi + off + 4 * MA_VLD),
+                c = lds_tr_b64(lo + off), d = lds_tr_b64(lo + off + 4 * MA_VLD);
     Frag f;
     f.hi = make_uint4(a.x, a.y, b.x, b.y);
     f.lo = make_uint4(c.x, c.y, d.x, d.y);
@@ -518,8 +559,8 @@ void attention_mfma_forward_kernel(
                                            p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]);
 #pragma unroll
                     for (int eh = 0; eh < 2; eh++)
-                        yacc[eh] = mma3(pf, read_cols(buf + u * MA_IMG + MA_VH, buf + u * MA_IMG + MA_VL,
-                                                      c32 + 32 * eh, h, s2), yacc[eh]);
+                        yacc[eh] = mma3(pf, read_cols_tr(buf + u * MA_IMG + MA_VH, buf + u * MA_IMG + MA_VL,
+                                                         32 * eh, lane, s2), yacc[eh]);
                 }
             }
         }
@@ -565,25 +606,37 @@ void attention_mfma_forward_kernel(
                 }
             }
         } else {
-            // [batch, E, S]: registers r = 4g .. 4g+3 are four consecutive rows of one e
+            // [batch, E, S]: registers 4g .. 4g+3 are four consecutive rows of one e, but
+            // stored straight from the accumulator layout every lane writes its own 16-byte
+            // piece 4 S bytes from its neighbour's (14 us of partial-line writes).  Through a
+            // wave-private LDS tile [e][row] instead: 8 lanes then cover 128 contiguous bytes
+            // of one e and a store instruction writes 8 such runs.
+            float *tile = reinterpret_cast<float *>(img) + wave * (32 * MA_TLD);
 #pragma unroll
             for (int eh = 0; eh < 2; eh++) {
-                float *col = y_b + (size_t)(c32 + 32 * eh) * S + i0;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const int il = 8 * g + 4 * h;
-                    const float4 o = make_float4(
+                    *reinterpret_cast<float4 *>(tile + c32 * MA_TLD + il) = make_float4(
                         yacc[eh][4 * g] * wstat[il], yacc[eh][4 * g + 1] * wstat[il + 1],
                         yacc[eh][4 * g + 2] * wstat[il + 2], yacc[eh][4 * g + 3] * wstat[il + 3]);
-                    if (i0 + il + 3 < S && (S & 3) == 0) {
-                        *reinterpret_cast<float4 *>(col + il) = o;
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++) {
+                    const int el = (lane >> 3) + 8 * k4, i4 = (lane & 7) * 4;
+                    const float4 o = *reinterpret_cast<const float4 *>(tile + el * MA_TLD + i4);
+                    float *dst = y_b + (size_t)(el + 32 * eh) * S + i0 + i4;
+                    if (i0 + i4 + 3 < S && (S & 3) == 0) {
+                        *reinterpret_cast<float4 *>(dst) = o;
                     } else {
                         const float ov[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
                         for (int u = 0; u < 4; u++)
-                            if (i0 + il + u < S) col[il + u] = ov[u];
+                            if (i0 + i4 + u < S) dst[u] = ov[u];
                     }
                 }
+                wave_lds_fence();
             }
         }
     }
@@ -611,16 +664,16 @@ void attention_mfma_forward_kernel(
 //   grad_q[i] = sum_j dS[i, j] k[j]     grad_k[j] = sum_i dS[i, j] q[i]     (kernels/sddmm.py)
 //   grad_v[j] = sum_i P[i, j] dY[i]     dP[i, j]  = dY[i] . v[j]            (kernels/spmm.py)
 
-// ---- row-owned: same skeleton as the forward; images K rows | V rows | K cols ----
-constexpr int MR_KR = 0, MR_VR = 2 * MA_RIMG, MR_KC = 4 * MA_RIMG,
-              MR_IMG = 4 * MA_RIMG + 2 * MA_CIMG;                           // 27648 B
+// ---- row-owned: same skeleton as the forward; images K rows | V rows (the K rows image also
+// feeds grad_q = dS^T K through the transposing read) ----
+constexpr int MR_KR = 0, MR_VR = 2 * MA_RIMG, MR_IMG = 4 * MA_RIMG;         // 18432 B
 struct RowsStager : TileStager {
     using TileStager::TileStager;
     __device__ __forceinline__ void store(char *buf, const TileRegs &r) const {
 #pragma unroll
         for (int u = 0; u < MA_RPT; u++) {
             const int row = jl + (MA_THREADS / 16) * u;
-            put4_along_e<true, true>(buf + MR_KR, buf + MR_KC, row, e4, r.kf[u]);
+            put4_along_e<true, false>(buf + MR_KR, nullptr, row, e4, r.kf[u]);
             put4_along_e<true, false>(buf + MR_VR, nullptr, row, e4, r.vf[u]);
         }
     }
@@ -685,6 +738,9 @@ void attention_mfma_backward_rows_kernel(
 #pragma unroll
     for (int r = 0; r < 16; r++) qacc[0][r] = qacc[1][r] = 0.f;
 
+    // (Measured: with the tile computation removed this loop still takes 53 of its 79 us -- the
+    // kernel moves ~290 MB through L2 / HBM in 256-byte rows 4 KiB apart at ~3 TB/s; a second
+    // tile in flight in registers did not help: 79 -> 83 us.)
     for (int t = 0; t < T; t++) {
         const char *buf = img + (t & 1) * MR_IMG;
         const TileRegs nxt = stager.load(min(t + 1, T - 1));
@@ -717,8 +773,8 @@ void attention_mfma_backward_rows_kernel(
                                        ds[8 * s2 + 4], ds[8 * s2 + 5], ds[8 * s2 + 6], ds[8 * s2 + 7]);
 #pragma unroll
                 for (int eh = 0; eh < 2; eh++)
-                    qacc[eh] = mma3(sf, read_cols(buf + MR_KC, buf + MR_KC + MA_CIMG,
-                                                  c32 + 32 * eh, h, s2), qacc[eh]);
+                    qacc[eh] = mma3(sf, read_cols_tr(buf + MR_KR, buf + MR_KR + MA_RIMG, 32 * eh,
+                                                     lane, s2), qacc[eh]);
             }
         }
         if (t + 1 < T) stager.store(img + ((t + 1) & 1) * MR_IMG, nxt);
@@ -744,9 +800,12 @@ void attention_mfma_backward_rows_kernel(
 // delta.  Tiles are computed as D[row, key], so the sums over rows take the accumulator tile
 // as the A operand.  Folded like the rows: waves 0-3 own key tiles 4g .. 4g+3 (many row
 // tiles), waves 4-7 their mirror images (few).
-constexpr int MK_QR = 0, MK_GR = 2 * MA_RIMG, MK_QC = 4 * MA_RIMG,
-              MK_GC = 4 * MA_RIMG + 2 * MA_CIMG, MK_ST = 4 * MA_RIMG + 4 * MA_CIMG,
-              MK_IMG = MK_ST + MA_WROWS * 4;                                // 36992 B
+// images: Q rows | dY (rows image, or -- GT, the operand arriving as [E][S] -- a cols image:
+// whichever its source layout fills with 8-byte stores; the other orientation of each operand
+// comes from the transposing read) | the rows' scaled delta
+constexpr int MK_QR = 0, MK_G = 2 * MA_RIMG, MK_ST = 4 * MA_RIMG,
+              MK_IMG = MK_ST + MA_WROWS * 4;                                // 18560 B
+static_assert(MA_CIMG == MA_RIMG, "the dY slot holds either orientation");
 template <bool GT>
 struct KeysStager {
     const float *q_b, *gy_b, *rs_b, *dl_b;
@@ -790,16 +849,16 @@ struct KeysStager {
 #pragma unroll
         for (int u = 0; u < MA_RPT; u++) {
             const int il = (tid >> 4) + (MA_THREADS / 16) * u;
-            put4_along_e<true, true>(buf + MK_QR, buf + MK_QC, il, e4, r.qf[u]);
+            put4_along_e<true, false>(buf + MK_QR, nullptr, il, e4, r.qf[u]);
             if (!GT) {
                 const float w = weight(r.rs[u].x, i0 + il);
-                put4_along_e<true, true>(
-                    buf + MK_GR, buf + MK_GC, il, e4,
+                put4_along_e<true, false>(
+                    buf + MK_G, nullptr, il, e4,
                     make_float4(w * r.gf[u].x, w * r.gf[u].y, w * r.gf[u].z, w * r.gf[u].w));
             } else {
                 const int i4 = (tid & 7) * 4;
-                put4_along_r<true, true>(
-                    buf + MK_GR, buf + MK_GC, (tid >> 3) + (MA_THREADS / 8) * u, i4,
+                put4_along_r<false, true>(
+                    nullptr, buf + MK_G, (tid >> 3) + (MA_THREADS / 8) * u, i4,
                     make_float4(weight(r.rs[u].x, i0 + i4) * r.gf[u].x,
                                 weight(r.rs[u].y, i0 + i4 + 1) * r.gf[u].y,
                                 weight(r.rs[u].z, i0 + i4 + 2) * r.gf[u].z,
@@ -885,7 +944,9 @@ void attention_mfma_backward_keys_kernel(
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 d = mma3(read_rows(buf + MK_QR, buf + MK_QR + MA_RIMG, lane, ks), kf[ks], d);
-                dp = mma3(read_rows(buf + MK_GR, buf + MK_GR + MA_RIMG, lane, ks), vf[ks], dp);
+                dp = mma3(GT ? read_rows_tr(buf + MK_G, buf + MK_G + MA_CIMG, lane, ks)
+                             : read_rows(buf + MK_G, buf + MK_G + MA_RIMG, lane, ks),
+                          vf[ks], dp);
             }
             // this lane: key j0 + c32, rows 8g + 4h + u of the tile in register 4g + u
             const float *st = reinterpret_cast<const float *>(buf + MK_ST);
@@ -912,10 +973,12 @@ void attention_mfma_backward_keys_kernel(
                                        ds[8 * s2 + 4], ds[8 * s2 + 5], ds[8 * s2 + 6], ds[8 * s2 + 7]);
 #pragma unroll
                 for (int eh = 0; eh < 2; eh++) {
-                    vacc[eh] = mma3(pf, read_cols(buf + MK_GC, buf + MK_GC + MA_CIMG,
-                                                  c32 + 32 * eh, h, s2), vacc[eh]);
-                    kacc[eh] = mma3(sf, read_cols(buf + MK_QC, buf + MK_QC + MA_CIMG,
-                                                  c32 + 32 * eh, h, s2), kacc[eh]);
+                    vacc[eh] = mma3(pf, GT ? read_cols(buf + MK_G, buf + MK_G + MA_CIMG,
+                                                       c32 + 32 * eh, h, s2)
+                                           : read_cols_tr(buf + MK_G, buf + MK_G + MA_RIMG,
+                                                          32 * eh, lane, s2), vacc[eh]);
+                    kacc[eh] = mma3(sf, read_cols_tr(buf + MK_QR, buf + MK_QR + MA_RIMG, 32 * eh,
+                                                     lane, s2), kacc[eh]);
                 }
             }
         }
