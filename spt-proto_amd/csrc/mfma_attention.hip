@@ -54,7 +54,6 @@ constexpr int MA_VLD = 72;                         // bytes per e row of V^T: 32
 constexpr int MA_KH = 0, MA_KL = MA_KT * MA_KLD, MA_VH = 2 * MA_KT * MA_KLD,
               MA_VL = 3 * MA_KT * MA_KLD, MA_IMG = 4 * MA_KT * MA_KLD;         // 18432 B
 constexpr int MA_CLD = 9;                          // words per row of the multiplicity tile
-constexpr int MA_CNT = MA_WROWS * MA_CLD * 4;      // prepare: one tile of counts, 1152 B
 constexpr int MA_CELLS = MA_WROWS * MA_KT;         // bytes of one stored cell tile
 constexpr int MA_TLD = 36;                         // floats per row of the epilogue's [e][row] tile
 
@@ -275,6 +274,52 @@ __device__ __forceinline__ void split_own_rows(Frag (&f)[4], const float (&x)[32
                        x[8 * ks + 6] * mult, x[8 * ks + 7] * mult);
 }
 
+// ---- 16-byte global accesses for operands whose register layout is element-wise ----
+// A 4-byte load or store per lane moves 256 bytes per wave instruction; the kernels' own-row
+// operands and results (8 KiB per wave and tensor) are therefore passed through a wave-private
+// LDS tile of 32 x MA_TLD floats, one 32-column half at a time.
+//
+// One e-half of a wave's 32-row accumulator tile (column = lane & 31, rows in the registers)
+// -> rows of `dst` (row stride ld floats), 8 rows x 128 bytes per store instruction.
+__device__ __forceinline__ void store_acc_half(const f32x16 &acc, float mult, float *tile,
+                                               float *dst, size_t ld, int rows_left, int lane) {
+    const int c32 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; r++) tile[acc_row(r, h) * MA_TLD + c32] = acc[r] * mult;
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int row = (lane >> 3) + 8 * k, e4 = (lane & 7) * 4;
+        const float4 o = *reinterpret_cast<const float4 *>(tile + row * MA_TLD + e4);
+        if (row < rows_left) *reinterpret_cast<float4 *>(dst + (size_t)row * ld + e4) = o;
+    }
+    wave_lds_fence();
+}
+// A wave's own 32 rows of an operand stored [E][S] (row i0 .. of every e) into the fragment
+// order of load_own_rows_raw: x[8 ks + j] = src[(8h + 16ks + j) * S + i0 + (lane & 31)].
+__device__ __forceinline__ void load_own_rows_transposed(float (&x)[32], const float *src, int S,
+                                                         int i0, float *tile, int lane) {
+    const int c32 = lane & 31, h = lane >> 5;
+    const int i4 = min(i0 + (lane & 7) * 4, S - 4) - i0;      // (S % 4 == 0; rows >= S unused)
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int el = (lane >> 3) + 8 * k;
+            const float4 v4 = *reinterpret_cast<const float4 *>(src + (size_t)(32 * hf + el) * S + i0 + i4);
+            *reinterpret_cast<float4 *>(tile + el * MA_TLD + (lane & 7) * 4) = v4;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                x[8 * (2 * hf + kk) + j] = tile[(8 * h + 16 * kk + j) * MA_TLD + c32];
+        }
+        wave_lds_fence();
+    }
+}
+
 // ---- cell tiles: multiplicity of every (row, key) cell, per 32 x 32 tile ----
 //   masks [batch][RT] uint64: bit t set <=> key tile t has a live entry in row tile rt
 //   cells [batch][RT (RT + 1) / 2][64 lanes][16] uint8: tile (rt, t <= rt) at rt (rt + 1) / 2 + t;
@@ -443,6 +488,9 @@ __device__ __forceinline__ float cell_count(unsigned word) {
 #endif
 #ifndef MA_SUB
 #define MA_SUB 1            // key tiles per forward iteration (2: 48 -> 58-71 us at the bench shape)
+#endif
+#ifndef MR_SUB
+#define MR_SUB 1            // key tiles per iteration of the row-owned backward kernel (2: no faster)
 #endif
 #ifndef MA_ROWS_WAVES_PER_EU
 #define MA_ROWS_WAVES_PER_EU 2
@@ -704,9 +752,22 @@ void attention_mfma_backward_rows_kernel(
     const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch, MA_WAVES - 1);
     const int T = min(RT, last_tile + 1);
     const ScoreMap sm(scale, clampv);
+    // An iteration = MR_SUB key tiles.  Measured by compiling phases out: without any tile
+    // arithmetic the kernel still takes 54 of its 80 us -- prologue (dY, Y, Q: 100 MB) 23 us, the
+    // loop's K / V / cell-tile loads (153 MB, L2 hits included) 23 us = 6.8 TB/s, epilogue 6 us,
+    // image stores 2 us, barriers 0: it is bound by the bytes it moves (2 x the algorithmic
+    // minimum: both workgroups of a slice stream K and V, and the 1 KiB cell tiles), which is
+    // why two tiles per iteration, a second tile in flight and 16-byte own-row accesses all
+    // measured the same.
+    constexpr int SUB = MR_SUB;
     const RowsStager stager(k + dv.base, v + dv.base, dv.ld, S, tid);
-    const TileRegs first = stager.load(0);
-    uint4 mcur = ct.load(0, lane);
+    TileRegs nxt[SUB];
+    uint4 mcur[SUB], mnxt[SUB];
+#pragma unroll
+    for (int u = 0; u < SUB; u++) {
+        nxt[u] = stager.load(min(u, T - 1));
+        mcur[u] = ct.load(u, lane);
+    }
     // own rows: dY (B operand of dP = V dY^T), delta = max(1e-9, dY . Y), Q (B operand of D)
     Frag gf[4], qf[4];
     float delta_i;
@@ -715,10 +776,20 @@ void attention_mfma_backward_rows_kernel(
     {
         float xr[32], yr[32], xq[32];
         const size_t ob = (size_t)b * S * MA_E;
-        load_own_rows_raw<GT>(xr, gy + ob, MA_E, S, i0, lane);
-        load_own_rows_raw<GT>(yr, y + ob, MA_E, S, i0, lane);
         load_own_rows_raw<false>(xq, q + dv.base, dv.ld, S, i0, lane);
-        stager.store(img, first);
+        if (GT) {
+            // [E][S] operands: 16-byte loads through the wave's LDS tile (the image buffers
+            // are free until the first key tile is staged)
+            float *tile = reinterpret_cast<float *>(img) + wave * (32 * MA_TLD);
+            load_own_rows_transposed(xr, gy + ob, S, i0, tile, lane);
+            load_own_rows_transposed(yr, y + ob, S, i0, tile, lane);
+            __syncthreads();
+        } else {
+            load_own_rows_raw<false>(xr, gy + ob, MA_E, S, i0, lane);
+            load_own_rows_raw<false>(yr, y + ob, MA_E, S, i0, lane);
+        }
+#pragma unroll
+        for (int u = 0; u < SUB; u++) stager.store(img + u * MR_IMG, nxt[u]);
         float dl = 0.f;
 #pragma unroll
         for (int x = 0; x < 32; x++) dl = fmaf(xr[x], yr[x], dl);
@@ -738,14 +809,21 @@ void attention_mfma_backward_rows_kernel(
 #pragma unroll
     for (int r = 0; r < 16; r++) qacc[0][r] = qacc[1][r] = 0.f;
 
-    // (Measured: with the tile computation removed this loop still takes 53 of its 79 us -- the
-    // kernel moves ~290 MB through L2 / HBM in 256-byte rows 4 KiB apart at ~3 TB/s; a second
-    // tile in flight in registers did not help: 79 -> 83 us.)
-    for (int t = 0; t < T; t++) {
-        const char *buf = img + (t & 1) * MR_IMG;
-        const TileRegs nxt = stager.load(min(t + 1, T - 1));
-        const uint4 mnxt = ct.load(t + 1, lane);
-        if (ct.live(t)) {
+    const int NIT = (T + SUB - 1) / SUB;
+    for (int it = 0; it < NIT; it++) {
+        const int t0 = it * SUB;
+        const char *stage = img + (it & 1) * SUB * MR_IMG;
+        bool lv[SUB];
+#pragma unroll
+        for (int u = 0; u < SUB; u++) {
+            nxt[u] = stager.load(min(t0 + SUB + u, T - 1));
+            mnxt[u] = ct.load(t0 + SUB + u, lane);
+            lv[u] = t0 + u < T && ct.live(t0 + u);
+        }
+#pragma unroll
+        for (int u = 0; u < SUB; u++) {
+            if (!lv[u]) continue;
+            const char *buf = stage + u * MR_IMG;
             f32x16 d, dp;
 #pragma unroll
             for (int r = 0; r < 16; r++) d[r] = dp[r] = 0.f;
@@ -754,16 +832,16 @@ void attention_mfma_backward_rows_kernel(
                 d = mma3(read_rows(buf + MR_KR, buf + MR_KR + MA_RIMG, lane, ks), qf[ks], d);
                 dp = mma3(read_rows(buf + MR_VR, buf + MR_VR + MA_RIMG, lane, ks), gf[ks], dp);
             }
-            const unsigned mw[4] = {mcur.x, mcur.y, mcur.z, mcur.w};
+            const unsigned mw[4] = {mcur[u].x, mcur[u].y, mcur[u].z, mcur[u].w};
             float ds[16];
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const float m4[4] = {cell_count<0>(mw[g]), cell_count<1>(mw[g]),
                                      cell_count<2>(mw[g]), cell_count<3>(mw[g])};
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int r = 4 * g + u;
-                    const float pw = m4[u] * sm.exp_of(d[r]);
+                for (int x = 0; x < 4; x++) {
+                    const int r = 4 * g + x;
+                    const float pw = m4[x] * sm.exp_of(d[r]);
                     ds[r] = sm.inside(d[r]) ? pw * (dp[r] - delta_i) : 0.0f;
                 }
             }
@@ -777,20 +855,20 @@ void attention_mfma_backward_rows_kernel(
                                                      lane, s2), qacc[eh]);
             }
         }
-        if (t + 1 < T) stager.store(img + ((t + 1) & 1) * MR_IMG, nxt);
-        mcur = mnxt;
+        if (it + 1 < NIT) {
+#pragma unroll
+            for (int u = 0; u < SUB; u++)
+                stager.store(img + (((it + 1) & 1) * SUB + u) * MR_IMG, nxt[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < SUB; u++) mcur[u] = mnxt[u];
         __syncthreads();
     }
     if (i0 < S) {
-        float *gq_b = grad_q + dv.base;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int il = acc_row(r, h);
-            if (i0 + il < S) {
-                gq_b[(size_t)(i0 + il) * dv.ld + c32] = qacc[0][r];
-                gq_b[(size_t)(i0 + il) * dv.ld + 32 + c32] = qacc[1][r];
-            }
-        }
+        float *tile = reinterpret_cast<float *>(img) + wave * (32 * MA_TLD);
+        float *gq_b = grad_q + dv.base + (size_t)i0 * dv.ld;
+        store_acc_half(qacc[0], 1.0f, tile, gq_b, dv.ld, S - i0, lane);
+        store_acc_half(qacc[1], 1.0f, tile, gq_b + 32, dv.ld, S - i0, lane);
     }
 }
 
@@ -988,18 +1066,13 @@ void attention_mfma_backward_keys_kernel(
         __syncthreads();
     }
     if (have) {
-        float *gk_b = grad_k + dv.base, *gv_b = grad_v + dv.base;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int jl = acc_row(r, h);
-            if (j0 + jl < S) {
-                const size_t at = (size_t)(j0 + jl) * dv.ld + c32;
-                gk_b[at] = scale * kacc[0][r];
-                gk_b[at + 32] = scale * kacc[1][r];
-                gv_b[at] = vacc[0][r];
-                gv_b[at + 32] = vacc[1][r];
-            }
-        }
+        float *tile = reinterpret_cast<float *>(img) + wave * (32 * MA_TLD);
+        float *gk_b = grad_k + dv.base + (size_t)j0 * dv.ld;
+        float *gv_b = grad_v + dv.base + (size_t)j0 * dv.ld;
+        store_acc_half(kacc[0], scale, tile, gk_b, dv.ld, S - j0, lane);
+        store_acc_half(kacc[1], scale, tile, gk_b + 32, dv.ld, S - j0, lane);
+        store_acc_half(vacc[0], 1.0f, tile, gv_b, dv.ld, S - j0, lane);
+        store_acc_half(vacc[1], 1.0f, tile, gv_b + 32, dv.ld, S - j0, lane);
     }
 }
 
@@ -1119,9 +1192,12 @@ extern "C" int spt_attention_mfma_backward(const void *tiles, const float *q, co
     const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, S);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
-    const size_t lds_r = 2 * MR_IMG, lds_k = 2 * MK_IMG;
+    const size_t lds_r = 2 * MR_SUB * MR_IMG, lds_k = 2 * MK_IMG;
 #define SPT_MB(GT)                                                                              \
     do {                                                                                        \
+        SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
+            (const void *)attention_mfma_backward_rows_kernel<GT>,                              \
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));                           \
         hipLaunchKernelGGL(attention_mfma_backward_rows_kernel<GT>, grid, block, lds_r, s,      \
                            ts.masks, ts.cells, q, k, v, grad_y, y, row_sum, grad_q, delta, S,   \
                            scale, clamp, heads, bpb);                                           \
