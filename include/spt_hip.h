@@ -275,7 +275,7 @@ int spt_attention_mfma_supported(int seq_length, int d_head, int nnz);
  * spt_attention_mfma_prepare buckets the CSR entries of every 32-row tile by 32-key tile (one
  * pass over `indices` [batch, nnz]) into `tiles`, an opaque device buffer of
  * spt_attention_mfma_tiles_bytes(...) bytes that the forward and the backward of the same
- * layer step share (it depends on `indices` only).
+ * layer step share (it depends on `indices` only; layout: mfma_attention.hip, "cell tiles").
  */
 int64_t spt_attention_mfma_tiles_bytes(int batch_size, int seq_length, int nnz);
 int spt_attention_mfma_prepare(const int32_t *indices, void *tiles, int batch_size,

@@ -321,12 +321,18 @@ __device__ __forceinline__ void load_own_rows_transposed(float (&x)[32], const f
 }
 
 // ---- cell tiles: multiplicity of every (row, key) cell, per 32 x 32 tile ----
-//   masks [batch][RT] uint64: bit t set <=> key tile t has a live entry in row tile rt
+//   masks [batch][RT][2] uint64: [0] bit t set <=> key tile t has a live entry in row tile rt;
+//     [1] bit t set <=> some cell of that tile has multiplicity >= 2 ("multi" tile)
 //   cells [batch][RT (RT + 1) / 2][64 lanes][16] uint8: tile (rt, t <= rt) at rt (rt + 1) / 2 + t;
 //     byte 4 g + u of lane (c, h) = multiplicity of key 32 t + 8 g + 4 h + u in row 32 rt + c --
 //     accumulator register 4 g + u of that lane when the tile is computed as D[key, row]
 //   cells_t, same indexing: byte 4 g + u of lane (c, h) = multiplicity of key 32 t + c in row
 //     32 rt + 8 g + 4 h + u -- the tile computed as D[row, key] (the key-owned backward)
+//   A tile that is not "multi" (all counts 0 or 1: every tile of a lookup pattern except those
+//     holding its zero padding) stores only 128 bytes per orientation instead: word c of the
+//     tile's slot = the 32-bit key mask of row c (cells_t: the row mask of key c); a consumer
+//     lane reads the 16 bytes holding its word and spreads its 16 bits back into the byte form.
+//     The consumers are bound by the bytes they move: this takes 36 MB off each of them.
 //   live = col <= row (softmax.cu:19-31 masks the others) and 0 <= col < S.
 // A wave owns a row tile and walks its key tiles in chunks of MB_CHUNK: the chunk's counts
 // live in LDS as [tile][row][key] bytes (4 keys per word); every entry whose column falls into
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kern
     unsigned char *out_t = cells_t + ((size_t)b * tri(RT) + tri(rt)) * MA_CELLS;
     const int c32 = lane & 31, h = lane >> 5;
     const int nbuckets = min(NT, rt + 1);               // live entries have col <= row
-    unsigned long long mask = 0;
+    unsigned long long mask = 0, multi = 0;
 
     auto count = [&](unsigned *word, unsigned sh) {
         if (!SATURATE) {
@@ -403,7 +409,6 @@ __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kern
             const uint4 mine = make_uint4(row[0], row[2], row[4], row[6]);
             if (__ballot((mine.x | mine.y | mine.z | mine.w) != 0u) == 0ull) continue;
             mask |= 1ull << (t0 + tl);
-            reinterpret_cast<uint4 *>(out + (size_t)(t0 + tl) * MA_CELLS)[lane] = mine;
             // transposed: byte 4 g + u of lane (c, h) = count of key c in row 8 g + 4 h + u
             const unsigned char *bytes = reinterpret_cast<const unsigned char *>(cnt) +
                                          (size_t)tl * MA_WROWS * MA_CLD * 4 + c32;
@@ -414,31 +419,72 @@ __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kern
                 w[g] = (unsigned)p0[0] | ((unsigned)p0[MA_CLD * 4] << 8) |
                        ((unsigned)p0[2 * MA_CLD * 4] << 16) | ((unsigned)p0[3 * MA_CLD * 4] << 24);
             }
-            reinterpret_cast<uint4 *>(out_t + (size_t)(t0 + tl) * MA_CELLS)[lane] =
-                make_uint4(w[0], w[1], w[2], w[3]);
+            uint4 *slot = reinterpret_cast<uint4 *>(out + (size_t)(t0 + tl) * MA_CELLS);
+            uint4 *slot_t = reinterpret_cast<uint4 *>(out_t + (size_t)(t0 + tl) * MA_CELLS);
+            const bool big = ((mine.x | mine.y | mine.z | mine.w) & 0xFEFEFEFEu) != 0u;
+            if (__ballot(big) != 0ull) {
+                multi |= 1ull << (t0 + tl);
+                slot[lane] = mine;
+                slot_t[lane] = make_uint4(w[0], w[1], w[2], w[3]);
+            } else {
+                // counts are 0 / 1: 16 of the row's (key's) 32 bits sit in this lane, the other
+                // 16 in lane ^ 32; bytes -> nibble by one multiply (no carries: each product
+                // term lands on its own bit)
+                auto bits16 = [&](unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+                    auto nib = [](unsigned x) { return ((x * 0x01020408u) >> 24) & 0xFu; };
+                    return (nib(w0) | (nib(w1) << 8) | (nib(w2) << 16) | (nib(w3) << 24)) << (4 * h);
+                };
+                unsigned rm = bits16(mine.x, mine.y, mine.z, mine.w);
+                unsigned cm = bits16(w[0], w[1], w[2], w[3]);
+                rm |= (unsigned)__shfl_xor((int)rm, 32, SPT_WAVE);
+                cm |= (unsigned)__shfl_xor((int)cm, 32, SPT_WAVE);
+                if (h == 0) {
+                    reinterpret_cast<unsigned *>(slot)[c32] = rm;
+                    reinterpret_cast<unsigned *>(slot_t)[c32] = cm;
+                }
+            }
         }
         wave_lds_fence();
     }
-    if (lane == 0) masks[gw] = mask;
+    if (lane == 0) {
+        masks[2 * (size_t)gw] = mask;
+        masks[2 * (size_t)gw + 1] = multi;
+    }
 }
 
+// a tile's 16 bytes as loaded -> the four count words of this lane (byte form)
+__device__ __forceinline__ uint4 cell_words(const uint4 &v, bool multi, int lane) {
+    if (multi) return v;
+    const int c = lane & 3;
+    const unsigned m = (c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w) >> (4 * (lane >> 5));
+    auto spread = [](unsigned n) { return ((n & 0xFu) * 0x00204081u) & 0x01010101u; };
+    return make_uint4(spread(m), spread(m >> 8), spread(m >> 16), spread(m >> 24));
+}
 // a consumer wave's view of its row tile's cell tiles
 struct CellTiles {
-    unsigned long long mask;
+    unsigned long long mask, multi;
     int last;                 // the row tile's own index = its last stored key tile
-    const uint4 *base;        // tile t of this row tile: base[t * 64 + lane]
+    const uint4 *base;        // tile t of this row tile: base[t * 64 + ...]
     __device__ __forceinline__ CellTiles(const unsigned long long *masks,
                                          const unsigned char *cells, int b, int RT, int rt,
                                          bool have) {
-        mask = have ? masks[(size_t)b * RT + rt] : 0ull;
+        mask = have ? masks[2 * ((size_t)b * RT + rt)] : 0ull;
+        multi = have ? masks[2 * ((size_t)b * RT + rt) + 1] : 0ull;
         last = have ? rt : 0;
         base = reinterpret_cast<const uint4 *>(
             cells + ((size_t)b * tri(RT) + tri(have ? rt : 0)) * MA_CELLS);
     }
     __device__ __forceinline__ bool live(int t) const { return (mask >> t) & 1ull; }
-    // always in bounds (t clamped), so the caller can load unconditionally
+    __device__ __forceinline__ bool is_multi(int t) const { return (multi >> min(t, 63)) & 1ull; }
+    // always in bounds (t clamped), so the caller can load unconditionally; ONE 16-byte load
+    // either way: the lane's own 16 counts, or the four row masks that include its row's
     __device__ __forceinline__ uint4 load(int t, int lane) const {
-        return base[min(t, last) * 64 + lane];
+        const int tc = min(t, last);
+        return base[tc * 64 + (is_multi(tc) ? lane : ((lane & 31) >> 2))];
+    }
+    // (the 16 bytes loaded for tile t) -> count words
+    __device__ __forceinline__ uint4 words(const uint4 &v, int t, int lane) const {
+        return cell_words(v, is_multi(min(t, last)), lane);
     }
 };
 
@@ -590,8 +636,9 @@ void attention_mfma_forward_kernel(
             for (int u = 0; u < SUB; u++) {
                 // cells: this lane holds row i0 + c32, keys 32t + acc_row(r, h); byte 4g + u of
                 // the cell word is the multiplicity of register 4g + u
-                const unsigned mw[4] = {lv[u] ? mcur[u].x : 0u, lv[u] ? mcur[u].y : 0u,
-                                        lv[u] ? mcur[u].z : 0u, lv[u] ? mcur[u].w : 0u};
+                const uint4 mm = ct.words(mcur[u], t0 + u, lane);
+                const unsigned mw[4] = {lv[u] ? mm.x : 0u, lv[u] ? mm.y : 0u,
+                                        lv[u] ? mm.z : 0u, lv[u] ? mm.w : 0u};
                 float p[16];
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
@@ -832,7 +879,8 @@ void attention_mfma_backward_rows_kernel(
                 d = mma3(read_rows(buf + MR_KR, buf + MR_KR + MA_RIMG, lane, ks), qf[ks], d);
                 dp = mma3(read_rows(buf + MR_VR, buf + MR_VR + MA_RIMG, lane, ks), gf[ks], dp);
             }
-            const unsigned mw[4] = {mcur[u].x, mcur[u].y, mcur[u].z, mcur[u].w};
+            const uint4 mm = ct.words(mcur[u], t0 + u, lane);
+            const unsigned mw[4] = {mm.x, mm.y, mm.z, mm.w};
             float ds[16];
 #pragma unroll
             for (int g = 0; g < 4; g++) {
@@ -981,12 +1029,19 @@ void attention_mfma_backward_keys_kernel(
     }
     // the slice's row-tile masks live in registers (lane rt: mask of row tile rt), so that the
     // loop body has no load whose result it needs at once
-    const unsigned long long mask_reg = lane < RT ? masks[(size_t)b * RT + lane] : 0ull;
-    auto mask_of = [&](int rt) -> unsigned long long {
+    const unsigned long long mask_reg = lane < RT ? masks[2 * ((size_t)b * RT + lane)] : 0ull;
+    const unsigned long long multi_reg = lane < RT ? masks[2 * ((size_t)b * RT + lane) + 1] : 0ull;
+    auto lane_u64 = [&](unsigned long long reg, int rt) -> unsigned long long {
         if (rt >= RT) return 0ull;
-        const unsigned lo = __builtin_amdgcn_readlane((unsigned)mask_reg, rt);
-        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(mask_reg >> 32), rt);
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)reg, rt);
+        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(reg >> 32), rt);
         return ((unsigned long long)hi << 32) | lo;
+    };
+    auto mask_of = [&](int rt) { return lane_u64(mask_reg, rt); };
+    // is the tile (row tile rt, this wave's key tile) stored in byte form?
+    auto multi_of = [&](int rt) {
+        const int rc = min(rt, RT - 1);
+        return (bool)((lane_u64(multi_reg, rc) >> min(kt, rc)) & 1ull);
     };
     const uint4 *cell_b = reinterpret_cast<const uint4 *>(cells_t + (size_t)b * tri(RT) * MA_CELLS);
     auto live = [&](unsigned long long m, int rt) {
@@ -995,7 +1050,7 @@ void attention_mfma_backward_keys_kernel(
     // always in bounds: the row tile clamped to the last one, the key tile to the diagonal
     auto cell_load = [&](int rt) {
         const int rc = min(rt, RT - 1);
-        return cell_b[(tri(rc) + min(kt, rc)) * 64 + lane];
+        return cell_b[(tri(rc) + min(kt, rc)) * 64 + (multi_of(rt) ? lane : (c32 >> 2))];
     };
 
     const int rt0 = (MA_WAVES / 2) * g;                 // the first row tile any wave needs
@@ -1028,7 +1083,8 @@ void attention_mfma_backward_keys_kernel(
             }
             // this lane: key j0 + c32, rows 8g + 4h + u of the tile in register 4g + u
             const float *st = reinterpret_cast<const float *>(buf + MK_ST);
-            const unsigned mw[4] = {mcur.x, mcur.y, mcur.z, mcur.w};
+            const uint4 mm = cell_words(mcur, multi_of(rt), lane);
+            const unsigned mw[4] = {mm.x, mm.y, mm.z, mm.w};
             float p[16], ds[16];
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
@@ -1094,7 +1150,7 @@ static size_t tile_cells_bytes(int B, int S) {
 }
 static size_t tile_mask_bytes(int B, int S) {
     const size_t RT = (S + MA_WROWS - 1) / MA_WROWS;
-    return (((size_t)B * RT * sizeof(unsigned long long)) + 255) & ~(size_t)255;
+    return (((size_t)B * RT * 2 * sizeof(unsigned long long)) + 255) & ~(size_t)255;
 }
 static TileSet carve_tiles(void *ws, int B, int S) {
     TileSet t;

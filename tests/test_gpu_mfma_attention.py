@@ -114,22 +114,28 @@ def test_mfma_unsupported_shapes_are_refused():
 
 
 def test_cell_tiles_hold_the_multiplicity_of_every_live_cell():
-    """spt_attention_mfma_prepare: per (32-row, 32-key) tile the count of each (row, col) cell,
-    stored in the accumulator permutation documented in include/spt_hip.h."""
+    """spt_attention_mfma_prepare: per (32-row, 32-key) tile the count of each (row, col) cell in
+    the accumulator permutation (byte form when some count is >= 2, else 32-bit row masks), as
+    documented in mfma_attention.hip."""
     import numpy as np
     from naive_gpt import ext
     gen = torch.Generator().manual_seed(9)
     B, S, Z = 6, 160, 16
     indices = torch.randint(0, S, [B, S * Z], generator=gen, dtype=torch.int32)
-    indices.view(B, S, Z)[:, :, :3] = 0                      # repeated column 0, as lookup pads
+    indices.view(B, S, Z)[:, :64, :3] = 0                    # repeated column 0, as lookup pads
+    # some rows with distinct columns only, so that tiles in mask form exist as well
+    for r in range(96, S):
+        for b in range(B):
+            indices.view(B, S, Z)[b, r] = torch.randperm(r + 1, generator=gen)[:Z].to(torch.int32)
     tiles = ext.attention_mfma_prepare(indices.cuda(), S)
     RT = S // 32
     raw = tiles.buffer.cpu().numpy()
-    mask_bytes = (B * RT * 8 + 255) // 256 * 256
-    masks = raw[:B * RT * 8].view('uint64').reshape(B, RT)
+    mask_bytes = (B * RT * 16 + 255) // 256 * 256
+    masks = raw[:B * RT * 16].view('uint64').reshape(B, RT, 2)
     ntile = RT * (RT + 1) // 2
-    cells, cells_t = raw[mask_bytes:mask_bytes + 2 * B * ntile * 1024].reshape(2, B, ntile, 64, 16)
+    cells, cells_t = raw[mask_bytes:mask_bytes + 2 * B * ntile * 1024].reshape(2, B, ntile, 1024)
     idx = indices.view(B, S, Z).numpy()
+    seen = set()
     for b in range(B):
         for rt in range(RT):
             want = np.zeros([RT, 32, 32], dtype=np.int64)       # [key tile][row][key]
@@ -138,17 +144,28 @@ def test_cell_tiles_hold_the_multiplicity_of_every_live_cell():
                     if c <= rt * 32 + r:
                         want[c // 32, r, c % 32] += 1
             for t in range(rt + 1):
-                live = bool((int(masks[b, rt]) >> t) & 1)
+                live = bool((int(masks[b, rt, 0]) >> t) & 1)
+                multi = bool((int(masks[b, rt, 1]) >> t) & 1)
                 assert live == bool(want[t].any())
                 if not live:
                     continue
+                assert multi == bool((want[t] >= 2).any())
+                seen.add(multi)
                 tile, tile_t = cells[b, rt * (rt + 1) // 2 + t], cells_t[b, rt * (rt + 1) // 2 + t]
-                for lane in range(64):
-                    c, h = lane % 32, lane // 32
-                    for g in range(4):
-                        for u in range(4):
-                            assert tile[lane, 4 * g + u] == want[t, c, 8 * g + 4 * h + u]
-                            assert tile_t[lane, 4 * g + u] == want[t, 8 * g + 4 * h + u, c]
+                if multi:
+                    tile, tile_t = tile.reshape(64, 16), tile_t.reshape(64, 16)
+                    for lane in range(64):
+                        c, h = lane % 32, lane // 32
+                        for g in range(4):
+                            for u in range(4):
+                                assert tile[lane, 4 * g + u] == want[t, c, 8 * g + 4 * h + u]
+                                assert tile_t[lane, 4 * g + u] == want[t, 8 * g + 4 * h + u, c]
+                else:
+                    rows, cols = tile[:128].view('uint32'), tile_t[:128].view('uint32')
+                    for c in range(32):
+                        assert int(rows[c]) == sum(int(want[t, c, k]) << k for k in range(32))
+                        assert int(cols[c]) == sum(int(want[t, r, c]) << r for r in range(32))
+    assert seen == {True, False}
 
 
 @pytest.mark.parametrize('kind', ['vanilla', 'rotary'])
