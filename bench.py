@@ -66,8 +66,9 @@ def algorithmic_bytes(op: str, B: int) -> int:
         # dY, v, k read, grad_q + dY rows written; indices, scores, attn read, dS written
         'sparse_attention_backward_rows': 5 * S * E * 4 + 4 * S * Z * 4,
         # matrix-core path (mfma_attention.hip): every dense operand once + the CSR information.
-        # prepare: indices read, the two sets of 1 KiB cell tiles (lower triangle) written
-        'attention_mfma_prepare': S * Z * 4 + 2 * (S // 32) * (S // 32 + 1) // 2 * 1024,
+        # prepare: indices read, the two sets of cell tiles (lower triangle) written
+        # (tiles of a lookup pattern are 0 / 1 counts: 128-byte mask form, both orientations)
+        'attention_mfma_prepare': S * Z * 4 + 2 * (S // 32) * (S // 32 + 1) // 2 * 128,
         'attention_mfma_forward': 4 * S * E * 4 + S * Z * 4,       # q k v -> y (+ the pattern)
         # q k v dY y read, three gradients written (+ the pattern); two launches
         'attention_mfma_backward': 8 * S * E * 4 + S * Z * 4,

@@ -799,13 +799,15 @@ void attention_mfma_backward_rows_kernel(
     const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch, MA_WAVES - 1);
     const int T = min(RT, last_tile + 1);
     const ScoreMap sm(scale, clampv);
-    // An iteration = MR_SUB key tiles.  Measured by compiling phases out: without any tile
-    // arithmetic the kernel still takes 54 of its 80 us -- prologue (dY, Y, Q: 100 MB) 23 us, the
-    // loop's K / V / cell-tile loads (153 MB, L2 hits included) 23 us = 6.8 TB/s, epilogue 6 us,
-    // image stores 2 us, barriers 0: it is bound by the bytes it moves (2 x the algorithmic
-    // minimum: both workgroups of a slice stream K and V, and the 1 KiB cell tiles), which is
-    // why two tiles per iteration, a second tile in flight and 16-byte own-row accesses all
-    // measured the same.
+    // An iteration = MR_SUB key tiles.  Measured by compiling phases out (80 us whole): without
+    // the tile arithmetic 54 us (prologue -- dY, Y, Q: 100 MB -- 23, the loop's loads 23,
+    // epilogue 6, image stores 2, barriers 0); WITH the arithmetic but without the loop's
+    // loads, stores and barriers 75 us.  So the loop's memory traffic hides behind the
+    // arithmetic, and the arithmetic (46 us for 16 us of MFMA-pipe time) is one wave per SIMD
+    // running its MFMA and VALU phases one after the other: at 187 VGPRs a CU holds one
+    // workgroup, and half of its waves (the short row tiles) finish early.  That is why two
+    // tiles per iteration, a second tile in flight, 16-byte own-row accesses and 8x smaller
+    // cell tiles all measured the same.
     constexpr int SUB = MR_SUB;
     const RowsStager stager(k + dv.base, v + dv.base, dv.ld, S, tid);
     TileRegs nxt[SUB];
