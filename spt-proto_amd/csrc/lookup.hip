@@ -382,18 +382,28 @@ __device__ __forceinline__ int rows_match(const uint32_t *__restrict__ kc, const
     return cnt;
 }
 
+#ifndef LR_WAVES_VALUE
+#define LR_WAVES_VALUE 4
+#endif
+constexpr int LR_WAVES = LR_WAVES_VALUE;     // waves per 64-row block: 2 or 4
+constexpr int LR_WPW = 4 / LR_WAVES;         // workers per wave
+constexpr int LR_THREADS = LR_WAVES * SPT_WAVE;
 template <int W>
-__global__ __launch_bounds__(SPT_WAVE) void lookup_rows_kernel(
+__global__ __launch_bounds__(LR_THREADS) void lookup_rows_kernel(
     const int32_t *__restrict__ query, const int32_t *__restrict__ key,
     int32_t *__restrict__ out, int B, int S, int M, int Z, int blocks_per_batch, int list_pitch,
     int out_pitch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (SPT_WAVE - 1);
+    // The four workers' lists are independent until the final fix-up, so the block's waves
+    // split them: all walk all column groups, wave wv only looks at its workers' columns of
+    // each.  A fraction of the walk per wave and more waves per CU for the same LDS: a lone
+    // wave per SIMD ran this loop at ~10 cycles per instruction (78 us with one wave per block;
+    // pairing heavy and light row blocks in one wave, equal work for every wave: 86 us; two
+    // waves per block 61 us).
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x % B;
-    // heavy row blocks first.  (Pairing block j with nb - 1 - j in one wave, equal work for
-    // every wave, measured slower -- 86 vs 78 us: with one wave per SIMD left, the walk runs at
-    // ~10 cycles per instruction; five single-wave blocks per CU overlap a little.)
-    const int blk = blocks_per_batch - 1 - (blockIdx.x / B);
+    const int blk = blocks_per_batch - 1 - (blockIdx.x / B);       // heavy row blocks first
     const int r0 = blk * SPT_WAVE, gy = r0 + lane;
     const int ncols = min(S, r0 + SPT_WAVE);
     const int ngroups = (ncols + 3) >> 2;
@@ -404,11 +414,13 @@ __global__ __launch_bounds__(SPT_WAVE) void lookup_rows_kernel(
                            (size_t)lane * list_pitch;    // [16 lists][Q] bytes + 8 last-group bytes
     unsigned short *orow = reinterpret_cast<unsigned short *>(
         smem + kbytes + (size_t)SPT_WAVE * list_pitch);   // [64][out_pitch]
+    unsigned *xch = reinterpret_cast<unsigned *>(
+        smem + kbytes + (size_t)SPT_WAVE * list_pitch + (size_t)SPT_WAVE * out_pitch * 2);  // [64][2]
     const int32_t *ksrc = key + (size_t)b * S * M;
     const int32_t *qsrc = query + ((size_t)b * S + min(gy, S - 1)) * M;
 
     // 4-bit form unless some code this block touches is outside [0, 16).  One pass: every lane
-    // loads the codes of its (<= 8) key columns with unconditional 16-byte loads (clamped
+    // loads the codes of its (<= 4) key columns with unconditional 16-byte loads (clamped
     // column: a load per code with a wait each, as a first version had, cost more than the
     // walk), checks them and packs them as nibbles; the packed words are only used if the
     // whole block passed the check.
@@ -439,11 +451,11 @@ __global__ __launch_bounds__(SPT_WAVE) void lookup_rows_kernel(
         for (int j = 0; j < 8; j++) word |= ((uint32_t)qraw[8 * d + j] & 0xFu) << (4 * j);   // pad: 0
         qc.w[d] = word;
     }
-    constexpr int KPL = 512 / SPT_WAVE;                 // key columns per lane at S <= 512
+    constexpr int KPL = 512 / LR_THREADS;               // key columns per thread at S <= 512
     int32_t kraw[KPL][16];
 #pragma unroll
     for (int i = 0; i < KPL; i++) {
-        const int col = min(lane + SPT_WAVE * i, ncols - 1);
+        const int col = min((int)threadIdx.x + LR_THREADS * i, ncols - 1);
         const int32_t *src = ksrc + (size_t)col * M;
 #pragma unroll
         for (int m = 0; m < 16; m++) kraw[i][m] = 0;
@@ -464,7 +476,7 @@ __global__ __launch_bounds__(SPT_WAVE) void lookup_rows_kernel(
     }
 #pragma unroll
     for (int i = 0; i < KPL; i++) {
-        const int col = lane + SPT_WAVE * i;
+        const int col = threadIdx.x + LR_THREADS * i;
 #pragma unroll
         for (int m = 0; m < 16; m++) wide |= kraw[i][m];
         if (col < 4 * ngroups) {
@@ -482,17 +494,17 @@ __global__ __launch_bounds__(SPT_WAVE) void lookup_rows_kernel(
             }
         }
     }
-    const bool nib = __builtin_amdgcn_ballot_w64((wide & ~0xF) != 0) == 0ull;
+    const bool nib = !__syncthreads_or((wide & ~0xF) != 0);        // (also publishes kcodes)
     unsigned char *lastg = lists + 16 * Q;            // [2 workers][4 slots]: last column / 4
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
 
     // slot = min(3, matches / (M / 4)) (lookup.cu:61-63) as a multiply-shift, as in lookup_row
     const int div = M >> 2;
     const unsigned magic = (32u + div - 1) / div;
-    // list sizes: worker tx, four 8-bit fields (slot 0..3): a list holds at most S / 4 <= 128
-    // columns at S <= 512
-    unsigned n8[4] = {0u, 0u, 0u, 0u};
+    // list sizes of this wave's two workers: four 8-bit fields (slot 0..3) each; a list holds
+    // at most S / 4 <= 128 columns at S <= 512
+    unsigned n8[LR_WPW];
+#pragma unroll
+    for (int t2 = 0; t2 < LR_WPW; t2++) n8[t2] = 0u;
 
     // the group's four codes are read together, one group ahead: read one by one they sat
     // behind the byte stores (same LDS, no alias information) with a full LDS latency each
@@ -505,6 +517,7 @@ __global__ __launch_bounds__(SPT_WAVE) void lookup_rows_kernel(
         }
     };
     const unsigned Q4 = 4u * Q;
+    const unsigned cap = LR_WPW * wv < 2 ? Q : Q - 1;   // workers 0, 1 keep Q, workers 2, 3 Q - 1
     auto walk = [&](auto nib_tag) {
         constexpr bool NIBF = decltype(nib_tag)::value;
         uint32_t nxt[4 * W];
@@ -515,17 +528,29 @@ __global__ __launch_bounds__(SPT_WAVE) void lookup_rows_kernel(
             for (int i = 0; i < 4 * W; i++) cur[i] = nxt[i];
             if (NIBF) group_codes(g + 1, nxt);
 #pragma unroll
-            for (int tx = 0; tx < 4; tx++) {
+            for (int t2 = 0; t2 < LR_WPW; t2++) {
+                const int tx = LR_WPW * wv + t2;
                 const int c = 4 * g + tx;
                 const int cs = min(c, S - 1);
-                const unsigned cnt = (unsigned)rows_match<W, NIBF>(cur + tx * W, qc,
-                                                                   ksrc + (size_t)cs * M, qraw, M);
+                uint32_t kw[W];
+#pragma unroll
+                for (int d = 0; d < W; d++) {
+                    // (wave-uniform choice of the worker's column among the group's four)
+                    const uint32_t a = cur[(t2)*W + d], bq = cur[(LR_WPW + t2) * W + d];
+                    if (LR_WPW == 2) {
+                        kw[d] = wv ? bq : a;
+                    } else {
+                        const uint32_t c2 = cur[2 * W + d], c3 = cur[3 * W + d];
+                        kw[d] = wv == 0 ? a : (wv == 1 ? bq : (wv == 2 ? c2 : c3));
+                    }
+                }
+                const unsigned cnt = (unsigned)rows_match<W, NIBF>(kw, qc, ksrc + (size_t)cs * M,
+                                                                   qraw, M);
                 const unsigned sl = min(3u, __umul24(cnt, magic) >> 5);
                 const bool active = c <= gy;          // (c < ncols <= S follows for real rows)
                 const unsigned sh = sl << 3;
-                const unsigned rank = (n8[tx] >> sh) & 0xFFu;
-                n8[tx] += (active ? 1u : 0u) << sh;
-                const unsigned cap = (tx < 2) ? Q : Q - 1;
+                const unsigned rank = (n8[t2] >> sh) & 0xFFu;
+                n8[t2] += (active ? 1u : 0u) << sh;
                 if (active && rank < cap) lists[__umul24(sl, Q4) + tx * Q + rank] = (unsigned char)g;
                 if (tx >= 2 && active) lastg[(tx - 2) * 4 + sl] = (unsigned char)g;
             }
@@ -533,54 +558,62 @@ __global__ __launch_bounds__(SPT_WAVE) void lookup_rows_kernel(
     };
     if (nib) walk(std::true_type{});
     else walk(std::false_type{});
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
 
-    // ---- the row is complete: sizes -> kept counts -> output positions ----
+    // ---- the rows are complete: sizes -> kept counts -> output positions of this wave's workers
     const int limit = min(gy + 1, Z);
     unsigned short *mine = orow + (size_t)lane * out_pitch;
-    int n[4][4], off[4][4];
+    int n[LR_WPW][4], off[LR_WPW][4];
 #pragma unroll
-    for (int tx = 0; tx < 4; tx++) {
-        n[tx][0] = n8[tx] & 0xFF; n[tx][1] = (n8[tx] >> 8) & 0xFF;
-        n[tx][2] = (n8[tx] >> 16) & 0xFF; n[tx][3] = n8[tx] >> 24;
-        const int cap = (tx < 2) ? Q : Q - 1;
-        const int k3 = min(n[tx][3], cap), k2 = min(n[tx][2], cap), k1 = min(n[tx][1], cap),
-                  k0 = min(n[tx][0], cap);
-        off[tx][3] = 0;
-        off[tx][2] = k3;
-        off[tx][1] = k3 + k2;
-        off[tx][0] = k3 + k2 + k1;
+    for (int t2 = 0; t2 < LR_WPW; t2++) {
+        const int tx = LR_WPW * wv + t2;
+        n[t2][0] = n8[t2] & 0xFF; n[t2][1] = (n8[t2] >> 8) & 0xFF;
+        n[t2][2] = (n8[t2] >> 16) & 0xFF; n[t2][3] = n8[t2] >> 24;
+        const int k3 = min(n[t2][3], (int)cap), k2 = min(n[t2][2], (int)cap),
+                  k1 = min(n[t2][1], (int)cap), k0 = min(n[t2][0], (int)cap);
+        off[t2][3] = 0;
+        off[t2][2] = k3;
+        off[t2][1] = k3 + k2;
+        off[t2][0] = k3 + k2 + k1;
         const int total = k3 + k2 + k1 + k0;
         // position index i of worker tx: the slot whose kept range holds it (slot 3 first)
         for (int i = 0; i < Q; i++) {
             const int p = tx + 4 * i;
-            const int sl = i < off[tx][2] ? 3 : (i < off[tx][1] ? 2 : (i < off[tx][0] ? 1 : 0));
-            const int r = i - sel4(off[tx][0], off[tx][1], off[tx][2], off[tx][3], sl);
+            const int sl = i < off[t2][2] ? 3 : (i < off[t2][1] ? 2 : (i < off[t2][0] ? 1 : 0));
+            const int r = i - sel4(off[t2][0], off[t2][1], off[t2][2], off[t2][3], sl);
             unsigned short v = 0;
             if (i < total && p < limit) v = (unsigned short)(4 * lists[(sl * 4 + tx) * Q + r] + tx);
             mine[p] = v;
         }
     }
+#pragma unroll
+    for (int t2 = 0; t2 < LR_WPW; t2++) {
+        const int tx = LR_WPW * wv + t2;
+        if (tx >= 2) xch[2 * lane + (tx - 2)] = n8[t2];
+    }
+    __syncthreads();
     // reference quirk: the cursor of worker 2 (3) saturates on the word that holds entry Q-1
-    // of worker 1 (0); its LAST candidate of the slot survives there if larger
+    // of worker 1 (0); its LAST candidate of the slot survives there if larger.  Applied by the
+    // wave that owns workers 0 and 1 (the positions), with wave 1's sizes and last columns.
 #pragma unroll
-    for (int sl = 0; sl < 4; sl++) {
+    for (int t2 = 0; t2 < LR_WPW; t2++) {
+        const int ptx = LR_WPW * wv + t2;                 // a worker this wave owns
+        if (ptx < 2) {
+            const int tx = 3 - ptx;                       // the worker whose cursor lands on it
 #pragma unroll
-        for (int tx = 2; tx < 4; tx++) {
-            const int ptx = 3 - tx;
-            if (n[tx][sl] >= Q && n[ptx][sl] >= Q) {
-                const int p = ptx + 4 * (off[ptx][sl] + Q - 1);
-                const int lastcol = 4 * lastg[(tx - 2) * 4 + sl] + tx;
-                if (p < limit) mine[p] = (unsigned short)max((int)mine[p], lastcol);
+            for (int sl = 0; sl < 4; sl++) {
+                const int ntx = (int)((xch[2 * lane + (tx - 2)] >> (8 * sl)) & 0xFFu);
+                if (ntx >= Q && n[t2][sl] >= Q) {
+                    const int p = ptx + 4 * (off[t2][sl] + Q - 1);
+                    const int lastcol = 4 * lastg[(tx - 2) * 4 + sl] + tx;
+                    if (p < limit) mine[p] = (unsigned short)max((int)mine[p], lastcol);
+                }
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- coalesced store, zeros included ----
+    __syncthreads();
+    // ---- coalesced store, zeros included: the waves take rows in turn ----
     const int nrows = min(SPT_WAVE, S - r0);
-    for (int r = 0; r < nrows; r++) {
+    for (int r = wv; r < nrows; r += LR_WAVES) {
         int32_t *dst = out + ((size_t)b * S + r0 + r) * Z;
         const unsigned short *src = orow + (size_t)r * out_pitch;
         for (int i = lane; i < Z; i += SPT_WAVE) dst[i] = src[i];
@@ -612,16 +645,16 @@ extern "C" int spt_lookup_forward(const int32_t *query, const int32_t *key, int3
         const int list_pitch = ((16 * Q + 8 + 3) & ~3) | 4;      // odd number of words
         const int out_pitch = Z + 2;                              // uint16: odd number of words
         const size_t lds = (size_t)(((S + 3) & ~3) + 4) * WN * 4 + (size_t)SPT_WAVE * list_pitch +
-                           (size_t)SPT_WAVE * out_pitch * 2;
+                           (size_t)SPT_WAVE * out_pitch * 2 + (size_t)SPT_WAVE * 8;
         const int nb = (S + SPT_WAVE - 1) / SPT_WAVE;
         const long long nblk = (long long)batch_size * nb;
         if (lds <= 64 * 1024 && nblk <= 0x7FFFFFFFLL) {
             if (WN == 1)
-                hipLaunchKernelGGL(lookup_rows_kernel<1>, dim3((unsigned)nblk), dim3(SPT_WAVE), lds,
+                hipLaunchKernelGGL(lookup_rows_kernel<1>, dim3((unsigned)nblk), dim3(LR_THREADS), lds,
                                    s, query, key, out, batch_size, S, M, Z, nb, list_pitch,
                                    out_pitch);
             else
-                hipLaunchKernelGGL(lookup_rows_kernel<2>, dim3((unsigned)nblk), dim3(SPT_WAVE), lds,
+                hipLaunchKernelGGL(lookup_rows_kernel<2>, dim3((unsigned)nblk), dim3(LR_THREADS), lds,
                                    s, query, key, out, batch_size, S, M, Z, nb, list_pitch,
                                    out_pitch);
             SPT_LAUNCH_CHECK();
