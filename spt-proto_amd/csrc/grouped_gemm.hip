@@ -17,8 +17,10 @@
 // (ceil(P/128) + G row tiles) and every workgroup finds its bucket from `offsets`.
 //
 // This is the one place of the hot path where the contraction is dense, so it runs on
-// the matrix cores: v_mfma_f32_32x32x2_f32, exact fp32 (a fixed-order fmaf chain), 157 TF
-// peak (MI355X_MICROARCH "Matrix cores").  128 x 128 output tile per 256-thread
+// the matrix cores: three v_mfma_f32_32x32x16_bf16 per 16 k's on fp32 operands split in two
+// (see GgFrag below; 212 TFLOP/s fp32-equivalent measured), or -- for the forward GEMM in front
+// of a ReLU -- v_mfma_f32_32x32x2_f32, exact fp32 (a fixed-order fmaf chain), 157 TF peak
+// (MI355X_MICROARCH "Matrix cores"; 98-116 TFLOP/s measured).  128 x 128 output tile per 256-thread
 // workgroup, each wave a 64 x 64 quadrant (2 x 2 MFMA tiles, 64 accumulator registers);
 // K is consumed in steps of 32 through LDS.  LDS image of an operand tile: [row][k] in
 // natural order; an MFMA contracts two k's, one from each half of the wave, and any
@@ -44,6 +46,40 @@ constexpr int GG_ROW = GG_BK + 4;    // floats per LDS row of a k-contiguous til
 constexpr int GG_BNROW = GG_BN + 4;  // floats per LDS row of an n-contiguous weight tile
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// Contraction on the bf16 matrix cores with fp32 operands split in two (x = hi + lo, hi = RNE
+// bf16 of x, lo = RNE bf16 of x - hi; lo*hi + hi*lo + hi*hi, fp32 accumulation): <= 2^-16
+// relative error per product at three v_mfma_f32_32x32x16_bf16 per 16 k's -- 1/5 of the time
+// of the eight v_mfma_f32_32x32x2_f32 they replace.  Same scheme as mfma_attention.hip.
+// -DGG_EXACT_FP32 keeps the fp32 MFMA (a fixed-order fmaf chain, bit-exact fp32).
+typedef __attribute__((ext_vector_type(8))) __bf16 gg_bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 gg_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float gg_f32x2;
+struct GgFrag { uint4 hi, lo; };
+__device__ __forceinline__ void gg_split2(float a, float b, unsigned &hi, unsigned &lo) {
+    const gg_f32x2 x = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, gg_bf16x2));
+    const gg_f32x2 hf = {__builtin_bit_cast(float, hi << 16),
+                         __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(x - hf, gg_bf16x2));
+}
+__device__ __forceinline__ GgFrag gg_split8(const float (&x)[8]) {
+    GgFrag f;
+    gg_split2(x[0], x[1], f.hi.x, f.lo.x);
+    gg_split2(x[2], x[3], f.hi.y, f.lo.y);
+    gg_split2(x[4], x[5], f.hi.z, f.lo.z);
+    gg_split2(x[6], x[7], f.hi.w, f.lo.w);
+    return f;
+}
+__device__ __forceinline__ f32x16 gg_mma(const uint4 &a, const uint4 &b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gg_bf16x8, a),
+                                                   __builtin_bit_cast(gg_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 gg_mma3(const GgFrag &a, const GgFrag &b, f32x16 c) {
+    c = gg_mma(a.lo, b.hi, c);
+    c = gg_mma(a.hi, b.lo, c);
+    return gg_mma(a.hi, b.hi, c);
+}
 
 enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DACT = 2 };
 enum { ACT_RELU = 0, ACT_GELU = 1, ACT_SILU = 2 };
@@ -176,6 +212,58 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
         }
     };
 
+    // The same 16 k's (two of the groups above) as one split-bf16 contraction: lane l holds
+    // A[row = l & 31][k = 16 q2 + 8 (l >> 5) + 0..7] -- eight consecutive floats of the
+    // natural-k image -- and B likewise.
+    auto mfma_group16 = [&](int q2, bool bt_image) {
+        GgFrag af[NI], bf[2];
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const float *p = &As[(wm + 32 * i + frow) * GG_ROW + 16 * q2 + 8 * fh];
+            const float4 lo4 = *reinterpret_cast<const float4 *>(p);
+            const float4 hi4 = *reinterpret_cast<const float4 *>(p + 4);
+            const float x[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+            af[i] = gg_split8(x);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            float x[8];
+            if (bt_image) {
+                const float *p = &Bs[(wn + 32 * j + frow) * GG_ROW + 16 * q2 + 8 * fh];
+                const float4 lo4 = *reinterpret_cast<const float4 *>(p);
+                const float4 hi4 = *reinterpret_cast<const float4 *>(p + 4);
+                x[0] = lo4.x; x[1] = lo4.y; x[2] = lo4.z; x[3] = lo4.w;
+                x[4] = hi4.x; x[5] = hi4.y; x[6] = hi4.z; x[7] = hi4.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    x[e] = Bs[(16 * q2 + 8 * fh + e) * GG_BNROW + wn + 32 * j + frow];
+            }
+            bf[j] = gg_split8(x);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            acc[i][0] = gg_mma3(af[i], bf[0], acc[i][0]);
+            acc[i][1] = gg_mma3(af[i], bf[1], acc[i][1]);
+        }
+    };
+    // The one contraction that stays on the exact fp32 MFMA: the forward GEMM whose result goes
+    // through ReLU.  A 1e-5 perturbation of a pre-activation that sits on the kink flips its
+    // derivative (measured: ~6 of 614 k elements, each an O(1) error in one token's gradients);
+    // every other product feeds smooth functions.
+#ifdef GG_EXACT_FP32
+    const bool exact_fp32 = true;
+#else
+    const bool exact_fp32 = (EPI == EPI_ACT) && g.act == ACT_RELU;
+#endif
+    auto contract = [&](int kmax, bool bt_image) {        // k = 0 .. kmax of the staged tiles
+        if (exact_fp32) {
+            for (int q = 0; q < (kmax + 7) / 8; q++) mfma_group(q, bt_image);
+        } else {
+            for (int q2 = 0; q2 < (kmax + 15) / 16; q2++) mfma_group16(q2, bt_image);
+        }
+    };
+
     // ---- K extension first: acc = (A2 / rowscale) . B2_g^T, so that the epilogue's single
     // rowscale * (acc + bias) yields rowscale * (A W^T + bias) + A2 B2^T ----
     if (EXT) {
@@ -206,7 +294,7 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
             *reinterpret_cast<float4 *>(&Bs[r * GG_ROW + 4 * s_kq]) = b;
         }
         __syncthreads();
-        for (int q = 0; q < (g.R + 7) / 8; q++) mfma_group(q, true);
+        contract(g.R, true);              // (the tiles are zero beyond R, up to GG_BK)
         // the main loop's first __syncthreads orders these reads before its LDS writes
     }
 
@@ -274,8 +362,13 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
         }
         __syncthreads();
         if (k_next < g.K) load_tile(a, b, k_next);   // this register set is free again
+        if (exact_fp32) {
 #pragma unroll
-        for (int q = 0; q < GG_BK / 8; q++) mfma_group(q, !BN_LAYOUT);
+            for (int q = 0; q < GG_BK / 8; q++) mfma_group(q, !BN_LAYOUT);
+        } else {
+#pragma unroll
+            for (int q2 = 0; q2 < GG_BK / 16; q2++) mfma_group16(q2, !BN_LAYOUT);
+        }
     };
     load_tile(av[0], bv[0], 0);
     for (int k0 = 0; k0 < g.K; k0 += GG_BK) k_step(av[0], bv[0], k0 + GG_BK);

@@ -12,6 +12,11 @@ from torch import nn
 pytestmark = pytest.mark.gpu
 
 
+def _scaled_close(got, want, rtol=1e-3, frac=3e-4):
+    """allclose with the absolute tolerance as a fraction of the reference's magnitude."""
+    return torch.allclose(got, want, rtol=rtol, atol=frac * want.abs().max().item())
+
+
 def ref_grouped(a, gather, w_full, view, bias, rowscale, offsets):
     n, k, gs, ldn, ldk = view
     a = a.double().cpu()
@@ -124,12 +129,15 @@ def test_routed_ffn_grouped_path_equals_torch_path(kind):
         (y2 * w).sum().backward()
     finally:
         grouped.usable = orig
-    assert torch.allclose(y1, y2, rtol=1e-3, atol=1e-4)
-    assert torch.allclose(gx1, x.grad, rtol=1e-3, atol=1e-4)
+    # the grouped GEMMs contract on the bf16 matrix cores with split fp32 operands (<= 2^-16 per
+    # product): errors are relative to the scale of the sums, so the absolute part of the
+    # tolerance is a fraction of the tensor's magnitude (bar: 1e-3)
+    assert _scaled_close(y1, y2)
+    assert _scaled_close(gx1, x.grad)
     g2 = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
     assert set(g1) == set(g2)
     for n in g1:
-        assert torch.allclose(g1[n], g2[n], rtol=2e-3, atol=2e-4), n
+        assert _scaled_close(g1[n], g2[n], rtol=2e-3), n
 
 
 # ------------------------------------------------------------------ fused epilogues
@@ -285,11 +293,11 @@ def test_fused_lora_routed_ffn_equals_torch_loop(act):
 
     y0, gx0, g0 = run(False)
     y1, gx1, g1 = run(True)
-    assert torch.allclose(y1, y0, rtol=1e-3, atol=1e-4)
-    assert torch.allclose(gx1, gx0, rtol=1e-3, atol=1e-4)
+    assert _scaled_close(y1, y0)
+    assert _scaled_close(gx1, gx0)
     assert set(g0) == set(g1) and len(g0) >= 6
     for n in g0:
-        assert torch.allclose(g1[n], g0[n], rtol=2e-3, atol=2e-4), n
+        assert _scaled_close(g1[n], g0[n], rtol=2e-3), n
 
 
 @pytest.mark.parametrize('T,G,k', [(8192, 4, 2), (1000, 8, 4), (77, 4, 2), (5, 2, 1), (40000, 4, 2)])
