@@ -326,3 +326,31 @@ def test_route_topk_ties_go_to_the_lower_block():
     token, block, offsets, pos = ext.route_topk(prob, 2)
     picked = [sorted(block[pos[t].long()].tolist()) for t in range(3)]
     assert picked == [[0, 1], [1, 2], [0, 2]]
+
+
+def test_frozen_lora_linear_on_the_matrix_core_gemm_equals_the_library_gemm(monkeypatch):
+    """layers.LoRALinear with frozen base weights: the one-bucket split-bf16 GEMM (base product,
+    bias and LoRA side product in one launch; grad_x likewise) against torch's fp32 matmul path."""
+    from naive_gpt import layers
+    from naive_gpt.layers.tuning import lora
+    torch.manual_seed(5)
+    lin = layers.LoRALinear(d_lora=16, in_features=256, out_features=384).cuda()
+    lin.lora.right.weight.data.normal_(0, 0.05)
+    x = torch.randn([4, 1024, 256], device='cuda', requires_grad=True)
+    w = torch.randn([4, 1024, 384], device='cuda')
+
+    def run(fast):
+        if not fast:
+            monkeypatch.setattr(lora, '_mfma_linear_usable', lambda *a: False)
+        x.grad = None
+        lin.zero_grad()
+        y = lin(x)
+        (y * w).sum().backward()
+        monkeypatch.undo()
+        return y.detach(), x.grad.clone(), lin.lora.left.weight.grad.clone(), \
+            lin.lora.right.weight.grad.clone()
+
+    assert lora._mfma_linear_usable(x.view(-1, 256), lin.weight, 16)
+    fast, slow = run(True), run(False)
+    for a, b, name in zip(fast, slow, ['y', 'grad_x', 'grad_left', 'grad_right']):
+        assert _scaled_close(a, b), name
