@@ -186,7 +186,7 @@ class EventTimer:
 
 def sparse_step(attn, q, k, v, trigger):
     if trigger:
-        attn.trigger.fill_(True)
+        attn.arm()        # = trigger.fill_(True) + a host-side note (utils.SparseTuner does the same)
     y = attn(q, k, v, attn_mask=None)
     loss = y.sum()
     if trigger:

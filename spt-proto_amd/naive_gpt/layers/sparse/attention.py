@@ -186,6 +186,14 @@ class _SparseCore:
             _SparseCore._indptr_cache[key] = cached
         return cached
 
+    def arm(self) -> None:
+        """Arm the one-shot PQ-loss trigger from the host.  Same effect as the reference's
+        ``module.trigger.fill_(True)`` plus a host-side note that it happened, so that the next
+        forward does not have to ASK the device (a blocking read: one pipeline drain per layer
+        and step in the tuning recipe, which arms every step)."""
+        self.trigger.fill_(True)
+        self.__dict__['_armed_hint'] = True
+
     def _take_trigger(self) -> bool:
         """One-shot flag: the training loop arms the device buffer `trigger`, the layer
         disarms it (reference: attention.py:98-104, which reads it with a blocking
@@ -193,6 +201,11 @@ class _SparseCore:
         anything wrote to it since the last look, so the device is only asked (one host
         sync) after a write: unarmed steps never synchronise."""
         t = self.trigger
+        if self.__dict__.pop('_armed_hint', False):
+            t.fill_(False)                        # disarm on the device, no read-back
+            if not t.is_inference():
+                self.__dict__['_trigger_seen'] = ((t.data_ptr(), t._version), False)
+            return True
         if t.is_inference():                      # no version counter to consult
             armed = bool(t.is_nonzero())
             if armed:

@@ -63,6 +63,9 @@ class SparseTuner:
         self.n_accumulate = max(1, int(n_accumulate))
         self._micro = 0
         self._triggers = [b for n, b in model.named_buffers() if n.endswith('.trigger')]
+        # layers that can be armed from the host without a device read-back (layers.sparse)
+        self._armable = [m for m in model.modules()
+                         if hasattr(m, 'arm') and isinstance(getattr(m, 'trigger', None), torch.Tensor)]
         self.last_grad_norm = None
 
     @classmethod
@@ -75,8 +78,13 @@ class SparseTuner:
 
     # ------------------------------------------------------------------ pieces of a step
     def arm_triggers(self) -> None:
-        for trigger in self._triggers:
-            trigger.fill_(True)
+        armed = set()
+        for module in self._armable:
+            module.arm()
+            armed.add(module.trigger.data_ptr())
+        for trigger in self._triggers:            # any other module with a `trigger` buffer
+            if trigger.data_ptr() not in armed:
+                trigger.fill_(True)
 
     def aux_loss(self):
         """Sum of the PQ codebook losses the armed attentions left in ``*.loss``."""

@@ -190,3 +190,24 @@ def test_layer_through_mfma_kernels_equals_separate_operators(kind, monkeypatch)
     fast, separate = run(True), run(False)
     for a, b, name in zip(fast, separate, ['y', 'grad_q', 'grad_k', 'grad_v']):
         assert torch.allclose(a, b, rtol=1e-3, atol=2e-4 * b.abs().max().item()), name
+
+
+def test_host_side_arming_equals_the_reference_protocol():
+    """module.arm() (no device read-back in the next forward) against the reference's
+    `module.trigger.fill_(True)`: same loss buffer, trigger disarmed afterwards, one-shot."""
+    from naive_gpt import layers
+    torch.manual_seed(1)
+    attn = layers.SparseVanillaAttentionV2(d_head=64, d_codeword=8, n_codewords=16,
+                                           p_dropout=0.0).cuda()
+    q, k, v = [torch.randn([2, 128, 16, 64], device='cuda') for _ in range(3)]
+    attn.trigger.fill_(True)
+    attn(q, k, v, attn_mask=None)
+    want = attn.loss.clone()
+    assert not bool(attn.trigger)
+    attn.loss.zero_()
+    attn.arm()
+    attn(q, k, v, attn_mask=None)
+    assert torch.equal(attn.loss, want) and not bool(attn.trigger)
+    attn.loss.zero_()
+    attn(q, k, v, attn_mask=None)                     # not armed any more: no loss computed
+    assert float(attn.loss) == 0.0
