@@ -18,9 +18,9 @@
 //
 // This is the one place of the hot path where the contraction is dense, so it runs on
 // the matrix cores: three v_mfma_f32_32x32x16_bf16 per 16 k's on fp32 operands split in two
-// (see GgFrag below; 212 TFLOP/s fp32-equivalent measured), or -- for the forward GEMM in front
-// of a ReLU -- v_mfma_f32_32x32x2_f32, exact fp32 (a fixed-order fmaf chain), 157 TF peak
-// (MI355X_MICROARCH "Matrix cores"; 98-116 TFLOP/s measured).  128 x 128 output tile per 256-thread
+// (see GgFrag below; 205-212 TFLOP/s fp32-equivalent measured), or -- for the forward GEMM in
+// front of a ReLU -- six on a three-way split (fp32-level accuracy).  The fp32 MFMA
+// v_mfma_f32_32x32x2_f32 (157 TF peak, 98-116 measured) remains behind -DGG_EXACT_FP32.  128 x 128 output tile per 256-thread
 // workgroup, each wave a 64 x 64 quadrant (2 x 2 MFMA tiles, 64 accumulator registers);
 // K is consumed in steps of 32 through LDS.  LDS image of an operand tile: [row][k] in
 // natural order; an MFMA contracts two k's, one from each half of the wave, and any
@@ -74,6 +74,36 @@ __device__ __forceinline__ GgFrag gg_split8(const float (&x)[8]) {
 __device__ __forceinline__ f32x16 gg_mma(const uint4 &a, const uint4 &b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gg_bf16x8, a),
                                                    __builtin_bit_cast(gg_bf16x8, b), c, 0, 0, 0);
+}
+// Three-way split x = hi + mid + lo (3 x 8 mantissa bits: exact to ~2^-24) and the six products
+// of order >= 2^-16: fp32-level accuracy (error ~2^-23 per product) at 6 x 32 cycles per 16 k
+// against 8 x 64 for the fp32 MFMA.  Used where a 1e-5 error is not acceptable: the
+// pre-activation of a ReLU (see exact_fp32 in gemm_tile).
+struct GgFrag3 { uint4 hi, mid, lo; };
+__device__ __forceinline__ void gg_split2x3(float a, float b, unsigned &hi, unsigned &mid,
+                                            unsigned &lo) {
+    gg_f32x2 x = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, gg_bf16x2));
+    x -= gg_f32x2{__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(x, gg_bf16x2));
+    x -= gg_f32x2{__builtin_bit_cast(float, mid << 16), __builtin_bit_cast(float, mid & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(x, gg_bf16x2));
+}
+__device__ __forceinline__ GgFrag3 gg_split8x3(const float (&x)[8]) {
+    GgFrag3 f;
+    gg_split2x3(x[0], x[1], f.hi.x, f.mid.x, f.lo.x);
+    gg_split2x3(x[2], x[3], f.hi.y, f.mid.y, f.lo.y);
+    gg_split2x3(x[4], x[5], f.hi.z, f.mid.z, f.lo.z);
+    gg_split2x3(x[6], x[7], f.hi.w, f.mid.w, f.lo.w);
+    return f;
+}
+__device__ __forceinline__ f32x16 gg_mma6(const GgFrag3 &a, const GgFrag3 &b, f32x16 c) {
+    c = gg_mma(a.lo, b.hi, c);      // small terms first
+    c = gg_mma(a.hi, b.lo, c);
+    c = gg_mma(a.mid, b.mid, c);
+    c = gg_mma(a.mid, b.hi, c);
+    c = gg_mma(a.hi, b.mid, c);
+    return gg_mma(a.hi, b.hi, c);
 }
 __device__ __forceinline__ f32x16 gg_mma3(const GgFrag &a, const GgFrag &b, f32x16 c) {
     c = gg_mma(a.lo, b.hi, c);
@@ -179,7 +209,7 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
     // MFMA step e of group q: lane l holds A[row = l & 31][k = 8 q + 4 (l >> 5) + e], B
     // likewise (any pairing of the k's is a valid contraction order).  `bt_image`: B tile
     // stored [n][k] (k-contiguous weights and the K extension), else [k][n].
-    auto mfma_group = [&](int q, bool bt_image) {
+    [[maybe_unused]] auto mfma_group = [&](int q, bool bt_image) {
         float4 af[NI];
 #pragma unroll
         for (int i = 0; i < NI; i++)
@@ -247,21 +277,56 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
             acc[i][1] = gg_mma3(af[i], bf[1], acc[i][1]);
         }
     };
-    // The one contraction that stays on the exact fp32 MFMA: the forward GEMM whose result goes
+    // the same 16 k's at fp32-level accuracy: three-way split, six products
+    auto mfma_group16x6 = [&](int q2, bool bt_image) {
+        GgFrag3 af[NI], bf[2];
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const float *p = &As[(wm + 32 * i + frow) * GG_ROW + 16 * q2 + 8 * fh];
+            const float4 lo4 = *reinterpret_cast<const float4 *>(p);
+            const float4 hi4 = *reinterpret_cast<const float4 *>(p + 4);
+            const float x[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+            af[i] = gg_split8x3(x);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            float x[8];
+            if (bt_image) {
+                const float *p = &Bs[(wn + 32 * j + frow) * GG_ROW + 16 * q2 + 8 * fh];
+                const float4 lo4 = *reinterpret_cast<const float4 *>(p);
+                const float4 hi4 = *reinterpret_cast<const float4 *>(p + 4);
+                x[0] = lo4.x; x[1] = lo4.y; x[2] = lo4.z; x[3] = lo4.w;
+                x[4] = hi4.x; x[5] = hi4.y; x[6] = hi4.z; x[7] = hi4.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    x[e] = Bs[(16 * q2 + 8 * fh + e) * GG_BNROW + wn + 32 * j + frow];
+            }
+            bf[j] = gg_split8x3(x);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            acc[i][0] = gg_mma6(af[i], bf[0], acc[i][0]);
+            acc[i][1] = gg_mma6(af[i], bf[1], acc[i][1]);
+        }
+    };
+    // The one contraction that needs fp32-level accuracy: the forward GEMM whose result goes
     // through ReLU.  A 1e-5 perturbation of a pre-activation that sits on the kink flips its
-    // derivative (measured: ~6 of 614 k elements, each an O(1) error in one token's gradients);
-    // every other product feeds smooth functions.
-#ifdef GG_EXACT_FP32
-    const bool exact_fp32 = true;
-#else
-    const bool exact_fp32 = (EPI == EPI_ACT) && g.act == ACT_RELU;
-#endif
+    // derivative (measured with the two-way split: ~6 of 614 k elements, each an O(1) error in
+    // one token's gradients); every other product feeds smooth functions.  It takes the
+    // three-way split (352 us on the fp32 MFMA at the block-bench shape); -DGG_EXACT_FP32 puts
+    // every contraction on the fp32 MFMA (a fixed-order fmaf chain) for comparison.
+    const bool fp32_level = (EPI == EPI_ACT) && g.act == ACT_RELU;
     auto contract = [&](int kmax, bool bt_image) {        // k = 0 .. kmax of the staged tiles
-        if (exact_fp32) {
-            for (int q = 0; q < (kmax + 7) / 8; q++) mfma_group(q, bt_image);
+#ifdef GG_EXACT_FP32
+        for (int q = 0; q < (kmax + 7) / 8; q++) mfma_group(q, bt_image);
+#else
+        if (fp32_level) {
+            for (int q2 = 0; q2 < (kmax + 15) / 16; q2++) mfma_group16x6(q2, bt_image);
         } else {
             for (int q2 = 0; q2 < (kmax + 15) / 16; q2++) mfma_group16(q2, bt_image);
         }
+#endif
     };
 
     // ---- K extension first: acc = (A2 / rowscale) . B2_g^T, so that the epilogue's single
@@ -362,13 +427,18 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
         }
         __syncthreads();
         if (k_next < g.K) load_tile(a, b, k_next);   // this register set is free again
-        if (exact_fp32) {
+#ifdef GG_EXACT_FP32
 #pragma unroll
-            for (int q = 0; q < GG_BK / 8; q++) mfma_group(q, !BN_LAYOUT);
+        for (int q = 0; q < GG_BK / 8; q++) mfma_group(q, !BN_LAYOUT);
+#else
+        if (fp32_level) {
+#pragma unroll
+            for (int q2 = 0; q2 < GG_BK / 16; q2++) mfma_group16x6(q2, !BN_LAYOUT);
         } else {
 #pragma unroll
             for (int q2 = 0; q2 < GG_BK / 16; q2++) mfma_group16(q2, !BN_LAYOUT);
         }
+#endif
     };
     load_tile(av[0], bv[0], 0);
     for (int k0 = 0; k0 < g.K; k0 += GG_BK) k_step(av[0], bv[0], k0 + GG_BK);
