@@ -42,8 +42,17 @@ constexpr int GG_BK = GG_BK_VALUE;
 constexpr int GG_KQ = GG_BK / 4;               // float4 per tile row
 constexpr int GG_RPP = GG_THREADS / GG_KQ;      // tile rows staged per pass
 constexpr int GG_NU = GG_BM / GG_RPP;           // passes (float4 loads per thread per operand)
-constexpr int GG_ROW = GG_BK + 4;    // floats per LDS row of a k-contiguous tile (16-byte pad)
-constexpr int GG_BNROW = GG_BN + 4;  // floats per LDS row of an n-contiguous weight tile
+// LDS images of a tile: bf16, one image per part of the split (hi, lo and -- GEMMs in front of a
+// ReLU -- mid), written ONCE when the tile is staged (each element is an operand of two waves'
+// MFMAs: splitting the fragments in every wave doubled the conversion work and had the matrix
+// pipe at 28 %).  k-contiguous tiles: rows of 32 k (64 B + 16 pad): a fragment (8 k of one row)
+// is one conflict-free ds_read_b128 per part.  n-contiguous weight tiles stay [k][n] (rows of
+// 128 n, 256 B + 64 pad) and are read with the transposing ds_read_b64_tr_b16.
+constexpr int GG_ROWB = GG_BK * 2 + 16;          // bytes per row of a k-contiguous image: 80
+constexpr int GG_BNROWB = GG_BN * 2 + 64;        // bytes per k-row of an n-contiguous image: 320
+constexpr int GG_AIMG = GG_BM * GG_ROWB;         // one part of the A tile: 10240 B
+constexpr int GG_BIMG = GG_BN * GG_ROWB;         // one part of a B tile (either orientation)
+static_assert(GG_BK * GG_BNROWB == GG_BIMG, "both B orientations fit the same slot");
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -70,6 +79,12 @@ __device__ __forceinline__ GgFrag gg_split8(const float (&x)[8]) {
     gg_split2(x[4], x[5], f.hi.z, f.lo.z);
     gg_split2(x[6], x[7], f.hi.w, f.lo.w);
     return f;
+}
+typedef short gg_v4s16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 gg_tr_b64(const char *p) {      // ds_read_b64_tr_b16
+    const gg_v4s16 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) gg_v4s16 *)(p));
+    return __builtin_bit_cast(uint2, r);
 }
 __device__ __forceinline__ f32x16 gg_mma(const uint4 &a, const uint4 &b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gg_bf16x8, a),
@@ -168,8 +183,9 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
                                           int row_lo, int row_hi, int col_tile) {
     constexpr int NI = BM / 64;               // 32-row sub-blocks per wave
     constexpr int NUA = BM / GG_RPP;          // float4 of A per thread per k-step
-    float *As = smem;
-    float *Bs = smem + GG_BM * GG_ROW;
+    constexpr int NPART = (EPI == EPI_ACT) ? 3 : 2;      // hi, lo (, mid)
+    char *As = reinterpret_cast<char *>(smem);            // [NPART][GG_AIMG]: hi | lo | mid
+    char *Bs = As + NPART * GG_AIMG;                       // [NPART][GG_BIMG]
     const int n0 = col_tile * GG_BN;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -206,70 +222,37 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
     const int frow = lane & 31, fh = lane >> 5;
-    // MFMA step e of group q: lane l holds A[row = l & 31][k = 8 q + 4 (l >> 5) + e], B
-    // likewise (any pairing of the k's is a valid contraction order).  `bt_image`: B tile
-    // stored [n][k] (k-contiguous weights and the K extension), else [k][n].
-    [[maybe_unused]] auto mfma_group = [&](int q, bool bt_image) {
-        float4 af[NI];
-#pragma unroll
-        for (int i = 0; i < NI; i++)
-            af[i] = *reinterpret_cast<const float4 *>(
-                &As[(wm + 32 * i + frow) * GG_ROW + 8 * q + 4 * fh]);
-        float b0[4], b1[4];
-        if (bt_image) {
-            const float4 bf0 = *reinterpret_cast<const float4 *>(
-                &Bs[(wn + frow) * GG_ROW + 8 * q + 4 * fh]);
-            const float4 bf1 = *reinterpret_cast<const float4 *>(
-                &Bs[(wn + 32 + frow) * GG_ROW + 8 * q + 4 * fh]);
-            b0[0] = bf0.x; b0[1] = bf0.y; b0[2] = bf0.z; b0[3] = bf0.w;
-            b1[0] = bf1.x; b1[1] = bf1.y; b1[2] = bf1.z; b1[3] = bf1.w;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int kk = 8 * q + 4 * fh + e;
-                b0[e] = Bs[kk * GG_BNROW + wn + frow];
-                b1[e] = Bs[kk * GG_BNROW + wn + 32 + frow];
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-#pragma unroll
-            for (int i = 0; i < NI; i++) {
-                const float a = e == 0 ? af[i].x : e == 1 ? af[i].y : e == 2 ? af[i].z : af[i].w;
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[e], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[e], acc[i][1], 0, 0, 0);
-            }
-        }
+    // ---- fragments: lane l holds A[row = l & 31][k = 16 q2 + 8 (l >> 5) + 0..7] (16 bytes of a
+    // k-contiguous image) and B likewise; `bt_image`: B tile stored [n][k] (k-contiguous weights
+    // and the K extension), else [k][n], read with the transposing ds_read_b64_tr_b16 (lane 4q+p
+    // of a 16-lane group supplies row k0 + q, columns 4p.. of the group's 16 n; lane i receives
+    // column i of the four rows: two blocks = the fragment's 8 k's) ----
+    auto frag_rows = [&](const char *img, int row, int q2) {
+        return *reinterpret_cast<const uint4 *>(img + row * GG_ROWB + 32 * q2 + 16 * fh);
     };
-
-    // The same 16 k's (two of the groups above) as one split-bf16 contraction: lane l holds
-    // A[row = l & 31][k = 16 q2 + 8 (l >> 5) + 0..7] -- eight consecutive floats of the
-    // natural-k image -- and B likewise.
+    auto frag_cols = [&](const char *img, int ncol0, int q2) {
+        const int gl = lane & 15;
+        const char *p = img + (16 * q2 + 8 * fh + (gl >> 2)) * GG_BNROWB +
+                        (ncol0 + 16 * ((lane >> 4) & 1) + 4 * (gl & 3)) * 2;
+        const uint2 lo = gg_tr_b64(p), hi = gg_tr_b64(p + 4 * GG_BNROWB);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    };
+    auto b_frag = [&](int part, int j, int q2, bool bt_image) {
+        const char *img = Bs + part * GG_BIMG;
+        return bt_image ? frag_rows(img, wn + 32 * j + frow, q2) : frag_cols(img, wn + 32 * j, q2);
+    };
+    // 16 k's, two-way split: three products
     auto mfma_group16 = [&](int q2, bool bt_image) {
         GgFrag af[NI], bf[2];
 #pragma unroll
         for (int i = 0; i < NI; i++) {
-            const float *p = &As[(wm + 32 * i + frow) * GG_ROW + 16 * q2 + 8 * fh];
-            const float4 lo4 = *reinterpret_cast<const float4 *>(p);
-            const float4 hi4 = *reinterpret_cast<const float4 *>(p + 4);
-            const float x[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-            af[i] = gg_split8(x);
+            af[i].hi = frag_rows(As, wm + 32 * i + frow, q2);
+            af[i].lo = frag_rows(As + GG_AIMG, wm + 32 * i + frow, q2);
         }
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            float x[8];
-            if (bt_image) {
-                const float *p = &Bs[(wn + 32 * j + frow) * GG_ROW + 16 * q2 + 8 * fh];
-                const float4 lo4 = *reinterpret_cast<const float4 *>(p);
-                const float4 hi4 = *reinterpret_cast<const float4 *>(p + 4);
-                x[0] = lo4.x; x[1] = lo4.y; x[2] = lo4.z; x[3] = lo4.w;
-                x[4] = hi4.x; x[5] = hi4.y; x[6] = hi4.z; x[7] = hi4.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; e++)
-                    x[e] = Bs[(16 * q2 + 8 * fh + e) * GG_BNROW + wn + 32 * j + frow];
-            }
-            bf[j] = gg_split8(x);
+            bf[j].hi = b_frag(0, j, q2, bt_image);
+            bf[j].lo = b_frag(1, j, q2, bt_image);
         }
 #pragma unroll
         for (int i = 0; i < NI; i++) {
@@ -282,27 +265,15 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
         GgFrag3 af[NI], bf[2];
 #pragma unroll
         for (int i = 0; i < NI; i++) {
-            const float *p = &As[(wm + 32 * i + frow) * GG_ROW + 16 * q2 + 8 * fh];
-            const float4 lo4 = *reinterpret_cast<const float4 *>(p);
-            const float4 hi4 = *reinterpret_cast<const float4 *>(p + 4);
-            const float x[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-            af[i] = gg_split8x3(x);
+            af[i].hi = frag_rows(As, wm + 32 * i + frow, q2);
+            af[i].lo = frag_rows(As + GG_AIMG, wm + 32 * i + frow, q2);
+            af[i].mid = frag_rows(As + 2 * GG_AIMG, wm + 32 * i + frow, q2);
         }
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            float x[8];
-            if (bt_image) {
-                const float *p = &Bs[(wn + 32 * j + frow) * GG_ROW + 16 * q2 + 8 * fh];
-                const float4 lo4 = *reinterpret_cast<const float4 *>(p);
-                const float4 hi4 = *reinterpret_cast<const float4 *>(p + 4);
-                x[0] = lo4.x; x[1] = lo4.y; x[2] = lo4.z; x[3] = lo4.w;
-                x[4] = hi4.x; x[5] = hi4.y; x[6] = hi4.z; x[7] = hi4.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; e++)
-                    x[e] = Bs[(16 * q2 + 8 * fh + e) * GG_BNROW + wn + 32 * j + frow];
-            }
-            bf[j] = gg_split8x3(x);
+            bf[j].hi = b_frag(0, j, q2, bt_image);
+            bf[j].lo = b_frag(1, j, q2, bt_image);
+            bf[j].mid = b_frag(2, j, q2, bt_image);
         }
 #pragma unroll
         for (int i = 0; i < NI; i++) {
@@ -310,23 +281,38 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
             acc[i][1] = gg_mma6(af[i], bf[1], acc[i][1]);
         }
     };
+    // ---- staging: four fp32 values -> the 8-byte pieces of every part of an image ----
+    // (lo of the two-way split = RNE(x - hi); of the three-way split the image order is
+    // hi | lo(last part) | mid, so that parts 0 and 1 are what mfma_group16 reads either way:
+    // a two-way tile just has a coarser `lo`)
+    auto put4 = [&](char *img, int part_stride, int off, const float4 &v, bool three) {
+        if (three) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            gg_split2x3(v.x, v.y, h0, m0, l0);
+            gg_split2x3(v.z, v.w, h1, m1, l1);
+            *reinterpret_cast<uint2 *>(img + off) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(img + part_stride + off) = make_uint2(l0, l1);
+            *reinterpret_cast<uint2 *>(img + 2 * part_stride + off) = make_uint2(m0, m1);
+        } else {
+            unsigned h0, l0, h1, l1;
+            gg_split2(v.x, v.y, h0, l0);
+            gg_split2(v.z, v.w, h1, l1);
+            *reinterpret_cast<uint2 *>(img + off) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(img + part_stride + off) = make_uint2(l0, l1);
+        }
+    };
     // The one contraction that needs fp32-level accuracy: the forward GEMM whose result goes
     // through ReLU.  A 1e-5 perturbation of a pre-activation that sits on the kink flips its
     // derivative (measured with the two-way split: ~6 of 614 k elements, each an O(1) error in
     // one token's gradients); every other product feeds smooth functions.  It takes the
-    // three-way split (352 us on the fp32 MFMA at the block-bench shape); -DGG_EXACT_FP32 puts
-    // every contraction on the fp32 MFMA (a fixed-order fmaf chain) for comparison.
+    // three-way split (this GEMM took 352 us on the fp32 MFMA at the block-bench shape).
     const bool fp32_level = (EPI == EPI_ACT) && g.act == ACT_RELU;
     auto contract = [&](int kmax, bool bt_image) {        // k = 0 .. kmax of the staged tiles
-#ifdef GG_EXACT_FP32
-        for (int q = 0; q < (kmax + 7) / 8; q++) mfma_group(q, bt_image);
-#else
-        if (fp32_level) {
+        if (EPI == EPI_ACT && fp32_level) {
             for (int q2 = 0; q2 < (kmax + 15) / 16; q2++) mfma_group16x6(q2, bt_image);
         } else {
             for (int q2 = 0; q2 < (kmax + 15) / 16; q2++) mfma_group16(q2, bt_image);
         }
-#endif
     };
 
     // ---- K extension first: acc = (A2 / rowscale) . B2_g^T, so that the epilogue's single
@@ -346,7 +332,7 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
                     v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
                 }
             }
-            *reinterpret_cast<float4 *>(&As[r * GG_ROW + 4 * s_kq]) = v;
+            put4(As, GG_AIMG, r * GG_ROWB + 8 * s_kq, v, EPI == EPI_ACT && fp32_level);
         }
 #pragma unroll
         for (int u = 0; u < GG_NU; u++) {
@@ -356,7 +342,7 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
             if (n < g.N && k < g.R)
                 b = *reinterpret_cast<const float4 *>(g.b2 + (size_t)bucket * g.b2_gstride +
                                                       (size_t)n * g.b2_ldn + k);
-            *reinterpret_cast<float4 *>(&Bs[r * GG_ROW + 4 * s_kq]) = b;
+            put4(Bs, GG_BIMG, r * GG_ROWB + 8 * s_kq, b, EPI == EPI_ACT && fp32_level);
         }
         __syncthreads();
         contract(g.R, true);              // (the tiles are zero beyond R, up to GG_BK)
@@ -407,38 +393,34 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
         __syncthreads();  // previous tile fully consumed
         // ---- registers -> LDS ----
         // (component-wise: a struct copy of a[u] keeps the whole array in scratch memory)
+        const bool three = EPI == EPI_ACT && fp32_level;
 #pragma unroll
         for (int u = 0; u < NUA; u++)
-            *reinterpret_cast<float4 *>(&As[(s_row + GG_RPP * u) * GG_ROW + 4 * s_kq]) =
-                make_float4(a[u].x, a[u].y, a[u].z, a[u].w);
+            put4(As, GG_AIMG, (s_row + GG_RPP * u) * GG_ROWB + 8 * s_kq,
+                 make_float4(a[u].x, a[u].y, a[u].z, a[u].w), three);
         if (!BN_LAYOUT) {
 #pragma unroll
             for (int u = 0; u < GG_NU; u++)
-                *reinterpret_cast<float4 *>(&Bs[(s_row + GG_RPP * u) * GG_ROW + 4 * s_kq]) =
-                    make_float4(b[u].x, b[u].y, b[u].z, b[u].w);
+                put4(Bs, GG_BIMG, (s_row + GG_RPP * u) * GG_ROWB + 8 * s_kq,
+                     make_float4(b[u].x, b[u].y, b[u].z, b[u].w), three);
         } else {
             // n-contiguous weights keep their orientation in LDS: Bs[k][n], rows of GG_BN + 4
             // floats (transposing them into the [n][k] image needs 4-byte writes 4 rows apart:
             // 16-way bank conflicts)
 #pragma unroll
             for (int u = 0; u < GG_NU; u++)
-                *reinterpret_cast<float4 *>(&Bs[((tid >> 5) + 8 * u) * GG_BNROW + 4 * (tid & 31)]) =
-                    make_float4(b[u].x, b[u].y, b[u].z, b[u].w);
+                put4(Bs, GG_BIMG, ((tid >> 5) + 8 * u) * GG_BNROWB + 8 * (tid & 31),
+                     make_float4(b[u].x, b[u].y, b[u].z, b[u].w), three);
         }
         __syncthreads();
         if (k_next < g.K) load_tile(a, b, k_next);   // this register set is free again
-#ifdef GG_EXACT_FP32
-#pragma unroll
-        for (int q = 0; q < GG_BK / 8; q++) mfma_group(q, !BN_LAYOUT);
-#else
-        if (fp32_level) {
+        if (EPI == EPI_ACT && fp32_level) {
 #pragma unroll
             for (int q2 = 0; q2 < GG_BK / 16; q2++) mfma_group16x6(q2, !BN_LAYOUT);
         } else {
 #pragma unroll
             for (int q2 = 0; q2 < GG_BK / 16; q2++) mfma_group16(q2, !BN_LAYOUT);
         }
-#endif
     };
     load_tile(av[0], bv[0], 0);
     for (int k0 = 0; k0 < g.K; k0 += GG_BK) k_step(av[0], bv[0], k0 + GG_BK);
@@ -561,7 +543,8 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
 template <bool BN_LAYOUT, int EPI, bool EXT, bool KTAIL>
 __global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_kernel(GroupedArgs g) {
     // As | Bs; the epilogue reuses the whole buffer as four per-wave C staging areas
-    __shared__ __attribute__((aligned(16))) float smem[(GG_BM + GG_BN) * GG_ROW];
+    // A | B images (two or, with an activation epilogue, three parts each)
+    __shared__ __attribute__((aligned(16))) float smem[((EPI == EPI_ACT) ? 3 : 2) * (GG_AIMG + GG_BIMG) / 4];
 
     const int n_col_tiles = (g.N + GG_BN - 1) / GG_BN;
     int row_tiles = 0;

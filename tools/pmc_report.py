@@ -1,8 +1,9 @@
-import csv, glob, collections, sys
+import csv, glob, collections, os, sys
 for d in sys.argv[1:]:
     f = glob.glob(f'/root/repo/gpurun_out/{d}/*/*counter_collection.csv')
     if not f: print('no file', d); continue
-    rows = list(csv.DictReader(open(f[0])))
+    f.sort(key=os.path.getmtime)                 # gpurun merges runs: newest pass
+    rows = list(csv.DictReader(open(f[-1])))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
         name = r['Kernel_Name'][:48]
