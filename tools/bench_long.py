@@ -4,7 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'spt-proto_amd'))
 import torch
 from naive_gpt import layers
-N, S, H, E = int(os.environ.get('BATCH', 2)), int(os.environ.get('SEQ', 2048)), 32, 64
+N, S, H, E = (int(os.environ.get('BATCH', 2)), int(os.environ.get('SEQ', 2048)), 32,
+              int(os.environ.get('DHEAD', 64)))
 dev = 'cuda'
 torch.manual_seed(0)
 q, k, v = [torch.randn([N, S, H, E], device=dev, requires_grad=True) for _ in range(3)]
@@ -13,7 +14,7 @@ def timeit(fn, n=10, w=3):
     torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3, torch.cuda.max_memory_allocated() / 1e9
-sparse = layers.SparseVanillaAttentionV2(d_head=E, d_codeword=8, n_codewords=16, p_dropout=0.0).to(dev)
+sparse = layers.SparseVanillaAttentionV2(d_head=E, d_codeword=8, n_codewords=16, p_dropout=0.0).to(dev)   # (M = E / 8 subspaces)
 dense = layers.VanillaAttention(d_head=E, p_dropout=0.0).to(dev)
 mask = torch.full([S, S], float('-inf'), device=dev).triu(1)
 def step(m, mk):
