@@ -265,7 +265,7 @@ int spt_sparse_attention_backward_rows(const int32_t *indices, const float *grad
  *   y[i]       = sum_p exp(s_p) v[col_p] / max(1e-9, row_sum[i]),
  *   s_p        = clamp(scale * q[i].k[col_p]),  entries with col_p > i take no part
  *   row_sum[i] = sum_p exp(s_p)                 (softmax.cu:17-30)
- * Any uniform-row CSR with Z = nnz / S <= 256, Z % 4 == 0, d_head == 64, S <= 2048;
+ * Any uniform-row CSR with Z = nnz / S <= 256, Z % 4 == 0, d_head 64 or 128, S <= 2048;
  * repeated columns count with their multiplicity, which saturates at 255 (reachable only
  * with Z == 256: row 0 of a lookup pattern, where it changes nothing).  SPT_EUNSUP otherwise.
  * Layouts of q, k, v (heads) and y (y_transposed) as in spt_sparse_attention_forward.

@@ -28,7 +28,21 @@
 // bytes with one global_load_dwordx4 a tile ahead and touches no LDS for them.
 #include "spt_common.h"
 
-namespace spt {
+// The file is compiled twice: for d_head 64 (this is the unit that also holds the cell-tile
+// pass and the C entry points) and, with -DMA_E_VALUE=128, for d_head 128 into namespace
+// spt::e128 (mfma_attention_e128.o), to which the entry points dispatch.
+#ifndef MA_E_VALUE
+#define MA_E_VALUE 64
+#endif
+#if MA_E_VALUE == 64
+#define MA_NS_OPEN namespace spt {
+#define MA_NS_CLOSE }
+#else
+#define MA_NS_OPEN namespace spt { namespace e128 {
+#define MA_NS_CLOSE } }
+#endif
+
+MA_NS_OPEN
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -39,16 +53,21 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #endif
 constexpr int MA_THREADS = MA_THREADS_VALUE;       // 512 or 256
 constexpr int MA_WAVES = MA_THREADS / SPT_WAVE;    // 8 or 4
-constexpr int MA_RPT = 512 / MA_THREADS;           // 32 x 64 tile: float4s per thread to stage
+constexpr int MA_E = MA_E_VALUE;                   // d_head: 64 or 128
+constexpr int MA_EQ = MA_E / 4;                    // float4 per row of a tile
+constexpr int MA_RPT = 32 * MA_EQ / MA_THREADS;    // 32 x E tile: float4s per thread to stage
+constexpr int MA_RPP = MA_THREADS / MA_EQ;         // tile rows covered by one float4 per thread
+constexpr int MA_KS = MA_E / 16;                   // k-steps of a contraction over e
+constexpr int MA_ET = MA_E / 32;                   // 32-column tiles of an [*, E] result
+constexpr int MA_BH = MA_E / 64;                   // backward launches: 64 gradient columns each
 constexpr int MA_WROWS = 32;                       // rows per wave = one MFMA tile
 constexpr int MA_ROWS = MA_WAVES * MA_WROWS;       // 256 rows per workgroup
 constexpr int MA_KT = 32;                          // keys per tile
-constexpr int MA_E = 64;
-constexpr int MA_MAXZ = 256;                       // entries per row (cell counts are bytes)
-constexpr int MA_MAXNT = 64;                       // key tiles: S <= 2048
+[[maybe_unused]] constexpr int MA_MAXZ = 256;      // entries per row (cell counts are bytes)
+[[maybe_unused]] constexpr int MA_MAXNT = 64;      // key tiles: S <= 2048
 
 // LDS images of one key tile, bf16: rows padded so that the operand reads are conflict-free
-constexpr int MA_KLD = 144;                        // bytes per key row: 64 bf16 + 16
+constexpr int MA_KLD = MA_E * 2 + 16;              // bytes per row of a rows image: E bf16 + 16
 constexpr int MA_VLD = 72;                         // bytes per e row of V^T: 32 bf16 + 8
 // the forward's tile: K rows image (hi, lo) | V rows image (hi, lo)
 constexpr int MA_KH = 0, MA_KL = MA_KT * MA_KLD, MA_VH = 2 * MA_KT * MA_KLD,
@@ -146,13 +165,13 @@ __device__ __forceinline__ void put4_along_r(char *rows, char *cols, int e, int 
 }
 
 // The forward's key tiles: K as a rows image, V as a cols image.  Thread t stages the
-// float4 (row (t >> 4) + (MA_THREADS / 16) u, columns 4 (t & 15) ..) for u < MA_RPT.
+// float4 (row t / (E/4) + MA_RPP u, columns 4 (t % (E/4)) ..) for u < MA_RPT.
 struct TileRegs { float4 kf[MA_RPT], vf[MA_RPT]; };
 struct TileStager {
     const float *k_b, *v_b;
     int ld, S, jl, e4;
     __device__ __forceinline__ TileStager(const float *k, const float *v, int ld_, int S_, int tid)
-        : k_b(k), v_b(v), ld(ld_), S(S_), jl(tid >> 4), e4((tid & 15) * 4) {}
+        : k_b(k), v_b(v), ld(ld_), S(S_), jl(tid / MA_EQ), e4((tid % MA_EQ) * 4) {}
     // Unconditional loads with clamped rows: a load under a branch makes the compiler wait
     // with vmcnt(0) for OLDER loads too (it cannot count what the branch issued), which
     // exposed the full memory latency in every iteration.  Keys >= S read row S - 1: finite
@@ -161,7 +180,7 @@ struct TileStager {
         TileRegs r;
 #pragma unroll
         for (int u = 0; u < MA_RPT; u++) {
-            const int j = min(t * MA_KT + jl + (MA_THREADS / 16) * u, S - 1);
+            const int j = min(t * MA_KT + jl + MA_RPP * u, S - 1);
             r.kf[u] = *reinterpret_cast<const float4 *>(k_b + (size_t)j * ld + e4);
             r.vf[u] = *reinterpret_cast<const float4 *>(v_b + (size_t)j * ld + e4);
         }
@@ -170,8 +189,8 @@ struct TileStager {
     __device__ __forceinline__ void store(char *buf, const TileRegs &r) const {
 #pragma unroll
         for (int u = 0; u < MA_RPT; u++) {
-            put4_along_e<true, false>(buf + MA_KH, nullptr, jl + (MA_THREADS / 16) * u, e4, r.kf[u]);
-            put4_along_e<true, false>(buf + MA_VH, nullptr, jl + (MA_THREADS / 16) * u, e4, r.vf[u]);
+            put4_along_e<true, false>(buf + MA_KH, nullptr, jl + MA_RPP * u, e4, r.kf[u]);
+            put4_along_e<true, false>(buf + MA_VH, nullptr, jl + MA_RPP * u, e4, r.vf[u]);
         }
     }
 };
@@ -244,12 +263,12 @@ __device__ __forceinline__ Frag read_rows_tr(const char *hi, const char *lo, int
 // B-operand fragments of a wave's own 32 rows of a dense operand: lane (r, h) holds row
 // i0 + r, elements 8h + 16ks .. + 8.  TR == false: x[row * ld + e]; TR: x[e * S + row].
 template <bool TR>
-__device__ __forceinline__ void load_own_rows_raw(float (&x)[32], const float *x_b, int ld, int S,
+__device__ __forceinline__ void load_own_rows_raw(float (&x)[MA_E / 2], const float *x_b, int ld, int S,
                                                   int i0, int lane) {
     // rows >= S read row S - 1 (unconditional loads; such rows are never stored)
     const int row = min(i0 + (lane & 31), S - 1), h = lane >> 5;
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
+    for (int ks = 0; ks < MA_KS; ks++) {
         if (!TR) {
             const float *p = x_b + (size_t)row * ld + 8 * h + 16 * ks;
             const float4 a = *reinterpret_cast<const float4 *>(p);
@@ -265,10 +284,10 @@ __device__ __forceinline__ void load_own_rows_raw(float (&x)[32], const float *x
 }
 // split into the four k-step fragments, optionally pre-multiplied (the score scale folded
 // into the operand: one multiply per element here instead of one per cell per tile)
-__device__ __forceinline__ void split_own_rows(Frag (&f)[4], const float (&x)[32],
+__device__ __forceinline__ void split_own_rows(Frag (&f)[MA_KS], const float (&x)[MA_E / 2],
                                                float mult = 1.0f) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++)
+    for (int ks = 0; ks < MA_KS; ks++)
         f[ks] = split8(x[8 * ks] * mult, x[8 * ks + 1] * mult, x[8 * ks + 2] * mult,
                        x[8 * ks + 3] * mult, x[8 * ks + 4] * mult, x[8 * ks + 5] * mult,
                        x[8 * ks + 6] * mult, x[8 * ks + 7] * mult);
@@ -297,12 +316,12 @@ __device__ __forceinline__ void store_acc_half(const f32x16 &acc, float mult, fl
 }
 // A wave's own 32 rows of an operand stored [E][S] (row i0 .. of every e) into the fragment
 // order of load_own_rows_raw: x[8 ks + j] = src[(8h + 16ks + j) * S + i0 + (lane & 31)].
-__device__ __forceinline__ void load_own_rows_transposed(float (&x)[32], const float *src, int S,
+__device__ __forceinline__ void load_own_rows_transposed(float (&x)[MA_E / 2], const float *src, int S,
                                                          int i0, float *tile, int lane) {
     const int c32 = lane & 31, h = lane >> 5;
     const int i4 = min(i0 + (lane & 7) * 4, S - 4) - i0;      // (S % 4 == 0; rows >= S unused)
 #pragma unroll
-    for (int hf = 0; hf < 2; hf++) {
+    for (int hf = 0; hf < MA_ET; hf++) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int el = (lane >> 3) + 8 * k;
@@ -530,7 +549,11 @@ __device__ __forceinline__ float cell_count(unsigned word) {
 // two workgroups per CU (4 waves per SIMD, 128 VGPRs): the barrier keeps the waves of one
 // workgroup in the same phase, a second workgroup fills the other pipes meanwhile
 #ifndef MA_WAVES_PER_EU
+#if MA_E_VALUE == 64
 #define MA_WAVES_PER_EU 4
+#else
+#define MA_WAVES_PER_EU 2       // (64 + 64 registers of Q fragments and accumulators alone)
+#endif
 #endif
 #ifndef MA_SUB
 #define MA_SUB 1            // key tiles per forward iteration (2: 48 -> 58-71 us at the bench shape)
@@ -589,9 +612,9 @@ void attention_mfma_forward_kernel(
         nxt[u] = stager.load(min(u, T - 1));
         mcur[u] = ct.load(u, lane);
     }
-    Frag qf[4];
+    Frag qf[MA_KS];
     {
-        float xq[32];
+        float xq[MA_E / 2];
         load_own_rows_raw<false>(xq, q + dv.base, dv.ld, S, i0, lane);
 #pragma unroll
         for (int u = 0; u < SUB; u++) stager.store(img + u * MA_IMG, nxt[u]);
@@ -599,9 +622,11 @@ void attention_mfma_forward_kernel(
     }
     __syncthreads();
 
-    f32x16 yacc[2];
+    f32x16 yacc[MA_ET];
 #pragma unroll
-    for (int r = 0; r < 16; r++) yacc[0][r] = yacc[1][r] = 0.f;
+    for (int eh = 0; eh < MA_ET; eh++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) yacc[eh][r] = 0.f;
     float rs = 0.f;
 
     const int NIT = (T + SUB - 1) / SUB;
@@ -626,7 +651,7 @@ void attention_mfma_forward_kernel(
                 for (int r = 0; r < 16; r++) d[u][r] = 0.f;
             }
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
+            for (int ks = 0; ks < MA_KS; ks++) {
 #pragma unroll
                 for (int u = 0; u < SUB; u++)
                     d[u] = mma3(read_rows(buf + u * MA_IMG + MA_KH, buf + u * MA_IMG + MA_KL, lane, ks),
@@ -653,7 +678,7 @@ void attention_mfma_forward_kernel(
                     const Frag pf = split8(p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3],
                                            p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]);
 #pragma unroll
-                    for (int eh = 0; eh < 2; eh++)
+                    for (int eh = 0; eh < MA_ET; eh++)
                         yacc[eh] = mma3(pf, read_cols_tr(buf + u * MA_IMG + MA_VH, buf + u * MA_IMG + MA_VL,
                                                          32 * eh, lane, s2), yacc[eh]);
                 }
@@ -696,8 +721,9 @@ void attention_mfma_forward_kernel(
                 const int il = acc_row(r, h);
                 const float sc = wstat[il];
                 if (i0 + il < S) {
-                    y_b[(size_t)(i0 + il) * MA_E + c32] = yacc[0][r] * sc;
-                    y_b[(size_t)(i0 + il) * MA_E + 32 + c32] = yacc[1][r] * sc;
+#pragma unroll
+                    for (int eh = 0; eh < MA_ET; eh++)
+                        y_b[(size_t)(i0 + il) * MA_E + 32 * eh + c32] = yacc[eh][r] * sc;
                 }
             }
         } else {
@@ -708,7 +734,7 @@ void attention_mfma_forward_kernel(
             // of one e and a store instruction writes 8 such runs.
             float *tile = reinterpret_cast<float *>(img) + wave * (32 * MA_TLD);
 #pragma unroll
-            for (int eh = 0; eh < 2; eh++) {
+            for (int eh = 0; eh < MA_ET; eh++) {
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const int il = 8 * g + 4 * h;
@@ -767,7 +793,7 @@ struct RowsStager : TileStager {
     __device__ __forceinline__ void store(char *buf, const TileRegs &r) const {
 #pragma unroll
         for (int u = 0; u < MA_RPT; u++) {
-            const int row = jl + (MA_THREADS / 16) * u;
+            const int row = jl + MA_RPP * u;
             put4_along_e<true, false>(buf + MR_KR, nullptr, row, e4, r.kf[u]);
             put4_along_e<true, false>(buf + MR_VR, nullptr, row, e4, r.vf[u]);
         }
@@ -783,7 +809,7 @@ void attention_mfma_backward_rows_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ gy, const float *__restrict__ y,
     const float *__restrict__ row_sum, float *__restrict__ grad_q, float *__restrict__ delta,
-    int S, float scale, float clampv, int heads, int blocks_per_batch) {
+    int S, float scale, float clampv, int heads, int blocks_per_batch, int half) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *img = smem;                                   // [2][MR_IMG]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -818,12 +844,12 @@ void attention_mfma_backward_rows_kernel(
         mcur[u] = ct.load(u, lane);
     }
     // own rows: dY (B operand of dP = V dY^T), delta = max(1e-9, dY . Y), Q (B operand of D)
-    Frag gf[4], qf[4];
+    Frag gf[MA_KS], qf[MA_KS];
     float delta_i;
     const int row = i0 + c32;
     const float rsum = row_sum[(size_t)b * S + min(row, S - 1)];
     {
-        float xr[32], yr[32], xq[32];
+        float xr[MA_E / 2], yr[MA_E / 2], xq[MA_E / 2];
         const size_t ob = (size_t)b * S * MA_E;
         load_own_rows_raw<false>(xq, q + dv.base, dv.ld, S, i0, lane);
         if (GT) {
@@ -841,7 +867,7 @@ void attention_mfma_backward_rows_kernel(
         for (int u = 0; u < SUB; u++) stager.store(img + u * MR_IMG, nxt[u]);
         float dl = 0.f;
 #pragma unroll
-        for (int x = 0; x < 32; x++) dl = fmaf(xr[x], yr[x], dl);
+        for (int x = 0; x < MA_E / 2; x++) dl = fmaf(xr[x], yr[x], dl);
         dl += __shfl_xor(dl, 32, SPT_WAVE);
         delta_i = fmaxf(1e-9f, dl);
         // scale / row_sum is a per-row factor of dS: folded into dY (and delta) once here
@@ -849,7 +875,7 @@ void attention_mfma_backward_rows_kernel(
         const float pscale = scale / fmaxf(1e-9f, rsum);
         split_own_rows(gf, xr, pscale);
         split_own_rows(qf, xq, sm.sl2);
-        if (h == 0 && row < S) delta[(size_t)b * S + row] = delta_i;
+        if (h == 0 && row < S && half == 0) delta[(size_t)b * S + row] = delta_i;
         delta_i *= pscale;
     }
     __syncthreads();
@@ -877,7 +903,7 @@ void attention_mfma_backward_rows_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) d[r] = dp[r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
+            for (int ks = 0; ks < MA_KS; ks++) {
                 d = mma3(read_rows(buf + MR_KR, buf + MR_KR + MA_RIMG, lane, ks), qf[ks], d);
                 dp = mma3(read_rows(buf + MR_VR, buf + MR_VR + MA_RIMG, lane, ks), gf[ks], dp);
             }
@@ -901,8 +927,8 @@ void attention_mfma_backward_rows_kernel(
                                        ds[8 * s2 + 4], ds[8 * s2 + 5], ds[8 * s2 + 6], ds[8 * s2 + 7]);
 #pragma unroll
                 for (int eh = 0; eh < 2; eh++)
-                    qacc[eh] = mma3(sf, read_cols_tr(buf + MR_KR, buf + MR_KR + MA_RIMG, 32 * eh,
-                                                     lane, s2), qacc[eh]);
+                    qacc[eh] = mma3(sf, read_cols_tr(buf + MR_KR, buf + MR_KR + MA_RIMG,
+                                                     64 * half + 32 * eh, lane, s2), qacc[eh]);
             }
         }
         if (it + 1 < NIT) {
@@ -916,7 +942,7 @@ void attention_mfma_backward_rows_kernel(
     }
     if (i0 < S) {
         float *tile = reinterpret_cast<float *>(img) + wave * (32 * MA_TLD);
-        float *gq_b = grad_q + dv.base + (size_t)i0 * dv.ld;
+        float *gq_b = grad_q + dv.base + (size_t)i0 * dv.ld + 64 * half;
         store_acc_half(qacc[0], 1.0f, tile, gq_b, dv.ld, S - i0, lane);
         store_acc_half(qacc[1], 1.0f, tile, gq_b + 32, dv.ld, S - i0, lane);
     }
@@ -931,9 +957,9 @@ void attention_mfma_backward_rows_kernel(
 // images: Q rows | dY (rows image, or -- GT, the operand arriving as [E][S] -- a cols image:
 // whichever its source layout fills with 8-byte stores; the other orientation of each operand
 // comes from the transposing read) | the rows' scaled delta
-constexpr int MK_QR = 0, MK_G = 2 * MA_RIMG, MK_ST = 4 * MA_RIMG,
-              MK_IMG = MK_ST + MA_WROWS * 4;                                // 18560 B
-static_assert(MA_CIMG == MA_RIMG, "the dY slot holds either orientation");
+constexpr int MK_GSLOT = MA_CIMG > MA_RIMG ? MA_CIMG : MA_RIMG;           // either orientation
+constexpr int MK_QR = 0, MK_G = 2 * MA_RIMG, MK_ST = 2 * MA_RIMG + 2 * MK_GSLOT,
+              MK_IMG = MK_ST + MA_WROWS * 4;                                // 18560 B at E = 64
 template <bool GT>
 struct KeysStager {
     const float *q_b, *gy_b, *rs_b, *dl_b;
@@ -945,10 +971,10 @@ struct KeysStager {
     __device__ __forceinline__ Regs load(int rt) const {
         Regs r;
         const int i0 = rt * MA_WROWS;
-        const int e4 = (tid & 15) * 4;
+        const int e4 = (tid % MA_EQ) * 4;
 #pragma unroll
         for (int u = 0; u < MA_RPT; u++) {
-            const int il = (tid >> 4) + (MA_THREADS / 16) * u;
+            const int il = tid / MA_EQ + MA_RPP * u;
             const int row = min(i0 + il, S - 1);
             r.qf[u] = *reinterpret_cast<const float4 *>(q_b + (size_t)row * ld + e4);
             if (!GT) {
@@ -970,13 +996,13 @@ struct KeysStager {
     // pre-multiplied by it, rows >= S by 0, and the rows' delta likewise
     __device__ __forceinline__ void store(char *buf, const Regs &r, int rt) const {
         const int i0 = rt * MA_WROWS;
-        const int e4 = (tid & 15) * 4;
+        const int e4 = (tid % MA_EQ) * 4;
         auto weight = [&](float rs, int row) {
             return row < S ? 1.0f / fmaxf(1e-9f, rs) : 0.0f;
         };
 #pragma unroll
         for (int u = 0; u < MA_RPT; u++) {
-            const int il = (tid >> 4) + (MA_THREADS / 16) * u;
+            const int il = tid / MA_EQ + MA_RPP * u;
             put4_along_e<true, false>(buf + MK_QR, nullptr, il, e4, r.qf[u]);
             if (!GT) {
                 const float w = weight(r.rs[u].x, i0 + il);
@@ -1006,7 +1032,7 @@ void attention_mfma_backward_keys_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ gy, const float *__restrict__ row_sum,
     const float *__restrict__ delta, float *__restrict__ grad_k, float *__restrict__ grad_v,
-    int S, float scale, float clampv, int heads, int blocks_per_batch) {
+    int S, float scale, float clampv, int heads, int blocks_per_batch, int half) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *img = smem;                                   // [2][MK_IMG]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1021,9 +1047,9 @@ void attention_mfma_backward_keys_kernel(
     const bool have = j0 < S;
 
     const ScoreMap sm(scale, clampv);
-    Frag kf[4], vf[4];
+    Frag kf[MA_KS], vf[MA_KS];
     {
-        float xk[32], xv[32];
+        float xk[MA_E / 2], xv[MA_E / 2];
         load_own_rows_raw<false>(xk, k + dv.base, dv.ld, S, j0, lane);
         load_own_rows_raw<false>(xv, v + dv.base, dv.ld, S, j0, lane);
         split_own_rows(kf, xk, sm.sl2);     // the score scale (log2 domain) folded into K
@@ -1077,7 +1103,7 @@ void attention_mfma_backward_keys_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) d[r] = dp[r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
+            for (int ks = 0; ks < MA_KS; ks++) {
                 d = mma3(read_rows(buf + MK_QR, buf + MK_QR + MA_RIMG, lane, ks), kf[ks], d);
                 dp = mma3(GT ? read_rows_tr(buf + MK_G, buf + MK_G + MA_CIMG, lane, ks)
                              : read_rows(buf + MK_G, buf + MK_G + MA_RIMG, lane, ks),
@@ -1109,11 +1135,12 @@ void attention_mfma_backward_keys_kernel(
                                        ds[8 * s2 + 4], ds[8 * s2 + 5], ds[8 * s2 + 6], ds[8 * s2 + 7]);
 #pragma unroll
                 for (int eh = 0; eh < 2; eh++) {
+                    const int col0 = 64 * half + 32 * eh;
                     vacc[eh] = mma3(pf, GT ? read_cols(buf + MK_G, buf + MK_G + MA_CIMG,
-                                                       c32 + 32 * eh, h, s2)
+                                                       c32 + col0, h, s2)
                                            : read_cols_tr(buf + MK_G, buf + MK_G + MA_RIMG,
-                                                          32 * eh, lane, s2), vacc[eh]);
-                    kacc[eh] = mma3(sf, read_cols_tr(buf + MK_QR, buf + MK_QR + MA_RIMG, 32 * eh,
+                                                          col0, lane, s2), vacc[eh]);
+                    kacc[eh] = mma3(sf, read_cols_tr(buf + MK_QR, buf + MK_QR + MA_RIMG, col0,
                                                      lane, s2), kacc[eh]);
                 }
             }
@@ -1125,8 +1152,8 @@ void attention_mfma_backward_keys_kernel(
     }
     if (have) {
         float *tile = reinterpret_cast<float *>(img) + wave * (32 * MA_TLD);
-        float *gk_b = grad_k + dv.base + (size_t)j0 * dv.ld;
-        float *gv_b = grad_v + dv.base + (size_t)j0 * dv.ld;
+        float *gk_b = grad_k + dv.base + (size_t)j0 * dv.ld + 64 * half;
+        float *gv_b = grad_v + dv.base + (size_t)j0 * dv.ld + 64 * half;
         store_acc_half(kacc[0], scale, tile, gk_b, dv.ld, S - j0, lane);
         store_acc_half(kacc[1], scale, tile, gk_b + 32, dv.ld, S - j0, lane);
         store_acc_half(vacc[0], 1.0f, tile, gv_b, dv.ld, S - j0, lane);
@@ -1134,13 +1161,81 @@ void attention_mfma_backward_keys_kernel(
     }
 }
 
-static bool mfma_shape_ok(int S, int E, int nnz) {
-    if (E != MA_E || S <= 0 || nnz <= 0 || nnz % S != 0) return false;
-    const int Z = nnz / S;
-    return Z <= MA_MAXZ && Z % 4 == 0 && S <= MA_MAXNT * MA_KT;
-}
 static size_t mfma_forward_lds() {
     return 2 * MA_SUB * MA_IMG + (size_t)MA_WAVES * MA_WROWS * sizeof(float);
+}
+
+// ---- launchers of this head dimension (the d_head 64 unit dispatches to spt::e128's) ----
+int launch_forward(const unsigned long long *masks, const unsigned char *cells, const float *q,
+                   const float *k, const float *v, float *y, float *row_sum, int batch_size,
+                   int S, float scale, float clamp, int heads, int y_transposed, hipStream_t s) {
+    const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
+    const size_t lds = mfma_forward_lds();
+    const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
+    SPT_HIP_TRY(hipFuncSetAttribute(
+        y_transposed ? (const void *)attention_mfma_forward_kernel<true>
+                     : (const void *)attention_mfma_forward_kernel<false>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (y_transposed)
+        hipLaunchKernelGGL(attention_mfma_forward_kernel<true>, grid, block, lds, s, masks, cells,
+                           q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
+    else
+        hipLaunchKernelGGL(attention_mfma_forward_kernel<false>, grid, block, lds, s, masks, cells,
+                           q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
+int launch_backward(const unsigned long long *masks, const unsigned char *cells,
+                    const unsigned char *cells_t, const float *q, const float *k, const float *v,
+                    const float *y, const float *grad_y, const float *row_sum, float *delta,
+                    float *grad_q, float *grad_k, float *grad_v, int batch_size, int S,
+                    float scale, float clamp, int heads, int transposed, hipStream_t s) {
+    const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
+    const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
+    const size_t lds_r = 2 * MR_SUB * MR_IMG, lds_k = 2 * MK_IMG;
+    // 64 gradient columns per launch (the accumulators of 128 would not fit the registers
+    // beside the operands' fragments): d_head 128 runs each kernel twice
+#define SPT_MB(GT)                                                                              \
+    do {                                                                                        \
+        SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
+            (const void *)attention_mfma_backward_rows_kernel<GT>,                              \
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));                           \
+        SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
+            (const void *)attention_mfma_backward_keys_kernel<GT>,                              \
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));                           \
+        for (int half = 0; half < MA_BH; half++)                                                \
+            hipLaunchKernelGGL(attention_mfma_backward_rows_kernel<GT>, grid, block, lds_r, s,  \
+                               masks, cells, q, k, v, grad_y, y, row_sum, grad_q, delta, S,     \
+                               scale, clamp, heads, bpb, half);                                 \
+        for (int half = 0; half < MA_BH; half++)                                                \
+            hipLaunchKernelGGL(attention_mfma_backward_keys_kernel<GT>, grid, block, lds_k, s,  \
+                               masks, cells_t, q, k, v, grad_y, row_sum, delta, grad_k, grad_v, \
+                               S, scale, clamp, heads, bpb, half);                              \
+    } while (0)
+    if (transposed) SPT_MB(true);
+    else SPT_MB(false);
+#undef SPT_MB
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
+#if MA_E_VALUE == 64
+namespace e128 {
+int launch_forward(const unsigned long long *masks, const unsigned char *cells, const float *q,
+                   const float *k, const float *v, float *y, float *row_sum, int batch_size,
+                   int S, float scale, float clamp, int heads, int y_transposed, hipStream_t s);
+int launch_backward(const unsigned long long *masks, const unsigned char *cells,
+                    const unsigned char *cells_t, const float *q, const float *k, const float *v,
+                    const float *y, const float *grad_y, const float *row_sum, float *delta,
+                    float *grad_q, float *grad_k, float *grad_v, int batch_size, int S,
+                    float scale, float clamp, int heads, int transposed, hipStream_t s);
+}  // namespace e128
+
+static bool mfma_shape_ok(int S, int E, int nnz) {
+    if ((E != 64 && E != 128) || S <= 0 || nnz <= 0 || nnz % S != 0) return false;
+    const int Z = nnz / S;
+    return Z <= MA_MAXZ && Z % 4 == 0 && S <= MA_MAXNT * MA_KT;
 }
 struct TileSet {
     unsigned long long *masks;
@@ -1161,9 +1256,11 @@ static TileSet carve_tiles(void *ws, int B, int S) {
     t.cells_t = t.cells + tile_cells_bytes(B, S);
     return t;
 }
+#endif
 
-}  // namespace spt
+MA_NS_CLOSE
 
+#if MA_E_VALUE == 64
 extern "C" int spt_attention_mfma_supported(int seq_length, int d_head, int nnz) {
     return spt::mfma_shape_ok(seq_length, d_head, nnz) ? 1 : 0;
 }
@@ -1211,24 +1308,13 @@ extern "C" int spt_attention_mfma_forward(const void *tiles, const float *q, con
     if (batch_size <= 0 || heads < 0) return SPT_EINVAL;
     if (!mfma_shape_ok(seq_length, d_head, nnz)) return SPT_EUNSUP;
     if (heads > 0 && batch_size % heads != 0) return SPT_ESHAPE;
-    const int S = seq_length;
-    const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
-    const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, S);
-    const size_t lds = mfma_forward_lds();
+    const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
-    SPT_HIP_TRY(hipFuncSetAttribute(
-        y_transposed ? (const void *)attention_mfma_forward_kernel<true>
-                     : (const void *)attention_mfma_forward_kernel<false>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (y_transposed)
-        hipLaunchKernelGGL(attention_mfma_forward_kernel<true>, grid, block, lds, s, ts.masks,
-                           ts.cells, q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
-    else
-        hipLaunchKernelGGL(attention_mfma_forward_kernel<false>, grid, block, lds, s, ts.masks,
-                           ts.cells, q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
-    SPT_LAUNCH_CHECK();
-    return SPT_OK;
+    return d_head == 64
+               ? launch_forward(ts.masks, ts.cells, q, k, v, y, row_sum, batch_size, seq_length,
+                                scale, clamp, heads, y_transposed, s)
+               : e128::launch_forward(ts.masks, ts.cells, q, k, v, y, row_sum, batch_size,
+                                      seq_length, scale, clamp, heads, y_transposed, s);
 }
 
 extern "C" int spt_attention_mfma_backward(const void *tiles, const float *q, const float *k,
@@ -1244,31 +1330,15 @@ extern "C" int spt_attention_mfma_backward(const void *tiles, const float *q, co
     if (batch_size <= 0 || heads < 0) return SPT_EINVAL;
     if (!mfma_shape_ok(seq_length, d_head, nnz)) return SPT_EUNSUP;
     if (heads > 0 && batch_size % heads != 0) return SPT_ESHAPE;
-    const int S = seq_length;
-    if (transposed && (S & 3)) return SPT_EUNSUP;
-    const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
-    const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, S);
+    if (transposed && (seq_length & 3)) return SPT_EUNSUP;
+    const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
-    const size_t lds_r = 2 * MR_SUB * MR_IMG, lds_k = 2 * MK_IMG;
-#define SPT_MB(GT)                                                                              \
-    do {                                                                                        \
-        SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
-            (const void *)attention_mfma_backward_rows_kernel<GT>,                              \
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));                           \
-        hipLaunchKernelGGL(attention_mfma_backward_rows_kernel<GT>, grid, block, lds_r, s,      \
-                           ts.masks, ts.cells, q, k, v, grad_y, y, row_sum, grad_q, delta, S,   \
-                           scale, clamp, heads, bpb);                                           \
-        SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
-            (const void *)attention_mfma_backward_keys_kernel<GT>,                              \
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));                           \
-        hipLaunchKernelGGL(attention_mfma_backward_keys_kernel<GT>, grid, block, lds_k, s,      \
-                           ts.masks, ts.cells_t, q, k, v, grad_y, row_sum, delta, grad_k,       \
-                           grad_v, S, scale, clamp, heads, bpb);                                \
-    } while (0)
-    if (transposed) SPT_MB(true);
-    else SPT_MB(false);
-#undef SPT_MB
-    SPT_LAUNCH_CHECK();
-    return SPT_OK;
+    return d_head == 64
+               ? launch_backward(ts.masks, ts.cells, ts.cells_t, q, k, v, y, grad_y, row_sum,
+                                 delta, grad_q, grad_k, grad_v, batch_size, seq_length, scale,
+                                 clamp, heads, transposed, s)
+               : e128::launch_backward(ts.masks, ts.cells, ts.cells_t, q, k, v, y, grad_y, row_sum,
+                                       delta, grad_q, grad_k, grad_v, batch_size, seq_length,
+                                       scale, clamp, heads, transposed, s);
 }
+#endif

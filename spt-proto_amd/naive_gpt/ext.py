@@ -486,7 +486,7 @@ def attention_mfma_forward(tiles, q: torch.Tensor, k: torch.Tensor, v: torch.Ten
     N, S, H, E = q.shape
     B = N * H
     if isinstance(tiles, torch.Tensor):
-        _require(E == 64, 'attention_mfma: d_head == 64')
+        _require(E in (64, 128), 'attention_mfma: d_head 64 or 128')
         tiles = attention_mfma_prepare(tiles, S)
     _require(tiles.batch == B and tiles.seq == S, 'tiles: prepared for [N * H, nnz] indices at S')
     dev = _same_device(tiles.buffer, q, k, v)

@@ -7,32 +7,35 @@ from test_gpu_fused_attention import CLAMP, causal_indices, oracle_chain
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [
-    (2, 16, 512, 64), (1, 32, 256, 32), (4, 8, 128, 16),
-    (2, 16, 80, 8),                    # S not a multiple of the 32-row tile
-    (1, 4, 1024, 64),                  # four row blocks per slice
-    (1, 2, 2048, 64),                  # the longest supported sequence
-    (1, 4, 96, 64),                    # Z close to S: many repeated columns
-    (1, 2, 2048, 256),                 # Z = S / 8 at the longest sequence: row 0 saturates a cell
-    (1, 2, 1024, 128),
+SHAPES = [                             # (N, H, S, Z, d_head)
+    (2, 16, 512, 64, 64), (1, 32, 256, 32, 64), (4, 8, 128, 16, 64),
+    (2, 16, 80, 8, 64),                # S not a multiple of the 32-row tile
+    (1, 4, 1024, 64, 64),              # four row blocks per slice
+    (1, 2, 2048, 64, 64),              # the longest supported sequence
+    (1, 4, 96, 64, 64),                # Z close to S: many repeated columns
+    (1, 2, 2048, 256, 64),             # Z = S / 8 at the longest sequence: row 0 saturates a cell
+    (1, 2, 1024, 128, 64),
+    (2, 8, 512, 64, 128),              # d_head 128 (LLaMA heads): the spt::e128 kernels,
+    (1, 4, 80, 8, 128),                # two 64-column backward launches each
+    (1, 2, 1024, 128, 128),
 ]
 
 
 @pytest.mark.parametrize('yt', [False, True])
-@pytest.mark.parametrize('N,H,S,Z', SHAPES)
-def test_mfma_forward_matches_oracle_chain(N, H, S, Z, yt):
+@pytest.mark.parametrize('N,H,S,Z,E', SHAPES)
+def test_mfma_forward_matches_oracle_chain(N, H, S, Z, E, yt):
     from naive_gpt import ext
     gen = torch.Generator().manual_seed(N * S + Z)
-    q, k, v = [torch.randn([N, S, H, 64], generator=gen) for _ in range(3)]
+    q, k, v = [torch.randn([N, S, H, E], generator=gen) for _ in range(3)]
     q = q * 3.0                                    # some scores beyond the clamp
     indices = causal_indices(N * H, S, Z, gen)     # random with repeats: multiplicities matter
-    scale = 64 ** -0.5
-    assert ext.attention_mfma_supported(S, 64, S * Z)
+    scale = E ** -0.5
+    assert ext.attention_mfma_supported(S, E, S * Z)
     want_scores, want_attn, want_y = oracle_chain(indices, q, k, v, scale)
     y, row_sum = ext.attention_mfma_forward(indices.cuda(), q.cuda(), k.cuda(), v.cuda(),
                                             scale, CLAMP, y_transposed=yt)
     if yt:
-        assert y.shape == (N * H, 64, S)
+        assert y.shape == (N * H, E, S)
         y = y.transpose(1, 2)
     rows = torch.arange(S).view(1, S, 1)
     live = (indices.view(N * H, S, Z) <= rows).float()
@@ -50,8 +53,8 @@ def test_mfma_forward_matches_oracle_chain(N, H, S, Z, yt):
 
 
 @pytest.mark.parametrize('gt', [False, True])
-@pytest.mark.parametrize('N,H,S,Z', SHAPES)
-def test_mfma_backward_matches_oracle_chain(N, H, S, Z, gt):
+@pytest.mark.parametrize('N,H,S,Z,E', SHAPES)
+def test_mfma_backward_matches_oracle_chain(N, H, S, Z, E, gt):
     """grad_q, grad_k, grad_v against the oracle operators chained as the reference's autograd
     does: dP = sddmm(dY, V); dS = clamp-mask(scale * softmax_backward(P, dP));
     dQ = spmm(dS, K); dK = spmm(dS^T, Q); dV = spmm(P^T, dY)."""
@@ -59,7 +62,7 @@ def test_mfma_backward_matches_oracle_chain(N, H, S, Z, gt):
     from oracle import ext_stub
     from naive_gpt import ext
     gen = torch.Generator().manual_seed(7 * N + S + Z)
-    B, E = N * H, 64
+    B = N * H
     q, k, v = [torch.randn([N, S, H, E], generator=gen) for _ in range(3)]
     q = q * 3.0
     gy = torch.randn([B, S, E], generator=gen)
@@ -104,7 +107,7 @@ def test_mfma_forward_masks_columns_beyond_the_row():
 
 def test_mfma_unsupported_shapes_are_refused():
     from naive_gpt import ext
-    assert not ext.attention_mfma_supported(128, 32, 128 * 16)        # d_head 32
+    assert not ext.attention_mfma_supported(128, 32, 128 * 16)        # d_head 32 (64 and 128 only)
     assert not ext.attention_mfma_supported(4096, 64, 4096 * 64)      # S > 2048
     assert not ext.attention_mfma_supported(4096, 64, 4096 * 512)     # Z > 256
     q = torch.randn([1, 4096, 2, 64], device='cuda')
