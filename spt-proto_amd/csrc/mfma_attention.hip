@@ -1024,7 +1024,12 @@ struct KeysStager {
     }
 };
 
-template <bool GT>
+// MODE 0: grad_k and grad_v together, 64 columns (`half`) per launch -- d_head 64.
+// d_head 128 cannot hold K, V fragments (128 registers) and four accumulator tiles beside the
+// tile arithmetic (the combined kernel spilled 41-60 registers: 281 us per launch), so there
+// MODE 1: grad_v alone, all 128 columns (needs P only: no V fragments, no dP, no delta);
+// MODE 2: grad_k alone, 64 columns per launch.
+template <bool GT, int MODE>
 __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_KEYS_WAVES_PER_EU, MA_KEYS_WAVES_PER_EU)))
 void attention_mfma_backward_keys_kernel(
@@ -1046,14 +1051,19 @@ void attention_mfma_backward_keys_kernel(
     const int RT = (S + MA_WROWS - 1) / MA_WROWS;
     const bool have = j0 < S;
 
+    constexpr bool WANT_K = MODE != 1, WANT_V = MODE != 2;
+    constexpr int NVT = MODE == 1 ? MA_ET : 2;           // 32-column tiles of grad_v produced
     const ScoreMap sm(scale, clampv);
-    Frag kf[MA_KS], vf[MA_KS];
+    Frag kf[MA_KS], vf[WANT_K ? MA_KS : 1];
     {
-        float xk[MA_E / 2], xv[MA_E / 2];
+        float xk[MA_E / 2];
         load_own_rows_raw<false>(xk, k + dv.base, dv.ld, S, j0, lane);
-        load_own_rows_raw<false>(xv, v + dv.base, dv.ld, S, j0, lane);
         split_own_rows(kf, xk, sm.sl2);     // the score scale (log2 domain) folded into K
-        split_own_rows(vf, xv);
+        if constexpr (WANT_K) {             // V only feeds dP, which only dS needs
+            float xv[MA_E / 2];
+            load_own_rows_raw<false>(xv, v + dv.base, dv.ld, S, j0, lane);
+            split_own_rows(vf, xv);
+        }
     }
     // the slice's row-tile masks live in registers (lane rt: mask of row tile rt), so that the
     // loop body has no load whose result it needs at once
@@ -1089,9 +1099,13 @@ void attention_mfma_backward_keys_kernel(
     uint4 mcur = cell_load(rt0);
     __syncthreads();
 
-    f32x16 kacc[2], vacc[2];
+    f32x16 kacc[2], vacc[NVT];
 #pragma unroll
-    for (int r = 0; r < 16; r++) kacc[0][r] = kacc[1][r] = vacc[0][r] = vacc[1][r] = 0.f;
+    for (int r = 0; r < 16; r++) kacc[0][r] = kacc[1][r] = 0.f;
+#pragma unroll
+    for (int e = 0; e < NVT; e++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) vacc[e][r] = 0.f;
 
     for (int rt = rt0; rt < RT; rt++) {
         const char *buf = img + ((rt - rt0) & 1) * MK_IMG;
@@ -1105,9 +1119,10 @@ void attention_mfma_backward_keys_kernel(
 #pragma unroll
             for (int ks = 0; ks < MA_KS; ks++) {
                 d = mma3(read_rows(buf + MK_QR, buf + MK_QR + MA_RIMG, lane, ks), kf[ks], d);
-                dp = mma3(GT ? read_rows_tr(buf + MK_G, buf + MK_G + MA_CIMG, lane, ks)
-                             : read_rows(buf + MK_G, buf + MK_G + MA_RIMG, lane, ks),
-                          vf[ks], dp);
+                if constexpr (WANT_K)
+                    dp = mma3(GT ? read_rows_tr(buf + MK_G, buf + MK_G + MA_CIMG, lane, ks)
+                                 : read_rows(buf + MK_G, buf + MK_G + MA_RIMG, lane, ks),
+                              vf[ks], dp);
             }
             // this lane: key j0 + c32, rows 8g + 4h + u of the tile in register 4g + u
             const float *st = reinterpret_cast<const float *>(buf + MK_ST);
@@ -1116,7 +1131,8 @@ void attention_mfma_backward_keys_kernel(
             float p[16], ds[16];
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
-                const float4 del4 = *reinterpret_cast<const float4 *>(st + 8 * g4 + 4 * h);
+                float4 del4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (WANT_K) del4 = *reinterpret_cast<const float4 *>(st + 8 * g4 + 4 * h);
                 const float del[4] = {del4.x, del4.y, del4.z, del4.w};
                 const float m4[4] = {cell_count<0>(mw[g4]), cell_count<1>(mw[g4]),
                                      cell_count<2>(mw[g4]), cell_count<3>(mw[g4])};
@@ -1124,7 +1140,9 @@ void attention_mfma_backward_keys_kernel(
                 for (int u = 0; u < 4; u++) {
                     const int r = 4 * g4 + u;
                     p[r] = m4[u] * sm.exp_of(d[r]);          // x 1 / row_sum: in the dY images
-                    ds[r] = sm.inside(d[r]) ? p[r] * (dp[r] - del[u]) : 0.0f;   // x scale: epilogue
+                    ds[r] = 0.0f;
+                    if constexpr (WANT_K)                    // x scale: in the epilogue
+                        ds[r] = sm.inside(d[r]) ? p[r] * (dp[r] - del[u]) : 0.0f;
                 }
             }
 #pragma unroll
@@ -1133,15 +1151,21 @@ void attention_mfma_backward_keys_kernel(
                                        p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]);
                 const Frag sf = split8(ds[8 * s2], ds[8 * s2 + 1], ds[8 * s2 + 2], ds[8 * s2 + 3],
                                        ds[8 * s2 + 4], ds[8 * s2 + 5], ds[8 * s2 + 6], ds[8 * s2 + 7]);
+                if constexpr (WANT_V) {
 #pragma unroll
-                for (int eh = 0; eh < 2; eh++) {
-                    const int col0 = 64 * half + 32 * eh;
-                    vacc[eh] = mma3(pf, GT ? read_cols(buf + MK_G, buf + MK_G + MA_CIMG,
-                                                       c32 + col0, h, s2)
-                                           : read_cols_tr(buf + MK_G, buf + MK_G + MA_RIMG,
-                                                          col0, lane, s2), vacc[eh]);
-                    kacc[eh] = mma3(sf, read_cols_tr(buf + MK_QR, buf + MK_QR + MA_RIMG, col0,
-                                                     lane, s2), kacc[eh]);
+                    for (int eh = 0; eh < NVT; eh++) {
+                        const int col0 = (MODE == 1 ? 0 : 64 * half) + 32 * eh;
+                        vacc[eh] = mma3(pf, GT ? read_cols(buf + MK_G, buf + MK_G + MA_CIMG,
+                                                           c32 + col0, h, s2)
+                                               : read_cols_tr(buf + MK_G, buf + MK_G + MA_RIMG,
+                                                              col0, lane, s2), vacc[eh]);
+                    }
+                }
+                if constexpr (WANT_K) {
+#pragma unroll
+                    for (int eh = 0; eh < 2; eh++)
+                        kacc[eh] = mma3(sf, read_cols_tr(buf + MK_QR, buf + MK_QR + MA_RIMG,
+                                                         64 * half + 32 * eh, lane, s2), kacc[eh]);
                 }
             }
         }
@@ -1152,12 +1176,17 @@ void attention_mfma_backward_keys_kernel(
     }
     if (have) {
         float *tile = reinterpret_cast<float *>(img) + wave * (32 * MA_TLD);
-        float *gk_b = grad_k + dv.base + (size_t)j0 * dv.ld + 64 * half;
-        float *gv_b = grad_v + dv.base + (size_t)j0 * dv.ld + 64 * half;
-        store_acc_half(kacc[0], scale, tile, gk_b, dv.ld, S - j0, lane);
-        store_acc_half(kacc[1], scale, tile, gk_b + 32, dv.ld, S - j0, lane);
-        store_acc_half(vacc[0], 1.0f, tile, gv_b, dv.ld, S - j0, lane);
-        store_acc_half(vacc[1], 1.0f, tile, gv_b + 32, dv.ld, S - j0, lane);
+        if constexpr (WANT_K) {
+            float *gk_b = grad_k + dv.base + (size_t)j0 * dv.ld + 64 * half;
+            store_acc_half(kacc[0], scale, tile, gk_b, dv.ld, S - j0, lane);
+            store_acc_half(kacc[1], scale, tile, gk_b + 32, dv.ld, S - j0, lane);
+        }
+        if constexpr (WANT_V) {
+            float *gv_b = grad_v + dv.base + (size_t)j0 * dv.ld + (MODE == 1 ? 0 : 64 * half);
+#pragma unroll
+            for (int eh = 0; eh < NVT; eh++)
+                store_acc_half(vacc[eh], 1.0f, tile, gv_b + 32 * eh, dv.ld, S - j0, lane);
+        }
     }
 }
 
@@ -1201,21 +1230,30 @@ int launch_backward(const unsigned long long *masks, const unsigned char *cells,
         SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
             (const void *)attention_mfma_backward_rows_kernel<GT>,                              \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));                           \
-        SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
-            (const void *)attention_mfma_backward_keys_kernel<GT>,                              \
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));                           \
         for (int half = 0; half < MA_BH; half++)                                                \
             hipLaunchKernelGGL(attention_mfma_backward_rows_kernel<GT>, grid, block, lds_r, s,  \
                                masks, cells, q, k, v, grad_y, y, row_sum, grad_q, delta, S,     \
                                scale, clamp, heads, bpb, half);                                 \
-        for (int half = 0; half < MA_BH; half++)                                                \
-            hipLaunchKernelGGL(attention_mfma_backward_keys_kernel<GT>, grid, block, lds_k, s,  \
-                               masks, cells_t, q, k, v, grad_y, row_sum, delta, grad_k, grad_v, \
-                               S, scale, clamp, heads, bpb, half);                              \
+        if (MA_BH == 1) {                                                                       \
+            SPT_KEYS(GT, 0, 0);                                                                 \
+        } else {                                                                                \
+            SPT_KEYS(GT, 1, 0);                                                                 \
+            for (int half = 0; half < MA_BH; half++) SPT_KEYS(GT, 2, half);                     \
+        }                                                                                       \
+    } while (0)
+#define SPT_KEYS(GT, MODE, HALF)                                                                \
+    do {                                                                                        \
+        SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
+            (const void *)attention_mfma_backward_keys_kernel<GT, MODE>,                        \
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));                           \
+        hipLaunchKernelGGL((attention_mfma_backward_keys_kernel<GT, MODE>), grid, block, lds_k, \
+                           s, masks, cells_t, q, k, v, grad_y, row_sum, delta, grad_k, grad_v,  \
+                           S, scale, clamp, heads, bpb, HALF);                                  \
     } while (0)
     if (transposed) SPT_MB(true);
     else SPT_MB(false);
 #undef SPT_MB
+#undef SPT_KEYS
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }
