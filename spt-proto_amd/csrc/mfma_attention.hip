@@ -558,6 +558,12 @@ __device__ __forceinline__ float cell_count(unsigned word) {
 #ifndef MA_SUB
 #define MA_SUB 1            // key tiles per forward iteration (2: 48 -> 58-71 us at the bench shape)
 #endif
+#ifndef MK_KTILES
+#define MK_KTILES 2         // 32-column tiles of grad_k per launch of the key-owned kernel
+#endif
+#ifndef MR_QTILES
+#define MR_QTILES 2         // 32-column tiles of grad_q per launch of the row-owned kernel
+#endif
 #ifndef MR_SUB
 #define MR_SUB 1            // key tiles per iteration of the row-owned backward kernel (2: no faster)
 #endif
@@ -880,9 +886,11 @@ void attention_mfma_backward_rows_kernel(
     }
     __syncthreads();
 
-    f32x16 qacc[2];
+    f32x16 qacc[MR_QTILES];
 #pragma unroll
-    for (int r = 0; r < 16; r++) qacc[0][r] = qacc[1][r] = 0.f;
+    for (int e = 0; e < MR_QTILES; e++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) qacc[e][r] = 0.f;
 
     const int NIT = (T + SUB - 1) / SUB;
     for (int it = 0; it < NIT; it++) {
@@ -926,9 +934,10 @@ void attention_mfma_backward_rows_kernel(
                 const Frag sf = split8(ds[8 * s2], ds[8 * s2 + 1], ds[8 * s2 + 2], ds[8 * s2 + 3],
                                        ds[8 * s2 + 4], ds[8 * s2 + 5], ds[8 * s2 + 6], ds[8 * s2 + 7]);
 #pragma unroll
-                for (int eh = 0; eh < 2; eh++)
+                for (int eh = 0; eh < MR_QTILES; eh++)
                     qacc[eh] = mma3(sf, read_cols_tr(buf + MR_KR, buf + MR_KR + MA_RIMG,
-                                                     64 * half + 32 * eh, lane, s2), qacc[eh]);
+                                                     32 * MR_QTILES * half + 32 * eh, lane, s2),
+                                    qacc[eh]);
             }
         }
         if (it + 1 < NIT) {
@@ -942,9 +951,10 @@ void attention_mfma_backward_rows_kernel(
     }
     if (i0 < S) {
         float *tile = reinterpret_cast<float *>(img) + wave * (32 * MA_TLD);
-        float *gq_b = grad_q + dv.base + (size_t)i0 * dv.ld + 64 * half;
-        store_acc_half(qacc[0], 1.0f, tile, gq_b, dv.ld, S - i0, lane);
-        store_acc_half(qacc[1], 1.0f, tile, gq_b + 32, dv.ld, S - i0, lane);
+        float *gq_b = grad_q + dv.base + (size_t)i0 * dv.ld + 32 * MR_QTILES * half;
+#pragma unroll
+        for (int eh = 0; eh < MR_QTILES; eh++)
+            store_acc_half(qacc[eh], 1.0f, tile, gq_b + 32 * eh, dv.ld, S - i0, lane);
     }
 }
 
@@ -1099,9 +1109,11 @@ void attention_mfma_backward_keys_kernel(
     uint4 mcur = cell_load(rt0);
     __syncthreads();
 
-    f32x16 kacc[2], vacc[NVT];
+    f32x16 kacc[MK_KTILES], vacc[NVT];
 #pragma unroll
-    for (int r = 0; r < 16; r++) kacc[0][r] = kacc[1][r] = 0.f;
+    for (int e = 0; e < MK_KTILES; e++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) kacc[e][r] = 0.f;
 #pragma unroll
     for (int e = 0; e < NVT; e++)
 #pragma unroll
@@ -1163,9 +1175,10 @@ void attention_mfma_backward_keys_kernel(
                 }
                 if constexpr (WANT_K) {
 #pragma unroll
-                    for (int eh = 0; eh < 2; eh++)
+                    for (int eh = 0; eh < MK_KTILES; eh++)
                         kacc[eh] = mma3(sf, read_cols_tr(buf + MK_QR, buf + MK_QR + MA_RIMG,
-                                                         64 * half + 32 * eh, lane, s2), kacc[eh]);
+                                                         32 * MK_KTILES * half + 32 * eh, lane, s2),
+                                        kacc[eh]);
                 }
             }
         }
@@ -1177,9 +1190,10 @@ void attention_mfma_backward_keys_kernel(
     if (have) {
         float *tile = reinterpret_cast<float *>(img) + wave * (32 * MA_TLD);
         if constexpr (WANT_K) {
-            float *gk_b = grad_k + dv.base + (size_t)j0 * dv.ld + 64 * half;
-            store_acc_half(kacc[0], scale, tile, gk_b, dv.ld, S - j0, lane);
-            store_acc_half(kacc[1], scale, tile, gk_b + 32, dv.ld, S - j0, lane);
+            float *gk_b = grad_k + dv.base + (size_t)j0 * dv.ld + 32 * MK_KTILES * half;
+#pragma unroll
+            for (int eh = 0; eh < MK_KTILES; eh++)
+                store_acc_half(kacc[eh], scale, tile, gk_b + 32 * eh, dv.ld, S - j0, lane);
         }
         if constexpr (WANT_V) {
             float *gv_b = grad_v + dv.base + (size_t)j0 * dv.ld + (MODE == 1 ? 0 : 64 * half);
@@ -1230,7 +1244,7 @@ int launch_backward(const unsigned long long *masks, const unsigned char *cells,
         SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
             (const void *)attention_mfma_backward_rows_kernel<GT>,                              \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));                           \
-        for (int half = 0; half < MA_BH; half++)                                                \
+        for (int half = 0; half < MA_ET / MR_QTILES; half++)                                    \
             hipLaunchKernelGGL(attention_mfma_backward_rows_kernel<GT>, grid, block, lds_r, s,  \
                                masks, cells, q, k, v, grad_y, y, row_sum, grad_q, delta, S,     \
                                scale, clamp, heads, bpb, half);                                 \
@@ -1238,7 +1252,7 @@ int launch_backward(const unsigned long long *masks, const unsigned char *cells,
             SPT_KEYS(GT, 0, 0);                                                                 \
         } else {                                                                                \
             SPT_KEYS(GT, 1, 0);                                                                 \
-            for (int half = 0; half < MA_BH; half++) SPT_KEYS(GT, 2, half);                     \
+            for (int half = 0; half < MA_ET / MK_KTILES; half++) SPT_KEYS(GT, 2, half);         \
         }                                                                                       \
     } while (0)
 #define SPT_KEYS(GT, MODE, HALF)                                                                \
