@@ -8,19 +8,32 @@ import torch
 from torch import nn, optim
 from naive_gpt import layers, utils
 
-d_model, n_heads, d_ff = 1024, 16, 4096
+# FAMILY=llama: RMSNorm, rotary attention, SiLU-gated FFN (BASELINE config 5 with
+# D_MODEL=4096 N_HEADS=32 D_FF=11008 SEQ=2048 BATCH=1)
+family = os.environ.get('FAMILY', 'opt')
+d_model, n_heads, d_ff = (int(os.environ.get('D_MODEL', 1024)), int(os.environ.get('N_HEADS', 16)),
+                          int(os.environ.get('D_FF', 4096)))
 N, S = int(os.environ.get('BATCH', 16)), int(os.environ.get('SEQ', 512))
 dev = 'cuda'
 
 
 def build(tuning):
     torch.manual_seed(0)
-    model = layers.TransformerBlock(
-        d_model=d_model, n_heads=n_heads, layernorm_fn=nn.LayerNorm(d_model),
-        attention_fn=layers.VanillaAttention(d_head=d_model // n_heads, p_dropout=0.0),
-        feedforward_fn=layers.Feedforward(d_model=d_model, d_feedforward=d_ff,
-                                          activation=nn.ReLU(), p_dropout=0.0),
-        attention_bias=True, pre_norm=True)
+    if family == 'llama':
+        model = layers.TransformerBlock(
+            d_model=d_model, n_heads=n_heads, layernorm_fn=layers.LlamaRMSNorm(d_model),
+            attention_fn=layers.RotaryAttention(d_head=d_model // n_heads, p_dropout=0.0,
+                                                max_length=S),
+            feedforward_fn=layers.LLaMaFeedforward(d_model=d_model, d_feedforward=d_ff,
+                                                   activation=nn.SiLU()),
+            attention_bias=False, pre_norm=True)
+    else:
+        model = layers.TransformerBlock(
+            d_model=d_model, n_heads=n_heads, layernorm_fn=nn.LayerNorm(d_model),
+            attention_fn=layers.VanillaAttention(d_head=d_model // n_heads, p_dropout=0.0),
+            feedforward_fn=layers.Feedforward(d_model=d_model, d_feedforward=d_ff,
+                                              activation=nn.ReLU(), p_dropout=0.0),
+            attention_bias=True, pre_norm=True)
     with contextlib.redirect_stdout(io.StringIO()):
         if tuning == 'lora':
             model = utils.ModuleUpgrader(utils.LoRAHandler(d_lora=16)).visit(model)
@@ -60,7 +73,7 @@ def run(tuning, steps=10, warmup=5):
     return res
 
 
-out = {'config': {'d_model': d_model, 'n_heads': n_heads, 'd_ff': d_ff, 'batch': N, 'seq': S,
+out = {'config': {'family': family, 'd_model': d_model, 'n_heads': n_heads, 'd_ff': d_ff, 'batch': N, 'seq': S,
                   'dtype': 'f32', 'what': 'one TransformerBlock, fwd+bwd+AdamW'}}
 tunings = os.environ.get('TUNINGS', 'full,lora,sparse').split(',')
 for tuning in tunings:

@@ -5,6 +5,8 @@ python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; tai
 python bench.py --trigger --no-cpu --no-dense > gpurun_out/final_bench_trigger.json 2>/dev/null
 python tools/bench_block.py > gpurun_out/final_block.json 2>/dev/null
 python tools/bench_ffn.py > gpurun_out/final_ffn.json 2>/dev/null
+D_MODEL=2048 N_HEADS=32 D_FF=8192 SEQ=2048 BATCH=2 python tools/bench_block.py > gpurun_out/final_block_opt1b3.json 2>/dev/null
+FAMILY=llama D_MODEL=4096 N_HEADS=32 D_FF=11008 SEQ=2048 BATCH=1 python tools/bench_block.py > gpurun_out/final_block_llama7b.json 2>/dev/null
 timeout -k 10 600 python tools/bench_model.py > gpurun_out/final_model.json 2>/dev/null
 python tools/bench_long.py > gpurun_out/final_long.json 2>/dev/null
 python tools/time_mfma.py > gpurun_out/final_mfma_ops.txt 2>/dev/null
