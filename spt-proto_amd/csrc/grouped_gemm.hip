@@ -39,6 +39,19 @@ constexpr int GG_BN = 128;
 #define GG_BK_VALUE 32
 #endif
 constexpr int GG_BK = GG_BK_VALUE;
+// Register sets of prefetched k-steps in flight per thread (each 32 VGPRs: 164 / 196 / 228), and
+// the workgroups per CU the round arithmetic of grouped_gemm_kernel counts on.  Measured at the
+// FFN shape (1040 tiles; tools/time_gemm_variants.sh): PF 2 and 3 = +-0 % (160 / 172 / 168 us),
+// so a k-step is not waiting for its loads; 2 slots per CU (more full tiles, fewer 64-row
+// halves -- a half stages 75 % of a full tile's bytes for half its products) 152 us against 162
+// with 3, the upgraded block 2.68 against 2.77 ms.
+#ifndef GG_PF_VALUE
+#define GG_PF_VALUE 1
+#endif
+#ifndef GG_SLOTS_PER_CU
+#define GG_SLOTS_PER_CU 2
+#endif
+constexpr int GG_PF = GG_PF_VALUE;
 constexpr int GG_KQ = GG_BK / 4;               // float4 per tile row
 constexpr int GG_RPP = GG_THREADS / GG_KQ;      // tile rows staged per pass
 constexpr int GG_NU = GG_BM / GG_RPP;           // passes (float4 loads per thread per operand)
@@ -66,6 +79,11 @@ typedef __attribute__((ext_vector_type(2))) __bf16 gg_bf16x2;
 typedef __attribute__((ext_vector_type(2))) float gg_f32x2;
 struct GgFrag { uint4 hi, lo; };
 __device__ __forceinline__ void gg_split2(float a, float b, unsigned &hi, unsigned &lo) {
+#ifdef GG_EXP_NOSPLIT   // timing experiment only (wrong numbers): what the split's VALU costs
+    hi = (__builtin_bit_cast(unsigned, a) >> 16) | (__builtin_bit_cast(unsigned, b) & 0xffff0000u);
+    lo = hi;
+    return;
+#endif
     const gg_f32x2 x = {a, b};
     hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, gg_bf16x2));
     const gg_f32x2 hf = {__builtin_bit_cast(float, hi << 16),
@@ -196,7 +214,16 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
 
     // ---- staging assignment: tile = rows x GG_KQ float4 along k ----
     // thread -> row (tid / GG_KQ) + GG_RPP u, k-quad tid % GG_KQ
+    // (8 lanes per row; the two rows of a 16-lane ds_write_b64 group are 4 apart: 320 bytes = 64
+    // mod 128, so their 64-byte pieces fall on disjoint banks -- adjacent rows, 80 bytes apart,
+    // share four: SQ_LDS_BANK_CONFLICT was a third of the LDS-array cycles)
+#ifdef GG_ROWS_IN_ORDER
     const int s_row = tid / GG_KQ, s_kq = tid % GG_KQ;
+#else
+    static_assert(GG_KQ == 8, "row interleave below assumes 8 lanes per tile row");
+    const int s_slot = (tid >> 3) & 7;
+    const int s_row = (tid >> 6) * 8 + (((s_slot & 1) << 2) | (s_slot >> 1)), s_kq = tid & 7;
+#endif
     // Rows past the bucket end and columns past N are computed but never stored, so their
     // operands only have to be readable: clamp them to the last valid row / column instead
     // of predicating the loads.
@@ -353,7 +380,7 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
     // of step t run; registers -> LDS happens at the top of the next step.  (A second
     // register set, two steps in flight, changed nothing for the half tiles of the last
     // round: +-0 % measured.) ----
-    constexpr int PF = 1;
+    constexpr int PF = GG_PF;
     float4 av[PF][NUA], bv[PF][GG_NU];
     // KTAIL == false (K % GG_BK == 0, every shape of the FFN): no predicate anywhere in the
     // loads.  The predicated form compiles into branches around the loads, 8 per k-step.
@@ -413,7 +440,17 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
                      make_float4(b[u].x, b[u].y, b[u].z, b[u].w), three);
         }
         __syncthreads();
+#ifdef GG_EXP_NOLOAD     // timing experiment only: no global loads after the second k-step
+        if (k_next < 2 * GG_BK) load_tile(a, b, k_next);
+#else
         if (k_next < g.K) load_tile(a, b, k_next);   // this register set is free again
+#endif
+#ifdef GG_EXP_NOMFMA     // timing experiment only: staging without the contraction
+        if (g.K > 0) return;
+#endif
+#ifdef GG_PRIO_MFMA
+        __builtin_amdgcn_s_setprio(GG_PRIO_MFMA);
+#endif
         if (EPI == EPI_ACT && fp32_level) {
 #pragma unroll
             for (int q2 = 0; q2 < GG_BK / 16; q2++) mfma_group16x6(q2, !BN_LAYOUT);
@@ -421,9 +458,18 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
 #pragma unroll
             for (int q2 = 0; q2 < GG_BK / 16; q2++) mfma_group16(q2, !BN_LAYOUT);
         }
+#ifdef GG_PRIO_MFMA
+        __builtin_amdgcn_s_setprio(GG_PRIO_STAGE);
+#endif
     };
-    load_tile(av[0], bv[0], 0);
-    for (int k0 = 0; k0 < g.K; k0 += GG_BK) k_step(av[0], bv[0], k0 + GG_BK);
+#pragma unroll
+    for (int st = 0; st < PF; st++)
+        if (st * GG_BK < g.K) load_tile(av[st], bv[st], st * GG_BK);
+    for (int k0 = 0; k0 < g.K; k0 += PF * GG_BK) {
+#pragma unroll
+        for (int st = 0; st < PF; st++)
+            if (k0 + st * GG_BK < g.K) k_step(av[st], bv[st], k0 + (st + PF) * GG_BK);
+    }
 
     // ---- epilogue ----
     // MFMA C layout: acc[i][j][r] = C[32 i + (r & 3) + 8 (r >> 2) + 4 (l >> 5)][32 j + (l & 31)]
@@ -634,7 +680,7 @@ __global__ __launch_bounds__(256) void rows_combine_kernel(
 
 using namespace spt;
 
-// Workgroups resident at a time: 3 per CU (166 VGPRs -> 3 waves per SIMD; 36 KiB LDS).
+// Workgroups per round: GG_SLOTS_PER_CU per CU (three fit: 166 VGPRs, 40 KiB LDS; two measured faster).
 static int resident_slots() {
     static int slots = 0;
     if (slots == 0) {
@@ -642,7 +688,7 @@ static int resident_slots() {
         if (hipGetDevice(&dev) != hipSuccess) return -1;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             return -1;
-        slots = 3 * cus;
+        slots = GG_SLOTS_PER_CU * cus;
     }
     return slots;
 }
