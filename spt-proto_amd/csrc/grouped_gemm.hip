@@ -416,8 +416,32 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
             }
         }
     };
+#ifdef GG_STAMP
+    // diagnostic build only: shader-clock time of wave 0 in each phase of the k-loop
+    // (barrier 1 | wait for the prefetched tile | split + LDS stores | barrier 2 | reads + MFMAs)
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};
+#define GG_PHASE(i)                                                        \
+    do {                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                 \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
+        ph[i] += now_ - ph_t;                                              \
+        ph_t = now_;                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                 \
+    } while (0)
+#else
+#define GG_PHASE(i)
+#endif
     auto k_step = [&](float4 (&a)[NUA], float4 (&b)[GG_NU], int k_next) {
+#ifdef GG_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long ph_t = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();  // previous tile fully consumed
+        GG_PHASE(0);
+#ifdef GG_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GG_PHASE(1);
+#endif
         // ---- registers -> LDS ----
         // (component-wise: a struct copy of a[u] keeps the whole array in scratch memory)
         const bool three = EPI == EPI_ACT && fp32_level;
@@ -439,7 +463,9 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
                 put4(Bs, GG_BIMG, ((tid >> 5) + 8 * u) * GG_BNROWB + 8 * (tid & 31),
                      make_float4(b[u].x, b[u].y, b[u].z, b[u].w), three);
         }
+        GG_PHASE(2);
         __syncthreads();
+        GG_PHASE(3);
 #ifdef GG_EXP_NOLOAD     // timing experiment only: no global loads after the second k-step
         if (k_next < 2 * GG_BK) load_tile(a, b, k_next);
 #else
@@ -461,6 +487,7 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
 #ifdef GG_PRIO_MFMA
         __builtin_amdgcn_s_setprio(GG_PRIO_STAGE);
 #endif
+        GG_PHASE(4);
     };
 #pragma unroll
     for (int st = 0; st < PF; st++)
@@ -471,6 +498,12 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
             if (k0 + st * GG_BK < g.K) k_step(av[st], bv[st], k0 + (st + PF) * GG_BK);
     }
 
+#ifdef GG_STAMP
+    if (EPI == EPI_PLAIN && g.pdot_main && tid == 0) {
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(g.pdot_main);
+        for (int i = 0; i < 5; i++) st[12 * blockIdx.x + 4 + i] = ph[i];
+    }
+#endif
     // ---- epilogue ----
     // MFMA C layout: acc[i][j][r] = C[32 i + (r & 3) + 8 (r >> 2) + 4 (l >> 5)][32 j + (l & 31)]
     // of the wave's (32 NI) x 64 part.  Each wave transposes it through LDS, 32 rows at a
@@ -649,10 +682,10 @@ __global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_kernel(GroupedArgs
 #ifdef GG_STAMP
     if (EPI == EPI_PLAIN && g.pdot_main && threadIdx.x == 0) {
         unsigned long long *st = reinterpret_cast<unsigned long long *>(g.pdot_main);
-        st[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - st_t0;
-        st[4 * blockIdx.x + 1] = st_r0;
-        st[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
-        st[4 * blockIdx.x + 3] = (unsigned long long)(half + 1);
+        st[12 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - st_t0;
+        st[12 * blockIdx.x + 1] = st_r0;
+        st[12 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+        st[12 * blockIdx.x + 3] = (unsigned long long)(half + 1);
     }
 #endif
 }

@@ -15,7 +15,7 @@ w1 = torch.randn([dff, d], device=dev)
 h = torch.randn([P, bs], device=dev)
 lib = ext.load_library()
 n_blocks = 2 * (P // 128 + 4) * 8
-stamps = torch.zeros([4 * n_blocks], dtype=torch.int64, device=dev)
+stamps = torch.zeros([12 * n_blocks], dtype=torch.int64, device=dev)
 out = torch.empty([P, 1024], device=dev)
 
 def launch(bn):
@@ -39,7 +39,7 @@ for bn in (False, True):
     stamps.zero_()
     launch(bn)
     torch.cuda.synchronize()
-    st = stamps.view(-1, 4).cpu()
+    st = stamps.view(-1, 12).cpu()
     st = st[st[:, 2] > 0]
     start = (st[:, 1] - st[:, 1].min()).double() / 100.0        # us
     end = (st[:, 2] - st[:, 1].min()).double() / 100.0
@@ -52,6 +52,13 @@ for bn in (False, True):
             print('   %s: n %d  start %.1f..%.1f  end %.1f..%.1f  dur median %.1f min %.1f max %.1f' % (
                 name, int(m.sum()), start[m].min(), start[m].max(), end[m].min(), end[m].max(),
                 dur[m].median(), dur[m].min(), dur[m].max()))
+    # wave 0's shader-clock time per phase of the k-loop, median over full tiles (cycles per tile)
+    names = ['barrier1', 'wait_loads', 'split+lds_store', 'barrier2', 'reads+mfma']
+    for name, m in (('full', full), ('half', halves)):
+        if m.any():
+            print('   %s phases (cycles per tile, median):' % name,
+                  {n: int(st[m][:, 4 + i].median()) for i, n in enumerate(names)},
+                  'tile total', int(st[m][:, 0].median()))
     # start-time histogram of all blocks in 20 us bins
     import collections
     bins = collections.Counter((start / 20).long().tolist())
