@@ -222,16 +222,20 @@ class RoutedLoRAFFN(torch.autograd.Function):
         dz_rows = dzt.index_select(0, bk.token_long)
         grad_coeff = dot_main + (dot_act - (du * u_rows).sum(dim=-1)
                                  - (dz_rows * z).sum(dim=-1)) / coeff
-        dxs = ext.grouped_gemm_fused(
-            ds, w1, bk.offsets, nb, n=d, k=bs, w_group_stride=bs * d, w_ldn=1, w_ldk=d,
-            n_rows=rows, rowscale=coeff, a2=du, b2=l1, b2_group_stride=0)
-        grad_x = ext.rows_combine(dxs, bk.pos)
-        # LoRA tables
+        # LoRA tables (before the last GEMM: ds [P, bs] is released as soon as that has read it --
+        # the step's peak memory is here, with h, ds, dxs and grad_x alive)
         du_tok = du[pos].sum(dim=1)                                          # [T, r]
         grad_l1 = _tn(x, du_tok)
         grad_r1 = _block_major(_tn(ds, _in_own_block(u_rows, bk.block, nb)), nb)
         grad_l2 = _block_major(_tn(h, _in_own_block(dz_rows, bk.block, nb)), nb)
         grad_r2 = _tn(dy, z[pos].sum(dim=1))
+        del dot_main, dot_act, u_rows, dz_rows, du_tok, dzt
+        dxs = ext.grouped_gemm_fused(
+            ds, w1, bk.offsets, nb, n=d, k=bs, w_group_stride=bs * d, w_ldn=1, w_ldk=d,
+            n_rows=rows, rowscale=coeff, a2=du, b2=l1, b2_group_stride=0)
+        del ds, du
+        grad_x = ext.rows_combine(dxs, bk.pos)
+        del dxs
         return (grad_x, grad_coeff, grad_l1, grad_r1, grad_l2, grad_r2,
                 None, None, None, None, None, None)
 
@@ -305,6 +309,7 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
             ag = activation(g_)
             dg, = torch.autograd.grad(ag, g_, dh * sd)
         dsd = dh * ag.detach()
+        del dh, ag, g_                       # [P, bs] each: the step's peak memory is in here
 
         def down(dpre, pre, w, u, l_table, r_table):
             """-> (dx rows [P, d], d coefficient [P], grad of the two LoRA tables)"""
@@ -319,8 +324,13 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
             return dxs, dc, grad_l, grad_r
 
         dxs_g, dc_g, grad_lg, grad_rg = down(dg, g, wg, ug, lg, rg)
+        del dg
         dxs_s, dc_s, grad_ls, grad_rs = down(dsd, sd, ws, us, ls, rs)
-        grad_x = ext.rows_combine(dxs_g.add_(dxs_s), bk.pos)
+        del dsd
+        dxs_g.add_(dxs_s)
+        del dxs_s
+        grad_x = ext.rows_combine(dxs_g, bk.pos)
+        del dxs_g
         grad_coeff = grad_coeff + dc_g + dc_s
         grad_ld = _block_major(_tn(h, _in_own_block(dz_rows, bk.block, nb)), nb)
         grad_rd = _tn(dy, z[pos].sum(dim=1))
