@@ -29,6 +29,7 @@
 // ds_write_b128 of the float4 that came from global memory (no register shuffling).  Rows
 // are padded by 16 bytes, which makes the b128 reads of 16 consecutive rows conflict-free.
 #include "spt_common.h"
+#include <type_traits>
 
 namespace spt {
 
@@ -51,6 +52,13 @@ constexpr int GG_BK = GG_BK_VALUE;
 #ifndef GG_SLOTS_PER_CU
 #define GG_SLOTS_PER_CU 2
 #endif
+// Two LDS stages (80 KiB per workgroup, two workgroups per CU): the next tile's images are
+// written while the current one is contracted, one barrier per k-step.  Not for the three-part
+// images of the activation epilogue (120 KiB: one workgroup per CU).
+#ifndef GG_DB_VALUE
+#define GG_DB_VALUE 0
+#endif
+template <int EPI> struct GgStages { static constexpr int value = (GG_DB_VALUE && EPI != 1) ? 2 : 1; };
 constexpr int GG_PF = GG_PF_VALUE;
 constexpr int GG_KQ = GG_BK / 4;               // float4 per tile row
 constexpr int GG_RPP = GG_THREADS / GG_KQ;      // tile rows staged per pass
@@ -202,7 +210,10 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
     constexpr int NI = BM / 64;               // 32-row sub-blocks per wave
     constexpr int NUA = BM / GG_RPP;          // float4 of A per thread per k-step
     constexpr int NPART = (EPI == EPI_ACT) ? 3 : 2;      // hi, lo (, mid)
-    char *As = reinterpret_cast<char *>(smem);            // [NPART][GG_AIMG]: hi | lo | mid
+    constexpr int STAGES = GgStages<EPI>::value;
+    constexpr int STAGE_BYTES = NPART * (GG_AIMG + GG_BIMG);
+    char *const lds0 = reinterpret_cast<char *>(smem);
+    char *As = lds0;                                      // [NPART][GG_AIMG]: hi | lo | mid
     char *Bs = As + NPART * GG_AIMG;                       // [NPART][GG_BIMG]
     const int n0 = col_tile * GG_BN;
     const int tid = threadIdx.x;
@@ -431,6 +442,39 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
 #else
 #define GG_PHASE(i)
 #endif
+    // ---- registers -> LDS images at (a_img, b_img) ----
+    // (component-wise: a struct copy of a[u] keeps the whole array in scratch memory)
+    auto stage_store = [&](float4 (&a)[NUA], float4 (&b)[GG_NU], char *a_img, char *b_img) {
+        const bool three = EPI == EPI_ACT && fp32_level;
+#pragma unroll
+        for (int u = 0; u < NUA; u++)
+            put4(a_img, GG_AIMG, (s_row + GG_RPP * u) * GG_ROWB + 8 * s_kq,
+                 make_float4(a[u].x, a[u].y, a[u].z, a[u].w), three);
+        if (!BN_LAYOUT) {
+#pragma unroll
+            for (int u = 0; u < GG_NU; u++)
+                put4(b_img, GG_BIMG, (s_row + GG_RPP * u) * GG_ROWB + 8 * s_kq,
+                     make_float4(b[u].x, b[u].y, b[u].z, b[u].w), three);
+        } else {
+            // n-contiguous weights keep their orientation in LDS: Bs[k][n], rows of GG_BN + 4
+            // floats (transposing them into the [n][k] image needs 4-byte writes 4 rows apart:
+            // 16-way bank conflicts)
+#pragma unroll
+            for (int u = 0; u < GG_NU; u++)
+                put4(b_img, GG_BIMG, ((tid >> 5) + 8 * u) * GG_BNROWB + 8 * (tid & 31),
+                     make_float4(b[u].x, b[u].y, b[u].z, b[u].w), three);
+        }
+    };
+    // one register of the next tile (no k tail here: only used by the interleaved steady state)
+    auto load_a1 = [&](int u, int k0) {
+        return *reinterpret_cast<const float4 *>(a_src[u] + k0 + 4 * s_kq);
+    };
+    auto load_b1 = [&](int u, int k0) {
+        if constexpr (!BN_LAYOUT)
+            return *reinterpret_cast<const float4 *>(b_src[u] + k0 + 4 * s_kq);
+        else
+            return *reinterpret_cast<const float4 *>(bn_src + (size_t)(k0 + (tid >> 5) + 8 * u) * g.ldk);
+    };
     auto k_step = [&](float4 (&a)[NUA], float4 (&b)[GG_NU], int k_next) {
 #ifdef GG_STAMP
         __builtin_amdgcn_sched_barrier(0);
@@ -442,27 +486,7 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GG_PHASE(1);
 #endif
-        // ---- registers -> LDS ----
-        // (component-wise: a struct copy of a[u] keeps the whole array in scratch memory)
-        const bool three = EPI == EPI_ACT && fp32_level;
-#pragma unroll
-        for (int u = 0; u < NUA; u++)
-            put4(As, GG_AIMG, (s_row + GG_RPP * u) * GG_ROWB + 8 * s_kq,
-                 make_float4(a[u].x, a[u].y, a[u].z, a[u].w), three);
-        if (!BN_LAYOUT) {
-#pragma unroll
-            for (int u = 0; u < GG_NU; u++)
-                put4(Bs, GG_BIMG, (s_row + GG_RPP * u) * GG_ROWB + 8 * s_kq,
-                     make_float4(b[u].x, b[u].y, b[u].z, b[u].w), three);
-        } else {
-            // n-contiguous weights keep their orientation in LDS: Bs[k][n], rows of GG_BN + 4
-            // floats (transposing them into the [n][k] image needs 4-byte writes 4 rows apart:
-            // 16-way bank conflicts)
-#pragma unroll
-            for (int u = 0; u < GG_NU; u++)
-                put4(Bs, GG_BIMG, ((tid >> 5) + 8 * u) * GG_BNROWB + 8 * (tid & 31),
-                     make_float4(b[u].x, b[u].y, b[u].z, b[u].w), three);
-        }
+        stage_store(a, b, As, Bs);
         GG_PHASE(2);
         __syncthreads();
         GG_PHASE(3);
@@ -489,13 +513,119 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
 #endif
         GG_PHASE(4);
     };
+    if constexpr (STAGES == 2) {
+        // k-step t: write tile t+1 (in registers since step t-1) into the other stage, fetch
+        // tile t+2, contract stage t & 1, ONE barrier: it closes both the writes of stage
+        // (t+1) & 1 and the reads of stage t & 1.
+        // `full`: neither condition can fail (steady state) -- one basic block, so that the
+        // split's VALU and the LDS stores can be spread over the MFMA gaps of the same wave
+        // (all waves of a CU otherwise fall into lockstep: every one staging, then every one
+        // waiting for the matrix pipe)
+        auto db_step = [&](auto cur, auto full, int k0) {
+            constexpr int CUR = decltype(cur)::value;
+            constexpr bool FULL = decltype(full)::value;
+            char *a_nxt = lds0 + (CUR ^ 1) * STAGE_BYTES;
+            if (FULL || k0 + GG_BK < g.K) stage_store(av[0], bv[0], a_nxt, a_nxt + NPART * GG_AIMG);
+            if (FULL || k0 + 2 * GG_BK < g.K) load_tile(av[0], bv[0], k0 + 2 * GG_BK);
+            As = lds0 + CUR * STAGE_BYTES;
+            Bs = As + NPART * GG_AIMG;
 #pragma unroll
-    for (int st = 0; st < PF; st++)
-        if (st * GG_BK < g.K) load_tile(av[st], bv[st], st * GG_BK);
-    for (int k0 = 0; k0 < g.K; k0 += PF * GG_BK) {
+            for (int q2 = 0; q2 < GG_BK / 16; q2++) mfma_group16(q2, !BN_LAYOUT);
+            __syncthreads();
+        };
+        // The same step written out for the steady state of a full tile: the wave's 24 MFMAs in
+        // eight groups of three (consecutive ones on different accumulators), and after each
+        // group one register of the next tile: wait for it, split, two LDS stores, and the
+        // global load that refills it for the tile after -- pinned in this order, so that every
+        // wave issues matrix work all along the step instead of staging first.
+        auto db_step_woven = [&](auto cur, int k0) {
+            constexpr int CUR = decltype(cur)::value;
+            char *a_nxt = lds0 + (CUR ^ 1) * STAGE_BYTES, *b_nxt = a_nxt + NPART * GG_AIMG;
+            As = lds0 + CUR * STAGE_BYTES;
+            Bs = As + NPART * GG_AIMG;
+            auto chunk = [&](int c) {
+                if (c < NUA) {
+                    const int u = c;
+                    put4(a_nxt, GG_AIMG, (s_row + GG_RPP * u) * GG_ROWB + 8 * s_kq,
+                         make_float4(av[0][u].x, av[0][u].y, av[0][u].z, av[0][u].w), false);
+                    av[0][u] = load_a1(u, k0 + 2 * GG_BK);
+                } else {
+                    const int u = c - NUA;
+                    const int off = BN_LAYOUT ? ((tid >> 5) + 8 * u) * GG_BNROWB + 8 * (tid & 31)
+                                              : (s_row + GG_RPP * u) * GG_ROWB + 8 * s_kq;
+                    put4(b_nxt, GG_BIMG, off,
+                         make_float4(bv[0][u].x, bv[0][u].y, bv[0][u].z, bv[0][u].w), false);
+                    bv[0][u] = load_b1(u, k0 + 2 * GG_BK);
+                }
+            };
+            GgFrag af[2][NI], bf[2][2];
+            auto read_frags = [&](int q2) {
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    af[q2][i].hi = frag_rows(As, wm + 32 * i + frow, q2);
+                    af[q2][i].lo = frag_rows(As + GG_AIMG, wm + 32 * i + frow, q2);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    bf[q2][j].hi = b_frag(0, j, q2, !BN_LAYOUT);
+                    bf[q2][j].lo = b_frag(1, j, q2, !BN_LAYOUT);
+                }
+            };
+            // product p of accumulator tile t: lo.hi, hi.lo, hi.hi (small terms first)
+            auto one = [&](int q2, int idx) {
+                const int pth = idx / (2 * NI), t = idx % (2 * NI), i = t >> 1, j = t & 1;
+                acc[i][j] = gg_mma(pth == 0 ? af[q2][i].lo : af[q2][i].hi,
+                                   pth == 1 ? bf[q2][j].lo : bf[q2][j].hi, acc[i][j]);
+            };
+            read_frags(0);
+#pragma unroll
+            for (int q2 = 0; q2 < 2; q2++) {
+#pragma unroll
+                for (int grp = 0; grp < 4; grp++) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < 3; m++) one(q2, 3 * grp + m);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (q2 == 0 && grp == 2) read_frags(1);
+                    chunk(4 * q2 + grp);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        };
+        using C0 = std::integral_constant<int, 0>;
+        using C1 = std::integral_constant<int, 1>;
+        load_tile(av[0], bv[0], 0);
+        __syncthreads();          // the K extension's reads of stage 0 are done
+        stage_store(av[0], bv[0], lds0, lds0 + NPART * GG_AIMG);
+        if (GG_BK < g.K) load_tile(av[0], bv[0], GG_BK);
+        __syncthreads();
+        int k0 = 0;
+        for (; k0 + 3 * GG_BK < g.K; k0 += 2 * GG_BK) {     // both steps store and load
+            if constexpr (GG_DB_VALUE == 2 && NI == 2 && NUA == 4 && GG_NU == 4 && GG_BK == 32 &&
+                          !KTAIL) {
+                db_step_woven(C0{}, k0);
+                db_step_woven(C1{}, k0 + GG_BK);
+            } else {
+                db_step(C0{}, std::true_type{}, k0);
+                db_step(C1{}, std::true_type{}, k0 + GG_BK);
+            }
+        }
+        for (; k0 < g.K; k0 += 2 * GG_BK) {                 // the last two or three steps
+            db_step(C0{}, std::false_type{}, k0);
+            if (k0 + GG_BK < g.K) db_step(C1{}, std::false_type{}, k0 + GG_BK);
+        }
+        As = lds0;
+        Bs = As + NPART * GG_AIMG;
+    } else {
 #pragma unroll
         for (int st = 0; st < PF; st++)
-            if (k0 + st * GG_BK < g.K) k_step(av[st], bv[st], k0 + (st + PF) * GG_BK);
+            if (st * GG_BK < g.K) load_tile(av[st], bv[st], st * GG_BK);
+        for (int k0 = 0; k0 < g.K; k0 += PF * GG_BK) {
+#pragma unroll
+            for (int st = 0; st < PF; st++)
+                if (k0 + st * GG_BK < g.K) k_step(av[st], bv[st], k0 + (st + PF) * GG_BK);
+        }
     }
 
 #ifdef GG_STAMP
@@ -623,7 +753,7 @@ template <bool BN_LAYOUT, int EPI, bool EXT, bool KTAIL>
 __global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_kernel(GroupedArgs g) {
     // As | Bs; the epilogue reuses the whole buffer as four per-wave C staging areas
     // A | B images (two or, with an activation epilogue, three parts each)
-    __shared__ __attribute__((aligned(16))) float smem[((EPI == EPI_ACT) ? 3 : 2) * (GG_AIMG + GG_BIMG) / 4];
+    __shared__ __attribute__((aligned(16))) float smem[GgStages<EPI>::value * ((EPI == EPI_ACT) ? 3 : 2) * (GG_AIMG + GG_BIMG) / 4];
 
     const int n_col_tiles = (g.N + GG_BN - 1) / GG_BN;
     int row_tiles = 0;
