@@ -93,9 +93,9 @@ OP_KERNEL = {
     'pq_loss_backward': 'spt::pq_loss_backward_kernel<8>',
     'sparse_attention_forward': 'spt::sparse_attention_forward_kernel<true, true>',
     'sparse_attention_backward_rows': 'spt::sparse_attention_backward_rows_kernel<true, true>',
-    'attention_mfma_prepare': 'spt::attention_cell_tiles_kernel',
+    'attention_mfma_prepare': 'spt::attention_cell_tiles_kernel<false>',
     'attention_mfma_forward': 'spt::attention_mfma_forward_kernel<true>',
-    'attention_mfma_backward': 'spt::attention_mfma_backward_keys_kernel<true>',
+    'attention_mfma_backward': 'spt::attention_mfma_backward_keys_kernel<true, 0>',
 }
 
 
@@ -104,7 +104,7 @@ OP_LAUNCHES = {
     'pq_loss_forward': ['spt::pq_loss_forward_kernel<8>', 'spt::pq_loss_finish_kernel'],
     'pq_loss_backward': ['spt::pq_loss_backward_kernel<8>', 'spt::pq_loss_table_reduce_kernel'],
     'attention_mfma_backward': ['spt::attention_mfma_backward_rows_kernel<true>',
-                                'spt::attention_mfma_backward_keys_kernel<true>'],
+                                'spt::attention_mfma_backward_keys_kernel<true, 0>'],
 }
 
 
