@@ -195,7 +195,12 @@ def sparse_step(attn, q, k, v, trigger):
 
 
 def allreduce_grads(params, world):
-    # one flat fp32 buffer, one RCCL all-reduce (naive_gpt/utils/distributed.py)
+    # one flat fp32 buffer, one RCCL all-reduce (naive_gpt/utils/distributed.py).  The only
+    # trainable tensors of the attention path are the PQ tables, and they receive a gradient
+    # only when the PQ loss is armed: without one there is nothing to exchange and the ranks
+    # (identical replicas running the same arming decision) all skip the collective.
+    if world == 1 or all(p.grad is None for p in params):
+        return
     from naive_gpt import utils
     utils.allreduce_gradients(params, world_size=world)
 
