@@ -567,6 +567,23 @@ __device__ __forceinline__ float cell_count(unsigned word) {
 #ifndef MR_SUB
 #define MR_SUB 1            // key tiles per iteration of the row-owned backward kernel (2: no faster)
 #endif
+// Row-owned backward, paired form (opt-in, -DMR_PAIRED=1; passes the tests): the two waves of a
+// SIMD (w and w + 4) share ONE row tile at a time -- first the long one (the mirror image), then
+// the short one -- and take alternate key tiles of it (two staged per iteration); the partial
+// grad_q tiles are added through LDS.  Measured with per-iteration stamps (-DMA_STAMP,
+// tools/time_mfma.py MA_STAMPS=1; shader clocks, workgroup 0 of the bench shape): as single
+// owners 16 iterations of 4.1 k clk after a 17 k prologue = 89 k; paired 8 + 2 iterations of
+// 5.8 k after two prologues of 14 k + 13 k = 100 k -- no gain.  The two waves of a SIMD run the
+// same program between the same barriers, so their MFMA phases coincide and their VALU phases
+// coincide: one tile costs its 36 MFMAs (1.15 k) PLUS its ~260 VALU (1.2 k) PLUS ~1 k of
+// reads, stores and barrier, and a second wave adds its own MFMA + VALU time on top.  Skipping
+// the loop's global loads changes nothing (5.8 k): the loads are hidden.  What is missing is
+// overlap of matrix and vector work inside a SIMD: tile t's D / dP products issued between the
+// vector instructions of tile t-1 (its exp, dS, splits), with a third LDS stage so that tile
+// t-1's K image outlives the barrier.
+#ifndef MR_PAIRED
+#define MR_PAIRED 0
+#endif
 #ifndef MA_ROWS_WAVES_PER_EU
 #define MA_ROWS_WAVES_PER_EU 2
 #endif
@@ -643,7 +660,11 @@ void attention_mfma_forward_kernel(
         bool lv[SUB], any = false;
 #pragma unroll
         for (int u = 0; u < SUB; u++) {
+#ifdef MR_EXP_NOLOAD     // timing experiment only: the loop re-stages the tiles it already holds
+            if (it < 0) nxt[u] = stager.load(min(t0 + SUB + u, T - 1));
+#else
             nxt[u] = stager.load(min(t0 + SUB + u, T - 1));
+#endif
             mnxt[u] = ct.load(t0 + SUB + u, lane);
             lv[u] = t0 + u < T && ct.live(t0 + u);
             any |= lv[u];
@@ -823,14 +844,37 @@ void attention_mfma_backward_rows_kernel(
     const int h = lane >> 5, c32 = lane & 31;
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int b = bid / blocks_per_batch;
-    const int i0 = MA_WROWS * folded_row_tile(bid % blocks_per_batch, blocks_per_batch, wave);
+    constexpr bool PAIRED = MR_PAIRED;
+    constexpr int HALFW = MA_WAVES / 2;
+    const int hf = wave / HALFW;                // which of a pair's two waves
     const DenseView dv = dense_view(b, S, MA_E, heads);
     const int RT = (S + MA_WROWS - 1) / MA_WROWS;
-
-    const CellTiles ct(masks, cells, b, RT, i0 / MA_WROWS, i0 < S);
-    const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch, MA_WAVES - 1);
-    const int T = min(RT, last_tile + 1);
     const ScoreMap sm(scale, clampv);
+#ifdef MA_STAMP
+    // diagnostic build only: workgroup 0's waves record the shader clock at the marks below
+    // (R_STAMP), written over grad_q rows 0..3 of head 0 at the end
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+    float st_v[32];
+    int st_n = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) st_v[i] = 0.f;
+#define R_STAMP()                                                                   \
+    do {                                                                            \
+        const float now_ = (float)(__builtin_amdgcn_s_memtime() - st_t0);           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++) st_v[i_] = (i_ == st_n) ? now_ : st_v[i_]; \
+        st_n++;                                                                     \
+    } while (0)
+#else
+#define R_STAMP()
+#endif
+  for (int pass = 0; pass < (PAIRED ? 2 : 1); pass++) {
+    // the row tile this wave works on in this pass, and the last one any wave of the block does
+    const int own = PAIRED ? (pass == 0 ? HALFW + wave % HALFW : wave % HALFW) : wave;
+    const int i0 = MA_WROWS * folded_row_tile(bid % blocks_per_batch, blocks_per_batch, own);
+    const CellTiles ct(masks, cells, b, RT, i0 / MA_WROWS, i0 < S);
+    const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch,
+                                          PAIRED && pass == 1 ? HALFW - 1 : MA_WAVES - 1);
+    const int T = min(RT, last_tile + 1);
     // An iteration = MR_SUB key tiles.  Measured by compiling phases out (80 us whole): without
     // the tile arithmetic 54 us (prologue -- dY, Y, Q: 100 MB -- 23, the loop's loads 23,
     // epilogue 6, image stores 2, barriers 0); WITH the arithmetic but without the loop's
@@ -840,7 +884,7 @@ void attention_mfma_backward_rows_kernel(
     // workgroup, and half of its waves (the short row tiles) finish early.  That is why two
     // tiles per iteration, a second tile in flight, 16-byte own-row accesses and 8x smaller
     // cell tiles all measured the same.
-    constexpr int SUB = MR_SUB;
+    constexpr int SUB = PAIRED ? 2 : MR_SUB;
     const RowsStager stager(k + dv.base, v + dv.base, dv.ld, S, tid);
     TileRegs nxt[SUB];
     uint4 mcur[SUB], mnxt[SUB];
@@ -881,10 +925,12 @@ void attention_mfma_backward_rows_kernel(
         const float pscale = scale / fmaxf(1e-9f, rsum);
         split_own_rows(gf, xr, pscale);
         split_own_rows(qf, xq, sm.sl2);
-        if (h == 0 && row < S && half == 0) delta[(size_t)b * S + row] = delta_i;
+        if (h == 0 && row < S && half == 0 && (!PAIRED || hf == 0))
+            delta[(size_t)b * S + row] = delta_i;
         delta_i *= pscale;
     }
     __syncthreads();
+    R_STAMP();                                   // prologue done
 
     f32x16 qacc[MR_QTILES];
 #pragma unroll
@@ -901,7 +947,7 @@ void attention_mfma_backward_rows_kernel(
         for (int u = 0; u < SUB; u++) {
             nxt[u] = stager.load(min(t0 + SUB + u, T - 1));
             mnxt[u] = ct.load(t0 + SUB + u, lane);
-            lv[u] = t0 + u < T && ct.live(t0 + u);
+            lv[u] = t0 + u < T && ct.live(t0 + u) && (!PAIRED || u == hf);
         }
 #pragma unroll
         for (int u = 0; u < SUB; u++) {
@@ -947,15 +993,48 @@ void attention_mfma_backward_rows_kernel(
         }
 #pragma unroll
         for (int u = 0; u < SUB; u++) mcur[u] = mnxt[u];
+        R_STAMP();                               // iteration's work done (before its barrier)
         __syncthreads();
     }
-    if (i0 < S) {
+    R_STAMP();                                   // loop done
+    if (PAIRED) {
+        // (the loop's last barrier freed the images) partner's partial sums: register layout,
+        // lane-contiguous, behind the eight waves' transpose tiles
+        float *xch = reinterpret_cast<float *>(img) + MA_WAVES * (32 * MA_TLD) +
+                     (wave % HALFW) * (MR_QTILES * 16 * 64);
+        if (hf == 1) {
+#pragma unroll
+            for (int eh = 0; eh < MR_QTILES; eh++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) xch[(eh * 16 + r) * 64 + lane] = qacc[eh][r];
+        }
+        __syncthreads();
+        if (hf == 0) {
+#pragma unroll
+            for (int eh = 0; eh < MR_QTILES; eh++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) qacc[eh][r] += xch[(eh * 16 + r) * 64 + lane];
+        }
+    }
+    if (i0 < S && (!PAIRED || hf == 0)) {
         float *tile = reinterpret_cast<float *>(img) + wave * (32 * MA_TLD);
         float *gq_b = grad_q + dv.base + (size_t)i0 * dv.ld + 32 * MR_QTILES * half;
 #pragma unroll
         for (int eh = 0; eh < MR_QTILES; eh++)
             store_acc_half(qacc[eh], 1.0f, tile, gq_b + 32 * eh, dv.ld, S - i0, lane);
     }
+    R_STAMP();                                   // pass done
+    if (PAIRED && pass == 0) __syncthreads();      // the next pass stages into the same LDS
+  }
+#ifdef MA_STAMP
+    __syncthreads();
+    if (bid == 0 && lane == 0) {
+        for (int i = 0; i < 32; i++) {
+            const int idx = wave * 32 + i;
+            grad_q[dv.base + (size_t)(idx / 64) * dv.ld + idx % 64] = st_v[i];
+        }
+    }
+#endif
 }
 
 // ---- key-owned: a wave owns 32 keys (K, V fragments and the grad_k, grad_v accumulators in
@@ -1236,7 +1315,9 @@ int launch_backward(const unsigned long long *masks, const unsigned char *cells,
                     float scale, float clamp, int heads, int transposed, hipStream_t s) {
     const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
     const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
-    const size_t lds_r = 2 * MR_SUB * MR_IMG, lds_k = 2 * MK_IMG;
+    const size_t lds_r = 2 * (MR_PAIRED ? 2 : MR_SUB) * MR_IMG, lds_k = 2 * MK_IMG;
+    static_assert(!MR_PAIRED || (size_t)MA_WAVES * 32 * MA_TLD * 4 + 4 * MR_QTILES * 16 * 64 * 4 <=
+                                    (size_t)4 * MR_IMG, "paired exchange area fits the images");
     // 64 gradient columns per launch (the accumulators of 128 would not fit the registers
     // beside the operands' fragments): d_head 128 runs each kernel twice
 #define SPT_MB(GT)                                                                              \

@@ -51,4 +51,10 @@ if os.environ.get('MA_STAMPS') == '1':
             row = st[wg, w]
             print('wg', wg, 'wave', w, 'rt', int(row[19]), 'T', int(row[18]), 'end', int(row[17]),
                   'iter ends', [int(x) for x in row[:17]])
+if os.environ.get('MA_STAMPS') == '1' and hasattr(ext, 'attention_mfma_backward'):
+    # row-owned backward, workgroup 0: marks = per pass [prologue, iteration ends..., loop, pass]
+    gq = ext.attention_mfma_backward(tiles, q, k, v, y1, gy, rs, 0.125, 10.0, transposed=True)[0]
+    st = gq[0, :4, 0, :].flatten().cpu().view(8, 32)
+    for w in range(8):
+        print('bwd rows wave', w, [int(x) for x in st[w] if x > 0])
 print(res)
