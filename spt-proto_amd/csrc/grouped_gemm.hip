@@ -33,8 +33,14 @@
 
 namespace spt {
 
-constexpr int GG_THREADS = 256;
-constexpr int GG_BM = 128;
+// Workgroup shape: 256 threads own a 128 x 128 tile (waves 2 x 2, 64 x 64 each); -DGG_WAVES_M=4:
+// 512 threads own 256 x 128 (waves 4 x 2), the B tile staged once per 256 rows -- 48 KiB of
+// operands per k-step for twice the products, one workgroup per CU.
+#ifndef GG_WAVES_M
+#define GG_WAVES_M 2
+#endif
+constexpr int GG_THREADS = 128 * GG_WAVES_M;
+constexpr int GG_BM = 64 * GG_WAVES_M;
 constexpr int GG_BN = 128;
 #ifndef GG_BK_VALUE
 #define GG_BK_VALUE 32
@@ -62,7 +68,8 @@ template <int EPI> struct GgStages { static constexpr int value = (GG_DB_VALUE &
 constexpr int GG_PF = GG_PF_VALUE;
 constexpr int GG_KQ = GG_BK / 4;               // float4 per tile row
 constexpr int GG_RPP = GG_THREADS / GG_KQ;      // tile rows staged per pass
-constexpr int GG_NU = GG_BM / GG_RPP;           // passes (float4 loads per thread per operand)
+constexpr int GG_NU = GG_BN / GG_RPP;           // float4 of B per thread per k-step
+constexpr int GG_BNK = GG_THREADS / 32;        // k rows of an n-contiguous B tile staged per pass
 // LDS images of a tile: bf16, one image per part of the split (hi, lo and -- GEMMs in front of a
 // ReLU -- mid), written ONCE when the tile is staged (each element is an operand of two waves'
 // MFMAs: splitting the fragments in every wave doubled the conversion work and had the matrix
@@ -207,7 +214,7 @@ __device__ __forceinline__ float act_derivative(int act, float s) {
 template <int BM, bool BN_LAYOUT, int EPI, bool EXT, bool KTAIL>
 __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int bucket,
                                           int row_lo, int row_hi, int col_tile) {
-    constexpr int NI = BM / 64;               // 32-row sub-blocks per wave
+    constexpr int NI = BM / (32 * GG_WAVES_M);   // 32-row sub-blocks per wave
     constexpr int NUA = BM / GG_RPP;          // float4 of A per thread per k-step
     constexpr int NPART = (EPI == EPI_ACT) ? 3 : 2;      // hi, lo (, mid)
     constexpr int STAGES = GgStages<EPI>::value;
@@ -219,7 +226,7 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = (wave >> 1) * (BM / 2);    // the wave's origin inside the tile
+    const int wm = (wave >> 1) * (BM / GG_WAVES_M);    // the wave's origin inside the tile
     const int wn = (wave & 1) * 64;
     const float *wg = g.w + (size_t)bucket * g.gstride;
 
@@ -418,7 +425,7 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
             // W_g(n, k), n contiguous: thread -> k row (tid >> 5) + 8 u, n-quad tid & 31
 #pragma unroll
             for (int u = 0; u < GG_NU; u++) {
-                const int kk = k0 + (tid >> 5) + 8 * u;
+                const int kk = k0 + (tid >> 5) + GG_BNK * u;
                 if constexpr (KTAIL)
                     b[u] = kk < g.K ? *reinterpret_cast<const float4 *>(bn_src + (size_t)kk * g.ldk)
                                     : zero;
@@ -461,7 +468,7 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
             // 16-way bank conflicts)
 #pragma unroll
             for (int u = 0; u < GG_NU; u++)
-                put4(b_img, GG_BIMG, ((tid >> 5) + 8 * u) * GG_BNROWB + 8 * (tid & 31),
+                put4(b_img, GG_BIMG, ((tid >> 5) + GG_BNK * u) * GG_BNROWB + 8 * (tid & 31),
                      make_float4(b[u].x, b[u].y, b[u].z, b[u].w), three);
         }
     };
@@ -473,7 +480,7 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
         if constexpr (!BN_LAYOUT)
             return *reinterpret_cast<const float4 *>(b_src[u] + k0 + 4 * s_kq);
         else
-            return *reinterpret_cast<const float4 *>(bn_src + (size_t)(k0 + (tid >> 5) + 8 * u) * g.ldk);
+            return *reinterpret_cast<const float4 *>(bn_src + (size_t)(k0 + (tid >> 5) + GG_BNK * u) * g.ldk);
     };
     auto k_step = [&](float4 (&a)[NUA], float4 (&b)[GG_NU], int k_next) {
 #ifdef GG_STAMP
@@ -551,7 +558,7 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
                     av[0][u] = load_a1(u, k0 + 2 * GG_BK);
                 } else {
                     const int u = c - NUA;
-                    const int off = BN_LAYOUT ? ((tid >> 5) + 8 * u) * GG_BNROWB + 8 * (tid & 31)
+                    const int off = BN_LAYOUT ? ((tid >> 5) + GG_BNK * u) * GG_BNROWB + 8 * (tid & 31)
                                               : (s_row + GG_RPP * u) * GG_ROWB + 8 * s_kq;
                     put4(b_nxt, GG_BIMG, off,
                          make_float4(bv[0][u].x, bv[0][u].y, bv[0][u].z, bv[0][u].w), false);
@@ -750,10 +757,12 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
 // [0, main) take the full rounds, ids [main, main + 2 R) the halves of the R remaining
 // tiles, and the rest of the (worst-case sized) grid exits at once.
 template <bool BN_LAYOUT, int EPI, bool EXT, bool KTAIL>
-__global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_kernel(GroupedArgs g) {
+__global__ __launch_bounds__(GG_THREADS, GG_WAVES_M == 2 ? 2 : 1) void grouped_gemm_kernel(GroupedArgs g) {
     // As | Bs; the epilogue reuses the whole buffer as four per-wave C staging areas
     // A | B images (two or, with an activation epilogue, three parts each)
-    __shared__ __attribute__((aligned(16))) float smem[GgStages<EPI>::value * ((EPI == EPI_ACT) ? 3 : 2) * (GG_AIMG + GG_BIMG) / 4];
+    constexpr int IMG_FLOATS = GgStages<EPI>::value * ((EPI == EPI_ACT) ? 3 : 2) * (GG_AIMG + GG_BIMG) / 4;
+    constexpr int EPI_FLOATS = (GG_THREADS / 64) * 32 * (64 + 4);       // per-wave C staging
+    __shared__ __attribute__((aligned(16))) float smem[IMG_FLOATS > EPI_FLOATS ? IMG_FLOATS : EPI_FLOATS];
 
     const int n_col_tiles = (g.N + GG_BN - 1) / GG_BN;
     int row_tiles = 0;
