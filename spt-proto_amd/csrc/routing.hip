@@ -12,8 +12,8 @@
 //   scan    exclusive prefix of the G counters over the 1024 threads (DPP wave scan + LDS);
 //   pass 2  position of (token, block) = offsets[block] + prefix + running count.
 //
-// Selection order: larger probability first, ties to the lower block index (a total order;
-// torch.topk leaves ties unspecified).  G <= 8, T <= 65536 (64 tokens per thread); bigger
+// Selection order: larger probability first (NaN above every number, as torch.topk ranks it),
+// ties to the lower block index (a total order; torch.topk leaves ties unspecified).  G <= 8, T <= 65536 (64 tokens per thread); bigger
 // problems use the torch composition (layers/sparse/grouped.py).
 #include "spt_common.h"
 
@@ -22,14 +22,28 @@ namespace spt {
 constexpr int RT_THREADS = 1024;
 constexpr int RT_MAXG = 8;
 
+// Orderable key of a probability: ascending unsigned order == ascending float order, -0 == +0,
+// and every NaN is the LARGEST key (torch.topk also ranks NaN above every number).  The rank
+// below is then a total order for any input, so exactly k bits are set per token: with the
+// float comparisons used before, a NaN compared false against everything, ranked 0 and let
+// a token select more than k blocks -- writes past the T * k rows the caller allocated.
+__device__ __forceinline__ unsigned order_key(float x) {
+    if (x != x) return 0xFFFFFFFFu;
+    const unsigned b = __float_as_uint(x + 0.0f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
 __device__ __forceinline__ unsigned select_topk(const float (&v)[RT_MAXG], int G, int k) {
+    unsigned key[RT_MAXG];
+#pragma unroll
+    for (int j = 0; j < RT_MAXG; j++) key[j] = order_key(v[j]);
     unsigned mask = 0u;
 #pragma unroll
     for (int j = 0; j < RT_MAXG; j++) {
         int rank = 0;
 #pragma unroll
         for (int i = 0; i < RT_MAXG; i++)
-            rank += (i < G) && (v[i] > v[j] || (v[i] == v[j] && i < j));
+            rank += (i < G) && (key[i] > key[j] || (key[i] == key[j] && i < j));
         if (j < G && rank < k) mask |= 1u << j;
     }
     return mask;

@@ -181,8 +181,11 @@ class _SparseCore:
         cached = _SparseCore._indptr_cache.get(key)
         if cached is None:
             top_k = seq_length // SPARSE_COEFF
-            cached = torch.arange(0, top_k * seq_length + 1, step=top_k,
-                                  dtype=torch.int, device=device)
+            # (a tensor created under torch.inference_mode() could not be saved for backward
+            # by a later training step: the process-wide cache holds a normal tensor)
+            with torch.inference_mode(False):
+                cached = torch.arange(0, top_k * seq_length + 1, step=top_k,
+                                      dtype=torch.int, device=device)
             _SparseCore._indptr_cache[key] = cached
         return cached
 

@@ -56,6 +56,20 @@ def make_buckets(prob: torch.Tensor, k: int) -> Buckets:
                    pos=pos.view(n_tokens, k).int())
 
 
+COEFF_FLOOR = 1e-12
+
+
+def _floor(coeff: torch.Tensor) -> torch.Tensor:
+    """The coefficient gradients below are recovered as (a dot that contains c) / c, where the
+    reference differentiates c * (x W^T + b) directly.  c = 2 sigmoid(logit) underflows to 0
+    for logit < -104 (0 / 0 = NaN here, a finite number there) and the quotient amplifies the
+    fp32 cancellation error of the numerator by 1 / c.  Both are harmless AFTER the chain
+    rule -- d c / d logit = c (1 - c / 2), so the factor 1 / c cancels and what reaches the
+    router is (numerator error) * (1 - c / 2) -- provided the division itself stays finite:
+    hence a floor far below any coefficient that still has a gradient in fp32."""
+    return coeff.clamp_min(COEFF_FLOOR)
+
+
 class GroupedLinear(torch.autograd.Function):
     """out[p] = rowscale[p] * (a[gather[p]] @ W_g(p)^T + bias[g(p)]) for frozen weights.
 
@@ -83,7 +97,7 @@ class GroupedLinear(torch.autograd.Function):
         grad_a = grad_scale = None
         if ctx.needs_input_grad[7] and rowscale is not None:
             # out = s * u  ->  ds = <dout, u> = <dout, out> / s   (s = 2 sigmoid(.) > 0)
-            grad_scale = (grad_out * out).sum(dim=-1) / rowscale
+            grad_scale = (grad_out * out).sum(dim=-1) / _floor(rowscale)
         if ctx.needs_input_grad[0]:
             # d a[src(p), kk] = s[p] * sum_n dout[p, n] W_g(n, kk): roles of n and k swap
             rows = ext.grouped_gemm(grad_out, weight, offsets, n_groups, k, n, gstride,
@@ -221,7 +235,7 @@ class RoutedLoRAFFN(torch.autograd.Function):
         # (the kernel's dot_main still contains the LoRA term <dzt, h L2_g> / c = <dzt, z> / c)
         dz_rows = dzt.index_select(0, bk.token_long)
         grad_coeff = dot_main + (dot_act - (du * u_rows).sum(dim=-1)
-                                 - (dz_rows * z).sum(dim=-1)) / coeff
+                                 - (dz_rows * z).sum(dim=-1)) / _floor(coeff)
         # LoRA tables (before the last GEMM: ds [P, bs] is released as soon as that has read it --
         # the step's peak memory is here, with h, ds, dxs and grad_x alive)
         du_tok = du[pos].sum(dim=1)                                          # [T, r]
@@ -302,7 +316,7 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
             dy, wd, bk.offsets, nb, n=bs, k=d, w_group_stride=bs, w_ldn=1, w_ldk=d_ff,
             n_rows=rows, gather=bk.token, rowscale=coeff, a2=dzt, gather2=bk.token, b2=ld,
             b2_group_stride=bs * rank)
-        grad_coeff = ((dh * h).sum(dim=-1) - (dz_rows * z).sum(dim=-1)) / coeff
+        grad_coeff = ((dh * h).sum(dim=-1) - (dz_rows * z).sum(dim=-1)) / _floor(coeff)
         # through h = act(g) * sd
         with torch.enable_grad():
             g_ = g.detach().requires_grad_(True)
@@ -315,7 +329,7 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
             """-> (dx rows [P, d], d coefficient [P], grad of the two LoRA tables)"""
             du = _own_block(torch.matmul(dpre, _block_cat(r_table, nb)), bk.block, nb).contiguous()
             u_rows = u.index_select(0, bk.token_long)
-            dc = ((dpre * pre).sum(dim=-1) - (du * u_rows).sum(dim=-1)) / coeff
+            dc = ((dpre * pre).sum(dim=-1) - (du * u_rows).sum(dim=-1)) / _floor(coeff)
             dxs = ext.grouped_gemm_fused(
                 dpre, w, bk.offsets, nb, n=d, k=bs, w_group_stride=bs * d, w_ldn=1, w_ldk=d,
                 n_rows=rows, rowscale=coeff, a2=du, b2=l_table, b2_group_stride=0)

@@ -61,7 +61,8 @@ def _one_group(rows: int, device) -> torch.Tensor:
     key = (rows, str(device))
     off = _OFFSETS.get(key)
     if off is None:
-        off = torch.tensor([0, rows], dtype=torch.int32, device=device)
+        with torch.inference_mode(False):      # never cache an inference tensor
+            off = torch.tensor([0, rows], dtype=torch.int32, device=device)
         _OFFSETS[key] = off
     return off
 

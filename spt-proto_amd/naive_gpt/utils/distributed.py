@@ -21,13 +21,21 @@ def trainable_parameters(module: torch.nn.Module) -> List[torch.nn.Parameter]:
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
     """Make every replica identical to rank ``src`` (parameters and buffers)."""
-    for t in list(module.parameters()) + list(module.buffers()):
-        if t.dtype == torch.bool:          # e.g. the `trigger` buffers: not a collective dtype
-            tmp = t.data.to(torch.uint8)
-            dist.broadcast(tmp, src=src, group=group)
-            t.data.copy_(tmp.to(torch.bool))
-        else:
-            dist.broadcast(t.data, src=src, group=group)
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            if t.dtype == torch.bool:      # e.g. the `trigger` buffers: not a collective dtype
+                tmp = t.to(torch.uint8)
+                dist.broadcast(tmp, src=src, group=group)
+                # written through `t` itself, not `t.data`: `.data` has a version counter of
+                # its own, and the sparse attentions trust `t._version` to tell whether their
+                # cached "disarmed" reading of the trigger is still valid
+                t.copy_(tmp.to(torch.bool))
+            else:
+                dist.broadcast(t.data, src=src, group=group)
+    # host-side notes about the triggers (layers/sparse/attention.py) describe the OLD values
+    for m in module.modules():
+        m.__dict__.pop('_trigger_seen', None)
+        m.__dict__.pop('_armed_hint', None)
 
 
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None,

@@ -181,3 +181,34 @@ def test_rccl_path_on_one_gpu():
         assert t.item() == 1.5
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ triggers under broadcast
+
+def _trigger_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from naive_gpt import layers, utils
+    attn = layers.SparseVanillaAttentionV2(d_head=16, d_codeword=8, n_codewords=16, p_dropout=0.0)
+    first = attn._take_trigger()          # an earlier forward: caches "disarmed" per version
+    if rank == 0:
+        attn.trigger.fill_(True)          # the reference's way of arming (4-sparse-tuning-0.py:71-78)
+    utils.broadcast_parameters(attn, src=0)
+    armed = attn._take_trigger()
+    again = attn._take_trigger()          # one-shot: disarmed by the look above
+    torch.save({'first': first, 'armed': armed, 'again': again}, out.format(rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_of_an_armed_trigger_is_seen_by_every_rank(tmp_path):
+    """`broadcast_parameters` must invalidate the layers' cached reading of `trigger`
+    (keyed on the buffer's version counter): a trigger armed on rank 0 only and then
+    broadcast has to make EVERY rank compute the PQ loss on its next forward."""
+    world = 2
+    out = str(tmp_path / 'trigger{}.pt')
+    mp.spawn(_trigger_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        got = torch.load(out.format(r), weights_only=True)
+        assert got == {'first': False, 'armed': True, 'again': False}, (r, got)

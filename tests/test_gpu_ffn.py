@@ -300,6 +300,59 @@ def test_fused_lora_routed_ffn_equals_torch_loop(act):
         assert _scaled_close(g1[n], g0[n], rtol=2e-3), n
 
 
+@pytest.mark.parametrize('family', ['opt', 'llama'])
+def test_fused_routed_ffn_with_saturated_router_coefficients(family):
+    """Router logits near -20 and -90 (coefficients 4e-9 and 1.6e-39, an fp32 denormal: no exact
+    zeros, which would tie in the top-k): the fused path recovers d coeff by a division by
+    coeff (layers/sparse/grouped.py: _floor); everything must stay finite and equal to the
+    torch loop, which never divides."""
+    from naive_gpt import layers
+    from naive_gpt.layers.sparse import grouped
+    torch.manual_seed(0)
+    if family == 'opt':
+        ffn = layers.LoRARoutedFFN(d_lora=8, block_size=64, d_model=64, d_feedforward=256,
+                                   activation=nn.ReLU()).cuda()
+    else:
+        ffn = layers.LoRARoutedLLaMaFFN(d_lora=8, block_size=64, d_model=64, d_feedforward=256,
+                                        activation=nn.SiLU()).cuda()
+    gen = torch.Generator().manual_seed(2)
+    for name, p in ffn.named_parameters():
+        if name.endswith('lora.right.weight'):
+            p.data.copy_(0.1 * torch.randn(p.shape, generator=gen).cuda())
+    router = ffn.router[0]
+    router.weight.data.mul_(0.01)
+    router.bias.data.copy_(torch.tensor([-90.0, -20.0, -95.0, -100.0]))     # top-2 = blocks 1, 0
+    x = torch.randn([2, 40, 64], generator=gen).cuda()
+    w = torch.randn([2, 40, 64], generator=gen).cuda()
+
+    def run(fused):
+        ffn.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        saved = grouped.usable
+        if not fused:
+            grouped.usable = lambda *a, **k: False
+        try:
+            y = ffn(xi)
+        finally:
+            grouped.usable = saved
+        (y * w).sum().backward()
+        return y.detach(), xi.grad, {n: p.grad.clone() for n, p in ffn.named_parameters()
+                                     if p.grad is not None}
+
+    y0, gx0, g0 = run(False)
+    y1, gx1, g1 = run(True)
+    prob = ffn.router(x.view(-1, 64))
+    assert float(prob[:, 0].max()) < 1e-30 and float(prob[:, 1].max()) < 1e-7
+    assert bool((prob[:, 0] > prob[:, 2]).all())                            # no ties in the top-2
+    for t in [y1, gx1] + list(g1.values()):
+        assert torch.isfinite(t).all()
+    assert torch.allclose(y1, y0, atol=1e-6) and torch.allclose(gx1, gx0, atol=1e-6)
+    assert set(g0) == set(g1)
+    for n in g0:
+        scale = max(float(g0[n].abs().max()), 1e-6)
+        assert float((g1[n] - g0[n]).abs().max()) <= 2e-3 * scale, n
+
+
 @pytest.mark.parametrize('T,G,k', [(8192, 4, 2), (1000, 8, 4), (77, 4, 2), (5, 2, 1), (40000, 4, 2)])
 def test_route_topk_is_the_stable_block_sort_of_topk(T, G, k):
     """spt_route_topk against the torch composition it replaces (topk -> stable argsort by
@@ -326,6 +379,48 @@ def test_route_topk_ties_go_to_the_lower_block():
     token, block, offsets, pos = ext.route_topk(prob, 2)
     picked = [sorted(block[pos[t].long()].tolist()) for t in range(3)]
     assert picked == [[0, 1], [1, 2], [0, 2]]
+
+
+def test_route_topk_nan_rows_select_exactly_k_and_stay_in_bounds():
+    """A NaN router probability (diverged training) must not make a token select more than k
+    blocks: every row of the outputs is written exactly once and nothing lands outside them.
+    NaN ranks above every number (torch.topk's order), ties to the lower block."""
+    import ctypes
+    from naive_gpt import ext
+    T, G, k = 300, 4, 2
+    gen = torch.Generator().manual_seed(11)
+    prob = torch.rand([T, G], generator=gen)
+    nan = float('nan')
+    prob[0] = nan                                   # all NaN: blocks 0, 1
+    prob[1] = torch.tensor([0.3, nan, 0.9, 0.1])    # NaN first, then 0.9: blocks 1, 2
+    prob[2] = torch.tensor([nan, 0.2, nan, nan])    # three NaNs: blocks 0, 2
+    prob[T - 1] = nan
+    prob = prob.cuda()
+    # outputs carved out of guarded buffers so that an out-of-bounds write is seen
+    pad, P = 64, T * k
+    bufs = {name: torch.full([n + 2 * pad], -7, dtype=torch.int32, device='cuda')
+            for name, n in (('token', P), ('block', P), ('offsets', G + 1), ('pos', P))}
+    view = {name: b[pad:b.numel() - pad] for name, b in bufs.items()}
+    lib = ext.load_library()
+    rc = lib.spt_route_topk(ctypes.c_void_p(prob.data_ptr()),
+                            *[ctypes.c_void_p(view[n].data_ptr())
+                              for n in ('token', 'block', 'offsets', 'pos')],
+                            T, G, k, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    for name, b in bufs.items():
+        assert (b[:pad] == -7).all() and (b[-pad:] == -7).all(), name + ': write outside the buffer'
+        assert (view[name] != -7).all(), name + ': rows left unwritten'
+    token, block, offsets, pos = [view[n] for n in ('token', 'block', 'offsets', 'pos')]
+    assert int(offsets[G]) == P and int(offsets[0]) == 0
+    assert torch.equal(torch.bincount(token.long(), minlength=T), torch.full([T], k, device='cuda'))
+    pos = pos.view(T, k).long()
+    picked = [sorted(block[pos[t]].tolist()) for t in (0, 1, 2, T - 1)]
+    assert picked == [[0, 1], [1, 2], [0, 2], [0, 1]]
+    # the NaN-free rows still match torch.topk
+    clean = ~torch.isnan(prob).any(dim=1)
+    sel = torch.topk(prob[clean], k=k, dim=-1).indices.sort(dim=-1).values
+    assert torch.equal(block.long()[pos[clean]].sort(dim=-1).values, sel)
 
 
 def test_frozen_lora_linear_on_the_matrix_core_gemm_equals_the_library_gemm(monkeypatch):

@@ -18,12 +18,13 @@ for d, name in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
             vals[r['Kernel_Name'].split('(')[0].replace('void ', '')].append(float(r['Counter_Value']))
     for k, v in vals.items():
         out[k][name + '_KiB'] = sum(v) / len(v)
+        out[k]['launches'] = len(v)
 res = {}
 for k, v in out.items():
     f, w = v.get('FETCH_SIZE_KiB', 0.0), v.get('WRITE_SIZE_KiB', 0.0)
-    res[k] = {'fetch_KiB_raw': f, 'write_KiB': w,
+    res[k] = {'fetch_KiB_raw': f, 'write_KiB': w, 'launches': v.get('launches', 1),
               'hbm_bytes_per_launch': (2.0 * f + w) * 1024.0}
-path = os.path.join(ROOT, 'profiles', tag + '_traffic.json')
+path = os.path.join(ROOT, 'gpurun_out', tag + '_traffic.json')
 json.dump(res, open(path, 'w'), indent=1, sort_keys=True)
 for k, v in sorted(res.items()):
     print('{:60s} {:10.1f} MB'.format(k[:60], v['hbm_bytes_per_launch'] / 1e6))
