@@ -268,6 +268,143 @@ def golden_block():
     save('block', **out)
 
 
+# --------------------------------------------------------------------------- N * H >= 32
+
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from helpers import fingerprint, seeded, seeded_fill  # noqa: E402
+
+# the shape class of the benchmark path: this repo's V2 layers run their matrix-core
+# kernels from n * h >= 32 (layers/sparse/attention.py: _mfma_ok); the N * H = 1 goldens
+# above take the separate-operator path
+MFMA_CASES = {
+    'v64': dict(kind='vanilla', N=2, H=16, S=256, E=64, heads=[3, 12]),
+    'r128': dict(kind='rotary', N=1, H=32, S=256, E=128, heads=[7, 29]),
+}
+
+
+def golden_attention_mfma():
+    """The reference's V2 attentions (orchestration attention.py:84-142 / :241-299 on the
+    oracle) at N * H = 32.  Inputs are seeded by name (tests/helpers.py: seeded); stored:
+    the outputs and gradients of two heads in full, per-(n, h) sums of all of them, the CSR
+    indices of those heads and a position-weighted checksum of every slice."""
+    out = {}
+    for tag, c in MFMA_CASES.items():
+        N, H, S, E, heads = c['N'], c['H'], c['S'], c['E'], c['heads']
+        q, k, v, w = [torch.from_numpy(seeded('attn_mfma.{}.{}'.format(tag, n), [N, S, H, E]))
+                      for n in 'qkvw']
+        for n, t in zip('qkvw', (q, k, v, w)):
+            out['{}.print.{}'.format(tag, n)] = fingerprint(t.numpy())
+
+        def build():
+            torch.manual_seed(41)
+            if c['kind'] == 'vanilla':
+                return layers.SparseVanillaAttentionV2(d_head=E, d_codeword=8, n_codewords=16,
+                                                       p_dropout=0.0)
+            return layers.SparseRotaryAttentionV2(d_head=E, p_dropout=0.0, d_codeword=8,
+                                                  n_codewords=16)
+
+        for variant in ('plain', 'train'):
+            model = build()
+            key = '{}.{}.'.format(tag, variant)
+            qi, ki, vi = [t.clone().requires_grad_(True) for t in (q, k, v)]
+            if variant == 'train':
+                model.trigger.fill_(True)
+            y = model(qi, ki, vi, attn_mask=None)
+            loss = (y * w).sum()
+            if variant == 'train':
+                loss = loss + 1e-2 * model.loss
+                out[key + 'pq_loss'] = t2n(model.loss)
+            loss.backward()
+            for name, t in (('y', y), ('grad_q', qi.grad), ('grad_k', ki.grad),
+                            ('grad_v', vi.grad)):
+                if variant == 'plain':
+                    out[key + name + '.heads'] = t2n(t[:, :, heads])
+                out[key + name + '.sums'] = t2n(t.double().sum(dim=(1, 3)))          # [N, H]
+                out[key + name + '.abs'] = t2n(t.double().abs().sum(dim=(1, 3)))
+            out.update(grads2n(model, key + 'grad.'))
+            if variant == 'plain':
+                out.update(sd2n(model, tag + '.sd.'))
+                indptr, indices, values = model._get_attn(q, k, attn_mask=None)
+                idx = t2n(indices).reshape(N, H, -1)
+                out[tag + '.indices.heads'] = idx[:, heads]
+                weights = (np.arange(idx.shape[-1], dtype=np.int64) % 8191) + 1
+                out[tag + '.indices.checksum'] = (idx.astype(np.int64) * weights).sum(-1)
+    for key in list(out):
+        if 'cos_cached' in key or 'sin_cached' in key or 'cached_ids' in key:
+            del out[key]
+    save('attention_mfma', **out)
+
+
+BLOCK_MFMA = {
+    'opt': dict(d_model=1024, n_heads=16, d_ff=256, N=2, S=128),      # 16 heads x 64
+    'llama': dict(d_model=2048, n_heads=16, d_ff=512, N=2, S=128),    # 16 heads x 128
+}
+
+
+def golden_block_mfma():
+    """Four-stage upgraded TransformerBlocks with N * H = 32 and BERT-large / LLaMA head
+    shapes.  Weights and inputs are seeded by name (4-16 MB per matrix: not stored)."""
+    out = {}
+    for kind, c in BLOCK_MFMA.items():
+        d_model, n_heads, d_ff, N, S = c['d_model'], c['n_heads'], c['d_ff'], c['N'], c['S']
+        if kind == 'opt':
+            block = layers.TransformerBlock(
+                d_model=d_model, n_heads=n_heads, layernorm_fn=nn.LayerNorm(d_model),
+                attention_fn=layers.VanillaAttention(d_head=d_model // n_heads, p_dropout=0.0),
+                feedforward_fn=layers.Feedforward(d_model=d_model, d_feedforward=d_ff,
+                                                  activation=nn.ReLU(), p_dropout=0.0),
+                attention_bias=True, pre_norm=True)
+        else:
+            block = layers.TransformerBlock(
+                d_model=d_model, n_heads=n_heads, layernorm_fn=layers.LlamaRMSNorm(d_model),
+                attention_fn=layers.RotaryAttention(d_head=d_model // n_heads, p_dropout=0.0,
+                                                    max_length=256),
+                feedforward_fn=layers.LLaMaFeedforward(d_model=d_model, d_feedforward=d_ff,
+                                                       activation=nn.SiLU()),
+                attention_bias=False, pre_norm=True)
+        model = quiet_upgrade(block, d_lora=4)
+        tag = 'block_mfma.{}.'.format(kind)
+        for key, fp in seeded_fill(model, tag).items():
+            out[kind + '.print.' + key] = fp
+        x = torch.from_numpy(seeded(tag + 'x', [N, S, d_model]))
+        w = torch.from_numpy(seeded(tag + 'w', [N, S, d_model]))
+        xi = x.clone().requires_grad_(True)
+        y = model(xi)
+        (y * w).sum().backward()
+        out[kind + '.trainable'] = np.array(
+            sorted(n for n, p in model.named_parameters() if p.requires_grad))
+        for name, t in (('y', y), ('grad_x', xi.grad)):
+            out['{}.{}.sub'.format(kind, name)] = t2n(t[:, ::4])
+            out['{}.{}.sums'.format(kind, name)] = t2n(t.double().sum(-1))            # [N, S]
+        out.update(grads2n(model, kind + '.grad.'))
+    save('block_mfma', **out)
+
+
+def golden_dense_chain():
+    """Pins the oracle's sddmm -> softmax -> spmm leg (and the reference's autograd wiring
+    of it, kernels/{sddmm,softmax,spmm}.py) to the reference's own DENSE attention: on the
+    full causal pattern (every row lists all S columns; softmax masks col > row) with
+    scores far inside the clamp, the sparse chain IS `VanillaAttention` with a causal mask
+    (naive_gpt/layers/basic/attention.py:41-57)."""
+    gen = torch.Generator().manual_seed(808)
+    N, S, H, E = 1, 64, 2, 32
+    q, k, v, noise = [0.5 * torch.randn([N, S, H, E], generator=gen) for _ in range(4)]
+    model = layers.VanillaAttention(d_head=E, p_dropout=0.0)
+    qi, ki, vi = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    causal = torch.full([S, S], float('-inf')).triu(1)
+    # The upstream gradient w keeps <w_i, y_i> > 0 in every row: softmax_backward clamps
+    # sum_j y_ij dy_ij = <dY_i, Y_i> at >= 1e-9 (softmax.cu:69, a reference quirk that its own
+    # test hides behind torch.max, test_softmax.py:71,78), so only there is the sparse
+    # backward the true softmax VJP that the dense attention differentiates.
+    with torch.no_grad():
+        w = model(q, k, v, attn_mask=causal) + 0.1 * noise
+        assert float((w * model(q, k, v, attn_mask=causal)).sum(-1).min()) > 1e-3
+    y = model(qi, ki, vi, attn_mask=causal)
+    (y * w).sum().backward()
+    save('dense_chain', q=t2n(q), k=t2n(k), v=t2n(v), w=t2n(w), y=t2n(y),
+         grad_q=t2n(qi.grad), grad_k=t2n(ki.grad), grad_v=t2n(vi.grad))
+
+
 # --------------------------------------------------------------------------- models + one tuning step
 
 def golden_models():
@@ -332,4 +469,7 @@ if __name__ == '__main__':
     golden_pq()
     golden_attention()
     golden_block()
+    golden_attention_mfma()
+    golden_block_mfma()
+    golden_dense_chain()
     golden_models()

@@ -77,3 +77,48 @@ def dense_from_csr(indptr, indices, values, S):
             for b in range(B):
                 dense[b, r, indices[b, p]] += values[b, p]
     return dense
+
+
+# ------------------------------------------------------------------ seeded tensors
+# Large inputs / weights of the N * H >= 32 goldens are not stored: both the generator
+# (tests/golden/make_golden.py, importing the reference) and the tests rebuild them from
+# the tensor's NAME.  numpy's PCG64 stream + ziggurat normal are the same on every
+# platform for one numpy version (the GPU box runs this image); the fixtures keep a
+# fingerprint of each seeded tensor so that a drifted generator fails loudly, not subtly.
+
+def seeded(name, shape, scale=1.0):
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    return (rng.standard_normal(size=tuple(shape), dtype=np.float32) * np.float32(scale))
+
+
+def fingerprint(a):
+    a = np.asarray(a, np.float64).reshape(-1)
+    return np.array([a[:8].sum(), a.sum(), np.abs(a).sum()])
+
+
+def seeded_fill(module, tag):
+    """Overwrite every floating-point entry of module.state_dict() (but the constant rotary
+    tables) with a seeded tensor named `tag + key`; returns {key: fingerprint}."""
+    import torch
+    prints = {}
+    for key, t in sorted(module.state_dict().items()):
+        if not t.is_floating_point() or 'cached' in key or key.endswith('attn_mask'):
+            continue
+        shape = tuple(t.shape)
+        if key.endswith('lora.left.weight'):
+            a = seeded(tag + key, shape, shape[0] ** -0.5)
+        elif key.endswith('lora.right.weight'):
+            a = seeded(tag + key, shape, 0.05)
+        elif t.dim() == 1 and 'norm' in key and key.endswith('weight'):
+            a = 1.0 + seeded(tag + key, shape, 0.1)
+        elif t.dim() <= 1:
+            a = seeded(tag + key, shape, 0.02)
+        elif t.dim() == 2:
+            a = seeded(tag + key, shape, shape[1] ** -0.5)
+        else:                                   # PQ codebooks [M, C, D]
+            a = seeded(tag + key, shape)
+        with torch.no_grad():
+            t.copy_(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)))
+        prints[key] = fingerprint(a)
+    return prints

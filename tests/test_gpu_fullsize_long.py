@@ -1,0 +1,142 @@
+"""BASELINE.json configs[3] and [4] at full head shape (S = 2048, Z = 256; OPT-1.3B: 32 heads
+x 64, LLaMA-7B: 32 heads x 128 with rotary embedding) through size-independent properties --
+the CPU oracle needs minutes per case here (it covers (1, 2, 2048, 256, {64,128}) slices in
+tests/test_gpu_mfma_attention.py).
+
+* structure: every lookup row is causal and zero padded behind its gy + 1 candidates;
+  rows that have more than Z candidates carry no repeated column (but the padding 0);
+* probabilities: y(v = 1) = 1 -- each row of P sums to one through the matrix-core kernels,
+  including row 0 whose cell count saturates at Z = 256 (include/spt_hip.h);
+* linearity in v, and the backward product is the adjoint of the forward one:
+  <y(v), w> = <v, grad_v(w)>;
+* determinism: forward and grad_q are bit-identical over two runs;
+* gradient: directional finite differences in q and k at a FIXED pattern agree with the
+  analytic gradients;
+* the layer (PQ encode -> lookup -> cell tiles -> kernels) takes the matrix-core path.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+S, Z = 2048, 256
+CASES = {'opt1b3': dict(N=2, H=32, E=64, rotary=False),       # BASELINE configs[3]
+         'llama7b': dict(N=1, H=32, E=128, rotary=True)}      # BASELINE configs[4], per GPU
+
+
+@pytest.fixture(scope='module', params=list(CASES))
+def case(request):
+    from naive_gpt import ext, kernels
+    c = CASES[request.param]
+    N, H, E = c['N'], c['H'], c['E']
+    torch.manual_seed(3)
+    q, k, v = [torch.randn([N, S, H, E], device='cuda') for _ in range(3)]
+    table = torch.randn([E // 8, 16, 8], device='cuda')
+    idx = kernels.lookup(ext.pq_encode_heads(q, table), ext.pq_encode_heads(k, table),
+                         sparse_coeff=8).flatten(1)
+    return c, q, k, v, idx
+
+
+def test_lookup_structure_long(case):
+    c, q, k, v, idx = case
+    B = c['N'] * c['H']
+    cols = idx.view(B, S, Z)
+    rows = torch.arange(S, device='cuda').view(1, S, 1)
+    assert int(cols.min()) >= 0 and bool((cols <= rows).all())
+    pos = torch.arange(Z, device='cuda').view(1, 1, Z)
+    assert bool((cols[(pos > rows).expand_as(cols)] == 0).all())
+    for b in range(0, B, 13):
+        for r in (Z, S // 2 + 5, S - 1):
+            nz = cols[b, r][cols[b, r] > 0]
+            assert nz.unique().numel() == nz.numel()
+
+
+def _forward(idx, q, k, v, E):
+    from naive_gpt import ext
+    tiles = ext.attention_mfma_prepare(idx, S)
+    y, row_sum = ext.attention_mfma_forward(tiles, q, k, v, E ** -0.5, 10.0, y_transposed=False)
+    return tiles, y, row_sum
+
+
+def test_probabilities_linearity_adjoint_long(case):
+    from naive_gpt import ext
+    c, q, k, v, idx = case
+    N, H, E = c['N'], c['H'], c['E']
+    assert ext.attention_mfma_supported(S, E, S * Z)
+    ones = torch.ones_like(v)
+    _, y1, _ = _forward(idx, q, k, ones, E)
+    assert torch.allclose(y1, torch.ones_like(y1), atol=2e-4)
+    v2 = torch.randn_like(v)
+    tiles, ya, row_sum = _forward(idx, q, k, v, E)
+    _, yb, _ = _forward(idx, q, k, v2, E)
+    _, yab, _ = _forward(idx, q, k, v + 2.0 * v2, E)
+    assert torch.allclose(yab, ya + 2.0 * yb, rtol=1e-3, atol=1e-3)
+    # adjoint: grad_v for the upstream gradient w is P^T w
+    w = torch.randn_like(ya)
+    gq, gk, gv = ext.attention_mfma_backward(tiles, q, k, v, ya, w, row_sum, E ** -0.5, 10.0,
+                                             transposed=False)
+    lhs = (ya.double() * w.double()).sum()
+    rhs = (gv.double() * v.double()).sum()          # gradients come back as [N, S, H, E]
+    assert abs(lhs - rhs) <= 1e-4 * abs(lhs) + 1e-2
+    # determinism of the forward and of the row-owned gradient
+    _, ya2, _ = _forward(idx, q, k, v, E)
+    gq2, _, _ = ext.attention_mfma_backward(tiles, q, k, v, ya, w, row_sum, E ** -0.5, 10.0,
+                                            transposed=False)
+    assert torch.equal(ya, ya2) and torch.equal(gq, gq2)
+
+
+def test_directional_derivatives_long(case):
+    from naive_gpt import ext
+    c, q, k, v, idx = case
+    N, H, E = c['N'], c['H'], c['E']
+    scale = E ** -0.5
+    tiles, y, row_sum = _forward(idx, q, k, v, E)
+    w = torch.randn_like(y)
+    gq, gk, gv = ext.attention_mfma_backward(tiles, q, k, v, y, w, row_sum, scale, 10.0,
+                                             transposed=False)
+
+    def loss(qq, kk):
+        yy, _ = ext.attention_mfma_forward(tiles, qq, kk, v, scale, 10.0, y_transposed=False)
+        return (yy.double() * w.double()).sum()
+
+    eps = 1e-2
+    for which, grad in (('q', gq), ('k', gk)):
+        d = torch.randn_like(q)
+        if which == 'q':
+            fd = (loss(q + eps * d, k) - loss(q - eps * d, k)) / (2 * eps)
+        else:
+            fd = (loss(q, k + eps * d) - loss(q, k - eps * d)) / (2 * eps)
+        an = (grad.double() * d.double()).sum()
+        # central difference: O(eps^2) truncation + the clamp's kinks; 2 % of the derivative
+        assert abs(fd - an) <= 2e-2 * abs(an) + 1.0, (which, float(fd), float(an))
+
+
+def test_layer_takes_the_matrix_core_path_long(case):
+    from naive_gpt import layers
+    c, q, k, v, idx = case
+    E = c['E']
+    torch.manual_seed(5)
+    if c['rotary']:
+        attn = layers.SparseRotaryAttentionV2(d_head=E, p_dropout=0.0, d_codeword=8,
+                                              n_codewords=16).cuda()
+    else:
+        attn = layers.SparseVanillaAttentionV2(d_head=E, d_codeword=8, n_codewords=16,
+                                               p_dropout=0.0).cuda()
+    assert attn._get_attn(q, k, None)[0] == 'mfma'
+    w = torch.randn_like(q)
+
+    def run():
+        qi, ki, vi = [t.clone().requires_grad_(True) for t in (q, k, v)]
+        y = attn(qi, ki, vi, attn_mask=None)
+        (y * w).sum().backward()
+        return y.detach(), qi.grad, ki.grad, vi.grad
+
+    a, b = run(), run()
+    assert all(torch.isfinite(t).all() for t in a)
+    assert torch.equal(a[0], b[0])
+    # v enters linearly: directional derivative of the layer in v is exact
+    d = torch.randn_like(v)
+    y0 = attn(q, k, v, attn_mask=None)
+    y1 = attn(q, k, v + d, attn_mask=None)
+    fd = ((y1 - y0).double() * w.double()).sum()
+    an = (a[3].double() * d.double()).sum()
+    assert abs(fd - an) <= 1e-3 * abs(an) + 1e-1

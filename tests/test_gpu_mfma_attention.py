@@ -18,7 +18,8 @@ SHAPES = [                             # (N, H, S, Z, d_head)
     (2, 8, 512, 64, 128),              # d_head 128 (LLaMA heads): the spt::e128 kernels,
     (1, 4, 80, 8, 128),                # two 64-column backward launches each
     (1, 2, 1024, 128, 128),
-]
+    (1, 2, 2048, 256, 128),            # BASELINE configs[4] (LLaMA-7B heads at S = 2048): cell
+]                                      # counts saturate in row 0, the e128 build at 2,080 tiles
 
 
 @pytest.mark.parametrize('yt', [False, True])

@@ -312,3 +312,237 @@ def test_upgraded_block_matches_reference_cpu(kind, oracle_ext, capsys):
 @pytest.mark.parametrize('kind', ['opt', 'llama'])
 def test_upgraded_block_matches_reference_gpu(kind):
     run_block(kind, 'cuda', 2e-3, 5e-4)
+
+
+# ------------------------------------------------------------------ N * H >= 32 (the matrix-core path)
+# tests/golden/attention_mfma.npz, block_mfma.npz: the imported reference's orchestration at
+# the shape class bench.py and real training run (n * h >= 32, d_head 64 and 128), where this
+# repo's V2 layers take `_MfmaAttention`.  Inputs / weights are seeded by name (helpers.seeded).
+
+from helpers import fingerprint, seeded, seeded_fill  # noqa: E402
+
+MFMA_CASES = {
+    'v64': dict(kind='vanilla', N=2, H=16, S=256, E=64, heads=[3, 12]),
+    'r128': dict(kind='rotary', N=1, H=32, S=256, E=128, heads=[7, 29]),
+}
+
+
+class _Spy:
+    """Counts the calls of the matrix-core attention entry points."""
+
+    def __init__(self, monkeypatch):
+        from naive_gpt import ext
+        self.calls = {'attention_mfma_forward': 0, 'attention_mfma_backward': 0}
+        for name in self.calls:
+            monkeypatch.setattr(ext, name, self._wrap(name, getattr(ext, name)))
+
+    def _wrap(self, name, fn):
+        def counted(*a, **kw):
+            self.calls[name] += 1
+            return fn(*a, **kw)
+        return counted
+
+
+def _slice_sums(t):
+    return t.detach().double().sum(dim=(1, 3)).cpu().numpy(), \
+        t.detach().double().abs().sum(dim=(1, 3)).cpu().numpy()
+
+
+def run_attn_mfma(tag, variant, device, rtol, atol):
+    from naive_gpt import layers
+    g, c = load('attention_mfma'), MFMA_CASES[tag]
+    N, H, S, E, heads = c['N'], c['H'], c['S'], c['E'], c['heads']
+    arrays = {n: seeded('attn_mfma.{}.{}'.format(tag, n), [N, S, H, E]) for n in 'qkvw'}
+    for n, a in arrays.items():
+        assert np.allclose(fingerprint(a), g['{}.print.{}'.format(tag, n)], rtol=1e-12), \
+            'the seeded generator drifted: regenerate tests/golden with make_golden.py'
+    if c['kind'] == 'vanilla':
+        model = layers.SparseVanillaAttentionV2(d_head=E, d_codeword=8, n_codewords=16,
+                                                p_dropout=0.0)
+    else:
+        model = layers.SparseRotaryAttentionV2(d_head=E, p_dropout=0.0, d_codeword=8,
+                                               n_codewords=16)
+    model = load_sd(model, g, tag + '.sd.', device)
+    q, k, v = [T(arrays[n], device).requires_grad_(True) for n in 'qkv']
+    if variant == 'train':
+        model.trigger.fill_(True)
+    y = model(q, k, v, attn_mask=None)
+    loss = (y * T(arrays['w'], device)).sum()
+    key = '{}.{}.'.format(tag, variant)
+    if variant == 'train':
+        loss = loss + 1e-2 * model.loss
+        check(model.loss, g[key + 'pq_loss'], rtol, atol, 'pq_loss')
+    loss.backward()
+    for name, t in (('y', y), ('grad_q', q.grad), ('grad_k', k.grad), ('grad_v', v.grad)):
+        if variant == 'plain':
+            check(t[:, :, heads], g[key + name + '.heads'], rtol, atol, name)
+        sums, abs_sums = _slice_sums(t)
+        # every (n, h) slice: the sum of S * E terms against the same sum of the reference
+        want, scale = g[key + name + '.sums'], g[key + name + '.abs']
+        assert (np.abs(sums - want) <= rtol * scale).all(), (name, np.abs(sums - want).max())
+        assert np.allclose(abs_sums, scale, rtol=rtol), name
+    if variant == 'train':
+        check_grads(model, g, key + 'grad.', rtol, 1e-5)
+
+
+def _mfma_structure(tag, device):
+    """CSR indices of the layer's lookup against the reference's, bit for bit."""
+    from naive_gpt import layers
+    g, c = load('attention_mfma'), MFMA_CASES[tag]
+    N, H, S, E, heads = c['N'], c['H'], c['S'], c['E'], c['heads']
+    q, k = [T(seeded('attn_mfma.{}.{}'.format(tag, n), [N, S, H, E]), device) for n in 'qk']
+    if c['kind'] == 'vanilla':
+        model = layers.SparseVanillaAttentionV2(d_head=E, d_codeword=8, n_codewords=16,
+                                                p_dropout=0.0)
+    else:
+        model = layers.SparseRotaryAttentionV2(d_head=E, p_dropout=0.0, d_codeword=8,
+                                               n_codewords=16)
+    model = load_sd(model, g, tag + '.sd.', device)
+    attn = model._get_attn(q, k, None)
+    indices = attn[2] if isinstance(attn[0], str) else attn[1]
+    idx = indices.cpu().numpy().reshape(N, H, -1)
+    assert np.array_equal(idx[:, heads], g[tag + '.indices.heads'])
+    weights = (np.arange(idx.shape[-1], dtype=np.int64) % 8191) + 1
+    assert np.array_equal((idx.astype(np.int64) * weights).sum(-1), g[tag + '.indices.checksum'])
+    return attn
+
+
+@pytest.mark.parametrize('variant', ['plain', 'train'])
+@pytest.mark.parametrize('tag', list(MFMA_CASES))
+def test_attention_heads32_matches_reference_cpu(tag, variant, oracle_ext):
+    run_attn_mfma(tag, variant, 'cpu', 1e-4, 2e-5)
+
+
+@pytest.mark.parametrize('tag', list(MFMA_CASES))
+def test_attention_heads32_csr_structure_cpu(tag, oracle_ext):
+    _mfma_structure(tag, 'cpu')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('variant', ['plain', 'train'])
+@pytest.mark.parametrize('tag', list(MFMA_CASES))
+def test_attention_heads32_matches_reference_gpu(tag, variant, monkeypatch):
+    """The matrix-core kernels (d_head 64 and the spt::e128 build) directly against the
+    imported reference's orchestration -- and the test insists that they ran."""
+    spy = _Spy(monkeypatch)
+    run_attn_mfma(tag, variant, 'cuda', 1e-3, 2e-4)
+    assert spy.calls == {'attention_mfma_forward': 1, 'attention_mfma_backward': 1}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', list(MFMA_CASES))
+def test_attention_heads32_csr_structure_gpu(tag):
+    attn = _mfma_structure(tag, 'cuda')
+    assert attn[0] == 'mfma'
+
+
+BLOCK_MFMA = {
+    'opt': dict(d_model=1024, n_heads=16, d_ff=256, N=2, S=128),
+    'llama': dict(d_model=2048, n_heads=16, d_ff=512, N=2, S=128),
+}
+
+
+def run_block_mfma(kind, device, rtol, atol):
+    from naive_gpt import layers
+    g, c = load('block_mfma'), BLOCK_MFMA[kind]
+    d_model, n_heads, d_ff, N, S = c['d_model'], c['n_heads'], c['d_ff'], c['N'], c['S']
+    if kind == 'opt':
+        block = layers.TransformerBlock(
+            d_model=d_model, n_heads=n_heads, layernorm_fn=nn.LayerNorm(d_model),
+            attention_fn=layers.VanillaAttention(d_head=d_model // n_heads, p_dropout=0.0),
+            feedforward_fn=layers.Feedforward(d_model=d_model, d_feedforward=d_ff,
+                                              activation=nn.ReLU(), p_dropout=0.0),
+            attention_bias=True, pre_norm=True)
+    else:
+        block = layers.TransformerBlock(
+            d_model=d_model, n_heads=n_heads, layernorm_fn=layers.LlamaRMSNorm(d_model),
+            attention_fn=layers.RotaryAttention(d_head=d_model // n_heads, p_dropout=0.0,
+                                                max_length=256),
+            feedforward_fn=layers.LLaMaFeedforward(d_model=d_model, d_feedforward=d_ff,
+                                                   activation=nn.SiLU()),
+            attention_bias=False, pre_norm=True)
+    model = upgrade(block)
+    tag = 'block_mfma.{}.'.format(kind)
+    prints = seeded_fill(model, tag)
+    wanted = {k[len(kind + '.print.'):]: v for k, v in g.items() if k.startswith(kind + '.print.')}
+    assert set(prints) == set(wanted)                     # identical state_dict keys
+    for key, fp in prints.items():
+        assert np.allclose(fp, wanted[key], rtol=1e-12), 'seeded generator drifted: ' + key
+    assert sorted(n for n, p in model.named_parameters() if p.requires_grad) \
+        == list(g[kind + '.trainable'])
+    model = model.to(device)
+    x = T(seeded(tag + 'x', [N, S, d_model]), device).requires_grad_(True)
+    w = T(seeded(tag + 'w', [N, S, d_model]), device)
+    y = model(x)
+    (y * w).sum().backward()
+    for name, t in (('y', y), ('grad_x', x.grad)):
+        want = g['{}.{}.sub'.format(kind, name)]
+        scale = float(np.abs(want).max())
+        check(t[:, ::4], want, rtol, atol * scale, name)
+        sums = t.detach().double().sum(-1).cpu().numpy()
+        assert (np.abs(sums - g['{}.{}.sums'.format(kind, name)])
+                <= rtol * d_model ** 0.5 * scale * 4).all(), name
+    n = 0
+    for name, p in model.named_parameters():
+        key = kind + '.grad.' + name
+        if key in g:
+            scale = max(float(np.abs(g[key]).max()), 1e-6)
+            check(p.grad, g[key], rtol, atol * scale, name)
+            n += 1
+        else:
+            assert p.grad is None, name
+    assert n >= 10
+
+
+@pytest.mark.parametrize('kind', list(BLOCK_MFMA))
+def test_upgraded_block_heads32_matches_reference_cpu(kind, oracle_ext, capsys):
+    run_block_mfma(kind, 'cpu', 1e-4, 1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', list(BLOCK_MFMA))
+def test_upgraded_block_heads32_matches_reference_gpu(kind, monkeypatch, capsys):
+    """Whole upgraded blocks (split-bf16 LoRA linears, routed FFN, matrix-core attention)
+    at BERT-large / LLaMA head shapes against the imported reference."""
+    spy = _Spy(monkeypatch)
+    run_block_mfma(kind, 'cuda', 2e-3, 1e-3)
+    assert spy.calls == {'attention_mfma_forward': 1, 'attention_mfma_backward': 1}
+
+
+# ------------------------------------------------------------------ sparse chain == dense attention
+# tests/golden/dense_chain.npz: the reference's dense VanillaAttention (causal mask) on small
+# inputs.  On the full causal pattern (every row lists all S columns, softmax masks col > row)
+# with scores inside the clamp the sparse chain sddmm -> scale, clamp -> softmax -> spmm and
+# its autograd wiring (kernels/{sddmm,softmax,spmm}.py) compute exactly that function: this is
+# the reference-run pin of the oracle's sddmm / softmax / spmm legs.
+
+def _dense_chain(device):
+    from naive_gpt import kernels
+    g = load('dense_chain')
+    q, k, v = [T(g[n], device) for n in 'qkv']
+    N, S, H, E = q.shape
+    flat = lambda t: t.transpose(1, 2).contiguous().view(N * H, S, E).requires_grad_(True)   # noqa: E731
+    qf, kf, vf = flat(q), flat(k), flat(v)
+    indptr = torch.arange(0, S * S + 1, S, dtype=torch.int32, device=device)
+    indices = torch.arange(S, dtype=torch.int32, device=device).repeat(N * H, S).contiguous()
+    scores = kernels.sddmm(indptr, indices, query=qf, key=kf)
+    scores = torch.clamp(E ** -0.5 * scores, min=-10.0, max=10.0)
+    assert float(scores.detach().abs().max()) < 10.0
+    attn = kernels.softmax(indptr, indices, values=scores)
+    y = kernels.spmm(indptr, indices, attn, vf)
+    heads = lambda t: t.view(N, H, S, E).transpose(1, 2)                    # noqa: E731
+    (heads(y) * T(g['w'], device)).sum().backward()
+    return g, heads(y), heads(qf.grad), heads(kf.grad), heads(vf.grad)
+
+
+def test_oracle_sparse_chain_equals_reference_dense_attention(oracle_ext):
+    g, y, gq, gk, gv = _dense_chain('cpu')
+    for got, name in ((y, 'y'), (gq, 'grad_q'), (gk, 'grad_k'), (gv, 'grad_v')):
+        check(got, g[name], 1e-5, 2e-6, name)
+
+
+@pytest.mark.gpu
+def test_hip_sparse_chain_equals_reference_dense_attention():
+    g, y, gq, gk, gv = _dense_chain('cuda')
+    for got, name in ((y, 'y'), (gq, 'grad_q'), (gk, 'grad_k'), (gv, 'grad_v')):
+        check(got, g[name], 1e-3, 1e-5, name)
