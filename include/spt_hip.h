@@ -42,7 +42,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 13
+#define SPT_ABI_VERSION 14
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -330,17 +330,20 @@ int spt_grouped_gemm(const float *a, const int32_t *gather, const float *w,
  *   epilogue SPT_EPI_PLAIN: out = v
  *            SPT_EPI_ACT  : out = act(v); out2 = v when out2 != NULL
  *            SPT_EPI_DACT : out = v * act'(s);
- *                           pdot_main[p, c] = sum_{n in c} t[p, n] * h[p, n]
+ *                           pdot_main[p, c] = sum_{n in c} v[p, n] * h[p, n]
  *                           pdot_act[p, c]  = sum_{n in c} out[p, n] * s[p, n]
- *              with t = v / rowscale - bias (the k-sum plus the second term over rowscale:
- *              the kernel accumulates a2 / rowscale first and scales once), c the
- *              64-column half tile of n (pdot_ld >= spt_grouped_gemm_pdot_width(n) of them
- *              per row; the caller adds them up), s = s_in, h = act(s_in) -- or, when
- *              s_in == NULL (ReLU only), s = h = h_in.
+ *              with c the 64-column half tile of n (pdot_ld >=
+ *              spt_grouped_gemm_pdot_width(n) of them per row; the caller adds them up),
+ *              s = s_in, h = act(s_in) -- or, when s_in == NULL (ReLU only), s = h = h_in.
+ *   The kernel multiplies its accumulators by rowscale after the k-loop and runs the second
+ *   term as one more k-step on top: nothing is ever divided by rowscale (0 is a legal router
+ *   coefficient: 2 sigmoid(logit) underflows below logit -104).
  * The second term is the LoRA side path (lora_ffn.py:97-100,108-110): r <= 32, r % 4 == 0.
- * The pdot rows are the two inner products the gradient of the router coefficient needs
- * (<dY W2_g^T, h> -- after subtracting <a2, h B2_g> / rowscale, which the caller has from the
- * forward pass -- and <dS, s>), which would otherwise each cost a pass over [P, n].
+ * The pdot rows are the two inner products the gradient of the router coefficient needs,
+ * <v, h> and <dS, s>: with c = rowscale, v = c (dY W2_g^T) + E and s = c (x W1_g^T + b1_g) + F,
+ * d c = <dY W2_g^T, h> + <dS, x W1_g^T + b1_g> = (<v, h> - <E, h> + <dS, s> - <dS, F>) / c, and
+ * the caller has <E, h> and <dS, F> as [*, r] dots from the LoRA side products.  Each would
+ * otherwise cost a pass over [P, n].
  * activation: 0 ReLU, 1 GELU (erf), 2 SiLU.
  */
 enum { SPT_EPI_PLAIN = 0, SPT_EPI_ACT = 1, SPT_EPI_DACT = 2 };

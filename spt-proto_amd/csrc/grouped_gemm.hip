@@ -7,7 +7,7 @@
 // range [offsets[g], offsets[g+1]) of the sorted order and ONE launch multiplies every
 // bucket by its own weight block:
 //
-//     out[p, n] = rowscale[p] * ( sum_k A[src(p), k] * W_g(n, k)  +  bias[g, n] )
+//     out[p, n] = rowscale[p] * ( sum_k A[src(p), k] * W_g(n, k)  +  bias[g, n] )  (+ A2 . B2_g^T)
 //     src(p) = gather ? gather[p] : p          (fuses the token gather)
 //     W_g(n, k) = w[g * gstride + n * ldn + k * ldk]
 //         ldk == 1 : "BT" weights, k contiguous  (forward: x.W1_g^T, h.W2_g^T)
@@ -187,7 +187,7 @@ struct GroupedArgs {
     float *out2;            // EPI_ACT: pre-activation (null: not kept, e.g. ReLU)
     const float *h_in;      // EPI_DACT: activated values [P, N] (used when s_in is null: ReLU)
     const float *s_in;      // EPI_DACT: pre-activation values [P, N] or null
-    float *pdot_main;       // EPI_DACT: [P, pdot_ld]: sum_n (v / rowscale - bias)[p, n] * h[p, n]
+    float *pdot_main;       // EPI_DACT: [P, pdot_ld]: sum_n v[p, n] * h[p, n], v = the value before act'
     float *pdot_act;        // EPI_DACT: [P, pdot_ld]: sum_n out[p, n] * s[p, n] per half tile
     int pdot_ld;
     int slots;              // workgroups resident at a time (CUs x occupancy)
@@ -359,40 +359,6 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
             for (int q2 = 0; q2 < (kmax + 15) / 16; q2++) mfma_group16(q2, bt_image);
         }
     };
-
-    // ---- K extension first: acc = (A2 / rowscale) . B2_g^T, so that the epilogue's single
-    // rowscale * (acc + bias) yields rowscale * (A W^T + bias) + A2 B2^T ----
-    if (EXT) {
-        const int k = 4 * s_kq;
-#pragma unroll
-        for (int u = 0; u < NUA; u++) {
-            const int r = s_row + GG_RPP * u;
-            const int p = row_lo + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < row_hi && k < g.R) {
-                const int src = g.gather2 ? g.gather2[p] : p;
-                v = *reinterpret_cast<const float4 *>(g.a2 + (size_t)src * g.lda2 + k);
-                if (g.rowscale) {
-                    const float inv = 1.0f / g.rowscale[p];
-                    v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
-                }
-            }
-            put4(As, GG_AIMG, r * GG_ROWB + 8 * s_kq, v, EPI == EPI_ACT && fp32_level);
-        }
-#pragma unroll
-        for (int u = 0; u < GG_NU; u++) {
-            const int r = s_row + GG_RPP * u;
-            const int n = n0 + r;
-            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < g.N && k < g.R)
-                b = *reinterpret_cast<const float4 *>(g.b2 + (size_t)bucket * g.b2_gstride +
-                                                      (size_t)n * g.b2_ldn + k);
-            put4(Bs, GG_BIMG, r * GG_ROWB + 8 * s_kq, b, EPI == EPI_ACT && fp32_level);
-        }
-        __syncthreads();
-        contract(g.R, true);              // (the tiles are zero beyond R, up to GG_BK)
-        // the main loop's first __syncthreads orders these reads before its LDS writes
-    }
 
     // ---- software pipeline: the global loads of k-step t+1 are in flight while the MFMAs
     // of step t run; registers -> LDS happens at the top of the next step.  (A second
@@ -635,6 +601,49 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
         }
     }
 
+    // ---- rowscale, then the K extension: acc = rowscale * (A W^T), acc += A2 . B2_g^T; the
+    // epilogue adds rowscale * bias.  (Until ABI 14 the extension ran FIRST on A2 / rowscale so
+    // that one multiplication in the epilogue served both: a router coefficient of 0 made that
+    // 0 * inf, and a tiny one cost the base product its mantissa.) ----
+    if (g.rowscale) {
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int p = row_lo + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const float rs = g.rowscale[min(p, row_hi - 1)];
+                acc[i][0][r] *= rs;
+                acc[i][1][r] *= rs;
+            }
+    }
+    if (EXT) {
+        __syncthreads();                  // the last k-step's tiles are consumed
+        const int k = 4 * s_kq;
+#pragma unroll
+        for (int u = 0; u < NUA; u++) {
+            const int r = s_row + GG_RPP * u;
+            const int p = row_lo + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < row_hi && k < g.R) {
+                const int src = g.gather2 ? g.gather2[p] : p;
+                v = *reinterpret_cast<const float4 *>(g.a2 + (size_t)src * g.lda2 + k);
+            }
+            put4(As, GG_AIMG, r * GG_ROWB + 8 * s_kq, v, EPI == EPI_ACT && fp32_level);
+        }
+#pragma unroll
+        for (int u = 0; u < GG_NU; u++) {
+            const int r = s_row + GG_RPP * u;
+            const int n = n0 + r;
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < g.N && k < g.R)
+                b = *reinterpret_cast<const float4 *>(g.b2 + (size_t)bucket * g.b2_gstride +
+                                                      (size_t)n * g.b2_ldn + k);
+            put4(Bs, GG_BIMG, r * GG_ROWB + 8 * s_kq, b, EPI == EPI_ACT && fp32_level);
+        }
+        __syncthreads();
+        contract(g.R, true);              // (the tiles are zero beyond R, up to GG_BK)
+    }
+
 #ifdef GG_STAMP
     if (EPI == EPI_PLAIN && g.pdot_main && tid == 0) {
         unsigned long long *st = reinterpret_cast<unsigned long long *>(g.pdot_main);
@@ -703,11 +712,11 @@ __device__ __forceinline__ void gemm_tile(const GroupedArgs &g, float *smem, int
             float pre[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
+                float v = fmaf(rs, b[e], c[e]);
                 if (EPI == EPI_DACT) {
                     const float hv = g.s_in ? act_forward(g.act, sv[e]) : sv[e];
-                    dot_h = fmaf(c[e], hv, dot_h);
+                    dot_h = fmaf(v, hv, dot_h);
                 }
-                float v = rs * (c[e] + b[e]);
                 pre[e] = v;
                 if (EPI == EPI_ACT) v = act_forward(g.act, v);
                 if (EPI == EPI_DACT) {

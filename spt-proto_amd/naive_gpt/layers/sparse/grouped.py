@@ -230,12 +230,13 @@ class RoutedLoRAFFN(torch.autograd.Function):
             epilogue=ext.EPI_DACT, activation=act, h_in=h, s_in=s)
         du = _own_block(torch.matmul(ds, _block_cat(r1, nb)), bk.block, nb).contiguous()  # [P, r]
         u_rows = u.index_select(0, bk.token_long)
-        # d/dc: <dy W2_g^T, h> + <ds, x W1_g^T + b1_g>, the second through
-        # s = c (x W1^T + b1) + u R1^T  =>  x W1^T + b1 = (s - u R1^T) / c
-        # (the kernel's dot_main still contains the LoRA term <dzt, h L2_g> / c = <dzt, z> / c)
+        # d/dc = <dy W2_g^T, h> + <ds, x W1_g^T + b1_g>.  The kernel's dot_main = <v, h> with
+        # v = c (dy W2_g^T) + dzt L2_g^T (the value before act'), dot_act = <ds, s> with
+        # s = c (x W1^T + b1) + u R1^T; the LoRA parts of both are [*, r] dots:
+        # <dzt L2_g^T, h> = <dzt, z> and <ds, u R1_g^T> = <du, u>
         dz_rows = dzt.index_select(0, bk.token_long)
-        grad_coeff = dot_main + (dot_act - (du * u_rows).sum(dim=-1)
-                                 - (dz_rows * z).sum(dim=-1)) / _floor(coeff)
+        grad_coeff = (dot_main + dot_act - (du * u_rows).sum(dim=-1)
+                      - (dz_rows * z).sum(dim=-1)) / _floor(coeff)
         # LoRA tables (before the last GEMM: ds [P, bs] is released as soon as that has read it --
         # the step's peak memory is here, with h, ds, dxs and grad_x alive)
         du_tok = du[pos].sum(dim=1)                                          # [T, r]

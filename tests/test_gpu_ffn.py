@@ -237,13 +237,11 @@ def test_fused_activation_derivative_epilogue_and_row_dots(act, layout):
     sd = s.double().requires_grad_(True)
     deriv = torch.autograd.grad(_act(act)(sd).sum(), sd)[0]
     want = (c['base'] + c['side']) * deriv
-    plain = ref_grouped(c['a'], c['gather'], c['w'], c['view'], None, None, c['offsets'])
     kw = dict(h_in=h.cuda(), s_in=None if act == 'relu' else s.cuda())
     out, dot_main, dot_act = _call_fused(c, epilogue=ext.EPI_DACT, activation=_act_code(act), **kw)
     _close64(out, want, 'out')
-    # dot_main: t = v / rowscale - bias = k-sum + second term / rowscale
-    t = plain + c['side'] / c['scale'].double()[:, None]
-    _close64(dot_main, (t * h.double()).sum(-1), 'dot_main')
+    # dot_main = <v, h>, v the value before the activation derivative
+    _close64(dot_main, ((c['base'] + c['side']) * h.double()).sum(-1), 'dot_main')
     s_like = h.double() if act == 'relu' else s.double()
     _close64(dot_act, (want * s_like).sum(-1), 'dot_act')
 
@@ -302,8 +300,8 @@ def test_fused_lora_routed_ffn_equals_torch_loop(act):
 
 @pytest.mark.parametrize('family', ['opt', 'llama'])
 def test_fused_routed_ffn_with_saturated_router_coefficients(family):
-    """Router logits near -20 and -90 (coefficients 4e-9 and 1.6e-39, an fp32 denormal: no exact
-    zeros, which would tie in the top-k): the fused path recovers d coeff by a division by
+    """Router logits near -20 and -80 (coefficients 4e-9 and 3.6e-35; the GPU's sigmoid flushes
+    denormals, and exact zeros would tie in the top-k): the fused path recovers d coeff by a division by
     coeff (layers/sparse/grouped.py: _floor); everything must stay finite and equal to the
     torch loop, which never divides."""
     from naive_gpt import layers
@@ -321,7 +319,7 @@ def test_fused_routed_ffn_with_saturated_router_coefficients(family):
             p.data.copy_(0.1 * torch.randn(p.shape, generator=gen).cuda())
     router = ffn.router[0]
     router.weight.data.mul_(0.01)
-    router.bias.data.copy_(torch.tensor([-90.0, -20.0, -95.0, -100.0]))     # top-2 = blocks 1, 0
+    router.bias.data.copy_(torch.tensor([-80.0, -20.0, -83.0, -85.0]))      # top-2 = blocks 1, 0
     x = torch.randn([2, 40, 64], generator=gen).cuda()
     w = torch.randn([2, 40, 64], generator=gen).cuda()
 
@@ -339,6 +337,14 @@ def test_fused_routed_ffn_with_saturated_router_coefficients(family):
         return y.detach(), xi.grad, {n: p.grad.clone() for n, p in ffn.named_parameters()
                                      if p.grad is not None}
 
+    # the scale of a router gradient when the coefficients are O(1): what the absolute error of
+    # the saturated case has to be small against (the quotient's error is eps * |dots| / c, and
+    # the chain rule multiplies it by d c / d logit ~ c / 2: an ABSOLUTE error of fp32 rounding
+    # size on a gradient whose true value has vanished with the coefficient)
+    saved_bias = router.bias.data.clone()
+    router.bias.data.zero_()
+    live = run(False)[2]
+    router.bias.data.copy_(saved_bias)
     y0, gx0, g0 = run(False)
     y1, gx1, g1 = run(True)
     prob = ffn.router(x.view(-1, 64))
@@ -346,11 +352,15 @@ def test_fused_routed_ffn_with_saturated_router_coefficients(family):
     assert bool((prob[:, 0] > prob[:, 2]).all())                            # no ties in the top-2
     for t in [y1, gx1] + list(g1.values()):
         assert torch.isfinite(t).all()
-    assert torch.allclose(y1, y0, atol=1e-6) and torch.allclose(gx1, gx0, atol=1e-6)
+    assert _scaled_close(y1, y0) and _scaled_close(gx1, gx0)
     assert set(g0) == set(g1)
     for n in g0:
-        scale = max(float(g0[n].abs().max()), 1e-6)
-        assert float((g1[n] - g0[n]).abs().max()) <= 2e-3 * scale, n
+        if n.startswith('router'):
+            assert float(g0[n].abs().max()) < 1e-6 * float(live[n].abs().max())   # vanished
+            assert float((g1[n] - g0[n]).abs().max()) <= 1e-4 * float(live[n].abs().max()), n
+        else:
+            scale = max(float(g0[n].abs().max()), 1e-6)
+            assert float((g1[n] - g0[n]).abs().max()) <= 2e-3 * scale, n
 
 
 @pytest.mark.parametrize('T,G,k', [(8192, 4, 2), (1000, 8, 4), (77, 4, 2), (5, 2, 1), (40000, 4, 2)])

@@ -10,8 +10,8 @@ tests/test_gpu_mfma_attention.py).
 * linearity in v, and the backward product is the adjoint of the forward one:
   <y(v), w> = <v, grad_v(w)>;
 * determinism: forward and grad_q are bit-identical over two runs;
-* gradient: directional finite differences in q and k at a FIXED pattern agree with the
-  analytic gradients;
+* a few (batch, head) slices of the full-size launch, forward and all gradients, against a
+  dense fp64 restatement in torch (independent of the kernels and of the C oracle);
 * the layer (PQ encode -> lookup -> cell tiles -> kernels) takes the matrix-core path.
 """
 import pytest
@@ -84,7 +84,32 @@ def test_probabilities_linearity_adjoint_long(case):
     assert torch.equal(ya, ya2) and torch.equal(gq, gq2)
 
 
-def test_directional_derivatives_long(case):
+def _dense_slice(idx_b, q, k, v, dy, scale):
+    """One (batch, head) slice of the sparse chain as DENSE fp64 torch algebra on the GPU:
+    cell multiplicities from the CSR row lists, the reference's two clamps (softmax.cu:30,69)
+    and the +-10 score clamp.  Independent of the kernels and of the oracle's C code."""
+    Sq = q.size(0)
+    q, k, v, dy = [t.double() for t in (q, k, v, dy)]
+    cnt = torch.zeros([Sq, Sq], dtype=torch.float64, device=q.device)
+    rows = torch.arange(Sq, device=q.device).view(Sq, 1).expand(Sq, idx_b.numel() // Sq)
+    cnt.index_put_((rows.reshape(-1), idx_b.long()), torch.ones([], dtype=torch.float64,
+                                                                device=q.device), accumulate=True)
+    cnt = cnt * (torch.arange(Sq, device=q.device).view(1, Sq) <= torch.arange(
+        Sq, device=q.device).view(Sq, 1))
+    raw = scale * (q @ k.t())
+    sc = raw.clamp(-10.0, 10.0)
+    e = cnt * sc.exp()
+    p = e / e.sum(-1, keepdim=True).clamp_min(1e-9)
+    y = p @ v
+    dp = dy @ v.t()
+    c = (p * dp).sum(-1, keepdim=True).clamp_min(1e-9)
+    ds = p * (dp - c) * scale * (raw.abs() < 10.0)
+    return y, ds @ k, ds.t() @ q, p.t() @ dy
+
+
+def test_slices_match_dense_fp64_algebra_long(case):
+    """Forward and all three gradients of a few slices of the full-size launch against the
+    dense fp64 restatement above (1e-3 of each tensor's scale, the north-star bar)."""
     from naive_gpt import ext
     c, q, k, v, idx = case
     N, H, E = c['N'], c['H'], c['E']
@@ -93,21 +118,13 @@ def test_directional_derivatives_long(case):
     w = torch.randn_like(y)
     gq, gk, gv = ext.attention_mfma_backward(tiles, q, k, v, y, w, row_sum, scale, 10.0,
                                              transposed=False)
-
-    def loss(qq, kk):
-        yy, _ = ext.attention_mfma_forward(tiles, qq, kk, v, scale, 10.0, y_transposed=False)
-        return (yy.double() * w.double()).sum()
-
-    eps = 1e-2
-    for which, grad in (('q', gq), ('k', gk)):
-        d = torch.randn_like(q)
-        if which == 'q':
-            fd = (loss(q + eps * d, k) - loss(q - eps * d, k)) / (2 * eps)
-        else:
-            fd = (loss(q, k + eps * d) - loss(q, k - eps * d)) / (2 * eps)
-        an = (grad.double() * d.double()).sum()
-        # central difference: O(eps^2) truncation + the clamp's kinks; 2 % of the derivative
-        assert abs(fd - an) <= 2e-2 * abs(an) + 1.0, (which, float(fd), float(an))
+    for b in (0, N * H // 2 + 1, N * H - 1):
+        n, h = divmod(b, H)
+        want = _dense_slice(idx[b], q[n, :, h], k[n, :, h], v[n, :, h], w[b], scale)
+        got = (y[b], gq[n, :, h], gk[n, :, h], gv[n, :, h])
+        for name, g_, w_ in zip(('y', 'grad_q', 'grad_k', 'grad_v'), got, want):
+            err = float((g_.double() - w_).abs().max())
+            assert err <= 1e-3 * float(w_.abs().max()), (b, name, err, float(w_.abs().max()))
 
 
 def test_layer_takes_the_matrix_core_path_long(case):
