@@ -15,6 +15,8 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cmd=$1; shift
+# rocprofv3 runs from /tmp: make the script path of `stats / traffic / pmc` absolute
+abs() { case $1 in /*) echo $1 ;; *) echo $R/$1 ;; esac; }
 case $cmd in
 tests)
     cd $R && python -m pytest tests -m gpu -x -q > $OUT/tests.log 2>&1; rc=$?
@@ -26,24 +28,24 @@ bench)
     tail -c 400 $OUT/bench.err; head -c 600 $OUT/bench.json; echo
     exit $rc ;;
 stats)
-    tag=$1; shift
+    tag=$1; script=$(abs $2); shift 2
     cd /tmp && export TMPDIR=/tmp && rm -rf $OUT/prof_$tag
-    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$tag -- python3 "$@" > $OUT/${tag}_run.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$tag -- python3 $script "$@" > $OUT/${tag}_run.log 2>&1
     rc=$?
     cd $R && python tools/kernel_stats.py $tag | head -40
     exit $rc ;;
 traffic)
-    tag=$1; shift
+    tag=$1; script=$(abs $2); shift 2
     cd /tmp && export TMPDIR=/tmp && rm -rf $OUT/pmc_fetch $OUT/pmc_write
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 "$@" > $OUT/pmc_fetch.log 2>&1 &&
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 "$@" > $OUT/pmc_write.log 2>&1
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $script "$@" > $OUT/pmc_fetch.log 2>&1 &&
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $script "$@" > $OUT/pmc_write.log 2>&1
     rc=$?
     cd $R && python tools/pmc_traffic_report.py $tag
     exit $rc ;;
 pmc)
-    tag=$1; counters=$2; shift 2
+    tag=$1; counters=$2; script=$(abs $3); shift 3
     cd /tmp && export TMPDIR=/tmp && rm -rf $OUT/pmc_$tag
-    rocprofv3 --kernel-trace --pmc $counters --output-format csv -d $OUT/pmc_$tag -- python3 "$@" > $OUT/pmc_$tag.log 2>&1
+    rocprofv3 --kernel-trace --pmc $counters --output-format csv -d $OUT/pmc_$tag -- python3 $script "$@" > $OUT/pmc_$tag.log 2>&1
     rc=$?
     cd $R && python tools/kernel_stats.py --pmc $tag | tee $OUT/${tag}_pmc.txt
     exit $rc ;;
