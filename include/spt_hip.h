@@ -30,6 +30,7 @@
 #ifndef SPT_HIP_H
 #define SPT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -42,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 14
+#define SPT_ABI_VERSION 15
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -372,9 +373,35 @@ typedef struct SptGroupedGemm {
     float *pdot_main;
     float *pdot_act;
     int32_t pdot_ld;
+    /* Pre-split operands (spt_split_bf16 below), both or neither: the image of the WHOLE
+     * `a` matrix [*, k] (rows are addressed through `gather` exactly as rows of `a`) and of
+     * the WHOLE weight `w` as it lies in memory (rows of w_ldn elements when w_ldk == 1, of
+     * w_ldk elements when w_ldn == 1; the group offsets g * w_group_stride are resolved
+     * inside it).  With images the operands go global -> LDS by LDS-DMA and the k-loop has
+     * no conversion work; taken when k % 32 == 0, the weight's row length and
+     * w_group_stride are multiples of 32 and the GEMM is not the three-way split
+     * (SPT_EPI_ACT with ReLU) -- otherwise the fp32 operands are used, which therefore
+     * stay mandatory unless the caller knows the image path applies. */
+    const void *a_image;
+    const void *w_image;
 } SptGroupedGemm;
 int spt_grouped_gemm_fused(const SptGroupedGemm *desc, void *stream);
 int spt_grouped_gemm_pdot_width(int n);
+/* 1 when spt_grouped_gemm_fused would run `desc` from its images, 0 when from the fp32 operands */
+int spt_grouped_gemm_image_path(const SptGroupedGemm *desc);
+
+/*
+ * The pre-split image of an fp32 matrix [rows, cols] (leading dimension ld, ld % 4 == 0,
+ * 16-byte aligned): every element x as hi = bf16(x) (round to nearest even) and
+ * lo = bf16(x - hi), laid out [row][ceil(cols / 32)][hi: 32 x bf16 | lo: 32 x bf16], i.e. one
+ * 128-byte block per row and 32 columns (columns past `cols` in the last block are zero).
+ * x = hi + lo to 2^-17 relative; three bf16 MFMAs (lo.hi + hi.lo + hi.hi) then give an fp32
+ * product to 2^-16.  spt_split_bf16_bytes = rows * ceil(cols / 32) * 128.
+ * No reference counterpart: the reference multiplies in fp32 on cuBLAS (lora_ffn.py:87-111).
+ */
+size_t spt_split_bf16_bytes(long long rows, int cols);
+int spt_split_bf16(const float *src, void *image, long long rows, int cols, long long ld,
+                   void *stream);
 
 /*
  * Bucketing for the routed FFN: the k largest of the n_blocks router probabilities of every

@@ -10,8 +10,10 @@ through torch's caching allocator, and enqueues hand-written gfx950 kernels from
 There is no CPU path and no fallback: without the built library, or with CPU
 tensors, every call raises ``RuntimeError``.
 """
+import collections
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -60,6 +62,9 @@ _PROTOTYPES = {
                                                                  _c_ptr], _c_int),
     'spt_grouped_gemm_fused': ([_c_ptr, _c_ptr], _c_int),
     'spt_grouped_gemm_pdot_width': ([_c_int], _c_int),
+    'spt_grouped_gemm_image_path': ([_c_ptr], _c_int),
+    'spt_split_bf16_bytes': ([ctypes.c_longlong, _c_int], ctypes.c_size_t),
+    'spt_split_bf16': ([_c_ptr, _c_ptr, ctypes.c_longlong, _c_int, ctypes.c_longlong, _c_ptr], _c_int),
     'spt_rows_combine': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_route_topk': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_forward': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
@@ -67,7 +72,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _lib = None
 
@@ -762,10 +767,12 @@ class _GroupedDesc(ctypes.Structure):
         ('epilogue', ctypes.c_int32), ('activation', ctypes.c_int32),
         ('out2', _c_ptr), ('h_in', _c_ptr), ('s_in', _c_ptr),
         ('pdot_main', _c_ptr), ('pdot_act', _c_ptr), ('pdot_ld', ctypes.c_int32),
+        ('a_image', _c_ptr), ('w_image', _c_ptr),
     ]
 
 
 EPI_PLAIN, EPI_ACT, EPI_DACT = 0, 1, 2
+LAST_GEMM_USED_IMAGES = False      # which operand path the last grouped_gemm_fused call took
 ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2
 
 
@@ -773,12 +780,95 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+class SplitImage:
+    """The pre-split bf16 image of an fp32 matrix (``spt_split_bf16``): every 32 columns of a
+    row as one 128-byte block [hi | lo].  Keeps the source's shape for the checks."""
+    __slots__ = ('buffer', 'rows', 'cols')
+
+    def __init__(self, buffer, rows, cols):
+        self.buffer, self.rows, self.cols = buffer, rows, cols
+
+
+def split_bf16(x: torch.Tensor) -> SplitImage:
+    """fp32 [rows, cols] (unit inner stride) -> its hi / lo bf16 image, one launch."""
+    _check_type(x, torch.float32, 'x')
+    _require(x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0,
+             'split_bf16: CUDA fp32 matrix with unit inner stride and 16-byte aligned rows')
+    rows, cols = x.shape
+    lib = load_library()
+    dev = x.device
+    with torch.cuda.device(dev):
+        buf = torch.empty([lib.spt_split_bf16_bytes(rows, cols)], dtype=torch.uint8, device=dev)
+        if rows > 0:
+            rc = lib.spt_split_bf16(x.data_ptr(), buf.data_ptr(), rows, cols, x.stride(0),
+                                    _stream(dev))
+            if rc != 0:
+                _raise(lib, rc, 'split_bf16')
+    return SplitImage(buf, rows, cols)
+
+
+# Images of the operands most recently split, keyed by (storage address, version, shape,
+# stride): the q / k / v projections of a block share one input, a frozen weight is read by
+# the forward and the backward GEMM.  The cache holds the SOURCE tensor too, so that its
+# address cannot be handed to another tensor while the entry lives; `_version` changes with
+# every in-place write.  Activations: a few entries (they are as large as the activations
+# themselves).  Weights: see `weight_image`.
+_IMAGE_CACHE = collections.OrderedDict()
+IMAGE_CACHE_ENTRIES = 2
+
+
+def _image_key(x: torch.Tensor):
+    return (x.data_ptr(), x._version, tuple(x.shape), x.stride(0), x.device.index)
+
+
+def image_of(x: torch.Tensor) -> SplitImage:
+    """`split_bf16(x)` through the small most-recently-used cache above."""
+    if x.is_inference():
+        return split_bf16(x)
+    key = _image_key(x)
+    hit = _IMAGE_CACHE.get(key)
+    if hit is not None:
+        _IMAGE_CACHE.move_to_end(key)
+        return hit[1]
+    img = split_bf16(x)
+    _IMAGE_CACHE[key] = (x, img)
+    while len(_IMAGE_CACHE) > IMAGE_CACHE_ENTRIES:
+        _IMAGE_CACHE.popitem(last=False)
+    return img
+
+
+def drop_images():
+    _IMAGE_CACHE.clear()
+    _WEIGHT_IMAGES.clear()
+
+
+# Frozen weights: their images never change, and keeping them costs as many bytes again as
+# the fp32 weights.  SPT_WEIGHT_IMAGES=keep (default) holds them for the life of the
+# parameter (keyed by the parameter object, dropped when `_version` moves);
+# SPT_WEIGHT_IMAGES=step re-splits a weight every time it is used (4 MiB -> ~4 us) and
+# keeps nothing.
+_WEIGHT_IMAGES = weakref.WeakKeyDictionary()
+KEEP_WEIGHT_IMAGES = os.environ.get('SPT_WEIGHT_IMAGES', 'keep') != 'step'
+
+
+def weight_image(w: torch.Tensor) -> SplitImage:
+    if not KEEP_WEIGHT_IMAGES or w.is_inference():
+        return split_bf16(w.detach())
+    hit = _WEIGHT_IMAGES.get(w)
+    if hit is not None and hit[0] == (w.data_ptr(), w._version):
+        return hit[1]
+    img = split_bf16(w.detach())
+    _WEIGHT_IMAGES[w] = ((w.data_ptr(), w._version), img)
+    return img
+
+
 def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Tensor,
                        n_groups: int, n: int, k: int, w_group_stride: int, w_ldn: int,
                        w_ldk: int, n_rows: int, gather=None, bias=None, rowscale=None,
                        a2=None, gather2=None, b2=None, b2_group_stride: int = 0,
                        epilogue: int = EPI_PLAIN, activation: int = ACT_RELU,
-                       keep_preact: bool = False, h_in=None, s_in=None):
+                       keep_preact: bool = False, h_in=None, s_in=None,
+                       a_image: SplitImage = None, w_image: SplitImage = None):
     """``spt_grouped_gemm_fused``: the block GEMM of a routed FFN with its LoRA side
     product, rowscale / bias, and the activation (EPI_ACT) or its derivative plus the two
     row dots of the coefficient gradient (EPI_DACT) folded in (include/spt_hip.h).
@@ -797,6 +887,13 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
     for t in (gather, bias, rowscale, a2, gather2, b2, h_in, s_in):
         if t is not None:
             _require(t.is_cuda and t.is_contiguous(), 'grouped_gemm_fused: contiguous CUDA operands')
+    images = a_image is not None and w_image is not None
+    if images:
+        _require(a_image.rows == a.size(0) and a_image.cols == a.size(1) == k
+                 and a.stride(0) == a.size(1), 'a_image: the image of the contiguous [*, k] matrix a')
+        _require(w_image.rows * w_image.cols == weight.numel()
+                 and w_image.cols == (w_ldn if w_ldk == 1 else w_ldk),
+                 'w_image: the image of the weight with rows of w_ldn (w_ldk) elements')
     lib = load_library()
     with torch.cuda.device(dev):
         out = torch.empty([n_rows, n], dtype=torch.float32, device=dev)
@@ -820,7 +917,11 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                 b2_ldn=b2.stride(-2) if b2 is not None else 0,
                 epilogue=epilogue, activation=activation, out2=_ptr(preact),
                 h_in=_ptr(h_in), s_in=_ptr(s_in), pdot_main=_ptr(dot_main),
-                pdot_act=_ptr(dot_act), pdot_ld=width)
+                pdot_act=_ptr(dot_act), pdot_ld=width,
+                a_image=a_image.buffer.data_ptr() if images else None,
+                w_image=w_image.buffer.data_ptr() if images else None)
+            global LAST_GEMM_USED_IMAGES
+            LAST_GEMM_USED_IMAGES = bool(lib.spt_grouped_gemm_image_path(ctypes.byref(desc)))
             rc = lib.spt_grouped_gemm_fused(ctypes.byref(desc), _stream(dev))
             if rc != 0:
                 _raise(lib, rc, 'grouped_gemm_fused')

@@ -181,11 +181,14 @@ def _fused_case(P, K, N, G, R, layout, seed):
                 a2=a2, b2=b2, base=base, side=side)
 
 
-def _call_fused(c, **kw):
+def _call_fused(c, images=False, **kw):
     from naive_gpt import ext
     N, K, gs, ldn, ldk = c['view']
     G = len(c['offsets']) - 1
     dev = 'cuda'
+    if images:
+        kw['a_image'] = ext.split_bf16(c['a'].to(dev))
+        kw['w_image'] = ext.split_bf16(c['w'].to(dev))
     return ext.grouped_gemm_fused(
         c['a'].to(dev), c['w'].to(dev), torch.tensor(c['offsets'], dtype=torch.int32, device=dev),
         G, n=N, k=K, w_group_stride=gs, w_ldn=ldn, w_ldk=ldk, n_rows=len(c['gather']),
@@ -244,6 +247,90 @@ def test_fused_activation_derivative_epilogue_and_row_dots(act, layout):
     _close64(dot_main, ((c['base'] + c['side']) * h.double()).sum(-1), 'dot_main')
     s_like = h.double() if act == 'relu' else s.double()
     _close64(dot_act, (want * s_like).sum(-1), 'dot_act')
+
+
+# ------------------------------------------------------------------ pre-split images + LDS-DMA
+
+def test_split_bf16_image_is_hi_lo_in_128_byte_blocks():
+    """spt_split_bf16: hi = bf16(x) (RNE), lo = bf16(x - hi), [row][cols / 32][hi | lo][32];
+    columns past `cols` in the last block are zero; a strided source is honoured."""
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(21)
+    for rows, cols, ld in [(37, 64, 64), (5, 40, 48), (130, 1024, 1024), (3, 8, 8)]:
+        x = torch.randn([rows, ld], generator=gen).cuda()[:, :cols]
+        x[0, 0] = 0.0
+        x[-1, -1] = 3.0e38                              # hi rounds up to inf? no: stays finite
+        img = ext.split_bf16(x)
+        blocks = (cols + 31) // 32
+        raw = img.buffer.view(torch.bfloat16).view(rows, blocks, 2, 32)
+        pad = torch.zeros([rows, blocks * 32], device='cuda')
+        pad[:, :cols] = x
+        hi = pad.bfloat16()
+        lo = (pad - hi.float()).bfloat16()
+        assert torch.equal(raw[:, :, 0].reshape(rows, -1).view(torch.int16), hi.view(torch.int16))
+        assert torch.equal(raw[:, :, 1].reshape(rows, -1).view(torch.int16), lo.view(torch.int16))
+        # what the three products see: x = hi + lo to 2^-17
+        back = raw[:, :, 0].float() + raw[:, :, 1].float()
+        finite = pad.abs() < 1e30
+        assert ((back.reshape(rows, -1) - pad).abs()[finite] <= 2.0 ** -16 * pad.abs()[finite]).all()
+
+
+@pytest.mark.parametrize('P,K,N,G,R,layout', [
+    (1000, 64, 128, 4, 16, 'bt'), (1000, 64, 128, 4, 16, 'bn'),
+    (4096, 256, 384, 4, 16, 'bt'), (4096, 256, 384, 4, 16, 'bn'),
+    (770, 96, 200, 3, 4, 'bt'), (770, 96, 224, 3, 4, 'bn'),      # N % 128 != 0; rank 4
+    (513, 128, 72, 4, 32, 'bt'),                                  # rank 32 = one full k-step
+    (64, 1024, 1024, 8, 16, 'bt'),                                # more buckets than rows / 128
+    (300, 32, 4000, 1, 8, 'bt'),                                  # a single k-step, many columns
+])
+def test_image_path_matches_per_bucket_product(P, K, N, G, R, layout):
+    """The LDS-DMA kernels on pre-split operands (both weight orientations, gathered rows,
+    ragged and empty buckets, group offsets inside the weight image) against the fp64
+    per-bucket product -- same bar as the register path."""
+    from naive_gpt import ext
+    c = _fused_case(P, K, N, G, R, layout, seed=P + R + 1)
+    out = _call_fused(c, images=True, epilogue=ext.EPI_PLAIN)
+    assert ext.LAST_GEMM_USED_IMAGES
+    _close64(out, c['base'] + c['side'], 'out')
+    regs = _call_fused(c, epilogue=ext.EPI_PLAIN)
+    assert not ext.LAST_GEMM_USED_IMAGES
+    # same split, same products, a different summation order only
+    assert (out - regs).abs().max() <= 1e-5 * regs.abs().max()
+
+
+@pytest.mark.parametrize('act', ['relu', 'gelu', 'silu'])
+@pytest.mark.parametrize('layout', ['bt', 'bn'])
+def test_image_path_activation_derivative_epilogue(act, layout):
+    from naive_gpt import ext
+    c = _fused_case(900, 64, 200 if layout == 'bt' else 224, 4, 8, layout, seed=12)
+    gen = torch.Generator().manual_seed(3)
+    N = c['view'][0]
+    s = torch.randn([900, N], generator=gen)
+    h = _act(act)(s)
+    sd = s.double().requires_grad_(True)
+    deriv = torch.autograd.grad(_act(act)(sd).sum(), sd)[0]
+    want = (c['base'] + c['side']) * deriv
+    kw = dict(h_in=h.cuda(), s_in=None if act == 'relu' else s.cuda())
+    out, dot_main, dot_act = _call_fused(c, images=True, epilogue=ext.EPI_DACT,
+                                         activation=_act_code(act), **kw)
+    assert ext.LAST_GEMM_USED_IMAGES
+    _close64(out, want, 'out')
+    _close64(dot_main, ((c['base'] + c['side']) * h.double()).sum(-1), 'dot_main')
+    s_like = h.double() if act == 'relu' else s.double()
+    _close64(dot_act, (want * s_like).sum(-1), 'dot_act')
+    # EPI_ACT: SiLU / GELU run from images, the GEMM in front of a ReLU keeps the three-way split
+    out2, pre = _call_fused(c, images=True, epilogue=ext.EPI_ACT, activation=_act_code(act),
+                            keep_preact=True)
+    assert ext.LAST_GEMM_USED_IMAGES == (act != 'relu')
+    _close64(pre, c['base'] + c['side'], 'preact')
+
+
+def test_image_path_is_refused_where_it_does_not_apply():
+    from naive_gpt import ext
+    c = _fused_case(300, 36, 128, 2, 4, 'bt', seed=5)          # K % 32 != 0
+    out = _call_fused(c, images=True, epilogue=ext.EPI_PLAIN)
+    assert not ext.LAST_GEMM_USED_IMAGES
+    _close64(out, c['base'] + c['side'], 'out')
 
 
 def test_rows_combine_is_a_fixed_order_gather_sum():
