@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 15
+#define SPT_ABI_VERSION 17
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -378,12 +378,27 @@ typedef struct SptGroupedGemm {
      * the WHOLE weight `w` as it lies in memory (rows of w_ldn elements when w_ldk == 1, of
      * w_ldk elements when w_ldn == 1; the group offsets g * w_group_stride are resolved
      * inside it).  With images the operands go global -> LDS by LDS-DMA and the k-loop has
-     * no conversion work; taken when k % 32 == 0, the weight's row length and
-     * w_group_stride are multiples of 32 and the GEMM is not the three-way split
-     * (SPT_EPI_ACT with ReLU) -- otherwise the fp32 operands are used, which therefore
-     * stay mandatory unless the caller knows the image path applies. */
+     * no conversion work; taken when k % 32 == 0 and the weight's row length and
+     * w_group_stride are multiples of 32 -- otherwise the fp32 operands are used, which
+     * therefore stay mandatory unless the caller knows the image path applies. */
     const void *a_image;
     const void *w_image;
+    /* SPT_EPI_ACT with ReLU only (mandatory there): Euclidean norms of the rows of `a`
+     * [rows of a] and of the vectors W_g(n, :) [n_groups, n] (upper bounds do).  A product of split
+     * operands is off by <= 2^-16 |a| |w|; a pre-activation within that of ZERO would get
+     * the wrong ReLU derivative -- an O(1) error in that token's gradients (measured: 6 of
+     * 614 k elements of one FFN).  The epilogue finds those elements (4e-4 of them at
+     * k = 1024) from the norms and recomputes each as a plain fp32 dot product, read from
+     * the fp32 operands `a` and `w`, which therefore have to be given as well. */
+    const float *a_norm;
+    const float *w_norm;
+    /* ... and, optionally, scratch for the queue of those elements: 16 KiB of counters +
+     * 8 bytes per element (256 segments; n_rows * n / 64 elements are 25 x the expected
+     * number).  With it the GEMM only queues them and a second launch recomputes all of them in
+     * parallel; without it, or where a segment overflows, the epilogue recomputes them itself,
+     * one after another (~2 us each).  16-byte aligned; contents on return are unspecified. */
+    void *relu_queue;
+    int64_t relu_queue_bytes;
 } SptGroupedGemm;
 int spt_grouped_gemm_fused(const SptGroupedGemm *desc, void *stream);
 int spt_grouped_gemm_pdot_width(int n);

@@ -20,7 +20,9 @@
 // Arithmetic: an fp32 operand is split x = hi + lo (hi = RNE bf16 of x, lo = RNE bf16 of
 // x - hi) and a product is three v_mfma_f32_32x32x16_bf16 (lo.hi + hi.lo + hi.hi, fp32
 // accumulation): <= 2^-16 relative error per product at 1/5 of the time of the fp32 MFMA.
-// The forward GEMM in front of a ReLU takes a three-way split and six MFMAs (~2^-23).
+// One place cannot live with 2^-16: the pre-activation of a ReLU that lies within the error of
+// zero (its derivative flips: an O(1) error in one token's gradients).  There the epilogue
+// recomputes the element in plain fp32 (gg_epilogue: "near the kink").
 //
 // Two operand paths, one tile shape (128 x 128 per 256-thread workgroup, each wave a 64 x 64
 // quadrant = 2 x 2 MFMA tiles, K in steps of 32), one epilogue:
@@ -33,8 +35,8 @@
 //     XOR swizzle applied on the SOURCE address of each lane (the LDS side of an LDS-DMA is
 //     lane-linear) and again on the fragment reads.
 //   * REGISTER path (gemm_tile_regs): fp32 operands, split while they are staged
-//     (global -> VGPR -> cvt -> ds_write).  Round 1's kernel; kept for what the image path
-//     does not take: K % 32 != 0 and the three-way split.
+//     (global -> VGPR -> cvt -> ds_write).  Round 1's kernel; kept for callers without images
+//     and for K % 32 != 0.
 //
 // Why the image path: per-phase shader-clock stamps of the register path
 // had a k-step at 4390 cycles of which 1355 were the split + 16 ds_write_b64 per lane and
@@ -49,6 +51,15 @@ constexpr int GG_BN = 128;
 constexpr int GG_BK = 32;
 // workgroups per CU the round arithmetic of the kernels counts on (both paths: two fit)
 constexpr int GG_SLOTS_PER_CU = 2;
+// behind the operand tiles either kernel's LDS array carries three rows of 128 floats for the
+// ReLU epilogue: |a2 row|^2 and |b2 row|^2 of the K extension's operands (written while they
+// are staged) and rowscale * |a row| of the tile's rows (loaded in the prologue)
+constexpr int GG_EXTRAS = 3 * 128;
+// The ReLU queue is cut into segments with a counter each (16 words apart: a line of their own),
+// a workgroup appends to segment blockIdx % GG_FIX_SEGS: ONE returning atomic counter takes
+// ~88 increments / us from the whole chip (MI355X_MICROARCH.md, "dequeue"), and a GEMM queues
+// ~10,000 elements -- measured 105 us on one counter.
+constexpr int GG_FIX_SEGS = 256;
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef __attribute__((ext_vector_type(8))) __bf16 gg_bf16x8;
@@ -64,17 +75,6 @@ __device__ __forceinline__ void gg_split2(float a, float b, unsigned &hi, unsign
                          __builtin_bit_cast(float, hi & 0xffff0000u)};
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(x - hf, gg_bf16x2));
 }
-// x = hi + mid + lo (3 x 8 mantissa bits: exact to ~2^-24)
-__device__ __forceinline__ void gg_split2x3(float a, float b, unsigned &hi, unsigned &mid,
-                                            unsigned &lo) {
-    gg_f32x2 x = {a, b};
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, gg_bf16x2));
-    x -= gg_f32x2{__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
-    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(x, gg_bf16x2));
-    x -= gg_f32x2{__builtin_bit_cast(float, mid << 16), __builtin_bit_cast(float, mid & 0xffff0000u)};
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(x, gg_bf16x2));
-}
-
 __device__ __forceinline__ uint2 gg_tr_b64(const char *p) {      // ds_read_b64_tr_b16
     const gg_v4s16 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (__attribute__((address_space(3))) gg_v4s16 *)(p));
@@ -85,23 +85,11 @@ __device__ __forceinline__ f32x16 gg_mma(const uint4 &a, const uint4 &b, f32x16 
                                                    __builtin_bit_cast(gg_bf16x8, b), c, 0, 0, 0);
 }
 struct GgFrag { uint4 hi, lo; };
-struct GgFrag3 { uint4 hi, mid, lo; };
 __device__ __forceinline__ f32x16 gg_mma3(const GgFrag &a, const GgFrag &b, f32x16 c) {
     c = gg_mma(a.lo, b.hi, c);      // small terms first
     c = gg_mma(a.hi, b.lo, c);
     return gg_mma(a.hi, b.hi, c);
 }
-// the six products of order >= 2^-16 of a three-way split: fp32-level accuracy (~2^-23 per
-// product) at 6 x 32 cycles per 16 k against 8 x 64 for the fp32 MFMA
-__device__ __forceinline__ f32x16 gg_mma6(const GgFrag3 &a, const GgFrag3 &b, f32x16 c) {
-    c = gg_mma(a.lo, b.hi, c);
-    c = gg_mma(a.hi, b.lo, c);
-    c = gg_mma(a.mid, b.mid, c);
-    c = gg_mma(a.mid, b.hi, c);
-    c = gg_mma(a.hi, b.mid, c);
-    return gg_mma(a.hi, b.hi, c);
-}
-
 enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DACT = 2 };
 enum { ACT_RELU = 0, ACT_GELU = 1, ACT_SILU = 2 };
 
@@ -133,6 +121,13 @@ struct GroupedArgs {
     float *pdot_main;       // EPI_DACT: [P, pdot_ld]: sum_n v[p, n] * h[p, n], v = the value before act'
     float *pdot_act;        // EPI_DACT: [P, pdot_ld]: sum_n out[p, n] * s[p, n] per half tile
     int pdot_ld;
+    // EPI_ACT with ReLU: row norms of a [rows of a] and of the weight [G, N] (upper bounds do),
+    // from which the epilogue tells which pre-activations lie within the split's error of zero
+    const float *a_norm;
+    const float *w_norm;
+    unsigned *fix_count;    // ... and where their (row, column) pairs are queued for
+    int2 *fix_list;         // relu_fix_kernel (null / full: recomputed in the epilogue itself):
+    int fix_cap;            // GG_FIX_SEGS segments of fix_cap entries, one counter each
     int slots;              // workgroups resident at a time (CUs x occupancy)
     // image path: pre-split operands (spt_split_bf16), byte strides of one image row
     const char *a_img;
@@ -156,6 +151,41 @@ __device__ __forceinline__ float act_derivative(int act, float s) {
     }
     const float sg = 1.0f / (1.0f + __expf(-s));
     return sg * (1.0f + s * (1.0f - sg));
+}
+
+// v[p, n] as a plain fp32 computation by one wave: rowscale (sum_k a[src, k] W_g(n, k) + bias)
+// + sum_j a2[src2, j] b2[n, j], every lane 4 k's per pass, butterfly sum.  All lanes return it.
+__device__ __forceinline__ float gg_exact_preact(const GroupedArgs &g, int bucket, int p, int n,
+                                                 int lane) {
+    const long long src = g.gather ? g.gather[p] : p;
+    const float *ar = g.a + src * g.lda;
+    const float *wr = g.w + (size_t)bucket * g.gstride + (size_t)n * g.ldn;
+    float part = 0.0f;
+    for (int k = 4 * lane; k < g.K; k += 256) {
+        const float4 x = *reinterpret_cast<const float4 *>(ar + k);
+        float4 y;
+        if (g.ldk == 1) {
+            y = *reinterpret_cast<const float4 *>(wr + k);
+        } else {            // n-contiguous weights: a strided column
+            y.x = wr[(size_t)k * g.ldk]; y.y = wr[(size_t)(k + 1) * g.ldk];
+            y.z = wr[(size_t)(k + 2) * g.ldk]; y.w = wr[(size_t)(k + 3) * g.ldk];
+        }
+        part = fmaf(x.x, y.x, part); part = fmaf(x.y, y.y, part);
+        part = fmaf(x.z, y.z, part); part = fmaf(x.w, y.w, part);
+    }
+    float side = 0.0f;
+    if (g.a2 && 4 * lane < g.R) {
+        const long long src2 = g.gather2 ? g.gather2[p] : p;
+        const float4 x = *reinterpret_cast<const float4 *>(g.a2 + src2 * g.lda2 + 4 * lane);
+        const float4 y = *reinterpret_cast<const float4 *>(
+            g.b2 + (size_t)bucket * g.b2_gstride + (size_t)n * g.b2_ldn + 4 * lane);
+        side = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, x.w * y.w)));
+    }
+    part = group_sum<64>(part);
+    side = group_sum<64>(side);
+    const float bb = g.bias ? g.bias[(size_t)bucket * g.N + n] : 0.0f;
+    const float rr = g.rowscale ? g.rowscale[p] : 1.0f;
+    return fmaf(rr, part + bb, side);
 }
 
 // acc = rowscale * acc, in the MFMA C layout (row = 32 i + (r & 3) + 8 (r >> 2) + 4 (l >> 5)).
@@ -187,10 +217,12 @@ __device__ __forceinline__ void gg_scale_rows(const GroupedArgs &g, f32x16 (&acc
 template <int NI, int EPI>
 __device__ __forceinline__ void gg_epilogue(const GroupedArgs &g, float *smem,
                                             f32x16 (&acc)[NI][2], int bucket, int row_lo,
-                                            int row_hi, int col_tile, int wm, int wn) {
+                                            int row_hi, int col_tile, int wm, int wn,
+                                            const float *extras, bool has_ext) {
     constexpr int CS_ROW = 64 + 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *cs = smem + wave * (32 * CS_ROW);
+    const bool relu_exact = EPI == EPI_ACT && g.act == ACT_RELU && g.a_norm != nullptr;
     const int ccol = lane & 31, chalf = lane >> 5;
     const int rrow = lane >> 4, rcol = 4 * (lane & 15);
     const int pslot = 2 * col_tile + (wave & 1);   // this wave's half tile of columns
@@ -207,6 +239,16 @@ __device__ __forceinline__ void gg_epilogue(const GroupedArgs &g, float *smem,
             bias4.z = n + 2 < g.N ? bp[2] : 0.f; bias4.w = n + 3 < g.N ? bp[3] : 0.f;
         }
     }
+    // ReLU epilogue: this lane's four columns' share of the error bound (see below)
+    float wn4[4] = {0.f, 0.f, 0.f, 0.f}, rn4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_ACT && relu_exact) {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (n + e < g.N) {
+                wn4[e] = g.w_norm[(size_t)bucket * g.N + n + e];
+                rn4[e] = has_ext ? extras[128 + wn + rcol + e] : 0.0f;
+            }
+    }
 #pragma unroll
     for (int i = 0; i < NI; i++) {
 #pragma unroll
@@ -216,7 +258,9 @@ __device__ __forceinline__ void gg_epilogue(const GroupedArgs &g, float *smem,
             cs[row * CS_ROW + 32 + ccol] = acc[i][1][r];
         }
         // (a wave only reads what it wrote: no workgroup barrier)
-#pragma unroll
+        // (not unrolled: the body is long -- with the ReLU recomputation inlined eight times the
+        // activation epilogues ran 30-45 us slower at the FFN shape)
+#pragma unroll 1
         for (int t = 0; t < 8; t++) {
             const int row = rrow + 4 * t;
             const int p = row_lo + wm + 32 * i + row;
@@ -255,6 +299,56 @@ __device__ __forceinline__ void gg_epilogue(const GroupedArgs &g, float *smem,
                     dot_s = fmaf(v, sv[e], dot_s);
                 }
                 c[e] = v;
+            }
+            if (EPI == EPI_ACT && relu_exact) {
+                // ---- near the kink: |v| within the error bound of the split products ----
+                // per product <= 2^-16 |a| |b| (hi.hi + hi.lo + lo.hi of RNE bf16 parts), so
+                // |error of v| <= 2^-16 (rs |a_p| |w_n| + |a2_p| |b2_n|) by Cauchy-Schwarz; a
+                // pre-activation inside 1.5 x that bound is recomputed as a plain fp32 dot product
+                // by a whole wave (6e-4 of the elements at K = 1024: ~10 per tile)
+                unsigned cand = 0;
+                if (live) {
+                    const float an = extras[256 + wm + 32 * i + row];      // rowscale |a row|
+                    const float un2 = has_ext ? extras[wm + 32 * i + row] : 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float bound = 2.2888e-5f * (an * wn4[e] + sqrtf(un2 * rn4[e]));
+                        cand |= (n + e < g.N && fabsf(pre[e]) <= bound ? 1u : 0u) << e;
+                    }
+                }
+                // queue them for relu_fix_kernel (one wave per element, all in parallel) ...
+                if (cand && g.fix_list) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (cand & (1u << e)) {
+                            const unsigned seg = blockIdx.x % GG_FIX_SEGS;
+                            const unsigned slot = atomicAdd(g.fix_count + 16 * seg, 1u);
+                            if (slot < (unsigned)g.fix_cap) {
+                                g.fix_list[(size_t)seg * g.fix_cap + slot] =
+                                    make_int2(p, (n + e) | (bucket << 24));
+                                cand &= ~(1u << e);
+                            }
+                        }
+                }
+                // ... or, without a queue (or with a full one), recompute here, wave by wave
+                unsigned long long todo = __ballot(cand != 0);
+                while (todo) {
+                    const int owner = __ffsll(todo) - 1;
+                    const unsigned m = __shfl(cand, owner, 64);
+                    const int e = __ffs(m) - 1;
+                    const float exact = gg_exact_preact(g, bucket, __shfl(p, owner, 64),
+                                                        __shfl(n, owner, 64) + e, lane);
+                    if (lane == owner) {
+#pragma unroll
+                        for (int ee = 0; ee < 4; ee++)
+                            if (ee == e) {
+                                pre[ee] = exact;
+                                c[ee] = act_forward(g.act, exact);
+                            }
+                        cand &= ~(1u << e);
+                    }
+                    todo = __ballot(cand != 0);
+                }
             }
             if (live) {
                 if (vec) {
@@ -335,30 +429,43 @@ __device__ __forceinline__ uint4 gi_frag_nc(const char *tile, int ncol0, int q2,
     const uint2 lo = gg_tr_b64(ptr), hi = gg_tr_b64(ptr + 4 * 512);
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
+template <int NI>
+struct GiFrags {
+    GgFrag a[NI], b[2];
+};
 template <int NI, int NA, bool KC_B>
-__device__ __forceinline__ void gi_contract(const GiLane<NI, NA> &c, const char *As, const char *Bs,
-                                            int q2, f32x16 (&acc)[NI][2]) {
-    GgFrag af[NI], bf[2];
+__device__ __forceinline__ void gi_read(const GiLane<NI, NA> &c, const char *As, const char *Bs,
+                                        int q2, GiFrags<NI> &f) {
 #pragma unroll
     for (int i = 0; i < NI; i++) {
-        af[i].hi = gi_frag_kc(As, c.wm + 32 * i + c.frow, q2, 0, c.fh);
-        af[i].lo = gi_frag_kc(As, c.wm + 32 * i + c.frow, q2, 1, c.fh);
+        f.a[i].hi = gi_frag_kc(As, c.wm + 32 * i + c.frow, q2, 0, c.fh);
+        f.a[i].lo = gi_frag_kc(As, c.wm + 32 * i + c.frow, q2, 1, c.fh);
     }
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         if constexpr (KC_B) {
-            bf[j].hi = gi_frag_kc(Bs, c.wn + 32 * j + c.frow, q2, 0, c.fh);
-            bf[j].lo = gi_frag_kc(Bs, c.wn + 32 * j + c.frow, q2, 1, c.fh);
+            f.b[j].hi = gi_frag_kc(Bs, c.wn + 32 * j + c.frow, q2, 0, c.fh);
+            f.b[j].lo = gi_frag_kc(Bs, c.wn + 32 * j + c.frow, q2, 1, c.fh);
         } else {
-            bf[j].hi = gi_frag_nc(Bs, c.wn + 32 * j, q2, 0, c.fh, c.lane);
-            bf[j].lo = gi_frag_nc(Bs, c.wn + 32 * j, q2, 1, c.fh, c.lane);
+            f.b[j].hi = gi_frag_nc(Bs, c.wn + 32 * j, q2, 0, c.fh, c.lane);
+            f.b[j].lo = gi_frag_nc(Bs, c.wn + 32 * j, q2, 1, c.fh, c.lane);
         }
     }
+}
+template <int NI>
+__device__ __forceinline__ void gi_mma(const GiFrags<NI> &f, f32x16 (&acc)[NI][2]) {
 #pragma unroll
     for (int i = 0; i < NI; i++) {
-        acc[i][0] = gg_mma3(af[i], bf[0], acc[i][0]);
-        acc[i][1] = gg_mma3(af[i], bf[1], acc[i][1]);
+        acc[i][0] = gg_mma3(f.a[i], f.b[0], acc[i][0]);
+        acc[i][1] = gg_mma3(f.a[i], f.b[1], acc[i][1]);
     }
+}
+template <int NI, int NA, bool KC_B>
+__device__ __forceinline__ void gi_contract(const GiLane<NI, NA> &c, const char *As, const char *Bs,
+                                            int q2, f32x16 (&acc)[NI][2]) {
+    GiFrags<NI> f;
+    gi_read<NI, NA, KC_B>(c, As, Bs, q2, f);
+    gi_mma<NI>(f, acc);
 }
 // k-step k0 .. k0 + 31 into the LDS stage at `dma` (instruction t = wave + 4 j: 1 KiB each)
 template <int NI, int NA, bool BN_LAYOUT>
@@ -383,12 +490,22 @@ template <int NI, int NA, bool BN_LAYOUT>
 __device__ __forceinline__ void gi_step(const GiLane<NI, NA> &c, char *__restrict__ dma,
                                         const char *__restrict__ cur, bool prefetch, int k_next,
                                         f32x16 (&acc)[NI][2]) {
+    // The order is pinned: the fragments of the step's second half are requested BEFORE the
+    // MFMAs of the first, so that their LDS latency passes behind 12 MFMAs.  The wait for the
+    // first half stands in front of those reads -- behind them hipcc makes it lgkmcnt(0) (no
+    // counted wait is available to it while an LDS-DMA is pending), a wait for the reads just
+    // issued.  Left alone, hipcc also sinks each group of reads to its first use and hoists the
+    // barrier that follows (with its vmcnt(0), the wait for the NEXT tile) above half the MFMAs.
+    GiFrags<NI> f0, f1;
     if (prefetch) gi_stage<NI, NA, BN_LAYOUT>(c, dma, k_next);
-    gi_contract<NI, NA, !BN_LAYOUT>(c, cur, cur + GI_TILE, 0, acc);
-    gi_contract<NI, NA, !BN_LAYOUT>(c, cur, cur + GI_TILE, 1, acc);
-    // keep the step's MFMAs in front of the barrier that follows: hipcc otherwise hoists the
-    // barrier -- and the vmcnt(0) in front of it, i.e. the wait for the NEXT tile -- above the
-    // second half of them (MFMAs touch no memory, nothing orders them against a barrier)
+    gi_read<NI, NA, !BN_LAYOUT>(c, cur, cur + GI_TILE, 0, f0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0) only
+    __builtin_amdgcn_sched_barrier(0);
+    gi_read<NI, NA, !BN_LAYOUT>(c, cur, cur + GI_TILE, 1, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    gi_mma<NI>(f0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    gi_mma<NI>(f1, acc);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -411,6 +528,11 @@ __device__ __forceinline__ void gemm_tile_img(const GroupedArgs &g, float *smem,
     c.w_rowb = g.w_rowb;
     const int wave = c.wave, wm = c.wm, wn = c.wn;
 
+    float *const extras = smem + GI_LDS_FLOATS;
+    if (EPI == EPI_ACT && g.act == ACT_RELU && g.a_norm && tid < BM) {
+        const int p = min(row_lo + tid, row_hi - 1);
+        extras[256 + tid] = g.a_norm[g.gather ? g.gather[p] : p] * (g.rowscale ? g.rowscale[p] : 1.0f);
+    }
     // ---- LDS-DMA sources.  KC tile: instruction t = wave + 4 j covers rows 8 t .. 8 t + 7,
     // lane -> row 8 t + (lane >> 3), physical chunk lane & 7.  Rows past the bucket end and
     // columns past N are computed but never stored: clamped, not predicated. ----
@@ -494,6 +616,8 @@ __device__ __forceinline__ void gemm_tile_img(const GroupedArgs &g, float *smem,
                 v = *reinterpret_cast<const float4 *>(g.a2 + src * g.lda2 + k);
             }
             put4(As, r, v);
+            const float ss = group_sum<8>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+            if (kq == 0) extras[r] = ss;                    // |a2 row|^2, for the epilogue
         }
 #pragma unroll
         for (int u = 0; u < GG_BN / 32; u++) {
@@ -504,13 +628,15 @@ __device__ __forceinline__ void gemm_tile_img(const GroupedArgs &g, float *smem,
                 b = *reinterpret_cast<const float4 *>(g.b2 + (size_t)bucket * g.b2_gstride +
                                                       (size_t)n * g.b2_ldn + k);
             put4(Bs, r, b);
+            const float ss = group_sum<8>(b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w);
+            if (kq == 0) extras[128 + r] = ss;              // |b2 row|^2
         }
         __syncthreads();
         gi_contract<NI, NA, true>(c, As, Bs, 0, acc);
         if (g.R > 16) gi_contract<NI, NA, true>(c, As, Bs, 1, acc);
         __syncthreads();
     }
-    gg_epilogue<NI, EPI>(g, smem, acc, bucket, row_lo, row_hi, col_tile, wm, wn);
+    gg_epilogue<NI, EPI>(g, smem, acc, bucket, row_lo, row_hi, col_tile, wm, wn, extras, EXT);
 }
 
 // ============================================================================ register path
@@ -528,6 +654,7 @@ constexpr int GG_BNROWB = GG_BN * 2 + 64;        // bytes per k-row of an n-cont
 constexpr int GG_AIMG = GG_BM * GG_ROWB;         // one part of the A tile: 10240 B
 constexpr int GG_BIMG = GG_BN * GG_ROWB;         // one part of a B tile (either orientation)
 static_assert(GG_BK * GG_BNROWB == GG_BIMG, "both B orientations fit the same slot");
+constexpr int GG_REGS_LDS_FLOATS = 2 * (GG_AIMG + GG_BIMG) / 4;   // A | B, hi | lo each
 
 // One output tile of BM x 128: BM = 128 (each wave a 64 x 64 quadrant) or BM = 64 (each
 // wave 32 x 64), same B tile, same LDS image, same epilogue.
@@ -536,9 +663,9 @@ __device__ __forceinline__ void gemm_tile_regs(const GroupedArgs &g, float *smem
                                                int row_lo, int row_hi, int col_tile) {
     constexpr int NI = BM / 64;                  // 32-row sub-blocks per wave
     constexpr int NUA = BM / GG_RPP;             // float4 of A per thread per k-step
-    constexpr int NPART = (EPI == EPI_ACT) ? 3 : 2;      // hi, lo (, mid)
+    constexpr int NPART = 2;                     // hi, lo
     char *const lds0 = reinterpret_cast<char *>(smem);
-    char *As = lds0;                                      // [NPART][GG_AIMG]: hi | lo | mid
+    char *As = lds0;                                      // [NPART][GG_AIMG]: hi | lo
     char *Bs = As + NPART * GG_AIMG;                      // [NPART][GG_BIMG]
     const int n0 = col_tile * GG_BN;
     const int tid = threadIdx.x;
@@ -548,6 +675,11 @@ __device__ __forceinline__ void gemm_tile_regs(const GroupedArgs &g, float *smem
     const int wn = (wave & 1) * 64;
     const float *wg = g.w + (size_t)bucket * g.gstride;
 
+    float *const extras = smem + GG_REGS_LDS_FLOATS;
+    if (EPI == EPI_ACT && g.act == ACT_RELU && g.a_norm && tid < BM) {
+        const int p = min(row_lo + tid, row_hi - 1);
+        extras[256 + tid] = g.a_norm[g.gather ? g.gather[p] : p] * (g.rowscale ? g.rowscale[p] : 1.0f);
+    }
     // ---- staging assignment: tile = rows x GG_KQ float4 along k ----
     // (8 lanes per row; the two rows of a 16-lane ds_write_b64 group are 4 apart: 320 bytes = 64
     // mod 128, so their 64-byte pieces fall on disjoint banks -- adjacent rows, 80 bytes apart,
@@ -616,57 +748,16 @@ __device__ __forceinline__ void gemm_tile_regs(const GroupedArgs &g, float *smem
             acc[i][1] = gg_mma3(af[i], bf[1], acc[i][1]);
         }
     };
-    // the same 16 k's at fp32-level accuracy: three-way split, six products
-    auto mfma_group16x6 = [&](int q2, bool bt_image) {
-        GgFrag3 af[NI], bf[2];
-#pragma unroll
-        for (int i = 0; i < NI; i++) {
-            af[i].hi = frag_rows(As, wm + 32 * i + frow, q2);
-            af[i].lo = frag_rows(As + GG_AIMG, wm + 32 * i + frow, q2);
-            af[i].mid = frag_rows(As + 2 * GG_AIMG, wm + 32 * i + frow, q2);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            bf[j].hi = b_frag(0, j, q2, bt_image);
-            bf[j].lo = b_frag(1, j, q2, bt_image);
-            bf[j].mid = b_frag(2, j, q2, bt_image);
-        }
-#pragma unroll
-        for (int i = 0; i < NI; i++) {
-            acc[i][0] = gg_mma6(af[i], bf[0], acc[i][0]);
-            acc[i][1] = gg_mma6(af[i], bf[1], acc[i][1]);
-        }
+    // ---- staging: four fp32 values -> the 8-byte pieces of both parts of an image ----
+    auto put4 = [&](char *img, int part_stride, int off, const float4 &v) {
+        unsigned h0, l0, h1, l1;
+        gg_split2(v.x, v.y, h0, l0);
+        gg_split2(v.z, v.w, h1, l1);
+        *reinterpret_cast<uint2 *>(img + off) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(img + part_stride + off) = make_uint2(l0, l1);
     };
-    // ---- staging: four fp32 values -> the 8-byte pieces of every part of an image ----
-    // (of the three-way split the image order is hi | lo(last part) | mid, so that parts 0
-    // and 1 are what mfma_group16 reads either way)
-    auto put4 = [&](char *img, int part_stride, int off, const float4 &v, bool three) {
-        if (three) {
-            unsigned h0, m0, l0, h1, m1, l1;
-            gg_split2x3(v.x, v.y, h0, m0, l0);
-            gg_split2x3(v.z, v.w, h1, m1, l1);
-            *reinterpret_cast<uint2 *>(img + off) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2 *>(img + part_stride + off) = make_uint2(l0, l1);
-            *reinterpret_cast<uint2 *>(img + 2 * part_stride + off) = make_uint2(m0, m1);
-        } else {
-            unsigned h0, l0, h1, l1;
-            gg_split2(v.x, v.y, h0, l0);
-            gg_split2(v.z, v.w, h1, l1);
-            *reinterpret_cast<uint2 *>(img + off) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2 *>(img + part_stride + off) = make_uint2(l0, l1);
-        }
-    };
-    // The one contraction that needs fp32-level accuracy: the forward GEMM whose result goes
-    // through ReLU.  A 1e-5 perturbation of a pre-activation that sits on the kink flips its
-    // derivative (measured with the two-way split: ~6 of 614 k elements, each an O(1) error in
-    // one token's gradients); every other product feeds smooth functions.
-    const bool fp32_level = (EPI == EPI_ACT) && g.act == ACT_RELU;
     auto contract = [&](int kmax, bool bt_image) {        // k = 0 .. kmax of the staged tiles
-        if (EPI == EPI_ACT && fp32_level) {
-            for (int q2 = 0; q2 < (kmax + 15) / 16; q2++) mfma_group16x6(q2, bt_image);
-        } else {
-            for (int q2 = 0; q2 < (kmax + 15) / 16; q2++) mfma_group16(q2, bt_image);
-        }
+        for (int q2 = 0; q2 < (kmax + 15) / 16; q2++) mfma_group16(q2, bt_image);
     };
 
     // ---- software pipeline: the global loads of k-step t+1 are in flight while the MFMAs
@@ -708,23 +799,22 @@ __device__ __forceinline__ void gemm_tile_regs(const GroupedArgs &g, float *smem
     // registers -> LDS images (component-wise: a struct copy of av[u] keeps the whole array in
     // scratch memory)
     auto stage_store = [&]() {
-        const bool three = EPI == EPI_ACT && fp32_level;
 #pragma unroll
         for (int u = 0; u < NUA; u++)
             put4(As, GG_AIMG, (s_row + GG_RPP * u) * GG_ROWB + 8 * s_kq,
-                 make_float4(av[u].x, av[u].y, av[u].z, av[u].w), three);
+                 make_float4(av[u].x, av[u].y, av[u].z, av[u].w));
         if (!BN_LAYOUT) {
 #pragma unroll
             for (int u = 0; u < GG_NU; u++)
                 put4(Bs, GG_BIMG, (s_row + GG_RPP * u) * GG_ROWB + 8 * s_kq,
-                     make_float4(bv[u].x, bv[u].y, bv[u].z, bv[u].w), three);
+                     make_float4(bv[u].x, bv[u].y, bv[u].z, bv[u].w));
         } else {
             // n-contiguous weights keep their orientation in LDS: Bs[k][n] (transposing them
             // into the [n][k] image needs 4-byte writes 4 rows apart: 16-way bank conflicts)
 #pragma unroll
             for (int u = 0; u < GG_NU; u++)
                 put4(Bs, GG_BIMG, ((tid >> 5) + GG_BNK * u) * GG_BNROWB + 8 * (tid & 31),
-                     make_float4(bv[u].x, bv[u].y, bv[u].z, bv[u].w), three);
+                     make_float4(bv[u].x, bv[u].y, bv[u].z, bv[u].w));
         }
     };
     if (g.K > 0) load_tile(0);
@@ -733,13 +823,8 @@ __device__ __forceinline__ void gemm_tile_regs(const GroupedArgs &g, float *smem
         stage_store();
         __syncthreads();
         if (k0 + GG_BK < g.K) load_tile(k0 + GG_BK);     // the registers are free again
-        if (EPI == EPI_ACT && fp32_level) {
 #pragma unroll
-            for (int q2 = 0; q2 < GG_BK / 16; q2++) mfma_group16x6(q2, !BN_LAYOUT);
-        } else {
-#pragma unroll
-            for (int q2 = 0; q2 < GG_BK / 16; q2++) mfma_group16(q2, !BN_LAYOUT);
-        }
+        for (int q2 = 0; q2 < GG_BK / 16; q2++) mfma_group16(q2, !BN_LAYOUT);
     }
 
     gg_scale_rows<NI>(g, acc, row_lo, row_hi, wm);
@@ -757,7 +842,9 @@ __device__ __forceinline__ void gemm_tile_regs(const GroupedArgs &g, float *smem
                 const int src = g.gather2 ? g.gather2[p] : p;
                 v = *reinterpret_cast<const float4 *>(g.a2 + (size_t)src * g.lda2 + k);
             }
-            put4(As, GG_AIMG, r * GG_ROWB + 8 * s_kq, v, EPI == EPI_ACT && fp32_level);
+            put4(As, GG_AIMG, r * GG_ROWB + 8 * s_kq, v);
+            const float ss = group_sum<8>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+            if (s_kq == 0) extras[r] = ss;                  // |a2 row|^2, for the epilogue
         }
 #pragma unroll
         for (int u = 0; u < GG_NU; u++) {
@@ -767,13 +854,15 @@ __device__ __forceinline__ void gemm_tile_regs(const GroupedArgs &g, float *smem
             if (n < g.N && k < g.R)
                 b = *reinterpret_cast<const float4 *>(g.b2 + (size_t)bucket * g.b2_gstride +
                                                       (size_t)n * g.b2_ldn + k);
-            put4(Bs, GG_BIMG, r * GG_ROWB + 8 * s_kq, b, EPI == EPI_ACT && fp32_level);
+            put4(Bs, GG_BIMG, r * GG_ROWB + 8 * s_kq, b);
+            const float ss = group_sum<8>(b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w);
+            if (s_kq == 0) extras[128 + r] = ss;            // |b2 row|^2
         }
         __syncthreads();
         contract(g.R, true);
     }
     __syncthreads();   // all waves are done with the operand tiles
-    gg_epilogue<NI, EPI>(g, smem, acc, bucket, row_lo, row_hi, col_tile, wm, wn);
+    gg_epilogue<NI, EPI>(g, smem, acc, bucket, row_lo, row_hi, col_tile, wm, wn, extras, EXT);
 }
 
 // Work distribution.  `slots` workgroups run at a time (two per CU), so a launch of T tiles
@@ -837,11 +926,10 @@ __device__ __forceinline__ GgWork gg_find_work(const GroupedArgs &g) {
 
 template <bool BN_LAYOUT, int EPI, bool EXT, bool KTAIL>
 __global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_kernel(GroupedArgs g) {
-    // A | B images (two or, with an activation epilogue, three parts each); the epilogue
-    // reuses the buffer as four per-wave C staging areas
-    constexpr int IMG_FLOATS = ((EPI == EPI_ACT) ? 3 : 2) * (GG_AIMG + GG_BIMG) / 4;
-    constexpr int EPI_FLOATS = (GG_THREADS / 64) * 32 * (64 + 4);
-    __shared__ __attribute__((aligned(16))) float smem[IMG_FLOATS > EPI_FLOATS ? IMG_FLOATS : EPI_FLOATS];
+    // A | B images (hi | lo each), then the ReLU epilogue's extras; the epilogue reuses the
+    // images as four per-wave C staging areas
+    static_assert(GG_REGS_LDS_FLOATS >= (GG_THREADS / 64) * 32 * (64 + 4), "");
+    __shared__ __attribute__((aligned(16))) float smem[GG_REGS_LDS_FLOATS + GG_EXTRAS];
     const GgWork w = gg_find_work(g);
     if (w.bucket < 0) return;  // uniform for the workgroup
     if (w.half < 0)
@@ -855,7 +943,7 @@ template <bool BN_LAYOUT, int EPI, bool EXT>
 __global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_img_kernel(GroupedArgs g) {
     // ALL of the kernel's LDS in one array (a second __shared__ object beside an LDS-DMA
     // target can make hipcc drain vmcnt before every ds_read: cdna guide, section 5)
-    __shared__ __attribute__((aligned(1024))) float smem[GI_LDS_FLOATS];
+    __shared__ __attribute__((aligned(1024))) float smem[GI_LDS_FLOATS + GG_EXTRAS];
     const GgWork w = gg_find_work(g);
     if (w.bucket < 0) return;
     if (w.half < 0)
@@ -896,6 +984,26 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict
     *reinterpret_cast<uint4 *>(dst + 64) = lo;
 }
 
+// The queue of the GEMM in front of a ReLU: one wave per queued (row, column), recomputed in
+// fp32 and written over what the epilogue stored.  (In the epilogue itself each costs the wave
+// that found it a serial ~2 us of dependent loads: 80 us of a 120 us GEMM at the FFN shape.)
+__global__ __launch_bounds__(256) void relu_fix_kernel(GroupedArgs g) {
+    // grid = 4 GG_FIX_SEGS workgroups: 16 waves per segment
+    const int lane = threadIdx.x & 63;
+    const unsigned seg = blockIdx.x % GG_FIX_SEGS;
+    const unsigned wave = (blockIdx.x / GG_FIX_SEGS) * 4 + (threadIdx.x >> 6);
+    const unsigned count = min(g.fix_count[16 * seg], (unsigned)g.fix_cap);
+    for (unsigned i = wave; i < count; i += 16) {
+        const int2 q = g.fix_list[(size_t)seg * g.fix_cap + i];
+        const int p = q.x, n = q.y & 0xFFFFFF, bucket = (unsigned)q.y >> 24;
+        const float exact = gg_exact_preact(g, bucket, p, n, lane);
+        if (lane == 0) {
+            g.out[(size_t)p * g.N + n] = act_forward(g.act, exact);
+            if (g.out2) g.out2[(size_t)p * g.N + n] = exact;
+        }
+    }
+}
+
 // y[t, :] = bias + sum_{j < k} rows[pos[t * k + j], :]  -- the un-bucketing of the routed
 // FFN (reference: `y[mask] += ...` per block, lora_ffn.py:107-111): a gather in a fixed
 // order instead of a scatter-add, so the result is deterministic.
@@ -931,13 +1039,11 @@ static int resident_slots() {
     return slots;
 }
 
-// The image path takes a GEMM when both images are given, K is a whole number of k-steps, the
-// group offsets of the weight fall on image rows / 128-byte blocks, and the product is not the
-// three-way split (the GEMM in front of a ReLU).
+// The image path takes a GEMM when both images are given, K is a whole number of k-steps and
+// the group offsets of the weight fall on image rows / 128-byte blocks.
 static bool image_path(GroupedArgs &g, int epilogue) {
     if (!g.a_img || !g.w_img) return false;
     if (g.K % GG_BK != 0) return false;
-    if (epilogue == EPI_ACT && g.act == ACT_RELU) return false;
     const long long row_len = g.ldk == 1 ? g.ldn : g.ldk;       // elements of one weight row
     if (row_len <= 0 || g.gstride % 32 != 0 || row_len % 32 != 0) return false;
     g.w_grow = g.gstride / row_len;
@@ -966,6 +1072,10 @@ static int launch_grouped(GroupedArgs g, int epilogue, void *stream) {
     const unsigned row_tiles = (unsigned)((g.P + GG_BM - 1) / GG_BM + g.G);
     const unsigned col_tiles = (unsigned)((g.N + GG_BN - 1) / GG_BN);
     if ((unsigned long long)row_tiles * col_tiles > 0x3FFFFFFFull) return SPT_EUNSUP;
+    if (epilogue == EPI_ACT && g.act == ACT_RELU) {
+        // the near-the-kink recomputation reads the fp32 operands
+        if (!g.a_norm || !g.w_norm || !g.a || !g.w) return SPT_EINVAL;
+    }
     if (epilogue == EPI_DACT) {
         if ((!g.h_in && !g.s_in) || !g.pdot_main || !g.pdot_act) return SPT_EINVAL;
         if (!g.s_in && g.act != ACT_RELU) return SPT_EINVAL;   // only ReLU is a function of h
@@ -997,6 +1107,12 @@ static int launch_grouped(GroupedArgs g, int epilogue, void *stream) {
         else SPT_GG(BN, EPI_DACT, EXT);                        \
     } while (0)
     const bool k_tail = (g.K % GG_BK) != 0;
+    const bool relu_queue = epilogue == EPI_ACT && g.act == ACT_RELU && g.fix_list && g.G < 256 &&
+                            g.N < (1 << 24);
+    if (relu_queue)
+        SPT_HIP_TRY(hipMemsetAsync(g.fix_count, 0, GG_FIX_SEGS * 64, s));
+    else
+        g.fix_list = nullptr;
     if (g.ldk == 1) {
         if (ext) SPT_GG_EPI(false, true); else SPT_GG_EPI(false, false);
     } else {
@@ -1005,6 +1121,10 @@ static int launch_grouped(GroupedArgs g, int epilogue, void *stream) {
 #undef SPT_GG_EPI
 #undef SPT_GG
     SPT_LAUNCH_CHECK();
+    if (relu_queue) {
+        hipLaunchKernelGGL(relu_fix_kernel, dim3(4 * GG_FIX_SEGS), dim3(256), 0, s, g);
+        SPT_LAUNCH_CHECK();
+    }
     return SPT_OK;
 }
 
@@ -1036,6 +1156,14 @@ extern "C" int spt_grouped_gemm_fused(const SptGroupedGemm *d, void *stream) {
     g.pdot_main = d->pdot_main; g.pdot_act = d->pdot_act; g.pdot_ld = d->pdot_ld;
     g.a_img = reinterpret_cast<const char *>(d->a_image);
     g.w_img = reinterpret_cast<const char *>(d->w_image);
+    g.a_norm = d->a_norm; g.w_norm = d->w_norm;
+    const long long header = GG_FIX_SEGS * 64;
+    if (d->relu_queue && d->relu_queue_bytes >= header + GG_FIX_SEGS * 8) {
+        g.fix_count = reinterpret_cast<unsigned *>(d->relu_queue);
+        g.fix_list = reinterpret_cast<int2 *>(reinterpret_cast<char *>(d->relu_queue) + header);
+        const long long cap = (d->relu_queue_bytes - header) / 8 / GG_FIX_SEGS;
+        g.fix_cap = (int)(cap > 0x7FFFFF ? 0x7FFFFF : cap);
+    }
     return launch_grouped(g, d->epilogue, stream);
 }
 

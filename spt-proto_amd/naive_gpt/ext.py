@@ -72,7 +72,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 15
+ABI_VERSION = 17
 
 _lib = None
 
@@ -767,12 +767,14 @@ class _GroupedDesc(ctypes.Structure):
         ('epilogue', ctypes.c_int32), ('activation', ctypes.c_int32),
         ('out2', _c_ptr), ('h_in', _c_ptr), ('s_in', _c_ptr),
         ('pdot_main', _c_ptr), ('pdot_act', _c_ptr), ('pdot_ld', ctypes.c_int32),
-        ('a_image', _c_ptr), ('w_image', _c_ptr),
+        ('a_image', _c_ptr), ('w_image', _c_ptr), ('a_norm', _c_ptr), ('w_norm', _c_ptr),
+        ('relu_queue', _c_ptr), ('relu_queue_bytes', ctypes.c_int64),
     ]
 
 
 EPI_PLAIN, EPI_ACT, EPI_DACT = 0, 1, 2
 LAST_GEMM_USED_IMAGES = False      # which operand path the last grouped_gemm_fused call took
+LAST_RELU_QUEUE = None              # (tests) the near-the-kink queue of the last ReLU GEMM
 ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2
 
 
@@ -840,6 +842,7 @@ def image_of(x: torch.Tensor) -> SplitImage:
 def drop_images():
     _IMAGE_CACHE.clear()
     _WEIGHT_IMAGES.clear()
+    _WEIGHT_NORMS.clear()
 
 
 # Frozen weights: their images never change, and keeping them costs as many bytes again as
@@ -847,18 +850,58 @@ def drop_images():
 # parameter (keyed by the parameter object, dropped when `_version` moves);
 # SPT_WEIGHT_IMAGES=step re-splits a weight every time it is used (4 MiB -> ~4 us) and
 # keeps nothing.
-_WEIGHT_IMAGES = weakref.WeakKeyDictionary()
+class _PerParameter:
+    """{parameter -> value} keyed by identity (a tensor's `==` is elementwise, which rules out
+    weakref.WeakKeyDictionary); an entry dies with its parameter or when `_version` moves."""
+
+    def __init__(self):
+        self.data = {}
+
+    def get(self, w):
+        hit = self.data.get(id(w))
+        if hit is not None and hit[0]() is w and hit[1] == (w.data_ptr(), w._version):
+            return hit[2]
+        return None
+
+    def put(self, w, value):
+        key = id(w)
+        self.data[key] = (weakref.ref(w, lambda _, k=key: self.data.pop(k, None)),
+                          (w.data_ptr(), w._version), value)
+
+    def clear(self):
+        self.data.clear()
+
+
+_WEIGHT_IMAGES = _PerParameter()
 KEEP_WEIGHT_IMAGES = os.environ.get('SPT_WEIGHT_IMAGES', 'keep') != 'step'
+
+
+def row_norms(x: torch.Tensor) -> torch.Tensor:
+    """Euclidean norm of every row of a matrix (fp32 [rows])."""
+    return torch.linalg.vector_norm(x.detach(), dim=1)
+
+
+_WEIGHT_NORMS = _PerParameter()
+
+
+def weight_row_norms(w: torch.Tensor) -> torch.Tensor:
+    """`row_norms` of a (frozen) weight, kept with the parameter like its image."""
+    if w.is_inference():
+        return row_norms(w)
+    norms = _WEIGHT_NORMS.get(w)
+    if norms is None:
+        norms = row_norms(w)
+        _WEIGHT_NORMS.put(w, norms)
+    return norms
 
 
 def weight_image(w: torch.Tensor) -> SplitImage:
     if not KEEP_WEIGHT_IMAGES or w.is_inference():
         return split_bf16(w.detach())
-    hit = _WEIGHT_IMAGES.get(w)
-    if hit is not None and hit[0] == (w.data_ptr(), w._version):
-        return hit[1]
-    img = split_bf16(w.detach())
-    _WEIGHT_IMAGES[w] = ((w.data_ptr(), w._version), img)
+    img = _WEIGHT_IMAGES.get(w)
+    if img is None:
+        img = split_bf16(w.detach())
+        _WEIGHT_IMAGES.put(w, img)
     return img
 
 
@@ -868,7 +911,9 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                        a2=None, gather2=None, b2=None, b2_group_stride: int = 0,
                        epilogue: int = EPI_PLAIN, activation: int = ACT_RELU,
                        keep_preact: bool = False, h_in=None, s_in=None,
-                       a_image: SplitImage = None, w_image: SplitImage = None):
+                       a_image: SplitImage = None, w_image: SplitImage = None,
+                       a_norm: torch.Tensor = None, w_norm: torch.Tensor = None,
+                       relu_queue_entries: int = None):
     """``spt_grouped_gemm_fused``: the block GEMM of a routed FFN with its LoRA side
     product, rowscale / bias, and the activation (EPI_ACT) or its derivative plus the two
     row dots of the coefficient gradient (EPI_DACT) folded in (include/spt_hip.h).
@@ -887,6 +932,20 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
     for t in (gather, bias, rowscale, a2, gather2, b2, h_in, s_in):
         if t is not None:
             _require(t.is_cuda and t.is_contiguous(), 'grouped_gemm_fused: contiguous CUDA operands')
+    if epilogue == EPI_ACT and activation == ACT_RELU:
+        # pre-activations within the split's error of zero are recomputed in fp32: the kernel
+        # finds them from the row norms of both operands (include/spt_hip.h)
+        if a_norm is None:
+            a_norm = row_norms(a)
+        if w_norm is None:          # |W_g(n, :)| for every (g, n): rows, or columns when n runs fastest
+            w_norm = row_norms(weight.view(-1, w_ldn)) if w_ldk == 1 else \
+                torch.linalg.vector_norm(weight.view(-1, w_ldk), dim=0)
+        for t, rows, name in ((a_norm, a.size(0), 'a_norm'), (w_norm, n_groups * n, 'w_norm')):
+            _check_type(t, torch.float32, name)
+            _require(t.is_cuda and t.is_contiguous() and t.numel() == rows,
+                     name + ': one fp32 norm per row')
+    else:
+        a_norm = w_norm = None
     images = a_image is not None and w_image is not None
     if images:
         _require(a_image.rows == a.size(0) and a_image.cols == a.size(1) == k
@@ -904,6 +963,11 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
         if epilogue == EPI_DACT:
             dot_main = torch.empty([n_rows, width], dtype=torch.float32, device=dev)
             dot_act = torch.empty([n_rows, width], dtype=torch.float32, device=dev)
+        queue = None
+        if a_norm is not None and relu_queue_entries != 0:
+            # scratch for the near-the-kink queue (default: 25 x the expected fill)
+            entries = relu_queue_entries or max(16384, n_rows * n // 64)
+            queue = torch.empty([256 * 64 + 8 * entries], dtype=torch.uint8, device=dev)
         if n_rows > 0:
             desc = _GroupedDesc(
                 a=_ptr(a), gather=_ptr(gather), w=_ptr(weight), bias=_ptr(bias),
@@ -919,13 +983,17 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                 h_in=_ptr(h_in), s_in=_ptr(s_in), pdot_main=_ptr(dot_main),
                 pdot_act=_ptr(dot_act), pdot_ld=width,
                 a_image=a_image.buffer.data_ptr() if images else None,
-                w_image=w_image.buffer.data_ptr() if images else None)
+                w_image=w_image.buffer.data_ptr() if images else None,
+                a_norm=_ptr(a_norm), w_norm=_ptr(w_norm), relu_queue=_ptr(queue),
+                relu_queue_bytes=queue.numel() if queue is not None else 0)
             global LAST_GEMM_USED_IMAGES
             LAST_GEMM_USED_IMAGES = bool(lib.spt_grouped_gemm_image_path(ctypes.byref(desc)))
             rc = lib.spt_grouped_gemm_fused(ctypes.byref(desc), _stream(dev))
             if rc != 0:
                 _raise(lib, rc, 'grouped_gemm_fused')
     if epilogue == EPI_ACT:
+        global LAST_RELU_QUEUE
+        LAST_RELU_QUEUE = queue
         return out, preact
     if epilogue == EPI_DACT:
         return out, dot_main.sum(dim=-1), dot_act.sum(dim=-1)

@@ -199,15 +199,26 @@ class RoutedLoRAFFN(torch.autograd.Function):
         bs, rank, rows = d_ff // nb, l1.size(1), bk.token.numel()
         x, coeff = x.contiguous(), coeff.contiguous()
         u = torch.matmul(x, l1)                                              # [T, r]
+        # Both block GEMMs run from pre-split images (ext.split_bf16): the weights' are kept
+        # with the frozen parameters, x's and h's cost one pass each.  In front of a ReLU the
+        # kernel also wants the row norms of both operands (include/spt_hip.h: a_norm).
+        relu = act == ext.ACT_RELU
+        imgs = _images_usable(x, w1, w2, d, bs)
         h, s = ext.grouped_gemm_fused(
             x, w1, bk.offsets, nb, n=bs, k=d, w_group_stride=bs * d, w_ldn=d, w_ldk=1,
             n_rows=rows, gather=bk.token, bias=b1, rowscale=coeff,
             a2=u, gather2=bk.token, b2=r1, b2_group_stride=bs * rank,
-            epilogue=ext.EPI_ACT, activation=act, keep_preact=(act != ext.ACT_RELU))
+            epilogue=ext.EPI_ACT, activation=act, keep_preact=not relu,
+            a_image=ext.image_of(x) if imgs else None,
+            w_image=ext.weight_image(w1) if imgs else None,
+            a_norm=ext.row_norms(x) if relu else None,
+            w_norm=ext.weight_row_norms(w1) if relu else None)
         z = _own_block(torch.matmul(h, _block_cat(l2, nb)), bk.block, nb).contiguous()   # [P, r]
         ys = ext.grouped_gemm_fused(
             h, w2, bk.offsets, nb, n=d, k=bs, w_group_stride=bs, w_ldn=d_ff, w_ldk=1,
-            n_rows=rows, rowscale=coeff, a2=z, b2=r2, b2_group_stride=0)
+            n_rows=rows, rowscale=coeff, a2=z, b2=r2, b2_group_stride=0,
+            a_image=ext.split_bf16(h) if imgs else None,
+            w_image=ext.weight_image(w2) if imgs else None)
         y = ext.rows_combine(ys, bk.pos, bias=b2)
         ctx.bk, ctx.act = bk, act
         ctx.save_for_backward(x, coeff, u, h, s, z, l1, r1, l2, r2, w1, w2)
@@ -223,11 +234,14 @@ class RoutedLoRAFFN(torch.autograd.Function):
         pos = bk.pos.long()
         dy = dy.contiguous()
         dzt = torch.matmul(dy, r2)                                           # [T, r]
+        imgs = _images_usable(dy, w1, w2, d, bs)
         ds, dot_main, dot_act = ext.grouped_gemm_fused(
             dy, w2, bk.offsets, nb, n=bs, k=d, w_group_stride=bs, w_ldn=1, w_ldk=d_ff,
             n_rows=rows, gather=bk.token, rowscale=coeff,
             a2=dzt, gather2=bk.token, b2=l2, b2_group_stride=bs * rank,
-            epilogue=ext.EPI_DACT, activation=act, h_in=h, s_in=s)
+            epilogue=ext.EPI_DACT, activation=act, h_in=h, s_in=s,
+            a_image=ext.split_bf16(dy) if imgs else None,
+            w_image=ext.weight_image(w2) if imgs else None)
         du = _own_block(torch.matmul(ds, _block_cat(r1, nb)), bk.block, nb).contiguous()  # [P, r]
         u_rows = u.index_select(0, bk.token_long)
         # d/dc = <dy W2_g^T, h> + <ds, x W1_g^T + b1_g>.  The kernel's dot_main = <v, h> with
@@ -259,6 +273,12 @@ def routed_lora_ffn(x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk: Buckets, act: 
     return RoutedLoRAFFN.apply(x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk, act)
 
 
+def _images_usable(a: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, d: int, bs: int) -> bool:
+    """The image path of the grouped GEMM: contraction lengths and block offsets in whole
+    32-element blocks (ext.grouped_gemm_fused falls back to the fp32 operands otherwise)."""
+    return d % 32 == 0 and bs % 32 == 0 and a.is_contiguous()
+
+
 def fused_usable(rank: int) -> bool:
     return rank % 4 == 0 and 0 < rank <= 32
 
@@ -285,18 +305,25 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
         x, coeff = x.contiguous(), coeff.contiguous()
         ug, us = torch.matmul(x, lg), torch.matmul(x, ls)                      # [T, r]
 
+        imgs = _images_usable(x, wg, wd, d, bs)
+        x_image = ext.split_bf16(x) if imgs else None        # read by both up projections
+
         def up(w, u, r_table):
             return ext.grouped_gemm_fused(
                 x, w, bk.offsets, nb, n=bs, k=d, w_group_stride=bs * d, w_ldn=d, w_ldk=1,
                 n_rows=rows, gather=bk.token, rowscale=coeff, a2=u, gather2=bk.token,
-                b2=r_table, b2_group_stride=bs * rank)
+                b2=r_table, b2_group_stride=bs * rank,
+                a_image=x_image, w_image=ext.weight_image(w) if imgs else None)
 
         g, sd = up(wg, ug, rg), up(ws, us, rs)
         h = activation(g) * sd
         z = _own_block(torch.matmul(h, _block_cat(ld, nb)), bk.block, nb).contiguous()
         ys = ext.grouped_gemm_fused(
             h, wd, bk.offsets, nb, n=d, k=bs, w_group_stride=bs, w_ldn=d_ff, w_ldk=1,
-            n_rows=rows, rowscale=coeff, a2=z, b2=rd, b2_group_stride=0)
+            n_rows=rows, rowscale=coeff, a2=z, b2=rd, b2_group_stride=0,
+            a_image=ext.split_bf16(h) if imgs else None,
+            w_image=ext.weight_image(wd) if imgs else None)
+        del x_image
         y = ext.rows_combine(ys, bk.pos)
         ctx.bk, ctx.activation = bk, activation
         ctx.save_for_backward(x, coeff, ug, us, g, sd, h, z, lg, rg, ls, rs, ld, rd, wg, ws, wd)
@@ -313,10 +340,13 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
         dy = dy.contiguous()
         dzt = torch.matmul(dy, rd)                                            # [T, r]
         dz_rows = dzt.index_select(0, bk.token_long)
+        imgs = _images_usable(dy, wg, wd, d, bs)
         dh = ext.grouped_gemm_fused(
             dy, wd, bk.offsets, nb, n=bs, k=d, w_group_stride=bs, w_ldn=1, w_ldk=d_ff,
             n_rows=rows, gather=bk.token, rowscale=coeff, a2=dzt, gather2=bk.token, b2=ld,
-            b2_group_stride=bs * rank)
+            b2_group_stride=bs * rank,
+            a_image=ext.split_bf16(dy) if imgs else None,
+            w_image=ext.weight_image(wd) if imgs else None)
         grad_coeff = ((dh * h).sum(dim=-1) - (dz_rows * z).sum(dim=-1)) / _floor(coeff)
         # through h = act(g) * sd
         with torch.enable_grad():

@@ -76,12 +76,20 @@ def _mfma_linear_usable(x2: torch.Tensor, weight: torch.Tensor, rank: int) -> bo
             and weight.size(0) % 4 == 0 and weight.size(1) % 4 == 0 and 0 < rank <= 32)
 
 
-def _mfma_gemm(a, weight, n, k, ldn, ldk, bias=None, a2=None, b2=None):
-    """out[p, :n] = a[p, :k] . W(n, k)^T (+ bias) (+ a2 . b2^T), W(n, k) = weight[n * ldn + k * ldk]."""
+def _mfma_gemm(a, weight, n, k, ldn, ldk, bias=None, a2=None, b2=None, images=False):
+    """out[p, :n] = a[p, :k] . W(n, k)^T (+ bias) (+ a2 . b2^T), W(n, k) = weight[n * ldn + k * ldk].
+
+    `images`: run from the pre-split bf16 images of both operands (LDS-DMA k-loop, ~20 % less
+    GEMM time).  The weight's image is kept with the frozen parameter; the activation's costs
+    one pass over it (about what the GEMM saves), so it pays where several GEMMs read the same
+    input -- the q / k / v projections -- which the small image cache of `ext` detects."""
     from naive_gpt import ext
     rows = a.size(0)
+    a_image = w_image = None
+    if images and k % 32 == 0 and a.is_contiguous():
+        a_image, w_image = ext.image_of(a), ext.weight_image(weight)
     return ext.grouped_gemm_fused(a, weight, _one_group(rows, a.device), 1, n, k, 0, ldn, ldk,
-                                  rows, bias=bias, a2=a2, b2=b2)
+                                  rows, bias=bias, a2=a2, b2=b2, a_image=a_image, w_image=w_image)
 
 
 class _FrozenLoRALinear(torch.autograd.Function):
@@ -99,7 +107,7 @@ class _FrozenLoRALinear(torch.autograd.Function):
         if ctx.mfma:
             # one launch: base product, bias and the side product (the K extension) together
             y = _mfma_gemm(x2, weight, n, k, k, 1, bias=None if bias is None else bias.view(1, n),
-                           a2=u.contiguous(), b2=right.contiguous())
+                           a2=u.contiguous(), b2=right.contiguous(), images=True)
         else:
             y = nn.functional.linear(x2, weight, bias)
             y.addmm_(u, right.t())

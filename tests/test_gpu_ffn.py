@@ -318,11 +318,73 @@ def test_image_path_activation_derivative_epilogue(act, layout):
     _close64(dot_main, ((c['base'] + c['side']) * h.double()).sum(-1), 'dot_main')
     s_like = h.double() if act == 'relu' else s.double()
     _close64(dot_act, (want * s_like).sum(-1), 'dot_act')
-    # EPI_ACT: SiLU / GELU run from images, the GEMM in front of a ReLU keeps the three-way split
     out2, pre = _call_fused(c, images=True, epilogue=ext.EPI_ACT, activation=_act_code(act),
                             keep_preact=True)
-    assert ext.LAST_GEMM_USED_IMAGES == (act != 'relu')
+    assert ext.LAST_GEMM_USED_IMAGES
     _close64(pre, c['base'] + c['side'], 'preact')
+
+
+@pytest.mark.parametrize('queue', [None, 0, 512])      # default queue / none / one that overflows (2 per segment)
+@pytest.mark.parametrize('images', [False, True])
+def test_relu_preactivations_near_the_kink_are_fp32_exact(images, queue):
+    """A product of split operands is off by up to 2^-16 |a| |w|: too much where it decides a
+    ReLU derivative.  The epilogue recomputes every pre-activation inside that bound in fp32.
+    Inputs are built so that thousands of pre-activations sit within 1e-6 .. 1e-4 of zero
+    (each row of the weight made orthogonal to one row of a, then nudged): their SIGN, and
+    their value to fp32 accuracy, must match the fp64 product -- which three bf16 MFMAs alone
+    miss (checked below, on the SiLU epilogue that shares everything but the recomputation)."""
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(31)
+    P, K, N, G, R = 512, 256, 256, 2, 8
+    a = torch.randn([P, K], generator=gen, dtype=torch.float64)
+    w = torch.randn([G * N, K], generator=gen, dtype=torch.float64)
+    offsets = [0, 200, P]
+    # weight row (g, n) . a row (lo_g + n): exactly `nudge`, where |nudge| ~ 1e-7 .. 1e-4
+    nudge = torch.randn([G * N], generator=gen, dtype=torch.float64) * 10.0 ** (
+        -4.0 - 3.0 * torch.rand([G * N], generator=gen, dtype=torch.float64))
+    for g in range(G):
+        for n in range(min(N, offsets[g + 1] - offsets[g])):
+            row, p = g * N + n, offsets[g] + n
+            w[row] -= (w[row] @ a[p] - nudge[row]) / (a[p] @ a[p]) * a[p]
+    a, w = a.float(), w.float()
+    a2 = 1e-3 * torch.randn([P, R], generator=gen)
+    b2 = 1e-3 * torch.randn([G * N, R], generator=gen)
+    want = torch.zeros([P, N], dtype=torch.float64)
+    for g in range(G):
+        lo, hi = offsets[g], offsets[g + 1]
+        want[lo:hi] = a[lo:hi].double() @ w[g * N:(g + 1) * N].double().T \
+            + a2[lo:hi].double() @ b2[g * N:(g + 1) * N].double().T
+    dev = 'cuda'
+    kw = dict(a_image=ext.split_bf16(a.to(dev)), w_image=ext.split_bf16(w.to(dev))) if images else {}
+
+    def run(act):
+        return ext.grouped_gemm_fused(
+            a.to(dev), w.to(dev), torch.tensor(offsets, dtype=torch.int32, device=dev), G, n=N, k=K,
+            w_group_stride=N * K, w_ldn=K, w_ldk=1, n_rows=P, a2=a2.to(dev), b2=b2.to(dev),
+            b2_group_stride=N * R, epilogue=ext.EPI_ACT, activation=act, keep_preact=True,
+            relu_queue_entries=queue, **kw)
+
+    h, pre = run(ext.ACT_RELU)
+    assert ext.LAST_GEMM_USED_IMAGES == images
+    _, pre_split = run(ext.ACT_SILU)                       # the same products, no recomputation
+    scale = (a.double().norm(dim=1)[:, None] * torch.cat(
+        [w[g * N:(g + 1) * N].double().norm(dim=1)[None, :].expand(offsets[g + 1] - offsets[g], N)
+         for g in range(G)]))
+    near = want.abs() < 2.0 ** -16 * scale                 # inside the kernel's recomputation bound
+    assert int(near.sum()) >= 300
+    err = (pre.double().cpu() - want).abs()
+    err_split = (pre_split.double().cpu() - want).abs()
+    assert (err[near] <= 3e-7 * scale[near]).all()         # fp32 dot product of K = 256 terms
+    assert (err_split[near] > 3e-7 * scale[near]).any()    # ... which the split products are not
+    wrong = (pre.double().cpu()[near] > 0) != (want[near] > 0)
+    decided = want.abs()[near] > 3e-7 * scale[near]
+    assert not (wrong & decided).any()                     # every ReLU derivative as in fp64
+    assert ((pre_split.double().cpu()[near] > 0) != (want[near] > 0)).any()
+    assert torch.equal(h, pre.clamp_min(0.0))
+    # away from zero (well outside the kernel's 1.5 x 2^-16 bound) nothing changes
+    far = want.abs() > 2.0 ** -14 * scale
+    assert int(far.sum()) > 0.9 * far.numel()
+    assert torch.equal(pre.cpu()[far], pre_split.cpu()[far])
 
 
 def test_image_path_is_refused_where_it_does_not_apply():

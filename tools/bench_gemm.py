@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'spt-proto_amd'))
 import torch
 from naive_gpt import ext
-d, dff, T = 1024, 4096, 8192
+d, dff, T = 1024, 4096, 8192 * int(os.environ.get('MULT', 1))     # MULT=16: ~1 ms launches (clock readings)
 P, bs = 2 * T, dff // 4
 dev = 'cuda'
 torch.manual_seed(0)
@@ -26,7 +26,7 @@ def timeit(fn, n=30, w=10):
 a = torch.randn([T, d], device=dev)
 gather = (torch.randperm(P, device=dev) % T).int()
 even = os.environ.get('EVEN', '0') == '1'
-cuts = [0, P // 4, P // 2, 3 * P // 4, P] if even else [0, 4000, 8300, 12100, P]
+cuts = [0, P // 4, P // 2, 3 * P // 4, P] if even else [0, P * 4000 // 16384, P * 8300 // 16384, P * 12100 // 16384, P]
 offsets = torch.tensor(cuts, dtype=torch.int32, device=dev)
 one = torch.tensor([0, T], dtype=torch.int32, device=dev)
 w1 = torch.randn([dff, d], device=dev)
@@ -90,3 +90,32 @@ wd = torch.randn([bs, d], device=dev)
 us = timeit(lambda: torch.matmul(b, wd.T))
 res['torch_fp32'] = {'us': round(us, 1), 'TFLOPs': round(2.0 * P * bs * d / us / 1e6, 1)}
 print(json.dumps(res))
+
+# ---- the FFN's first GEMM as the layer calls it: what each epilogue feature costs (image path)
+if os.environ.get('EPILOGUES', '1') == '1':
+    res2 = {}
+    coeff = (torch.rand([P], device=dev) + 0.5)
+    b1 = torch.randn([4, bs], device=dev)
+    u = torch.randn([T, 16], device=dev)
+    r1 = 0.05 * torch.randn([dff, 16], device=dev)
+    ai, wi = ext.split_bf16(a), ext.split_bf16(w1)
+    an, wn = ext.row_norms(a), ext.row_norms(w1)
+
+    def up(**kw):
+        return ext.grouped_gemm_fused(a, w1, offsets, 4, bs, d, bs * d, d, 1, P, gather=gather,
+                                      a_image=ai, w_image=wi, **kw)
+    full = dict(bias=b1, rowscale=coeff, a2=u, gather2=gather, b2=r1, b2_group_stride=bs * 16)
+    cases = {
+        'plain': {},
+        'bias+rowscale': dict(bias=b1, rowscale=coeff),
+        'ext': dict(a2=u, gather2=gather, b2=r1, b2_group_stride=bs * 16),
+        'bias+rowscale+ext': full,
+        'act_gelu': dict(full, epilogue=ext.EPI_ACT, activation=ext.ACT_GELU),
+        'act_gelu_keep': dict(full, epilogue=ext.EPI_ACT, activation=ext.ACT_GELU, keep_preact=True),
+        'act_relu': dict(full, epilogue=ext.EPI_ACT, activation=ext.ACT_RELU, a_norm=an, w_norm=wn),
+        'act_relu_noqueue': dict(full, epilogue=ext.EPI_ACT, activation=ext.ACT_RELU, a_norm=an,
+                                 w_norm=wn, relu_queue_entries=0),
+    }
+    for tag, kw in cases.items():
+        res2[tag] = round(timeit(lambda: up(**kw)), 1)
+    print(json.dumps({'ffn_up_image_us': res2}))
