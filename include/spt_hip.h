@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 17
+#define SPT_ABI_VERSION 18
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -277,11 +277,20 @@ int spt_attention_mfma_supported(int seq_length, int d_head, int nnz);
  * pass over `indices` [batch, nnz]) into `tiles`, an opaque device buffer of
  * spt_attention_mfma_tiles_bytes(...) bytes that the forward and the backward of the same
  * layer step share (it depends on `indices` only; layout: mfma_attention.hip, "cell tiles").
+ * Two layouts, the same one to be named in all four calls:
+ *   SPT_TILES_FULL     any uniform-row CSR;
+ *   SPT_TILES_COMPACT  a quarter of the memory (S = 512: 66 instead of 272 KiB per slice) for
+ *                      patterns in which only columns < 32 may repeat inside a row -- every
+ *                      lookup pattern: its one repeated column is the padding column 0
+ *                      (lookup.cu:107-109).  A pattern that breaks the promise is computed as
+ *                      if each repeated column outside key tile 0 occurred once, and bit 0 of
+ *                      the second 32-bit word of `tiles` is set.
  */
-int64_t spt_attention_mfma_tiles_bytes(int batch_size, int seq_length, int nnz);
+enum { SPT_TILES_FULL = 0, SPT_TILES_COMPACT = 1 };
+int64_t spt_attention_mfma_tiles_bytes(int batch_size, int seq_length, int nnz, int layout);
 int spt_attention_mfma_prepare(const int32_t *indices, void *tiles, int batch_size,
-                               int seq_length, int nnz, void *stream);
-int spt_attention_mfma_forward(const void *tiles, const float *q, const float *k,
+                               int seq_length, int nnz, int layout, void *stream);
+int spt_attention_mfma_forward(const void *tiles, int layout, const float *q, const float *k,
                                const float *v, float *y, float *row_sum, int batch_size,
                                int seq_length, int d_head, int nnz, float scale, float clamp,
                                int heads, int y_transposed, void *stream);
@@ -296,7 +305,7 @@ int spt_attention_mfma_forward(const void *tiles, const float *q, const float *k
  * q, k, v and the three gradients follow `heads` as in the forward.  row_sum is the forward's
  * output; delta [batch, S] is scratch that the first launch fills for the second.
  */
-int spt_attention_mfma_backward(const void *tiles, const float *q, const float *k,
+int spt_attention_mfma_backward(const void *tiles, int layout, const float *q, const float *k,
                                 const float *v, const float *y, const float *grad_y,
                                 const float *row_sum, float *delta, float *grad_q,
                                 float *grad_k, float *grad_v, int batch_size, int seq_length,

@@ -367,13 +367,16 @@ constexpr int MB_WAVES = 4;
 constexpr int MB_CHUNK = 8;                          // key tiles per pass over the entries
 constexpr int MB_CNT_WORDS = MB_CHUNK * MA_WROWS * MA_CLD;     // one orientation: 2304 words
 __host__ __device__ __forceinline__ size_t tri(size_t n) { return n * (n + 1) / 2; }
+// bytes of a tile's slot: 1 KiB in the full layout, 128 in the compact one (see CellTiles)
+__device__ __forceinline__ int cell_slot_bytes(const void *pool) { return pool ? 128 : MA_CELLS; }
 __host__ __device__ __forceinline__ size_t prepare_lds_per_wave() {
     return (size_t)MB_CNT_WORDS * 4;                 // 9216 B
 }
 template <bool SATURATE>
 __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kernel(
     const int32_t *__restrict__ indices, unsigned long long *__restrict__ masks,
-    unsigned char *__restrict__ cells, unsigned char *__restrict__ cells_t, int S, int Z, int NT,
+    unsigned char *__restrict__ cells, unsigned char *__restrict__ cells_t,
+    unsigned char *__restrict__ pool, unsigned char *__restrict__ pool_t, int S, int Z, int NT,
     int RT, int n_tiles_total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -387,8 +390,9 @@ __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kern
     const int nrows = min(MA_WROWS, S - i0);
     const int n4 = nrows * Z / 4;
     const int4 *src = reinterpret_cast<const int4 *>(indices + ((size_t)b * S + i0) * Z);
-    unsigned char *out = cells + ((size_t)b * tri(RT) + tri(rt)) * MA_CELLS;
-    unsigned char *out_t = cells_t + ((size_t)b * tri(RT) + tri(rt)) * MA_CELLS;
+    const int slot_bytes = cell_slot_bytes(pool);
+    unsigned char *out = cells + ((size_t)b * tri(RT) + tri(rt)) * slot_bytes;
+    unsigned char *out_t = cells_t + ((size_t)b * tri(RT) + tri(rt)) * slot_bytes;
     const int c32 = lane & 31, h = lane >> 5;
     const int nbuckets = min(NT, rt + 1);               // live entries have col <= row
     unsigned long long mask = 0, multi = 0;
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kern
         for (int tl = 0; tl < tend; tl++) {
             // word 2 g + h of row c holds keys 8 g + 4 h .. + 3: exactly this lane's bytes 4 g ..
             const unsigned *row = cnt + (tl * MA_WROWS + c32) * MA_CLD + h;
-            const uint4 mine = make_uint4(row[0], row[2], row[4], row[6]);
+            uint4 mine = make_uint4(row[0], row[2], row[4], row[6]);
             if (__ballot((mine.x | mine.y | mine.z | mine.w) != 0u) == 0ull) continue;
             mask |= 1ull << (t0 + tl);
             // transposed: byte 4 g + u of lane (c, h) = count of key c in row 8 g + 4 h + u
@@ -438,14 +442,30 @@ __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kern
                 w[g] = (unsigned)p0[0] | ((unsigned)p0[MA_CLD * 4] << 8) |
                        ((unsigned)p0[2 * MA_CLD * 4] << 16) | ((unsigned)p0[3 * MA_CLD * 4] << 24);
             }
-            uint4 *slot = reinterpret_cast<uint4 *>(out + (size_t)(t0 + tl) * MA_CELLS);
-            uint4 *slot_t = reinterpret_cast<uint4 *>(out_t + (size_t)(t0 + tl) * MA_CELLS);
+            uint4 *slot = reinterpret_cast<uint4 *>(out + (size_t)(t0 + tl) * slot_bytes);
+            uint4 *slot_t = reinterpret_cast<uint4 *>(out_t + (size_t)(t0 + tl) * slot_bytes);
             const bool big = ((mine.x | mine.y | mine.z | mine.w) & 0xFEFEFEFEu) != 0u;
-            if (__ballot(big) != 0ull) {
+            // (compact layout: byte forms exist for key tile 0 only -- the caller vouches that
+            // no other tile repeats a column, as lookup patterns do not; a tile that breaks the
+            // promise is stored as if its counts were 0 / 1 and flagged in the header)
+            const bool pooled_ok = pool == nullptr || t0 + tl == 0;
+            if (__ballot(big) != 0ull && pooled_ok) {
                 multi |= 1ull << (t0 + tl);
+                if (pool) {
+                    slot = reinterpret_cast<uint4 *>(pool + ((size_t)b * RT + rt) * MA_CELLS);
+                    slot_t = reinterpret_cast<uint4 *>(pool_t + ((size_t)b * RT + rt) * MA_CELLS);
+                }
                 slot[lane] = mine;
                 slot_t[lane] = make_uint4(w[0], w[1], w[2], w[3]);
             } else {
+                if (__ballot(big) != 0ull) {
+                    if (lane == 0) atomicOr(reinterpret_cast<unsigned *>(masks) - 64 + 1, 1u);
+                    auto clamp1 = [](unsigned x) { return (x | (x >> 1) | (x >> 2) | (x >> 3) | (x >> 4) |
+                                                           (x >> 5) | (x >> 6) | (x >> 7)) & 0x01010101u; };
+                    mine = make_uint4(clamp1(mine.x), clamp1(mine.y), clamp1(mine.z), clamp1(mine.w));
+#pragma unroll
+                    for (int g = 0; g < 4; g++) w[g] = clamp1(w[g]);
+                }
                 // counts are 0 / 1: 16 of the row's (key's) 32 bits sit in this lane, the other
                 // 16 in lane ^ 32; bytes -> nibble by one multiply (no carries: each product
                 // term lands on its own bit)
@@ -479,19 +499,33 @@ __device__ __forceinline__ uint4 cell_words(const uint4 &v, bool multi, int lane
     auto spread = [](unsigned n) { return ((n & 0xFu) * 0x00204081u) & 0x01010101u; };
     return make_uint4(spread(m), spread(m >> 8), spread(m >> 16), spread(m >> 24));
 }
+// Two layouts of the stored tiles (chosen by the caller of spt_attention_mfma_prepare):
+//   full     every tile owns a 1 KiB slot, which holds its byte form or (first 128 bytes) its
+//            mask form;
+//   compact  every tile owns a 128-byte slot for its mask form; a byte form lives in a pool of
+//            one 1 KiB slot per ROW TILE and is allowed for key tile 0 only -- what a lookup
+//            pattern needs (its only repeated column is the padding column 0), at 1/4 of the
+//            memory (S = 512: 66 instead of 272 KiB per slice and step).
+// `pool == nullptr` selects the full layout.
 // a consumer wave's view of its row tile's cell tiles
 struct CellTiles {
     unsigned long long mask, multi;
     int last;                 // the row tile's own index = its last stored key tile
-    const uint4 *base;        // tile t of this row tile: base[t * 64 + ...]
+    int stride;               // uint4 per slot
+    const uint4 *base;        // tile t of this row tile: base[t * stride + ...]
+    const uint4 *pooled;      // compact layout: the byte form of key tile 0, else nullptr
     __device__ __forceinline__ CellTiles(const unsigned long long *masks,
-                                         const unsigned char *cells, int b, int RT, int rt,
-                                         bool have) {
+                                         const unsigned char *cells, const unsigned char *pool,
+                                         int b, int RT, int rt, bool have) {
         mask = have ? masks[2 * ((size_t)b * RT + rt)] : 0ull;
         multi = have ? masks[2 * ((size_t)b * RT + rt) + 1] : 0ull;
         last = have ? rt : 0;
+        stride = cell_slot_bytes(pool) / 16;
         base = reinterpret_cast<const uint4 *>(
-            cells + ((size_t)b * tri(RT) + tri(have ? rt : 0)) * MA_CELLS);
+            cells + ((size_t)b * tri(RT) + tri(have ? rt : 0)) * cell_slot_bytes(pool));
+        pooled = pool ? reinterpret_cast<const uint4 *>(
+                            pool + ((size_t)b * RT + (have ? rt : 0)) * MA_CELLS)
+                      : nullptr;
     }
     __device__ __forceinline__ bool live(int t) const { return (mask >> t) & 1ull; }
     __device__ __forceinline__ bool is_multi(int t) const { return (multi >> min(t, 63)) & 1ull; }
@@ -499,7 +533,8 @@ struct CellTiles {
     // either way: the lane's own 16 counts, or the four row masks that include its row's
     __device__ __forceinline__ uint4 load(int t, int lane) const {
         const int tc = min(t, last);
-        return base[tc * 64 + (is_multi(tc) ? lane : ((lane & 31) >> 2))];
+        if (is_multi(tc)) return pooled ? pooled[lane] : base[tc * stride + lane];
+        return base[tc * stride + ((lane & 31) >> 2)];
     }
     // (the 16 bytes loaded for tile t) -> count words
     __device__ __forceinline__ uint4 words(const uint4 &v, int t, int lane) const {
@@ -595,6 +630,7 @@ __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_WAVES_PER_EU, MA_WAVES_PER_EU)))
 void attention_mfma_forward_kernel(
     const unsigned long long *__restrict__ masks, const unsigned char *__restrict__ cells,
+    const unsigned char *__restrict__ pool,
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     float *__restrict__ y, float *__restrict__ row_sum, int S, float scale, float clampv,
     int heads, int blocks_per_batch) {
@@ -617,7 +653,7 @@ void attention_mfma_forward_kernel(
 #pragma unroll
     for (int i = 0; i < 20; i++) st_it[i] = 0.f;
 #endif
-    const CellTiles ct(masks, cells, b, RT, i0 / MA_WROWS, i0 < S);
+    const CellTiles ct(masks, cells, pool, b, RT, i0 / MA_WROWS, i0 < S);
     // tiles any row of this workgroup can see: keys <= its last row (that of wave 7)
     const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch, MA_WAVES - 1);
     const int T = min(RT, last_tile + 1);
@@ -833,6 +869,7 @@ __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_ROWS_WAVES_PER_EU, MA_ROWS_WAVES_PER_EU)))
 void attention_mfma_backward_rows_kernel(
     const unsigned long long *__restrict__ masks, const unsigned char *__restrict__ cells,
+    const unsigned char *__restrict__ pool,
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ gy, const float *__restrict__ y,
     const float *__restrict__ row_sum, float *__restrict__ grad_q, float *__restrict__ delta,
@@ -871,7 +908,7 @@ void attention_mfma_backward_rows_kernel(
     // the row tile this wave works on in this pass, and the last one any wave of the block does
     const int own = PAIRED ? (pass == 0 ? HALFW + wave % HALFW : wave % HALFW) : wave;
     const int i0 = MA_WROWS * folded_row_tile(bid % blocks_per_batch, blocks_per_batch, own);
-    const CellTiles ct(masks, cells, b, RT, i0 / MA_WROWS, i0 < S);
+    const CellTiles ct(masks, cells, pool, b, RT, i0 / MA_WROWS, i0 < S);
     const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch,
                                           PAIRED && pass == 1 ? HALFW - 1 : MA_WAVES - 1);
     const int T = min(RT, last_tile + 1);
@@ -1123,6 +1160,7 @@ __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_KEYS_WAVES_PER_EU, MA_KEYS_WAVES_PER_EU)))
 void attention_mfma_backward_keys_kernel(
     const unsigned long long *__restrict__ masks, const unsigned char *__restrict__ cells_t,
+    const unsigned char *__restrict__ pool_t,
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ gy, const float *__restrict__ row_sum,
     const float *__restrict__ delta, float *__restrict__ grad_k, float *__restrict__ grad_v,
@@ -1170,14 +1208,19 @@ void attention_mfma_backward_keys_kernel(
         const int rc = min(rt, RT - 1);
         return (bool)((lane_u64(multi_reg, rc) >> min(kt, rc)) & 1ull);
     };
-    const uint4 *cell_b = reinterpret_cast<const uint4 *>(cells_t + (size_t)b * tri(RT) * MA_CELLS);
+    const int cstride = cell_slot_bytes(pool_t) / 16;
+    const uint4 *cell_b = reinterpret_cast<const uint4 *>(
+        cells_t + (size_t)b * tri(RT) * cell_slot_bytes(pool_t));
+    const uint4 *pool_b = pool_t ? reinterpret_cast<const uint4 *>(pool_t + (size_t)b * RT * MA_CELLS)
+                                 : nullptr;
     auto live = [&](unsigned long long m, int rt) {
         return have && rt >= kt && rt < RT && ((m >> kt) & 1ull);
     };
     // always in bounds: the row tile clamped to the last one, the key tile to the diagonal
     auto cell_load = [&](int rt) {
         const int rc = min(rt, RT - 1);
-        return cell_b[(tri(rc) + min(kt, rc)) * 64 + (multi_of(rt) ? lane : (c32 >> 2))];
+        if (multi_of(rt)) return pool_b ? pool_b[rc * 64 + lane] : cell_b[(tri(rc) + min(kt, rc)) * 64 + lane];
+        return cell_b[(tri(rc) + min(kt, rc)) * cstride + (c32 >> 2)];
     };
 
     const int rt0 = (MA_WAVES / 2) * g;                 // the first row tile any wave needs
@@ -1288,7 +1331,8 @@ static size_t mfma_forward_lds() {
 }
 
 // ---- launchers of this head dimension (the d_head 64 unit dispatches to spt::e128's) ----
-int launch_forward(const unsigned long long *masks, const unsigned char *cells, const float *q,
+int launch_forward(const unsigned long long *masks, const unsigned char *cells,
+                   const unsigned char *pool, const float *q,
                    const float *k, const float *v, float *y, float *row_sum, int batch_size,
                    int S, float scale, float clamp, int heads, int y_transposed, hipStream_t s) {
     const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
@@ -1300,16 +1344,17 @@ int launch_forward(const unsigned long long *masks, const unsigned char *cells, 
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (y_transposed)
         hipLaunchKernelGGL(attention_mfma_forward_kernel<true>, grid, block, lds, s, masks, cells,
-                           q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
+                           pool, q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
     else
         hipLaunchKernelGGL(attention_mfma_forward_kernel<false>, grid, block, lds, s, masks, cells,
-                           q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
+                           pool, q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }
 
 int launch_backward(const unsigned long long *masks, const unsigned char *cells,
-                    const unsigned char *cells_t, const float *q, const float *k, const float *v,
+                    const unsigned char *cells_t, const unsigned char *pool,
+                    const unsigned char *pool_t, const float *q, const float *k, const float *v,
                     const float *y, const float *grad_y, const float *row_sum, float *delta,
                     float *grad_q, float *grad_k, float *grad_v, int batch_size, int S,
                     float scale, float clamp, int heads, int transposed, hipStream_t s) {
@@ -1327,7 +1372,8 @@ int launch_backward(const unsigned long long *masks, const unsigned char *cells,
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));                           \
         for (int half = 0; half < MA_ET / MR_QTILES; half++)                                    \
             hipLaunchKernelGGL(attention_mfma_backward_rows_kernel<GT>, grid, block, lds_r, s,  \
-                               masks, cells, q, k, v, grad_y, y, row_sum, grad_q, delta, S,     \
+                               masks, cells, pool, q, k, v, grad_y, y, row_sum, grad_q, delta,  \
+                               S,                                                               \
                                scale, clamp, heads, bpb, half);                                 \
         if (MA_BH == 1) {                                                                       \
             SPT_KEYS(GT, 0, 0);                                                                 \
@@ -1342,8 +1388,8 @@ int launch_backward(const unsigned long long *masks, const unsigned char *cells,
             (const void *)attention_mfma_backward_keys_kernel<GT, MODE>,                        \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));                           \
         hipLaunchKernelGGL((attention_mfma_backward_keys_kernel<GT, MODE>), grid, block, lds_k, \
-                           s, masks, cells_t, q, k, v, grad_y, row_sum, delta, grad_k, grad_v,  \
-                           S, scale, clamp, heads, bpb, HALF);                                  \
+                           s, masks, cells_t, pool_t, q, k, v, grad_y, row_sum, delta, grad_k,  \
+                           grad_v, S, scale, clamp, heads, bpb, HALF);                          \
     } while (0)
     if (transposed) SPT_MB(true);
     else SPT_MB(false);
@@ -1355,11 +1401,13 @@ int launch_backward(const unsigned long long *masks, const unsigned char *cells,
 
 #if MA_E_VALUE == 64
 namespace e128 {
-int launch_forward(const unsigned long long *masks, const unsigned char *cells, const float *q,
+int launch_forward(const unsigned long long *masks, const unsigned char *cells,
+                   const unsigned char *pool, const float *q,
                    const float *k, const float *v, float *y, float *row_sum, int batch_size,
                    int S, float scale, float clamp, int heads, int y_transposed, hipStream_t s);
 int launch_backward(const unsigned long long *masks, const unsigned char *cells,
-                    const unsigned char *cells_t, const float *q, const float *k, const float *v,
+                    const unsigned char *cells_t, const unsigned char *pool,
+                    const unsigned char *pool_t, const float *q, const float *k, const float *v,
                     const float *y, const float *grad_y, const float *row_sum, float *delta,
                     float *grad_q, float *grad_k, float *grad_v, int batch_size, int S,
                     float scale, float clamp, int heads, int transposed, hipStream_t s);
@@ -1370,23 +1418,37 @@ static bool mfma_shape_ok(int S, int E, int nnz) {
     const int Z = nnz / S;
     return Z <= MA_MAXZ && Z % 4 == 0 && S <= MA_MAXNT * MA_KT;
 }
+// Workspace: 256-byte header (word 0: layout, word 1: flags -- bit 0: a compact layout was
+// given a pattern that repeats a column outside key tile 0) | masks | cells | cells_t
+// [| pool | pool_t in the compact layout].
 struct TileSet {
     unsigned long long *masks;
-    unsigned char *cells, *cells_t;
+    unsigned char *cells, *cells_t, *pool, *pool_t;
 };
-static size_t tile_cells_bytes(int B, int S) {
+constexpr size_t MA_HEADER = 256;
+static size_t tile_cells_bytes(int B, int S, int layout) {
     const size_t RT = (S + MA_WROWS - 1) / MA_WROWS;
-    return (size_t)B * tri(RT) * MA_CELLS;
+    return (size_t)B * tri(RT) * (layout == SPT_TILES_COMPACT ? 128 : MA_CELLS);
+}
+static size_t tile_pool_bytes(int B, int S, int layout) {
+    const size_t RT = (S + MA_WROWS - 1) / MA_WROWS;
+    return layout == SPT_TILES_COMPACT ? (size_t)B * RT * MA_CELLS : 0;
 }
 static size_t tile_mask_bytes(int B, int S) {
     const size_t RT = (S + MA_WROWS - 1) / MA_WROWS;
     return (((size_t)B * RT * 2 * sizeof(unsigned long long)) + 255) & ~(size_t)255;
 }
-static TileSet carve_tiles(void *ws, int B, int S) {
+static TileSet carve_tiles(void *ws, int B, int S, int layout) {
     TileSet t;
-    t.masks = static_cast<unsigned long long *>(ws);
-    t.cells = reinterpret_cast<unsigned char *>(static_cast<char *>(ws) + tile_mask_bytes(B, S));
-    t.cells_t = t.cells + tile_cells_bytes(B, S);
+    char *p = static_cast<char *>(ws) + MA_HEADER;
+    t.masks = reinterpret_cast<unsigned long long *>(p);
+    t.cells = reinterpret_cast<unsigned char *>(p + tile_mask_bytes(B, S));
+    t.cells_t = t.cells + tile_cells_bytes(B, S, layout);
+    t.pool = t.pool_t = nullptr;
+    if (layout == SPT_TILES_COMPACT) {
+        t.pool = t.cells_t + tile_cells_bytes(B, S, layout);
+        t.pool_t = t.pool + tile_pool_bytes(B, S, layout);
+    }
     return t;
 }
 #endif
@@ -1398,80 +1460,88 @@ extern "C" int spt_attention_mfma_supported(int seq_length, int d_head, int nnz)
     return spt::mfma_shape_ok(seq_length, d_head, nnz) ? 1 : 0;
 }
 
-extern "C" int64_t spt_attention_mfma_tiles_bytes(int batch_size, int seq_length, int nnz) {
+extern "C" int64_t spt_attention_mfma_tiles_bytes(int batch_size, int seq_length, int nnz,
+                                                  int layout) {
     using namespace spt;
     if (batch_size <= 0 || !mfma_shape_ok(seq_length, MA_E, nnz)) return 0;
-    return (int64_t)(tile_mask_bytes(batch_size, seq_length) +
-                     2 * tile_cells_bytes(batch_size, seq_length));
+    if (layout != SPT_TILES_FULL && layout != SPT_TILES_COMPACT) return 0;
+    return (int64_t)(MA_HEADER + tile_mask_bytes(batch_size, seq_length) +
+                     2 * tile_cells_bytes(batch_size, seq_length, layout) +
+                     2 * tile_pool_bytes(batch_size, seq_length, layout));
 }
 
 extern "C" int spt_attention_mfma_prepare(const int32_t *indices, void *tiles, int batch_size,
-                                          int seq_length, int nnz, void *stream) {
+                                          int seq_length, int nnz, int layout, void *stream) {
     using namespace spt;
     if (!indices || !tiles || batch_size <= 0) return SPT_EINVAL;
+    if (layout != SPT_TILES_FULL && layout != SPT_TILES_COMPACT) return SPT_EINVAL;
     if (!mfma_shape_ok(seq_length, MA_E, nnz)) return SPT_EUNSUP;
     const int S = seq_length, Z = nnz / S, NT = (S + MA_KT - 1) / MA_KT;
     const int RT = (S + MA_WROWS - 1) / MA_WROWS, total = batch_size * RT;
-    const TileSet ts = carve_tiles(tiles, batch_size, S);
+    const TileSet ts = carve_tiles(tiles, batch_size, S, layout);
     const size_t lds = (size_t)MB_WAVES * prepare_lds_per_wave();
     const dim3 grid((total + MB_WAVES - 1) / MB_WAVES), block(MB_WAVES * SPT_WAVE);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    SPT_HIP_TRY(hipMemsetAsync(tiles, 0, MA_HEADER, s));
     if (Z > 255) {
         SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_cell_tiles_kernel<true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(attention_cell_tiles_kernel<true>, grid, block, lds, s, indices,
-                           ts.masks, ts.cells, ts.cells_t, S, Z, NT, RT, total);
+                           ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, S, Z, NT, RT, total);
     } else {
         SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_cell_tiles_kernel<false>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(attention_cell_tiles_kernel<false>, grid, block, lds, s, indices,
-                           ts.masks, ts.cells, ts.cells_t, S, Z, NT, RT, total);
+                           ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, S, Z, NT, RT, total);
     }
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }
 
-extern "C" int spt_attention_mfma_forward(const void *tiles, const float *q, const float *k,
-                                          const float *v, float *y, float *row_sum,
-                                          int batch_size, int seq_length, int d_head, int nnz,
-                                          float scale, float clamp, int heads, int y_transposed,
-                                          void *stream) {
+extern "C" int spt_attention_mfma_forward(const void *tiles, int layout, const float *q,
+                                          const float *k, const float *v, float *y,
+                                          float *row_sum, int batch_size, int seq_length,
+                                          int d_head, int nnz, float scale, float clamp, int heads,
+                                          int y_transposed, void *stream) {
     using namespace spt;
     if (!tiles || !q || !k || !v || !y || !row_sum) return SPT_EINVAL;
     if (batch_size <= 0 || heads < 0) return SPT_EINVAL;
+    if (layout != SPT_TILES_FULL && layout != SPT_TILES_COMPACT) return SPT_EINVAL;
     if (!mfma_shape_ok(seq_length, d_head, nnz)) return SPT_EUNSUP;
     if (heads > 0 && batch_size % heads != 0) return SPT_ESHAPE;
-    const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length);
+    const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length, layout);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return d_head == 64
-               ? launch_forward(ts.masks, ts.cells, q, k, v, y, row_sum, batch_size, seq_length,
-                                scale, clamp, heads, y_transposed, s)
-               : e128::launch_forward(ts.masks, ts.cells, q, k, v, y, row_sum, batch_size,
+               ? launch_forward(ts.masks, ts.cells, ts.pool, q, k, v, y, row_sum, batch_size,
+                                seq_length, scale, clamp, heads, y_transposed, s)
+               : e128::launch_forward(ts.masks, ts.cells, ts.pool, q, k, v, y, row_sum, batch_size,
                                       seq_length, scale, clamp, heads, y_transposed, s);
 }
 
-extern "C" int spt_attention_mfma_backward(const void *tiles, const float *q, const float *k,
-                                           const float *v, const float *y, const float *grad_y,
-                                           const float *row_sum, float *delta, float *grad_q,
-                                           float *grad_k, float *grad_v, int batch_size,
-                                           int seq_length, int d_head, int nnz, float scale,
-                                           float clamp, int heads, int transposed, void *stream) {
+extern "C" int spt_attention_mfma_backward(const void *tiles, int layout, const float *q,
+                                           const float *k, const float *v, const float *y,
+                                           const float *grad_y, const float *row_sum, float *delta,
+                                           float *grad_q, float *grad_k, float *grad_v,
+                                           int batch_size, int seq_length, int d_head, int nnz,
+                                           float scale, float clamp, int heads, int transposed,
+                                           void *stream) {
     using namespace spt;
     if (!tiles || !q || !k || !v || !y || !grad_y || !row_sum || !delta || !grad_q || !grad_k ||
         !grad_v)
         return SPT_EINVAL;
     if (batch_size <= 0 || heads < 0) return SPT_EINVAL;
+    if (layout != SPT_TILES_FULL && layout != SPT_TILES_COMPACT) return SPT_EINVAL;
     if (!mfma_shape_ok(seq_length, d_head, nnz)) return SPT_EUNSUP;
     if (heads > 0 && batch_size % heads != 0) return SPT_ESHAPE;
     if (transposed && (seq_length & 3)) return SPT_EUNSUP;
-    const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length);
+    const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length, layout);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return d_head == 64
-               ? launch_backward(ts.masks, ts.cells, ts.cells_t, q, k, v, y, grad_y, row_sum,
-                                 delta, grad_q, grad_k, grad_v, batch_size, seq_length, scale,
-                                 clamp, heads, transposed, s)
-               : e128::launch_backward(ts.masks, ts.cells, ts.cells_t, q, k, v, y, grad_y, row_sum,
-                                       delta, grad_q, grad_k, grad_v, batch_size, seq_length,
-                                       scale, clamp, heads, transposed, s);
+               ? launch_backward(ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, q, k, v, y,
+                                 grad_y, row_sum, delta, grad_q, grad_k, grad_v, batch_size,
+                                 seq_length, scale, clamp, heads, transposed, s)
+               : e128::launch_backward(ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, q, k, v,
+                                       y, grad_y, row_sum, delta, grad_q, grad_k, grad_v,
+                                       batch_size, seq_length, scale, clamp, heads, transposed, s);
 }
 #endif

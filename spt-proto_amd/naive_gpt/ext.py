@@ -54,12 +54,12 @@ _PROTOTYPES = {
     'spt_sparse_attention_backward_rows': ([_c_ptr] * 9 + [_c_int] * 4 + [_c_f32, _c_f32] +
                                            [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_attention_mfma_supported': ([_c_int] * 3, _c_int),
-    'spt_attention_mfma_tiles_bytes': ([_c_int] * 3, ctypes.c_int64),
-    'spt_attention_mfma_prepare': ([_c_ptr] * 2 + [_c_int] * 3 + [_c_ptr], _c_int),
-    'spt_attention_mfma_forward': ([_c_ptr] * 6 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int,
-                                                               _c_ptr], _c_int),
-    'spt_attention_mfma_backward': ([_c_ptr] * 11 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int,
-                                                                 _c_ptr], _c_int),
+    'spt_attention_mfma_tiles_bytes': ([_c_int] * 4, ctypes.c_int64),
+    'spt_attention_mfma_prepare': ([_c_ptr] * 2 + [_c_int] * 4 + [_c_ptr], _c_int),
+    'spt_attention_mfma_forward': ([_c_ptr, _c_int] + [_c_ptr] * 5 + [_c_int] * 4 +
+                                   [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int),
+    'spt_attention_mfma_backward': ([_c_ptr, _c_int] + [_c_ptr] * 10 + [_c_int] * 4 +
+                                    [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int),
     'spt_grouped_gemm_fused': ([_c_ptr, _c_ptr], _c_int),
     'spt_grouped_gemm_pdot_width': ([_c_int], _c_int),
     'spt_grouped_gemm_image_path': ([_c_ptr], _c_int),
@@ -72,7 +72,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _lib = None
 
@@ -452,28 +452,40 @@ class MfmaTiles:
     """The CSR entries bucketed by (32-row tile, 32-key tile): ``spt_attention_mfma_prepare``.
     Depends on ``indices`` only; shared by the forward and the backward of a layer step."""
 
-    __slots__ = ('buffer', 'batch', 'seq', 'nnz')
+    __slots__ = ('buffer', 'batch', 'seq', 'nnz', 'layout')
 
-    def __init__(self, buffer, batch, seq, nnz):
-        self.buffer, self.batch, self.seq, self.nnz = buffer, batch, seq, nnz
+    def __init__(self, buffer, batch, seq, nnz, layout):
+        self.buffer, self.batch, self.seq, self.nnz, self.layout = buffer, batch, seq, nnz, layout
+
+    def broke_promise(self) -> bool:
+        """(synchronises) compact layout: did the pattern repeat a column outside key tile 0?"""
+        return bool(self.buffer[4:8].view(torch.int32).item() & 1)
 
 
-def attention_mfma_prepare(indices: torch.Tensor, seq_length: int) -> MfmaTiles:
+TILES_FULL, TILES_COMPACT = 0, 1
+
+
+def attention_mfma_prepare(indices: torch.Tensor, seq_length: int,
+                           lookup_pattern: bool = False) -> MfmaTiles:
+    """``lookup_pattern``: the caller vouches that only columns < 32 repeat inside a row -- true
+    of every output of ``lookup_forward_cuda``, whose one repeated column is the padding
+    column 0 -- which allows the compact tile layout (a quarter of the memory)."""
+    layout = TILES_COMPACT if lookup_pattern else TILES_FULL
     _check_dim(indices, 2, 'indices')
     _check_type(indices, torch.int32, 'indices')
     _require(indices.is_contiguous(), 'contiguous indices')
     dev = _same_device(indices)
     B, nnz = indices.shape
     lib = load_library()
-    size = lib.spt_attention_mfma_tiles_bytes(B, int(seq_length), nnz)
+    size = lib.spt_attention_mfma_tiles_bytes(B, int(seq_length), nnz, layout)
     _require(size > 0, 'attention_mfma: unsupported shape (d_head 64, Z <= 256, Z % 4 == 0, S <= 2048)')
     with torch.cuda.device(dev):
         buf = torch.empty([size], dtype=torch.uint8, device=dev)
         rc = lib.spt_attention_mfma_prepare(indices.data_ptr(), buf.data_ptr(), B, int(seq_length),
-                                            nnz, _stream(dev))
+                                            nnz, layout, _stream(dev))
     if rc != 0:
         _raise(lib, rc, 'attention_mfma_prepare')
-    return MfmaTiles(buf, B, int(seq_length), nnz)
+    return MfmaTiles(buf, B, int(seq_length), nnz, layout)
 
 
 def attention_mfma_forward(tiles, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
@@ -500,7 +512,7 @@ def attention_mfma_forward(tiles, q: torch.Tensor, k: torch.Tensor, v: torch.Ten
         y = torch.empty([B, E, S] if y_transposed else [B, S, E], dtype=torch.float32, device=dev)
         row_sum = torch.empty([B, S], dtype=torch.float32, device=dev)
         rc = lib.spt_attention_mfma_forward(
-            tiles.buffer.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(),
+            tiles.buffer.data_ptr(), tiles.layout, q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(),
             row_sum.data_ptr(), B, S, E, tiles.nnz, float(scale), float(clamp), H,
             int(bool(y_transposed)), _stream(dev))
     if rc != 0:
@@ -531,7 +543,7 @@ def attention_mfma_backward(tiles: MfmaTiles, q: torch.Tensor, k: torch.Tensor, 
         grad_q, grad_k, grad_v = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         delta = torch.empty([B, S], dtype=torch.float32, device=dev)
         rc = lib.spt_attention_mfma_backward(
-            tiles.buffer.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(),
+            tiles.buffer.data_ptr(), tiles.layout, q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(),
             grad_y.data_ptr(), row_sum.data_ptr(), delta.data_ptr(), grad_q.data_ptr(),
             grad_k.data_ptr(), grad_v.data_ptr(), B, S, E, tiles.nnz, float(scale), float(clamp),
             H, int(bool(transposed)), _stream(dev))
@@ -845,11 +857,11 @@ def drop_images():
     _WEIGHT_NORMS.clear()
 
 
-# Frozen weights: their images never change, and keeping them costs as many bytes again as
-# the fp32 weights.  SPT_WEIGHT_IMAGES=keep (default) holds them for the life of the
-# parameter (keyed by the parameter object, dropped when `_version` moves);
-# SPT_WEIGHT_IMAGES=step re-splits a weight every time it is used (4 MiB -> ~4 us) and
-# keeps nothing.
+# Frozen weights: their images never change, but keeping them costs as many bytes again as the
+# fp32 weights (+1.2 GB on the 24-layer BERT-large-dims model, 8 % of its peak).  Default
+# (SPT_WEIGHT_IMAGES unset or 'step'): a weight is re-split every time it is used (4 MiB ->
+# ~4 us, ~1.5 % of a step) and nothing is kept; SPT_WEIGHT_IMAGES=keep holds the image for the
+# life of the parameter (dropped when `_version` moves).
 class _PerParameter:
     """{parameter -> value} keyed by identity (a tensor's `==` is elementwise, which rules out
     weakref.WeakKeyDictionary); an entry dies with its parameter or when `_version` moves."""
@@ -873,7 +885,7 @@ class _PerParameter:
 
 
 _WEIGHT_IMAGES = _PerParameter()
-KEEP_WEIGHT_IMAGES = os.environ.get('SPT_WEIGHT_IMAGES', 'keep') != 'step'
+KEEP_WEIGHT_IMAGES = os.environ.get('SPT_WEIGHT_IMAGES', 'step') == 'keep'
 
 
 def row_norms(x: torch.Tensor) -> torch.Tensor:

@@ -52,7 +52,7 @@ def test_lookup_structure_long(case):
 
 def _forward(idx, q, k, v, E):
     from naive_gpt import ext
-    tiles = ext.attention_mfma_prepare(idx, S)
+    tiles = ext.attention_mfma_prepare(idx, S, lookup_pattern=True)
     y, row_sum = ext.attention_mfma_forward(tiles, q, k, v, E ** -0.5, 10.0, y_transposed=False)
     return tiles, y, row_sum
 

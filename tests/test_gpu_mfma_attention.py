@@ -133,7 +133,7 @@ def test_cell_tiles_hold_the_multiplicity_of_every_live_cell():
             indices.view(B, S, Z)[b, r] = torch.randperm(r + 1, generator=gen)[:Z].to(torch.int32)
     tiles = ext.attention_mfma_prepare(indices.cuda(), S)
     RT = S // 32
-    raw = tiles.buffer.cpu().numpy()
+    raw = tiles.buffer.cpu().numpy()[256:]                   # behind the 256-byte header
     mask_bytes = (B * RT * 16 + 255) // 256 * 256
     masks = raw[:B * RT * 16].view('uint64').reshape(B, RT, 2)
     ntile = RT * (RT + 1) // 2
@@ -215,3 +215,57 @@ def test_host_side_arming_equals_the_reference_protocol():
     attn.loss.zero_()
     attn(q, k, v, attn_mask=None)                     # not armed any more: no loss computed
     assert float(attn.loss.detach()) == 0.0
+
+
+# ------------------------------------------------------------------ compact tile layout
+
+def _lookup_like(B, S, Z, gen):
+    """Rows as lookup emits them: distinct columns <= row, then zero padding."""
+    idx = torch.zeros([B, S, Z], dtype=torch.int32)
+    for r in range(S):
+        n = min(r + 1, Z)
+        for b in range(B):
+            idx[b, r, :n] = torch.randperm(r + 1, generator=gen)[:n].int()
+    return idx.view(B, S * Z)
+
+
+@pytest.mark.parametrize('N,H,S,Z,E', [(1, 4, 512, 64, 64), (1, 2, 2048, 256, 64), (1, 2, 256, 32, 128),
+                                       (1, 3, 80, 8, 64)])
+def test_compact_tiles_equal_full_tiles_on_lookup_patterns(N, H, S, Z, E):
+    """SPT_TILES_COMPACT (128-byte mask slots + one byte-form slot per row tile for key tile 0)
+    against SPT_TILES_FULL: bit-identical forward and backward on patterns whose only repeated
+    column is the padding column 0, at a quarter of the workspace."""
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(S + Z + E)
+    B = N * H
+    q, k, v = [torch.randn([N, S, H, E], generator=gen).cuda() for _ in range(3)]
+    gy = torch.randn([B, S, E], generator=gen).cuda()
+    idx = _lookup_like(B, S, Z, gen).cuda()
+    full = ext.attention_mfma_prepare(idx, S)
+    compact = ext.attention_mfma_prepare(idx, S, lookup_pattern=True)
+    assert compact.layout == ext.TILES_COMPACT and not compact.broke_promise()
+    if S >= 512:
+        assert compact.buffer.numel() < 0.3 * full.buffer.numel()
+    outs = []
+    for tiles in (full, compact):
+        y, row_sum = ext.attention_mfma_forward(tiles, q, k, v, E ** -0.5, CLAMP)
+        grads = ext.attention_mfma_backward(tiles, q, k, v, y, gy, row_sum, E ** -0.5, CLAMP)
+        outs.append((y, row_sum) + tuple(grads))
+    for a, b, name in zip(outs[0], outs[1], ['y', 'row_sum', 'grad_q', 'grad_k', 'grad_v']):
+        if name in ('grad_k', 'grad_v'):
+            # the order in which a key's duplicate entries are summed is not fixed (DESIGN 3)
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(a.abs().max())), name
+        else:
+            assert torch.equal(a, b), name
+    # and it is the right answer
+    want = oracle_chain(idx.cpu(), q.cpu(), k.cpu(), v.cpu(), E ** -0.5)[2]
+    assert torch.allclose(outs[1][0].cpu(), want, rtol=1e-3, atol=1e-4)
+
+
+def test_compact_tiles_flag_a_pattern_that_repeats_other_columns():
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(8)
+    idx = causal_indices(4, 256, 32, gen).cuda()          # random repeats anywhere
+    tiles = ext.attention_mfma_prepare(idx, 256, lookup_pattern=True)
+    assert tiles.broke_promise()
+    assert not ext.attention_mfma_prepare(idx, 256).broke_promise()
