@@ -821,31 +821,30 @@ def split_bf16(x: torch.Tensor) -> SplitImage:
     return SplitImage(buf, rows, cols)
 
 
-# Images of the operands most recently split, keyed by (storage address, version, shape,
-# stride): the q / k / v projections of a block share one input, a frozen weight is read by
-# the forward and the backward GEMM.  The cache holds the SOURCE tensor too, so that its
-# address cannot be handed to another tensor while the entry lives; `_version` changes with
-# every in-place write.  Activations: a few entries (they are as large as the activations
-# themselves).  Weights: see `weight_image`.
+# Images of the activations most recently split.  The q / k / v projections of a block read ONE
+# tensor: the first splits it, the other two find the image here.  An entry is identified by
+# the OWNER object (the tensor the layer was called with, held through a weak reference -- no
+# lifetime is extended, and an address handed to another tensor cannot alias) and its
+# `_version` (every in-place write moves it).  Two entries: they are as large as activations.
 _IMAGE_CACHE = collections.OrderedDict()
 IMAGE_CACHE_ENTRIES = 2
 
 
-def _image_key(x: torch.Tensor):
-    return (x.data_ptr(), x._version, tuple(x.shape), x.stride(0), x.device.index)
-
-
-def image_of(x: torch.Tensor) -> SplitImage:
-    """`split_bf16(x)` through the small most-recently-used cache above."""
-    if x.is_inference():
+def image_of(x: torch.Tensor, owner: torch.Tensor = None) -> SplitImage:
+    """`split_bf16(x)` through the small cache above; `owner`: the tensor object `x` is a view
+    of (default: x itself) -- what callers that share an input have in common."""
+    owner = x if owner is None else owner
+    if owner.is_inference():
         return split_bf16(x)
-    key = _image_key(x)
+    key = id(owner)
     hit = _IMAGE_CACHE.get(key)
-    if hit is not None:
+    if hit is not None and hit[0]() is owner and hit[1] == (owner._version, tuple(x.shape)):
         _IMAGE_CACHE.move_to_end(key)
-        return hit[1]
+        return hit[2]
     img = split_bf16(x)
-    _IMAGE_CACHE[key] = (x, img)
+    _IMAGE_CACHE[key] = (weakref.ref(owner, lambda _, k=key: _IMAGE_CACHE.pop(k, None)),
+                         (owner._version, tuple(x.shape)), img)
+    _IMAGE_CACHE.move_to_end(key)
     while len(_IMAGE_CACHE) > IMAGE_CACHE_ENTRIES:
         _IMAGE_CACHE.popitem(last=False)
     return img

@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from .multihead import project_heads
+from ..tuning import recompute
 
 
 class MultiheadAttention(nn.Module):
@@ -44,8 +45,10 @@ class TransformerBlock(nn.Module):
     def forward(self, x: torch.Tensor, attn_mask: torch.Tensor = None):
         assert x.dim() == 3
         if self.pre_norm:
-            h = self.norm1(x)
+            # (the norm outputs are tagged so that the LoRA layers behind them can recompute
+            # them in the backward instead of keeping them: layers/tuning/recompute.py)
+            h = recompute.tag(self.norm1(x), self.norm1, x)
             x = x + self.mha(h, h, h, attn_mask=attn_mask)
-            return x + self.ffd(self.norm2(x))
+            return x + self.ffd(recompute.tag(self.norm2(x), self.norm2, x))
         x = self.norm1(x + self.mha(x, x, x, attn_mask=attn_mask))
         return self.norm2(x + self.ffd(x))

@@ -32,3 +32,9 @@ class LlamaRMSNorm(nn.Module):
         if self.weight.dtype in (torch.float16, torch.bfloat16):
             x = x.to(self.weight.dtype)
         return self.weight * x
+
+
+# a pure function of its input: may be recomputed in the backward (layers/tuning/recompute.py)
+from ..tuning import recompute as _recompute  # noqa: E402
+
+_recompute.register(LlamaRMSNorm)

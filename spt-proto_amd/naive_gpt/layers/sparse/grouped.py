@@ -16,6 +16,7 @@ from typing import NamedTuple
 import torch
 
 from naive_gpt import ext
+from naive_gpt.layers.tuning import recompute
 
 
 class Buckets(NamedTuple):
@@ -193,7 +194,8 @@ class RoutedLoRAFFN(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk: Buckets, act: int):
+    def forward(ctx, x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk: Buckets, act: int,
+                origin_input=None, origin_module=None):
         nb = bk.n_blocks
         d_ff, d = w1.shape
         bs, rank, rows = d_ff // nb, l1.size(1), bk.token.numel()
@@ -209,7 +211,7 @@ class RoutedLoRAFFN(torch.autograd.Function):
             n_rows=rows, gather=bk.token, bias=b1, rowscale=coeff,
             a2=u, gather2=bk.token, b2=r1, b2_group_stride=bs * rank,
             epilogue=ext.EPI_ACT, activation=act, keep_preact=not relu,
-            a_image=ext.image_of(x) if imgs else None,
+            a_image=ext.split_bf16(x) if imgs else None,
             w_image=ext.weight_image(w1) if imgs else None,
             a_norm=ext.row_norms(x) if relu else None,
             w_norm=ext.weight_row_norms(w1) if relu else None)
@@ -221,12 +223,17 @@ class RoutedLoRAFFN(torch.autograd.Function):
             w_image=ext.weight_image(w2) if imgs else None)
         y = ext.rows_combine(ys, bk.pos, bias=b2)
         ctx.bk, ctx.act = bk, act
-        ctx.save_for_backward(x, coeff, u, h, s, z, l1, r1, l2, r2, w1, w2)
+        # x is a norm output the block can recompute: keep its origin instead (tuning/recompute.py)
+        ctx.origin_module = origin_module
+        ctx.save_for_backward(x if origin_module is None else origin_input, coeff, u, h, s, z,
+                              l1, r1, l2, r2, w1, w2)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, coeff, u, h, s, z, l1, r1, l2, r2, w1, w2 = ctx.saved_tensors
+        if ctx.origin_module is not None:
+            x = recompute.output(ctx.origin_module, x).view(-1, w1.size(1))
         bk, act = ctx.bk, ctx.act
         nb = bk.n_blocks
         d_ff, d = w1.shape
@@ -266,11 +273,14 @@ class RoutedLoRAFFN(torch.autograd.Function):
         grad_x = ext.rows_combine(dxs, bk.pos)
         del dxs
         return (grad_x, grad_coeff, grad_l1, grad_r1, grad_l2, grad_r2,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
-def routed_lora_ffn(x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk: Buckets, act: int):
-    return RoutedLoRAFFN.apply(x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk, act)
+def routed_lora_ffn(x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk: Buckets, act: int, origin=None):
+    if origin is None:
+        return RoutedLoRAFFN.apply(x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk, act)
+    return RoutedLoRAFFN.apply(x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk, act,
+                               origin.input, origin.module)
 
 
 def _images_usable(a: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, d: int, bs: int) -> bool:
@@ -298,7 +308,8 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
     identity for the two up projections."""
 
     @staticmethod
-    def forward(ctx, x, coeff, lg, rg, ls, rs, ld, rd, wg, ws, wd, bk: Buckets, activation):
+    def forward(ctx, x, coeff, lg, rg, ls, rs, ld, rd, wg, ws, wd, bk: Buckets, activation,
+                origin_input=None, origin_module=None):
         nb = bk.n_blocks
         d_ff, d = wg.shape
         bs, rank, rows = d_ff // nb, lg.size(1), bk.token.numel()
@@ -326,12 +337,16 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
         del x_image
         y = ext.rows_combine(ys, bk.pos)
         ctx.bk, ctx.activation = bk, activation
-        ctx.save_for_backward(x, coeff, ug, us, g, sd, h, z, lg, rg, ls, rs, ld, rd, wg, ws, wd)
+        ctx.origin_module = origin_module
+        ctx.save_for_backward(x if origin_module is None else origin_input, coeff, ug, us, g, sd,
+                              h, z, lg, rg, ls, rs, ld, rd, wg, ws, wd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, coeff, ug, us, g, sd, h, z, lg, rg, ls, rs, ld, rd, wg, ws, wd = ctx.saved_tensors
+        if ctx.origin_module is not None:
+            x = recompute.output(ctx.origin_module, x).view(-1, wg.size(1))
         bk, activation = ctx.bk, ctx.activation
         nb = bk.n_blocks
         d_ff, d = wg.shape
@@ -380,8 +395,12 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
         grad_ld = _block_major(_tn(h, _in_own_block(dz_rows, bk.block, nb)), nb)
         grad_rd = _tn(dy, z[pos].sum(dim=1))
         return (grad_x, grad_coeff, grad_lg, grad_rg, grad_ls, grad_rs, grad_ld, grad_rd,
-                None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
-def routed_lora_llama_ffn(x, coeff, lg, rg, ls, rs, ld, rd, wg, ws, wd, bk: Buckets, activation):
-    return RoutedLoRALLaMAFFN.apply(x, coeff, lg, rg, ls, rs, ld, rd, wg, ws, wd, bk, activation)
+def routed_lora_llama_ffn(x, coeff, lg, rg, ls, rs, ld, rd, wg, ws, wd, bk: Buckets, activation,
+                          origin=None):
+    if origin is None:
+        return RoutedLoRALLaMAFFN.apply(x, coeff, lg, rg, ls, rs, ld, rd, wg, ws, wd, bk, activation)
+    return RoutedLoRALLaMAFFN.apply(x, coeff, lg, rg, ls, rs, ld, rd, wg, ws, wd, bk, activation,
+                                    origin.input, origin.module)

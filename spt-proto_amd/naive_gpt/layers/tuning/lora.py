@@ -9,6 +9,8 @@ is applied (``scaling`` is stored but unused, as in the reference).
 import torch
 from torch import nn
 
+from . import recompute
+
 
 class LoRABase(nn.Module):
     def __init__(self, d_lora: int, in_features: int, out_features: int,
@@ -76,7 +78,7 @@ def _mfma_linear_usable(x2: torch.Tensor, weight: torch.Tensor, rank: int) -> bo
             and weight.size(0) % 4 == 0 and weight.size(1) % 4 == 0 and 0 < rank <= 32)
 
 
-def _mfma_gemm(a, weight, n, k, ldn, ldk, bias=None, a2=None, b2=None, images=False):
+def _mfma_gemm(a, weight, n, k, ldn, ldk, bias=None, a2=None, b2=None, images=False, owner=None):
     """out[p, :n] = a[p, :k] . W(n, k)^T (+ bias) (+ a2 . b2^T), W(n, k) = weight[n * ldn + k * ldk].
 
     `images`: run from the pre-split bf16 images of both operands (LDS-DMA k-loop, ~20 % less
@@ -87,7 +89,7 @@ def _mfma_gemm(a, weight, n, k, ldn, ldk, bias=None, a2=None, b2=None, images=Fa
     rows = a.size(0)
     a_image = w_image = None
     if images and k % 32 == 0 and a.is_contiguous():
-        a_image, w_image = ext.image_of(a), ext.weight_image(weight)
+        a_image, w_image = ext.image_of(a, owner), ext.weight_image(weight)
     return ext.grouped_gemm_fused(a, weight, _one_group(rows, a.device), 1, n, k, 0, ldn, ldk,
                                   rows, bias=bias, a2=a2, b2=b2, a_image=a_image, w_image=w_image)
 
@@ -107,17 +109,22 @@ class _FrozenLoRALinear(torch.autograd.Function):
         if ctx.mfma:
             # one launch: base product, bias and the side product (the K extension) together
             y = _mfma_gemm(x2, weight, n, k, k, 1, bias=None if bias is None else bias.view(1, n),
-                           a2=u.contiguous(), b2=right.contiguous(), images=True)
+                           a2=u.contiguous(), b2=right.contiguous(), images=True, owner=x)
         else:
             y = nn.functional.linear(x2, weight, bias)
             y.addmm_(u, right.t())
-        ctx.save_for_backward(x2, u, weight, left, right)
+        # a tagged norm output is not kept: its origin is (layers/tuning/recompute.py)
+        origin = recompute.origin_of(x)
+        ctx.origin_module = origin.module if origin is not None else None
+        ctx.save_for_backward(origin.input if origin is not None else x2, u, weight, left, right)
         ctx.x_shape = x.shape
         return y.view(*x.shape[:-1], weight.size(0))
 
     @staticmethod
     def backward(ctx, dy):
         x2, u, weight, left, right = ctx.saved_tensors
+        if ctx.origin_module is not None:
+            x2 = recompute.output(ctx.origin_module, x2).reshape(-1, weight.size(1))
         dy2 = dy.reshape(-1, dy.size(-1))
         du = torch.matmul(dy2, right)                                # [T, r]
         grad_x = None

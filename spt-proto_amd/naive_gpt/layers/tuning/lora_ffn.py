@@ -18,6 +18,7 @@ from torch import nn
 
 from naive_gpt import layers
 from naive_gpt.layers.sparse import grouped, routing
+from . import recompute
 
 
 def _load_routed(model: nn.Module, source: nn.Module):
@@ -47,12 +48,21 @@ class LoRARoutedFFN(layers.RoutedFFN):
                               activation=source.activation)
         return _load_routed(model, source)
 
-    def _forward_grouped(self, x: torch.Tensor):
+    def _router(self, x: torch.Tensor, origin):
+        """router probabilities; a tagged norm output is not kept for the router's weight
+        gradient either (layers/tuning/recompute.py)"""
+        if origin is None:
+            return self.router(x)
+        linear = self.router[0]
+        return self.router[1](recompute.RecomputedLinear.apply(
+            x, origin.input, linear.weight, linear.bias, origin.module))
+
+    def _forward_grouped(self, x: torch.Tensor, origin=None):
         """MI355X path: device-side bucketing + grouped MFMA GEMMs for the frozen base
         weights (layers/sparse/grouped.py); LoRA side paths as dense K = n_blocks * r
         matmuls on the same row space.  No host synchronisation."""
         nb, bs, d, r = self.n_blocks, self.block_size, self.d_model, self.fc1.lora.left.weight.size(1)
-        prob = self.router(x)
+        prob = self._router(x, origin)
         bk = grouped.make_buckets(prob, k=nb // 2)
         coeff = (2.0 * bk.coeff).contiguous()
         act = grouped.activation_code(self.activation)
@@ -62,7 +72,8 @@ class LoRARoutedFFN(layers.RoutedFFN):
             return grouped.routed_lora_ffn(
                 x, coeff, self.fc1.lora.left.weight, self.fc1.lora.right.weight,
                 self.fc2.lora.left.weight, self.fc2.lora.right.weight,
-                self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, bk, act)
+                self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, bk, act,
+                origin=origin)
         rows = torch.arange(bk.block.numel(), device=x.device)
 
         g1 = grouped.grouped_linear(
@@ -85,10 +96,11 @@ class LoRARoutedFFN(layers.RoutedFFN):
 
     def forward(self, x: torch.Tensor):
         x_size = x.size()
+        origin = recompute.origin_of(x) if x.is_contiguous() else None
         x = x.view([-1, self.d_model])
         if grouped.usable(x, self.fc1.weight, self.fc1.bias, self.fc2.weight) \
                 and self.d_model % 4 == 0 and self.block_size % 4 == 0:
-            return self._forward_grouped(x.contiguous()).view(x_size)
+            return self._forward_grouped(x.contiguous(), origin).view(x_size)
         prob = self.router(x)
         route = routing.route_topk(prob, k=self.n_blocks // 2)
 
@@ -134,10 +146,12 @@ class LoRARoutedLLaMaFFN(layers.RoutedLLaMaFFN):
                                    activation=source.activation)
         return _load_routed(model, source)
 
-    def _forward_grouped(self, x: torch.Tensor):
+    _router = LoRARoutedFFN._router
+
+    def _forward_grouped(self, x: torch.Tensor, origin=None):
         """MI355X path, see LoRARoutedFFN._forward_grouped."""
         nb, bs, d, r = self.n_blocks, self.block_size, self.d_model, self.gate.lora.left.weight.size(1)
-        prob = self.router(x)
+        prob = self._router(x, origin)
         bk = grouped.make_buckets(prob, k=nb // 2)
         coeff = (2.0 * bk.coeff).contiguous()
         if grouped.fused_usable(r):
@@ -146,7 +160,8 @@ class LoRARoutedLLaMaFFN(layers.RoutedLLaMaFFN):
                 x, coeff, self.gate.lora.left.weight, self.gate.lora.right.weight,
                 self.side.lora.left.weight, self.side.lora.right.weight,
                 self.down.lora.left.weight, self.down.lora.right.weight,
-                self.gate.weight, self.side.weight, self.down.weight, bk, self.activation)
+                self.gate.weight, self.side.weight, self.down.weight, bk, self.activation,
+                origin=origin)
         rows = torch.arange(bk.block.numel(), device=x.device)
 
         def up(linear):
@@ -169,10 +184,11 @@ class LoRARoutedLLaMaFFN(layers.RoutedLLaMaFFN):
 
     def forward(self, x: torch.Tensor):
         x_size = x.size()
+        origin = recompute.origin_of(x) if x.is_contiguous() else None
         x = x.view([-1, self.d_model])
         if grouped.usable(x, self.gate.weight, self.side.weight, self.down.weight) \
                 and self.d_model % 4 == 0 and self.block_size % 4 == 0:
-            return self._forward_grouped(x.contiguous()).view(x_size)
+            return self._forward_grouped(x.contiguous(), origin).view(x_size)
         prob = self.router(x)
         route = routing.route_topk(prob, k=self.n_blocks // 2)
 

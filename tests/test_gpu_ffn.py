@@ -608,3 +608,60 @@ def test_frozen_lora_linear_on_the_matrix_core_gemm_equals_the_library_gemm(monk
     fast, slow = run(True), run(False)
     for a, b, name in zip(fast, slow, ['y', 'grad_x', 'grad_left', 'grad_right']):
         assert _scaled_close(a, b), name
+
+
+def test_norm_outputs_are_recomputed_not_kept(monkeypatch):
+    """layers/tuning/recompute.py: in a pre-norm block the LoRA layers behind a norm save the
+    norm's INPUT and recompute its output in their backward.  Same numbers bit for bit, two
+    [N * S, d] activations fewer alive between forward and backward."""
+    from naive_gpt import layers, utils
+    from naive_gpt.layers.tuning import recompute
+    import contextlib
+    import io
+    d, heads, d_ff, N, S = 1024, 16, 4096, 4, 512
+
+    def build():
+        torch.manual_seed(0)
+        block = layers.TransformerBlock(
+            d_model=d, n_heads=heads, layernorm_fn=nn.LayerNorm(d),
+            attention_fn=layers.VanillaAttention(d_head=d // heads, p_dropout=0.0),
+            feedforward_fn=layers.Feedforward(d_model=d, d_feedforward=d_ff, activation=nn.ReLU(),
+                                              p_dropout=0.0),
+            attention_bias=True, pre_norm=True)
+        with contextlib.redirect_stdout(io.StringIO()):
+            for stage in ('lora', 'ffn', 'mha_v1', 'mha_v2'):
+                block = utils.ModuleUpgrader(utils.SparseLoRAHandler(d_lora=16, stage=stage)).visit(block)
+        for name, p in block.named_parameters():
+            if name.endswith('lora.right.weight'):
+                p.data.normal_(0, 0.02)
+        return block.cuda()
+
+    x0 = torch.randn([N, S, d], device='cuda')
+
+    def run(block):
+        from naive_gpt import ext
+        x = x0.clone().requires_grad_(True)
+        ext.drop_images()                  # the operand-image cache holds the last activations
+        recompute.release()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        before = torch.cuda.memory_allocated()
+        y = block(x)
+        held = torch.cuda.memory_allocated() - before          # alive for the backward
+        y.square().sum().backward()
+        grads = {n: p.grad.clone() for n, p in block.named_parameters() if p.grad is not None}
+        return y.detach(), x.grad.clone(), grads, held
+
+    block = build()
+    run(block)                             # first use: per-weight caches (row norms) fill up
+    block.zero_grad()
+    y1, gx1, g1, held1 = run(block)
+    monkeypatch.setattr(recompute, 'tag', lambda output, module, input: output)
+    block.zero_grad()
+    y0, gx0, g0, held0 = run(block)
+    assert torch.equal(y1, y0) and torch.equal(gx1, gx0)
+    assert set(g0) == set(g1)
+    for n in g0:
+        assert torch.equal(g1[n], g0[n]), n
+    act = N * S * d * 4
+    assert held0 - held1 >= 1.9 * act, (held0, held1, act)     # both norm outputs are gone
