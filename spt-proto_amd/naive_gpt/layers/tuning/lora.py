@@ -69,13 +69,17 @@ def _one_group(rows: int, device) -> torch.Tensor:
     return off
 
 
-def _mfma_linear_usable(x2: torch.Tensor, weight: torch.Tensor, rank: int) -> bool:
+def _mfma_linear_usable(x2: torch.Tensor, weight: torch.Tensor, rank: int, forward: bool = True) -> bool:
     """Shapes for which the frozen product goes through the library's split-bf16 matrix-core
-    GEMM (grouped_gemm.hip with one bucket; 205 TFLOP/s against ~130 for the fp32 library GEMM):
-    fp32, contiguous, k and n multiples of 4, rank inside one k-tile, enough rows to fill the GPU."""
+    GEMM (grouped_gemm.hip with one bucket; ~320 TFLOP/s against ~125 for the fp32 library
+    GEMM): fp32, contiguous, the contraction length a multiple of 4 (rows of A are read 16
+    bytes at a time), rank inside one k-tile, enough rows to fill the GPU.  The forward
+    contracts over in_features, the backward (dX = dY W) over out_features -- a vocabulary of
+    30522 takes the forward only."""
+    n, k = weight.shape
     return (x2.is_cuda and x2.dtype == torch.float32 and weight.dtype == torch.float32
             and x2.is_contiguous() and weight.is_contiguous() and x2.size(0) >= 2048
-            and weight.size(0) % 4 == 0 and weight.size(1) % 4 == 0 and 0 < rank <= 32)
+            and k % 4 == 0 and (forward or n % 4 == 0) and 0 < rank <= 32)
 
 
 def _mfma_gemm(a, weight, n, k, ldn, ldk, bias=None, a2=None, b2=None, images=False, owner=None):
@@ -130,7 +134,7 @@ class _FrozenLoRALinear(torch.autograd.Function):
         grad_x = None
         if ctx.needs_input_grad[0]:
             n, k = weight.shape
-            if ctx.mfma and dy2.is_contiguous():
+            if ctx.mfma and dy2.is_contiguous() and _mfma_linear_usable(dy2, weight, left.size(1), False):
                 # dX = dY W + dU L^T: the weight read with n contiguous... W'(k', n) = W[n, k']
                 grad_x = _mfma_gemm(dy2, weight, k, n, 1, k, a2=du.contiguous(),
                                     b2=left.contiguous())

@@ -665,3 +665,38 @@ def test_norm_outputs_are_recomputed_not_kept(monkeypatch):
         assert torch.equal(g1[n], g0[n]), n
     act = N * S * d * 4
     assert held0 - held1 >= 1.9 * act, (held0, held1, act)     # both norm outputs are gone
+
+
+def test_frozen_lora_linear_with_a_ragged_output_width(monkeypatch):
+    """out_features % 4 != 0 (the LM head: vocabulary 30522): the forward runs on the matrix-core
+    GEMM (scalar stores in the epilogue), the backward -- whose contraction length would be the
+    ragged one -- on the library GEMM."""
+    from naive_gpt import ext, layers
+    from naive_gpt.layers.tuning import lora
+    torch.manual_seed(6)
+    lin = layers.LoRALinear(d_lora=16, in_features=256, out_features=1022, bias=False).cuda()
+    lin.lora.right.weight.data.normal_(0, 0.05)
+    x = torch.randn([4, 1024, 256], device='cuda', requires_grad=True)
+    w = torch.randn([4, 1024, 1022], device='cuda')
+    calls = []
+    orig = ext.grouped_gemm_fused
+    monkeypatch.setattr(ext, 'grouped_gemm_fused', lambda *a, **k: (calls.append(a[4]), orig(*a, **k))[1])
+
+    def run(fast):
+        if not fast:
+            monkeypatch.setattr(lora, '_mfma_linear_usable', lambda *a: False)
+        x.grad = None
+        lin.zero_grad()
+        y = lin(x)
+        (y * w).sum().backward()
+        if not fast:
+            monkeypatch.setattr(lora, '_mfma_linear_usable', usable)
+        return y.detach(), x.grad.clone(), lin.lora.left.weight.grad.clone(), \
+            lin.lora.right.weight.grad.clone()
+
+    usable = lora._mfma_linear_usable
+    fast = run(True)
+    assert calls == [1022]                     # one GEMM launch: the forward (n = 1022)
+    slow = run(False)
+    for a, b, name in zip(fast, slow, ['y', 'grad_x', 'grad_left', 'grad_right']):
+        assert _scaled_close(a, b), name
