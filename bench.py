@@ -16,8 +16,10 @@ AdamW -- on resident synthetic tokens.  Data parallel: every rank its own micro-
 Rank 0 prints ONE JSON line: tokens/s over all ranks and peak HBM, plus
   full / lora  -- the same model and step as a dense full fine-tune and as LoRA only, on the
                   same GPU (the >= 2x / <= 50 % claims; N = 1 only)
+  graphed      -- the headline step captured as one HIP graph (SparseTuner.capture), N = 1 only
   block        -- ONE TransformerBlock under the protocol of script/0-profile.py:203-226
-                  (fwd + bwd + AdamW on randn[16, 512, 1024]): sparse / full / lora
+                  (fwd + bwd + AdamW on randn[16, 512, 1024]): sparse / full / lora, and the
+                  sparse step as a HIP graph
   attention    -- BASELINE.json configs[1] (sparse MHA only, fwd + bwd), last round's headline
   roofline     -- the dominant HIP kernel of the headline step (the split-bf16 grouped GEMM),
                   HIP events around every 7th launch inside the timed steps
@@ -215,6 +217,63 @@ def model_record(tuning, args, world, rank, dev, gemm_timer=None):
     if world > 1:
         rec['allreduce_bytes_per_step'] = 4 * trainable
     del model, tuner
+    _release()
+    return rec
+
+
+def graphed_model_record(args, dev):
+    """The same sparse step captured as ONE HIP graph (`SparseTuner.capture`): what the host's
+    ~3,900 launches per step cost.  N = 1 only."""
+    from naive_gpt import utils
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    model = build_model('sparse', dev, args.layers)
+    tuner = utils.SparseTuner(model)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    N = args.batch
+    tuner.capture([N, S + 2], pq_loss=True, warmup=max(args.warmup, 3),
+                  example=torch.randint(3, VOCAB, [N, S + 2], device=dev, generator=gen))
+
+    def step():
+        tuner.training_step(torch.randint(3, VOCAB, [N, S + 2], device=dev, generator=gen))
+
+    dt = timed_loop(step, args.steps, 2, 1)
+    rec = {'value': N * S * args.steps / dt, 'unit': 'tokens/s', 'ms_per_step': 1e3 * dt / args.steps,
+           'peak_hbm_gb': torch.cuda.max_memory_allocated() / 1e9,
+           'what': 'SparseTuner.capture(): forward, backward, clip and AdamW (capturable) of the '
+                   'same step replayed as one HIP graph'}
+    del model, tuner
+    _release()
+    return rec
+
+
+def graphed_block_record(args, dev):
+    """The sparse block step of `block_record` as one HIP graph (x = randn inside the graph)."""
+    torch.cuda.empty_cache()
+    block = build_block('sparse', dev)
+    params = [p for p in block.parameters() if p.requires_grad]
+    opt = optim.AdamW(params, lr=torch.tensor(1e-4, device=dev), weight_decay=1e-2, capturable=True)
+    N = args.batch
+
+    def step():
+        x = torch.randn([N, S, D_MODEL], device=dev, requires_grad=True)
+        block(x, attn_mask=None).sum().backward()
+        opt.step()
+        block.zero_grad()
+
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(5):
+            step()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    steps = max(args.steps, 20)
+    dt = timed_loop(graph.replay, steps, 20, 1)
+    rec = {'value': N * S * steps / dt, 'unit': 'tokens/s', 'ms_per_step': 1e3 * dt / steps}
+    del block, opt, graph
     _release()
     return rec
 
@@ -417,13 +476,14 @@ def main():
     ap.add_argument('--no-block', action='store_true')
     ap.add_argument('--no-attention', action='store_true')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='skip the HIP-graph records')
     ap.add_argument('--no-gemm-events', action='store_true')
     ap.add_argument('--only', action='store_true', help='the headline step alone')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--cpu-seqs', type=int, default=16)
     args = ap.parse_args()
     if args.only:
-        args.no_baselines = args.no_block = args.no_attention = args.no_cpu = True
+        args.no_baselines = args.no_block = args.no_attention = args.no_cpu = args.no_graph = True
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -497,8 +557,20 @@ def main():
         result['peak_hbm_vs_dense'] = result['peak_hbm_gb'] / result['full']['peak_hbm_gb']
         result['speedup_vs_lora'] = result['value'] / result['lora']['value']
         result['peak_hbm_vs_lora'] = result['peak_hbm_gb'] / result['lora']['peak_hbm_gb']
+    if single and not args.no_graph:
+        # never lose the line over the extra measurement
+        try:
+            result['graphed'] = graphed_model_record(args, dev)
+            result['graphed']['speedup_vs_eager'] = result['graphed']['value'] / result['value']
+        except Exception as exc:
+            result['graphed'] = {'error': repr(exc)}
     if single and not args.no_block:
         blk = {t: block_record(t, args, dev) for t in ('sparse', 'full', 'lora')}
+        if not args.no_graph:
+            try:
+                blk['sparse_graphed'] = graphed_block_record(args, dev)
+            except Exception as exc:
+                blk['sparse_graphed'] = {'error': repr(exc)}
         blk['what'] = ('one TransformerBlock, protocol of script/0-profile.py:203-226: fwd + bwd '
                        '+ AdamW on randn[{}, {}, {}], triggers never armed'.format(N, S, D_MODEL))
         blk['speedup_vs_dense'] = blk['sparse']['value'] / blk['full']['value']

@@ -36,6 +36,11 @@ def register(cls):
 
 
 def tag(output: torch.Tensor, module: nn.Module, input: torch.Tensor) -> torch.Tensor:
+    # A forward is under way: whatever `output()` recomputed last belongs to an earlier
+    # backward.  Its key (module, address, version) could match a NEW activation -- the
+    # allocator hands the same addresses out step after step -- so it is dropped here; inside
+    # one backward the saved input is alive and its address cannot be reused.
+    release()
     if torch.is_grad_enabled() and input.requires_grad and isinstance(module, _RECOMPUTABLE) \
             and input.is_cuda and not input.is_inference():
         output._spt_origin = Origin(module, input)

@@ -67,6 +67,8 @@ class SparseTuner:
         self._armable = [m for m in model.modules()
                          if hasattr(m, 'arm') and isinstance(getattr(m, 'trigger', None), torch.Tensor)]
         self.last_grad_norm = None
+        self._graph = None
+        self._graph_lr = None
 
     @classmethod
     def from_checkpoint(cls, path: str, d_lora: int = 16, device=None, **kwargs):
@@ -101,7 +103,16 @@ class SparseTuner:
 
     def training_step(self, batch: torch.Tensor, pq_loss: bool = True) -> torch.Tensor:
         """One micro-batch: forward, backward; every ``n_accumulate``-th call also
-        exchanges, clips and applies the gradients.  Returns the (detached) loss."""
+        exchanges, clips and applies the gradients.  Returns the (detached) loss.
+        After `capture()` a batch of the captured shape replays the HIP graph."""
+        if self._graph is not None and batch.shape == self._graph_batch.shape \
+                and pq_loss == self._graph_pq:
+            self._graph_batch.copy_(batch)
+            self._graph.replay()
+            return self._graph_loss
+        return self._eager_step(batch, pq_loss)
+
+    def _eager_step(self, batch: torch.Tensor, pq_loss: bool = True) -> torch.Tensor:
         assert batch.dim() == 2
         self.model.train()
         if pq_loss:
@@ -126,6 +137,56 @@ class SparseTuner:
 
     def end_epoch(self) -> None:
         self.scheduler.step()
+        if self._graph_lr is not None:
+            # the capturable AdamW reads its learning rate from a device tensor
+            self._graph_lr.fill_(self.scheduler.get_last_lr()[0])
+
+    # ------------------------------------------------------------------ one step as a HIP graph
+    def use_capturable_optimizer(self) -> None:
+        """AdamW with `capturable=True` and its learning rate in a device tensor (what a captured
+        step needs; the same arithmetic up to rounding).  The optimiser state starts afresh."""
+        device = self.params[0].device
+        lr = self.lr
+        self._graph_lr = torch.tensor(lr, dtype=torch.float32, device=device)
+        group = self.optimizer.param_groups[0]
+        self.optimizer = optim.AdamW(self.params, lr=self._graph_lr, betas=group['betas'],
+                                     eps=group['eps'], weight_decay=group['weight_decay'],
+                                     capturable=True)
+        gamma = self.scheduler.gamma
+        self.scheduler = optim.lr_scheduler.ExponentialLR(
+            optim.SGD([torch.zeros(1, requires_grad=True)], lr=lr), gamma=gamma)
+
+    def capture(self, batch_shape, pq_loss: bool = True, warmup: int = 3, example=None) -> None:
+        """Capture `training_step` (forward, backward, clip, AdamW) for token batches of
+        `batch_shape` as ONE HIP graph (torch.cuda.CUDAGraph): a step is ~3,900 kernel launches
+        at BERT-large dimensions, and a replay costs the host one call.  Every launch of
+        libspt_hip goes to torch's current stream with caller-allocated outputs, so the
+        kernels capture as they are; what changes is the optimiser (AdamW `capturable=True`,
+        learning rate in a device tensor) -- same arithmetic.  Single process only: the
+        data-parallel step keeps the eager path (its all-reduce is not captured here).
+        Afterwards `training_step` replays the graph for batches of that shape.
+        The `warmup` steps before the capture are real optimisation steps, on `example` (a
+        token batch of that shape) or on an all-zero batch; the optimiser state starts afresh."""
+        if self.world_size != 1:
+            raise RuntimeError('SparseTuner.capture: single-process only')
+        if self.n_accumulate != 1:
+            raise RuntimeError('SparseTuner.capture: n_accumulate == 1 only')
+        device = self.params[0].device
+        self.use_capturable_optimizer()
+        self._graph_batch = torch.zeros(batch_shape, dtype=torch.long, device=device)
+        if example is not None:
+            self._graph_batch.copy_(example)
+        self._graph_pq = pq_loss
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):       # warm-up off the capture: lazy initialisations
+            for _ in range(warmup):
+                self._eager_step(self._graph_batch, pq_loss)
+        torch.cuda.current_stream(device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._graph_loss = self._eager_step(self._graph_batch, pq_loss)
+        self._graph = graph
 
     @torch.no_grad()
     def validation_step(self, batch: torch.Tensor) -> dict:
@@ -145,4 +206,4 @@ class SparseTuner:
 
     @property
     def lr(self) -> float:
-        return self.optimizer.param_groups[0]['lr']
+        return float(self.optimizer.param_groups[0]['lr'])

@@ -700,3 +700,46 @@ def test_frozen_lora_linear_with_a_ragged_output_width(monkeypatch):
     slow = run(False)
     for a, b, name in zip(fast, slow, ['y', 'grad_x', 'grad_left', 'grad_right']):
         assert _scaled_close(a, b), name
+
+
+def test_recomputed_norm_output_is_never_stale_across_steps():
+    """Two steps with DIFFERENT inputs that land at the same addresses (the allocator reuses
+    them): the second backward must recompute its own norm outputs, not find the first step's
+    under an (address, version) key."""
+    from naive_gpt import layers, utils
+    from naive_gpt.layers.tuning import recompute
+    import contextlib
+    import io
+    d, heads, d_ff = 1024, 16, 4096
+    torch.manual_seed(0)
+    block = layers.TransformerBlock(
+        d_model=d, n_heads=heads, layernorm_fn=nn.LayerNorm(d),
+        attention_fn=layers.VanillaAttention(d_head=d // heads, p_dropout=0.0),
+        feedforward_fn=layers.Feedforward(d_model=d, d_feedforward=d_ff, activation=nn.ReLU(),
+                                          p_dropout=0.0),
+        attention_bias=True, pre_norm=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        for stage in ('lora', 'ffn', 'mha_v1', 'mha_v2'):
+            block = utils.ModuleUpgrader(utils.SparseLoRAHandler(d_lora=16, stage=stage)).visit(block)
+    for name, p in block.named_parameters():
+        if name.endswith('lora.right.weight'):
+            p.data.normal_(0, 0.02)
+    block = block.cuda()
+    xs = [torch.randn([2, 512, d], device='cuda') for _ in range(2)]
+
+    def grads(x0, keep):
+        block.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        block(x).square().sum().backward()
+        out = {n: p.grad.clone() for n, p in block.named_parameters() if p.grad is not None}
+        out['x'] = x.grad.clone()
+        if not keep:
+            recompute.release()
+        return out
+
+    grads(xs[0], keep=True)                      # leaves a recomputed output behind ...
+    second = grads(xs[1], keep=True)             # ... which this step must not pick up
+    recompute.release()
+    fresh = grads(xs[1], keep=False)
+    for n in fresh:
+        assert torch.equal(second[n], fresh[n]), n
