@@ -36,6 +36,14 @@ constexpr int LK_THREADS = 256;
 constexpr int LK_WAVES = LK_THREADS / SPT_WAVE;
 constexpr int LK_ROWS = 16;  // query rows per block
 
+// slot = min(3, matches / (M / 4)) (lookup.cu:61-63) as a multiply-shift with magic =
+// ceil(32 / (M / 4)): exact for matches <= 16 and M / 4 in 1..4.  (Written out: min() of an
+// unsigned and __umul24's int resolves to the double overload -- three fp64 instructions.)
+__device__ __forceinline__ unsigned slot_of(unsigned matches, unsigned magic) {
+    const unsigned t = (unsigned)__umul24(matches, magic) >> 5;
+    return t < 3u ? t : 3u;
+}
+
 __device__ __forceinline__ int sel4(int v0, int v1, int v2, int v3, int s) {
     const int lo = (s & 1) ? v1 : v0;
     const int hi = (s & 1) ? v3 : v2;
@@ -546,7 +554,7 @@ __global__ __launch_bounds__(LR_THREADS) void lookup_rows_kernel(
                 }
                 const unsigned cnt = (unsigned)rows_match<W, NIBF>(kw, qc, ksrc + (size_t)cs * M,
                                                                    qraw, M);
-                const unsigned sl = min(3u, __umul24(cnt, magic) >> 5);
+                const unsigned sl = slot_of(cnt, magic);
                 const bool active = c <= gy;          // (c < ncols <= S follows for real rows)
                 const unsigned sh = sl << 3;
                 const unsigned rank = (n8[t2] >> sh) & 0xFFu;
@@ -620,6 +628,241 @@ __global__ __launch_bounds__(LR_THREADS) void lookup_rows_kernel(
     }
 }
 
+
+// ---- rows-on-lanes form for long rows (S > 512): two walks instead of parked candidates ------
+// Above S = 512 the per-lane candidate lists of lookup_rows_kernel no longer fit: a list holds
+// up to Q = Z / 4 entries of 9+ bits, 16 lists per row, 64 rows per block = 128 KiB at Z = 256.
+// But the lists are only needed because a candidate's output position depends on the FINAL sizes
+// of the higher slots.  So: walk once counting (sizes of the four slot lists of the wave's
+// worker, 16-bit fields of one 64-bit register; last column per slot for workers 2 and 3), derive
+// the slot offsets, walk again with the same running counters and write every kept candidate
+// straight to its output position in the LDS row.  Twice the comparisons, no list memory, no
+// position loop; the key codes are stored per worker ([worker][group][W]) so that a wave reads
+// the codes of its next four columns with one ds_read_b128 (W = 1).  Same closed form, same
+// quirks, bit-identical output (tests: test_lookup_bit_exact at S = 1024 / 2048, M = 8 / 10 / 16).
+template <int W>
+__global__ __launch_bounds__(256) void lookup_rows_long_kernel(
+    const int32_t *__restrict__ query, const int32_t *__restrict__ key,
+    int32_t *__restrict__ out, int B, int S, int M, int Z, int blocks_per_batch, int GP,
+    int out_pitch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & (SPT_WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = the worker (column mod 4)
+    const int b = blockIdx.x % B;
+    const int blk = blocks_per_batch - 1 - (blockIdx.x / B);           // heavy row blocks first
+    const int r0 = blk * SPT_WAVE, gy = r0 + lane;
+    const int ncols = min(S, r0 + SPT_WAVE);
+    const int ngroups = (ncols + 3) >> 2;
+    const int Q = Z >> 2;
+    uint32_t *kcodes = reinterpret_cast<uint32_t *>(smem);                        // [4][GP][W]
+    const size_t kbytes = (size_t)4 * GP * W * 4;
+    unsigned short *orow = reinterpret_cast<unsigned short *>(smem + kbytes);     // [64][out_pitch]
+    unsigned short *lastg_all = orow + (size_t)SPT_WAVE * out_pitch;              // [64][2][4]
+    unsigned long long *xch = reinterpret_cast<unsigned long long *>(
+        smem + kbytes + (size_t)SPT_WAVE * out_pitch * 2 + (size_t)SPT_WAVE * 16);   // [64][2]
+    const int32_t *ksrc = key + (size_t)b * S * M;
+    const int32_t *qsrc = query + ((size_t)b * S + min(gy, S - 1)) * M;
+
+    // the block's output rows start as zeros (lookup.cu:107-109)
+    for (int i = threadIdx.x; i < SPT_WAVE * out_pitch / 2; i += 256)
+        reinterpret_cast<uint32_t *>(orow)[i] = 0u;
+
+    // own query row: raw codes (exact form) and nibbles
+    int wide = 0;
+    int32_t qraw[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) qraw[m] = 0;
+    if ((M & 3) == 0) {
+#pragma unroll
+        for (int m4 = 0; m4 < 4; m4++) {
+            if (4 * m4 < M) {
+                const int4 t = reinterpret_cast<const int4 *>(qsrc)[m4];
+                qraw[4 * m4] = t.x; qraw[4 * m4 + 1] = t.y; qraw[4 * m4 + 2] = t.z; qraw[4 * m4 + 3] = t.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 16; m++)
+            if (m < M) qraw[m] = qsrc[m];
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) wide |= qraw[m];
+    Code<W> qc;
+#pragma unroll
+    for (int d = 0; d < W; d++) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) word |= ((uint32_t)qraw[8 * d + j] & 0xFu) << (4 * j);   // pad: 0
+        qc.w[d] = word;
+    }
+    // key codes as nibbles, per worker; groups past the last real column (the walk's four-group
+    // steps and its read-ahead touch them) hold 0xF nibbles, which match nothing
+    const int gfill = min(GP, ((ngroups + 3) & ~3) + 4);
+    for (int col = threadIdx.x; col < 4 * gfill; col += 256) {
+        uint32_t word[W];
+#pragma unroll
+        for (int d = 0; d < W; d++) word[d] = 0xFFFFFFFFu;
+        if (col < ncols) {
+            const int32_t *src = ksrc + (size_t)col * M;
+            int32_t kraw[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) kraw[m] = 15;
+            if ((M & 3) == 0) {
+#pragma unroll
+                for (int m4 = 0; m4 < 4; m4++) {
+                    if (4 * m4 < M) {
+                        const int4 t = reinterpret_cast<const int4 *>(src)[m4];
+                        kraw[4 * m4] = t.x; kraw[4 * m4 + 1] = t.y; kraw[4 * m4 + 2] = t.z; kraw[4 * m4 + 3] = t.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 16; m++)
+                    if (m < M) kraw[m] = src[m];
+            }
+#pragma unroll
+            for (int m = 0; m < 16; m++)
+                if (m < M) wide |= kraw[m];
+#pragma unroll
+            for (int d = 0; d < W; d++) {
+                uint32_t wd = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int m = 8 * d + j;
+                    wd |= ((m < M) ? ((uint32_t)kraw[m] & 0xFu) : 0xFu) << (4 * j);
+                }
+                word[d] = wd;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < W; d++) kcodes[((size_t)(col & 3) * GP + (col >> 2)) * W + d] = word[d];
+    }
+    const bool nib = !__syncthreads_or((wide & ~0xF) != 0);        // (also publishes kcodes, orow)
+
+    // slot = min(3, matches / (M / 4)) (lookup.cu:61-63) as a multiply-shift, as in lookup_row
+    const int div = M >> 2;
+    const unsigned magic = (32u + div - 1) / div;
+    const uint32_t *mycodes = kcodes + (size_t)wv * GP * W;
+    auto load4 = [&](int g, uint32_t (&raw)[4 * W]) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(mycodes + (size_t)g * W);
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            const uint4 t = src[i];
+            raw[4 * i + 0] = t.x; raw[4 * i + 1] = t.y; raw[4 * i + 2] = t.z; raw[4 * i + 3] = t.w;
+        }
+    };
+    // visit(group, column, slot shift (16 * slot), candidate?) for every column of this wave's worker
+    auto walk = [&](auto nib_tag, auto &&visit) {
+        constexpr bool NIBF = decltype(nib_tag)::value;
+        uint32_t nxt[4 * W];
+        if (NIBF) load4(0, nxt);
+        for (int g = 0; g < ngroups; g += 4) {
+            uint32_t cur[4 * W];
+#pragma unroll
+            for (int i = 0; i < 4 * W; i++) cur[i] = nxt[i];
+            if (NIBF) load4(g + 4, nxt);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int c = 4 * (g + j) + wv;
+                unsigned cnt = 0;
+                if (NIBF) {
+                    Code<W> k;
+#pragma unroll
+                    for (int d = 0; d < W; d++) k.w[d] = cur[j * W + d];
+                    cnt = (unsigned)match_count<W, true>(k, qc);
+                } else {                    // exact uint16 comparison (lookup.cu:22,43)
+                    const int32_t *kraw = ksrc + (size_t)min(c, S - 1) * M;
+                    for (int m = 0; m < M; m++) cnt += ((kraw[m] ^ qraw[m]) & 0xFFFF) == 0;
+                }
+                const unsigned sl = slot_of(cnt, magic);
+                visit(g + j, c, sl << 4, c <= gy);   // (c < ncols <= S follows for real rows)
+            }
+        }
+    };
+
+    // ---- walk 1: list sizes (and the last column / 4 per slot of workers 2, 3) ----
+    // Branch-free: the sizes are four 16-bit fields of one 64-bit register; "last group + 1" per
+    // slot is a packed 16-bit maximum (groups come in ascending order).
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    unsigned long long n64 = 0ull;
+    u16x2 last_lo = {0, 0}, last_hi = {0, 0};
+    auto count = [&](int g, int c, unsigned sh, bool active) {
+        n64 += (unsigned long long)(active ? 1u : 0u) << sh;
+    };
+    auto count_last = [&](int g, int c, unsigned sh, bool active) {
+        n64 += (unsigned long long)(active ? 1u : 0u) << sh;
+        const unsigned long long cand = (unsigned long long)(active ? (unsigned)g + 1u : 0u) << sh;
+        last_lo = __builtin_elementwise_max(last_lo, __builtin_bit_cast(u16x2, (unsigned)cand));
+        last_hi = __builtin_elementwise_max(last_hi, __builtin_bit_cast(u16x2, (unsigned)(cand >> 32)));
+    };
+    if (wv >= 2) {
+        if (nib) walk(std::true_type{}, count_last);
+        else walk(std::false_type{}, count_last);
+    } else {
+        if (nib) walk(std::true_type{}, count);
+        else walk(std::false_type{}, count);
+    }
+    unsigned short *lastg = lastg_all + (size_t)lane * 8;
+    if (wv >= 2) {                       // (read only for lists with >= Q entries)
+        lastg[(wv - 2) * 4 + 0] = (unsigned short)(last_lo.x - 1);
+        lastg[(wv - 2) * 4 + 1] = (unsigned short)(last_lo.y - 1);
+        lastg[(wv - 2) * 4 + 2] = (unsigned short)(last_hi.x - 1);
+        lastg[(wv - 2) * 4 + 3] = (unsigned short)(last_hi.y - 1);
+    }
+
+    // kept entries per list and the output offset of each slot (slot 3 first)
+    const int cap = wv < 2 ? Q : Q - 1;                  // workers 0, 1 keep Q, workers 2, 3 Q - 1
+    const int limit = min(gy + 1, Z);
+    int n[4], off[4];
+#pragma unroll
+    for (int sl = 0; sl < 4; sl++) n[sl] = (int)((n64 >> (16 * sl)) & 0xFFFFull);
+    off[3] = 0;
+    off[2] = min(n[3], cap);
+    off[1] = off[2] + min(n[2], cap);
+    off[0] = off[1] + min(n[1], cap);
+    const unsigned long long off64 = (unsigned long long)off[0] | ((unsigned long long)off[1] << 16) |
+                                     ((unsigned long long)off[2] << 32);
+    // ---- walk 2: placement (only this wave writes positions = wv mod 4 of a row).  A column
+    // that is not kept goes to the row's spare entry Z + 1: no branch around the store. ----
+    unsigned short *mine = orow + (size_t)lane * out_pitch;
+    unsigned long long r64 = 0ull;
+    auto place = [&](int g, int c, unsigned sh, bool active) {
+        const int rank = (int)((r64 >> sh) & 0xFFFFull);
+        r64 += (unsigned long long)(active ? 1u : 0u) << sh;
+        const int p = wv + 4 * ((int)((off64 >> sh) & 0xFFFFull) + rank);
+        const bool keep = active && rank < cap && p < limit;
+        mine[keep ? p : Z + 1] = (unsigned short)c;
+    };
+    if (nib) walk(std::true_type{}, place);
+    else walk(std::false_type{}, place);
+
+    if (wv >= 2) xch[2 * lane + (wv - 2)] = n64;
+    __syncthreads();
+    // reference quirk: the cursor of worker 2 (3) saturates on the word that holds entry Q-1
+    // of worker 1 (0); its LAST candidate of the slot survives there if larger.
+    if (wv < 2) {
+        const int tx = 3 - wv;                            // the worker whose cursor lands on ours
+        const unsigned long long theirs = xch[2 * lane + (tx - 2)];
+#pragma unroll
+        for (int sl = 0; sl < 4; sl++) {
+            const int ntx = (int)((theirs >> (16 * sl)) & 0xFFFFull);
+            if (ntx >= Q && n[sl] >= Q) {
+                const int p = wv + 4 * (off[sl] + Q - 1);
+                const int lastcol = 4 * (int)lastg[(tx - 2) * 4 + sl] + tx;
+                if (p < limit) mine[p] = (unsigned short)max((int)mine[p], lastcol);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- coalesced store, zeros included: the waves take rows in turn ----
+    const int nrows = min(SPT_WAVE, S - r0);
+    for (int r = wv; r < nrows; r += 4) {
+        int32_t *dst = out + ((size_t)b * S + r0 + r) * Z;
+        const unsigned short *src = orow + (size_t)r * out_pitch;
+        for (int i = lane; i < Z; i += SPT_WAVE) dst[i] = src[i];
+    }
+}
+
 }  // namespace spt
 
 using namespace spt;
@@ -657,6 +900,26 @@ extern "C" int spt_lookup_forward(const int32_t *query, const int32_t *key, int3
                 hipLaunchKernelGGL(lookup_rows_kernel<2>, dim3((unsigned)nblk), dim3(LR_THREADS), lds,
                                    s, query, key, out, batch_size, S, M, Z, nb, list_pitch,
                                    out_pitch);
+            SPT_LAUNCH_CHECK();
+            return SPT_OK;
+        }
+    }
+    if (S <= 65535) {
+        // long rows on lanes: two walks (columns fit 16 bits, so do the list sizes)
+        const int WN = (M + 7) / 8;
+        const int GP = S / 4 + 8;
+        const int out_pitch = Z + 2;                              // uint16: odd number of words
+        const size_t lds = (size_t)4 * GP * WN * 4 + (size_t)SPT_WAVE * out_pitch * 2 +
+                           (size_t)SPT_WAVE * 16 + (size_t)SPT_WAVE * 16;
+        const int nb = (S + SPT_WAVE - 1) / SPT_WAVE;
+        const long long nblk = (long long)batch_size * nb;
+        if (lds <= 64 * 1024 && nblk <= 0x7FFFFFFFLL) {
+            if (WN == 1)
+                hipLaunchKernelGGL(lookup_rows_long_kernel<1>, dim3((unsigned)nblk), dim3(256), lds, s,
+                                   query, key, out, batch_size, S, M, Z, nb, GP, out_pitch);
+            else
+                hipLaunchKernelGGL(lookup_rows_long_kernel<2>, dim3((unsigned)nblk), dim3(256), lds, s,
+                                   query, key, out, batch_size, S, M, Z, nb, GP, out_pitch);
             SPT_LAUNCH_CHECK();
             return SPT_OK;
         }

@@ -105,6 +105,10 @@ def test_cdist_backward(M, NQ, C, D):
     (2, 256, 10, 4, 8), (2, 256, 16, 3, 8), (1, 128, 5, 2, 4), (3, 64, 8, 4, 4),
     (1, 2048, 8, 16, 8),    # config 4: Z = 256 (beyond the reference's templates)
     (1, 2048, 16, 16, 8),   # config 5: M = 16
+    # the long-row kernel (S > 512): saturated lists + the overwrite quirk, every column a full
+    # match, M = 10, codes beyond 4 bits (exact uint16 form), a last row block of 32 rows
+    (2, 1024, 8, 2, 8), (1, 1024, 8, 1, 8), (1, 2048, 8, 2, 8), (1, 1024, 10, 4, 8),
+    (1, 1024, 16, 40, 8), (1, 768, 8, 300, 4), (2, 544, 8, 3, 2),
 ])
 def test_lookup_bit_exact(B, S, M, hi, coeff):
     from naive_gpt import ext
