@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 18
+#define SPT_ABI_VERSION 19
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -70,6 +70,12 @@ int spt_cdist_forward(const float *query, const float *table, float *distance,
 int spt_pq_encode_heads(const float *z, const float *table, int32_t *codes,
                         int batch, int seq_length, int n_heads, int n_subspaces,
                         int n_codewords, int d_code, void *stream);
+/* The same from bf16 storage: z holds raw bf16 patterns, widened exactly to fp32 before the
+ * same distance / argmin arithmetic -- the codes equal those of spt_pq_encode_heads on the
+ * widened values bit for bit. */
+int spt_pq_encode_heads_bf16(const uint16_t *z, const float *table, int32_t *codes,
+                             int batch, int seq_length, int n_heads, int n_subspaces,
+                             int n_codewords, int d_code, void *stream);
 
 /*
  * PQ codebook training loss, PQBase.forward(mode='train')[-1] of the reference
@@ -311,6 +317,28 @@ int spt_attention_mfma_backward(const void *tiles, int layout, const float *q, c
                                 float *grad_k, float *grad_v, int batch_size, int seq_length,
                                 int d_head, int nnz, float scale, float clamp, int heads,
                                 int transposed, void *stream);
+
+/*
+ * bf16 STORAGE variants (BASELINE configs[1] "bf16"; no reference counterpart -- the reference is
+ * fp32 only): q, k, v, y, grad_y and the three gradients hold raw bf16 patterns in the same
+ * layouts; row_sum and delta stay fp32; `tiles` is the same object.  A stored value is its own
+ * matrix-core operand (no split, one MFMA where the fp32 path needs two or three); everything
+ * computed on the way (scaled q, probabilities, dS, dY / row_sum) is fp32 split in two as in the
+ * fp32 path, so the results are those of spt_attention_mfma_forward / _backward on the widened
+ * inputs (to the split's 2^-16) rounded once, to nearest even, when stored.
+ */
+int spt_attention_mfma_forward_bf16(const void *tiles, int layout, const uint16_t *q,
+                                    const uint16_t *k, const uint16_t *v, uint16_t *y,
+                                    float *row_sum, int batch_size, int seq_length, int d_head,
+                                    int nnz, float scale, float clamp, int heads,
+                                    int y_transposed, void *stream);
+int spt_attention_mfma_backward_bf16(const void *tiles, int layout, const uint16_t *q,
+                                     const uint16_t *k, const uint16_t *v, const uint16_t *y,
+                                     const uint16_t *grad_y, const float *row_sum, float *delta,
+                                     uint16_t *grad_q, uint16_t *grad_k, uint16_t *grad_v,
+                                     int batch_size, int seq_length, int d_head, int nnz,
+                                     float scale, float clamp, int heads, int transposed,
+                                     void *stream);
 
 /*
  * Routed FFN: token-bucketed grouped GEMM on the fp32 matrix cores.

@@ -297,9 +297,10 @@ extern "C" int spt_cdist_backward(const float *query, const float *table,
 // argmin contract as cdist_forward_kernel.
 namespace spt {
 
-template <int D>
+// T: float, or uint16_t = bf16 storage (raw patterns, widened exactly: same arithmetic after)
+template <int D, typename T>
 __global__ __launch_bounds__(CD_THREADS) void pq_encode_heads_kernel(
-    const float *__restrict__ z, const float *__restrict__ table, int32_t *__restrict__ codes,
+    const T *__restrict__ z, const float *__restrict__ table, int32_t *__restrict__ codes,
     int n_vectors, int S, int H, int M, int C) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [M][C*D + 4]: the 8 lanes of a token read the SAME codeword of 8 DIFFERENT subspaces;
@@ -319,10 +320,19 @@ __global__ __launch_bounds__(CD_THREADS) void pq_encode_heads_kernel(
         const int vec = t / M;                // index into [N, S, H]
         const int m = t - vec * M;
         float qv[D];
-        const float4 *qp = reinterpret_cast<const float4 *>(z + (size_t)vec * (M * D) + m * D);
+        const T *qp = z + (size_t)vec * (M * D) + m * D;
 #pragma unroll
         for (int i = 0; i < D / 4; i++) {
-            const float4 v = qp[i];
+            float4 v;
+            if constexpr (sizeof(T) == 4) {
+                v = reinterpret_cast<const float4 *>(qp)[i];
+            } else {
+                const uint2 w = reinterpret_cast<const uint2 *>(qp)[i];
+                v = make_float4(__builtin_bit_cast(float, w.x << 16),
+                                __builtin_bit_cast(float, w.x & 0xffff0000u),
+                                __builtin_bit_cast(float, w.y << 16),
+                                __builtin_bit_cast(float, w.y & 0xffff0000u));
+            }
             qv[4 * i + 0] = v.x; qv[4 * i + 1] = v.y; qv[4 * i + 2] = v.z; qv[4 * i + 3] = v.w;
         }
         int best_i = 0;
@@ -354,9 +364,11 @@ __global__ __launch_bounds__(CD_THREADS) void pq_encode_heads_kernel(
 
 }  // namespace spt
 
-extern "C" int spt_pq_encode_heads(const float *z, const float *table, int32_t *codes,
-                                   int batch, int seq_length, int n_heads, int n_subspaces,
-                                   int n_codewords, int d_code, void *stream) {
+template <typename T>
+static int pq_encode_heads_any(const T *z, const float *table, int32_t *codes, int batch,
+                               int seq_length, int n_heads, int n_subspaces, int n_codewords,
+                               int d_code, void *stream) {
+    using namespace spt;
     if (!z || !table || !codes) return SPT_EINVAL;
     if (batch <= 0 || seq_length <= 0 || n_heads <= 0 || n_subspaces <= 0 || n_codewords <= 0 ||
         d_code <= 0)
@@ -371,7 +383,7 @@ extern "C" int spt_pq_encode_heads(const float *z, const float *table, int32_t *
     if (nblk > 256 * 8) nblk = 256 * 8;  // grid-stride: the codebook load is per block
     hipStream_t s = (hipStream_t)stream;
 #define SPT_PQ(DD)                                                                       \
-    hipLaunchKernelGGL((spt::pq_encode_heads_kernel<DD>), dim3((unsigned)nblk),          \
+    hipLaunchKernelGGL((spt::pq_encode_heads_kernel<DD, T>), dim3((unsigned)nblk),       \
                        dim3(spt::CD_THREADS), lds, s, z, table, codes, (int)n_vectors,   \
                        seq_length, n_heads, n_subspaces, n_codewords)
     switch (d_code) {
@@ -385,4 +397,18 @@ extern "C" int spt_pq_encode_heads(const float *z, const float *table, int32_t *
 #undef SPT_PQ
     SPT_LAUNCH_CHECK();
     return SPT_OK;
+}
+
+extern "C" int spt_pq_encode_heads(const float *z, const float *table, int32_t *codes,
+                                   int batch, int seq_length, int n_heads, int n_subspaces,
+                                   int n_codewords, int d_code, void *stream) {
+    return pq_encode_heads_any(z, table, codes, batch, seq_length, n_heads, n_subspaces,
+                               n_codewords, d_code, stream);
+}
+
+extern "C" int spt_pq_encode_heads_bf16(const uint16_t *z, const float *table, int32_t *codes,
+                                        int batch, int seq_length, int n_heads, int n_subspaces,
+                                        int n_codewords, int d_code, void *stream) {
+    return pq_encode_heads_any(z, table, codes, batch, seq_length, n_heads, n_subspaces,
+                               n_codewords, d_code, stream);
 }

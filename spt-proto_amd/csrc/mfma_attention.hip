@@ -81,6 +81,10 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // two floats -> packed bf16 pairs (first value in the low half): hi = RNE, lo = RNE(x - hi).
 // Whole-vector conversions: element-wise (__bf16) casts compile to one v_cvt_pk_bf16_f32 per
 // ELEMENT plus re-packing (81 conversions per tile instead of 24).
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const f32x2 x = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+}
 __device__ __forceinline__ Split split2(float a, float b) {
     const f32x2 x = {a, b};
     Split s;
@@ -104,10 +108,12 @@ __device__ __forceinline__ f32x16 mma(const uint4 &a, const uint4 &b, f32x16 c) 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
                                                    __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// (a.hi + a.lo)(b.hi + b.lo) without the lo*lo term, small terms first
-__device__ __forceinline__ f32x16 mma3(const Frag &a, const Frag &b, f32x16 c) {
-    c = mma(a.lo, b.hi, c);
-    c = mma(a.hi, b.lo, c);
+// (a.hi + a.lo)(b.hi + b.lo) without the lo*lo term, small terms first.  PA / PB = parts of the
+// operand: 2 = an fp32 value split in two, 1 = a value that IS a bf16 (bf16 storage: no lo part).
+template <int PA, int PB>
+__device__ __forceinline__ f32x16 mm(const Frag &a, const Frag &b, f32x16 c) {
+    if (PA == 2) c = mma(a.lo, b.hi, c);
+    if (PB == 2) c = mma(a.hi, b.lo, c);
     return mma(a.hi, b.hi, c);
 }
 __device__ __forceinline__ void wave_lds_fence() {
@@ -120,89 +126,107 @@ __device__ __forceinline__ void wave_lds_fence() {
 // accumulator register r of lane half h holds tile row  (r & 3) + 8 (r >> 2) + 4 h
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// ---- 32-row tiles of a dense operand: global fp32 -> registers -> bf16 LDS images ----
+// ---- element types of the dense operands (q, k, v, y and their gradients) ----
+// float: the reference's fp32 tensors, every value split in two bf16 parts on its way to the
+// matrix cores.  bf16_t (raw 16-bit patterns): bf16 STORAGE -- a stored value is its own hi part
+// and has no lo part, so operands that go to LDS unchanged (K, V, Q tiles) are copied, not
+// converted, and their products cost one MFMA per part of the OTHER operand.  Values computed in
+// fp32 on the way (scaled Q, probabilities, dS, weighted dY) are split in two as before, so the
+// only rounding the bf16 path adds is that of its stored outputs.
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int PARTS = 2;
+    typedef float4 raw4;                                 // four consecutive elements, as loaded
+    static __device__ __forceinline__ float4 f4(const float4 &r) { return r; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int PARTS = 1;
+    typedef uint2 raw4;
+    static __device__ __forceinline__ float4 f4(const uint2 &r) {
+        return make_float4(bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y));
+    }
+};
+template <typename T>
+__device__ __forceinline__ typename Elem<T>::raw4 ld_raw4(const T *p) {
+    return *reinterpret_cast<const typename Elem<T>::raw4 *>(p);
+}
+template <typename T>
+__device__ __forceinline__ float4 ld4(const T *p) { return Elem<T>::f4(ld_raw4(p)); }
+__device__ __forceinline__ void st4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t *p, const float4 &v) {
+    *reinterpret_cast<uint2 *>(p) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+}
+__device__ __forceinline__ void st1(float *p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t *p, float v) { *p = (bf16_t)(pack_bf16(v, 0.0f) & 0xffffu); }
+
+// ---- 32-row tiles of a dense operand: global -> registers -> bf16 LDS images ----
 // "rows" image [r][e] (144-byte rows): A-operand fragments by read_rows;
 // "cols" image [e][r] (72-byte rows):  B-operand fragments in accumulator k order by read_cols.
-constexpr int MA_RIMG = MA_KT * MA_KLD;            // one rows image (hi or lo): 4608 B
-constexpr int MA_CIMG = MA_E * MA_VLD;             // one cols image (hi or lo): 4608 B
-// four values of row r at e4 .. e4 + 3
-template <bool ROWS, bool COLS>
-__device__ __forceinline__ void put4_along_e(char *rows, char *cols, int r, int e4,
-                                             const float4 &x) {
+// An image is a hi part followed (fp32 sources) by a lo part of the same shape.
+constexpr int MA_RIMG = MA_KT * MA_KLD;            // one rows image part: 4608 B
+constexpr int MA_CIMG = MA_E * MA_VLD;             // one cols image part: 4608 B
+// four values of row r at e4 .. e4 + 3 into a rows image: fp32 (split, two parts) ...
+__device__ __forceinline__ void put_rows4(char *img, int r, int e4, const float4 &x) {
     const Split a = split2(x.x, x.y), b = split2(x.z, x.w);
-    if (ROWS) {
-        *reinterpret_cast<uint2 *>(rows + r * MA_KLD + e4 * 2) = make_uint2(a.hi, b.hi);
-        *reinterpret_cast<uint2 *>(rows + MA_RIMG + r * MA_KLD + e4 * 2) = make_uint2(a.lo, b.lo);
-    }
-    if (COLS) {
-        auto st = [&](char *img, int e, unsigned v16) {
-            *reinterpret_cast<unsigned short *>(img + e * MA_VLD + r * 2) = (unsigned short)v16;
-        };
-        st(cols, e4 + 0, a.hi & 0xffffu); st(cols, e4 + 1, a.hi >> 16);
-        st(cols, e4 + 2, b.hi & 0xffffu); st(cols, e4 + 3, b.hi >> 16);
-        st(cols + MA_CIMG, e4 + 0, a.lo & 0xffffu); st(cols + MA_CIMG, e4 + 1, a.lo >> 16);
-        st(cols + MA_CIMG, e4 + 2, b.lo & 0xffffu); st(cols + MA_CIMG, e4 + 3, b.lo >> 16);
-    }
+    *reinterpret_cast<uint2 *>(img + r * MA_KLD + e4 * 2) = make_uint2(a.hi, b.hi);
+    *reinterpret_cast<uint2 *>(img + MA_RIMG + r * MA_KLD + e4 * 2) = make_uint2(a.lo, b.lo);
 }
-// four values of column e at rows r4 .. r4 + 3 (an operand stored [E][S])
-template <bool ROWS, bool COLS>
-__device__ __forceinline__ void put4_along_r(char *rows, char *cols, int e, int r4,
-                                             const float4 &x) {
+// ... or stored bf16 (copied, one part)
+__device__ __forceinline__ void put_rows4(char *img, int r, int e4, const uint2 &x) {
+    *reinterpret_cast<uint2 *>(img + r * MA_KLD + e4 * 2) = x;
+}
+// four fp32 values of column e at rows r4 .. r4 + 3 (an operand stored [E][S]) into a cols image
+__device__ __forceinline__ void put_cols4(char *img, int e, int r4, const float4 &x) {
     const Split a = split2(x.x, x.y), b = split2(x.z, x.w);
-    if (COLS) {
-        *reinterpret_cast<uint2 *>(cols + e * MA_VLD + r4 * 2) = make_uint2(a.hi, b.hi);
-        *reinterpret_cast<uint2 *>(cols + MA_CIMG + e * MA_VLD + r4 * 2) = make_uint2(a.lo, b.lo);
-    }
-    if (ROWS) {
-        auto st = [&](char *img, int r, unsigned v16) {
-            *reinterpret_cast<unsigned short *>(img + r * MA_KLD + e * 2) = (unsigned short)v16;
-        };
-        st(rows, r4 + 0, a.hi & 0xffffu); st(rows, r4 + 1, a.hi >> 16);
-        st(rows, r4 + 2, b.hi & 0xffffu); st(rows, r4 + 3, b.hi >> 16);
-        st(rows + MA_RIMG, r4 + 0, a.lo & 0xffffu); st(rows + MA_RIMG, r4 + 1, a.lo >> 16);
-        st(rows + MA_RIMG, r4 + 2, b.lo & 0xffffu); st(rows + MA_RIMG, r4 + 3, b.lo >> 16);
-    }
+    *reinterpret_cast<uint2 *>(img + e * MA_VLD + r4 * 2) = make_uint2(a.hi, b.hi);
+    *reinterpret_cast<uint2 *>(img + MA_CIMG + e * MA_VLD + r4 * 2) = make_uint2(a.lo, b.lo);
 }
 
-// The forward's key tiles: K as a rows image, V as a cols image.  Thread t stages the
-// float4 (row t / (E/4) + MA_RPP u, columns 4 (t % (E/4)) ..) for u < MA_RPT.
-struct TileRegs { float4 kf[MA_RPT], vf[MA_RPT]; };
+// Key tiles of the forward and of the row-owned backward: K rows image | V rows image (each
+// hi, lo).  Thread t stages the four elements (row t / (E/4) + MA_RPP u, columns 4 (t % (E/4)) ..)
+// for u < MA_RPT.
+template <typename T>
+struct TileRegs { typename Elem<T>::raw4 kf[MA_RPT], vf[MA_RPT]; };
+template <typename T>
 struct TileStager {
-    const float *k_b, *v_b;
+    const T *k_b, *v_b;
     int ld, S, jl, e4;
-    __device__ __forceinline__ TileStager(const float *k, const float *v, int ld_, int S_, int tid)
+    __device__ __forceinline__ TileStager(const T *k, const T *v, int ld_, int S_, int tid)
         : k_b(k), v_b(v), ld(ld_), S(S_), jl(tid / MA_EQ), e4((tid % MA_EQ) * 4) {}
     // Unconditional loads with clamped rows: a load under a branch makes the compiler wait
     // with vmcnt(0) for OLDER loads too (it cannot count what the branch issued), which
     // exposed the full memory latency in every iteration.  Keys >= S read row S - 1: finite
     // data whose cells have multiplicity 0.
-    __device__ __forceinline__ TileRegs load(int t) const {
-        TileRegs r;
+    __device__ __forceinline__ TileRegs<T> load(int t) const {
+        TileRegs<T> r;
 #pragma unroll
         for (int u = 0; u < MA_RPT; u++) {
             const int j = min(t * MA_KT + jl + MA_RPP * u, S - 1);
-            r.kf[u] = *reinterpret_cast<const float4 *>(k_b + (size_t)j * ld + e4);
-            r.vf[u] = *reinterpret_cast<const float4 *>(v_b + (size_t)j * ld + e4);
+            r.kf[u] = ld_raw4(k_b + (size_t)j * ld + e4);
+            r.vf[u] = ld_raw4(v_b + (size_t)j * ld + e4);
         }
         return r;
     }
-    __device__ __forceinline__ void store(char *buf, const TileRegs &r) const {
+    __device__ __forceinline__ void store(char *buf, const TileRegs<T> &r) const {
 #pragma unroll
         for (int u = 0; u < MA_RPT; u++) {
-            put4_along_e<true, false>(buf + MA_KH, nullptr, jl + MA_RPP * u, e4, r.kf[u]);
-            put4_along_e<true, false>(buf + MA_VH, nullptr, jl + MA_RPP * u, e4, r.vf[u]);
+            put_rows4(buf + MA_KH, jl + MA_RPP * u, e4, r.kf[u]);
+            put_rows4(buf + MA_VH, jl + MA_RPP * u, e4, r.vf[u]);
         }
     }
 };
 
 // A-operand fragment of k-step ks from a row-major image: lane (r, h) reads row r, elements
-// 8h + 16ks .. + 8 (16 bytes)
+// 8h + 16ks .. + 8 (16 bytes).  NP = parts the image holds (the lo read is skipped for 1).
+template <int NP>
 __device__ __forceinline__ Frag read_rows(const char *hi, const char *lo, int lane, int ks) {
     const int off = (lane & 31) * MA_KLD + 16 * (lane >> 5) + 32 * ks;
     Frag f;
-
     f.hi = *reinterpret_cast<const uint4 *>(hi + off);
-    f.lo = *reinterpret_cast<const uint4 *>(lo + off);
+    f.lo = NP == 2 ? *reinterpret_cast<const uint4 *>(lo + off) : make_uint4(0u, 0u, 0u, 0u);
     return f;
 }
 // B-operand fragment whose k order matches an accumulator tile used as the A operand
@@ -234,15 +258,19 @@ __device__ __forceinline__ uint2 lds_tr_b64(const char *p) {
         (__attribute__((address_space(3))) v4s16 *)(p));
     return __builtin_bit_cast(uint2, r);
 }
+template <int NP>
 __device__ __forceinline__ Frag read_cols_tr(const char *hi, const char *lo, int col0, int lane,
                                              int s) {
     const int gl = lane & 15, q = gl >> 2, p = gl & 3, h = lane >> 5;
     const int off = (16 * s + 4 * h + q) * MA_KLD + (col0 + 16 * ((lane >> 4) & 1) + 4 * p) * 2;
-    const uint2 a = lds_tr_b64(hi + off), b = lds_tr_b64(hi + off + 8 * MA_KLD),
-                c = lds_tr_b64(lo + off), d = lds_tr_b64(lo + off + 8 * MA_KLD);
+    const uint2 a = lds_tr_b64(hi + off), b = lds_tr_b64(hi + off + 8 * MA_KLD);
     Frag f;
     f.hi = make_uint4(a.x, a.y, b.x, b.y);
-    f.lo = make_uint4(c.x, c.y, d.x, d.y);
+    f.lo = make_uint4(0u, 0u, 0u, 0u);
+    if (NP == 2) {
+        const uint2 c = lds_tr_b64(lo + off), d = lds_tr_b64(lo + off + 8 * MA_KLD);
+        f.lo = make_uint4(c.x, c.y, d.x, d.y);
+    }
     return f;
 }
 
@@ -260,26 +288,19 @@ __device__ __forceinline__ Frag read_rows_tr(const char *hi, const char *lo, int
     return f;
 }
 
-// B-operand fragments of a wave's own 32 rows of a dense operand: lane (r, h) holds row
-// i0 + r, elements 8h + 16ks .. + 8.  TR == false: x[row * ld + e]; TR: x[e * S + row].
-template <bool TR>
-__device__ __forceinline__ void load_own_rows_raw(float (&x)[MA_E / 2], const float *x_b, int ld, int S,
+// B-operand fragments of a wave's own 32 rows of a dense operand x[row * ld + e]: lane (r, h)
+// holds row i0 + r, elements 8h + 16ks .. + 8.
+template <typename T>
+__device__ __forceinline__ void load_own_rows_raw(float (&x)[MA_E / 2], const T *x_b, int ld, int S,
                                                   int i0, int lane) {
     // rows >= S read row S - 1 (unconditional loads; such rows are never stored)
     const int row = min(i0 + (lane & 31), S - 1), h = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < MA_KS; ks++) {
-        if (!TR) {
-            const float *p = x_b + (size_t)row * ld + 8 * h + 16 * ks;
-            const float4 a = *reinterpret_cast<const float4 *>(p);
-            const float4 b = *reinterpret_cast<const float4 *>(p + 4);
-            x[8 * ks + 0] = a.x; x[8 * ks + 1] = a.y; x[8 * ks + 2] = a.z; x[8 * ks + 3] = a.w;
-            x[8 * ks + 4] = b.x; x[8 * ks + 5] = b.y; x[8 * ks + 6] = b.z; x[8 * ks + 7] = b.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                x[8 * ks + j] = x_b[(size_t)(8 * h + 16 * ks + j) * S + row];
-        }
+        const T *p = x_b + (size_t)row * ld + 8 * h + 16 * ks;
+        const float4 a = ld4(p), b = ld4(p + 4);
+        x[8 * ks + 0] = a.x; x[8 * ks + 1] = a.y; x[8 * ks + 2] = a.z; x[8 * ks + 3] = a.w;
+        x[8 * ks + 4] = b.x; x[8 * ks + 5] = b.y; x[8 * ks + 6] = b.z; x[8 * ks + 7] = b.w;
     }
 }
 // split into the four k-step fragments, optionally pre-multiplied (the score scale folded
@@ -293,15 +314,16 @@ __device__ __forceinline__ void split_own_rows(Frag (&f)[MA_KS], const float (&x
                        x[8 * ks + 6] * mult, x[8 * ks + 7] * mult);
 }
 
-// ---- 16-byte global accesses for operands whose register layout is element-wise ----
+// ---- wide global accesses for operands whose register layout is element-wise ----
 // A 4-byte load or store per lane moves 256 bytes per wave instruction; the kernels' own-row
 // operands and results (8 KiB per wave and tensor) are therefore passed through a wave-private
 // LDS tile of 32 x MA_TLD floats, one 32-column half at a time.
 //
 // One e-half of a wave's 32-row accumulator tile (column = lane & 31, rows in the registers)
-// -> rows of `dst` (row stride ld floats), 8 rows x 128 bytes per store instruction.
+// -> rows of `dst` (row stride ld elements), 8 rows x 32 elements per store instruction.
+template <typename T>
 __device__ __forceinline__ void store_acc_half(const f32x16 &acc, float mult, float *tile,
-                                               float *dst, size_t ld, int rows_left, int lane) {
+                                               T *dst, size_t ld, int rows_left, int lane) {
     const int c32 = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int r = 0; r < 16; r++) tile[acc_row(r, h) * MA_TLD + c32] = acc[r] * mult;
@@ -310,13 +332,14 @@ __device__ __forceinline__ void store_acc_half(const f32x16 &acc, float mult, fl
     for (int k = 0; k < 4; k++) {
         const int row = (lane >> 3) + 8 * k, e4 = (lane & 7) * 4;
         const float4 o = *reinterpret_cast<const float4 *>(tile + row * MA_TLD + e4);
-        if (row < rows_left) *reinterpret_cast<float4 *>(dst + (size_t)row * ld + e4) = o;
+        if (row < rows_left) st4(dst + (size_t)row * ld + e4, o);
     }
     wave_lds_fence();
 }
 // A wave's own 32 rows of an operand stored [E][S] (row i0 .. of every e) into the fragment
 // order of load_own_rows_raw: x[8 ks + j] = src[(8h + 16ks + j) * S + i0 + (lane & 31)].
-__device__ __forceinline__ void load_own_rows_transposed(float (&x)[MA_E / 2], const float *src, int S,
+template <typename T>
+__device__ __forceinline__ void load_own_rows_transposed(float (&x)[MA_E / 2], const T *src, int S,
                                                          int i0, float *tile, int lane) {
     const int c32 = lane & 31, h = lane >> 5;
     const int i4 = min(i0 + (lane & 7) * 4, S - 4) - i0;      // (S % 4 == 0; rows >= S unused)
@@ -325,7 +348,7 @@ __device__ __forceinline__ void load_own_rows_transposed(float (&x)[MA_E / 2], c
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int el = (lane >> 3) + 8 * k;
-            const float4 v4 = *reinterpret_cast<const float4 *>(src + (size_t)(32 * hf + el) * S + i0 + i4);
+            const float4 v4 = ld4(src + (size_t)(32 * hf + el) * S + i0 + i4);
             *reinterpret_cast<float4 *>(tile + el * MA_TLD + (lane & 7) * 4) = v4;
         }
         wave_lds_fence();
@@ -554,9 +577,6 @@ __device__ __forceinline__ int folded_row_tile(int g, int blocks_per_batch, int 
 
 // ===================================== forward =============================================
 // grid: batch * ceil(S / 256) workgroups.
-// -DMA_STAMP (diagnostic build only; tools/time_mfma.py with MA_STAMPS=1 and SPT_HIP_LIBRARY):
-// every wave of workgroups 0 and 1 records the shader clock at the end of each of its forward
-// iterations, written over the first row sums.
 
 // exp(clamp(scale d)) = exp2(med3(d * scale log2e, -+clamp log2e)); without a clamp the
 // exponent is bounded at 2^127 so that dead cells (m = 0) stay 0 and not 0 * inf
@@ -583,60 +603,34 @@ __device__ __forceinline__ float cell_count(unsigned word) {
 
 // two workgroups per CU (4 waves per SIMD, 128 VGPRs): the barrier keeps the waves of one
 // workgroup in the same phase, a second workgroup fills the other pipes meanwhile
-#ifndef MA_WAVES_PER_EU
 #if MA_E_VALUE == 64
 #define MA_WAVES_PER_EU 4
 #else
 #define MA_WAVES_PER_EU 2       // (64 + 64 registers of Q fragments and accumulators alone)
 #endif
-#endif
-#ifndef MA_SUB
-#define MA_SUB 1            // key tiles per forward iteration (2: 48 -> 58-71 us at the bench shape)
-#endif
-#ifndef MK_KTILES
-#define MK_KTILES 2         // 32-column tiles of grad_k per launch of the key-owned kernel
-#endif
-#ifndef MR_QTILES
-#define MR_QTILES 2         // 32-column tiles of grad_q per launch of the row-owned kernel
-#endif
-#ifndef MR_SUB
-#define MR_SUB 1            // key tiles per iteration of the row-owned backward kernel (2: no faster)
-#endif
-// Row-owned backward, paired form (opt-in, -DMR_PAIRED=1; passes the tests): the two waves of a
-// SIMD (w and w + 4) share ONE row tile at a time -- first the long one (the mirror image), then
-// the short one -- and take alternate key tiles of it (two staged per iteration); the partial
-// grad_q tiles are added through LDS.  Measured with per-iteration stamps (-DMA_STAMP,
-// tools/time_mfma.py MA_STAMPS=1; shader clocks, workgroup 0 of the bench shape): as single
-// owners 16 iterations of 4.1 k clk after a 17 k prologue = 89 k; paired 8 + 2 iterations of
-// 5.8 k after two prologues of 14 k + 13 k = 100 k -- no gain.  The two waves of a SIMD run the
-// same program between the same barriers, so their MFMA phases coincide and their VALU phases
-// coincide: one tile costs its 36 MFMAs (1.15 k) PLUS its ~260 VALU (1.2 k) PLUS ~1 k of
-// reads, stores and barrier, and a second wave adds its own MFMA + VALU time on top.  Skipping
-// the loop's global loads changes nothing (5.8 k): the loads are hidden.  What is missing is
-// overlap of matrix and vector work inside a SIMD: tile t's D / dP products issued between the
-// vector instructions of tile t-1 (its exp, dS, splits), with a third LDS stage so that tile
-// t-1's K image outlives the barrier.
-#ifndef MR_PAIRED
-#define MR_PAIRED 0
-#endif
-#ifndef MA_ROWS_WAVES_PER_EU
+// One key tile per iteration in the forward and in the row-owned backward (two per iteration,
+// i.e. fewer barriers and two independent chains, measured 58-71 against 48 us in the forward and
+// no faster in the backward; sharing a row tile between the two waves of a SIMD -- alternate key
+// tiles, partial grad_q summed through LDS -- measured 100 k against 89 k clocks: the two waves
+// of a SIMD run the same program between the same barriers, so their MFMA phases coincide and
+// their VALU phases coincide).
+constexpr int MK_KTILES = MA_ET;    // 32-column tiles of grad_k per launch of the key-owned kernel
+constexpr int MR_QTILES = MA_ET;    // 32-column tiles of grad_q per launch of the row-owned kernel
 #define MA_ROWS_WAVES_PER_EU 2
-#endif
-#ifndef MA_KEYS_WAVES_PER_EU
 #define MA_KEYS_WAVES_PER_EU 2
-#endif
-template <bool YT>
+template <typename T, bool YT>
 __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_WAVES_PER_EU, MA_WAVES_PER_EU)))
 void attention_mfma_forward_kernel(
     const unsigned long long *__restrict__ masks, const unsigned char *__restrict__ cells,
     const unsigned char *__restrict__ pool,
-    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
-    float *__restrict__ y, float *__restrict__ row_sum, int S, float scale, float clampv,
+    const T *__restrict__ q, const T *__restrict__ k, const T *__restrict__ v,
+    T *__restrict__ y, float *__restrict__ row_sum, int S, float scale, float clampv,
     int heads, int blocks_per_batch) {
+    constexpr int PI = Elem<T>::PARTS;                  // parts of the K / V images
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *img = smem;                                   // [2][MA_SUB][MA_IMG]
-    float *stat = reinterpret_cast<float *>(smem + 2 * MA_SUB * MA_IMG);   // [waves][32]
+    char *img = smem;                                   // [2][MA_IMG]
+    float *stat = reinterpret_cast<float *>(smem + 2 * MA_IMG);   // [waves][32]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c32 = lane & 31;
@@ -645,38 +639,22 @@ void attention_mfma_forward_kernel(
     const int i0 = MA_WROWS * folded_row_tile(bid % blocks_per_batch, blocks_per_batch, wave);
     const DenseView dv = dense_view(b, S, MA_E, heads);
     const int RT = (S + MA_WROWS - 1) / MA_WROWS;
-    const float *k_b = k + dv.base, *v_b = v + dv.base;
+    const T *k_b = k + dv.base, *v_b = v + dv.base;
 
-#ifdef MA_STAMP
-    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
-    float st_it[20];
-#pragma unroll
-    for (int i = 0; i < 20; i++) st_it[i] = 0.f;
-#endif
     const CellTiles ct(masks, cells, pool, b, RT, i0 / MA_WROWS, i0 < S);
     // tiles any row of this workgroup can see: keys <= its last row (that of wave 7)
     const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch, MA_WAVES - 1);
-    const int T = min(RT, last_tile + 1);
+    const int T_ = min(RT, last_tile + 1);
     const ScoreMap sm(scale, clampv);
-    // An iteration = MA_SUB key tiles: the per-iteration latencies (barrier, LDS round trips,
-    // the MFMA chain's tail) are paid once per MA_SUB tiles, and the tiles of one iteration
-    // are independent instruction chains (one's MFMAs beside the other's cell arithmetic).
-    constexpr int SUB = MA_SUB;
     // every prologue load is issued before the first result is needed
-    const TileStager stager(k_b, v_b, dv.ld, S, tid);
-    TileRegs nxt[SUB];
-    uint4 mcur[SUB], mnxt[SUB];
-#pragma unroll
-    for (int u = 0; u < SUB; u++) {
-        nxt[u] = stager.load(min(u, T - 1));
-        mcur[u] = ct.load(u, lane);
-    }
+    const TileStager<T> stager(k_b, v_b, dv.ld, S, tid);
+    TileRegs<T> nxt = stager.load(0);
+    uint4 mcur = ct.load(0, lane), mnxt;
     Frag qf[MA_KS];
     {
         float xq[MA_E / 2];
-        load_own_rows_raw<false>(xq, q + dv.base, dv.ld, S, i0, lane);
-#pragma unroll
-        for (int u = 0; u < SUB; u++) stager.store(img + u * MA_IMG, nxt[u]);
+        load_own_rows_raw(xq, q + dv.base, dv.ld, S, i0, lane);
+        stager.store(img, nxt);
         split_own_rows(qf, xq, sm.sl2);
     }
     __syncthreads();
@@ -688,84 +666,45 @@ void attention_mfma_forward_kernel(
         for (int r = 0; r < 16; r++) yacc[eh][r] = 0.f;
     float rs = 0.f;
 
-    const int NIT = (T + SUB - 1) / SUB;
-    for (int it = 0; it < NIT; it++) {
-        const int t0 = it * SUB;
-        const char *buf = img + (it & 1) * SUB * MA_IMG;
-        // the next iteration's tiles (K, V and this wave's cell counts) are in flight meanwhile
-        bool lv[SUB], any = false;
+    for (int t = 0; t < T_; t++) {
+        const char *buf = img + (t & 1) * MA_IMG;
+        // the next tile (K, V and this wave's cell counts) is in flight meanwhile
+        nxt = stager.load(min(t + 1, T_ - 1));
+        mnxt = ct.load(t + 1, lane);
+        if (ct.live(t)) {
+            f32x16 d;
 #pragma unroll
-        for (int u = 0; u < SUB; u++) {
-#ifdef MR_EXP_NOLOAD     // timing experiment only: the loop re-stages the tiles it already holds
-            if (it < 0) nxt[u] = stager.load(min(t0 + SUB + u, T - 1));
-#else
-            nxt[u] = stager.load(min(t0 + SUB + u, T - 1));
-#endif
-            mnxt[u] = ct.load(t0 + SUB + u, lane);
-            lv[u] = t0 + u < T && ct.live(t0 + u);
-            any |= lv[u];
-        }
-        if (any) {
-            // a dead tile of a live iteration is computed with all multiplicities 0
-            f32x16 d[SUB];
+            for (int r = 0; r < 16; r++) d[r] = 0.f;
 #pragma unroll
-            for (int u = 0; u < SUB; u++) {
+            for (int ks = 0; ks < MA_KS; ks++)
+                d = mm<PI, 2>(read_rows<PI>(buf + MA_KH, buf + MA_KL, lane, ks), qf[ks], d);
+            // cells: this lane holds row i0 + c32, keys 32t + acc_row(r, h); byte 4g + u of
+            // the cell word is the multiplicity of register 4g + u
+            const uint4 mm4 = ct.words(mcur, t, lane);
+            const unsigned mw[4] = {mm4.x, mm4.y, mm4.z, mm4.w};
+            float p[16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) d[u][r] = 0.f;
+            for (int g = 0; g < 4; g++) {
+                p[4 * g + 0] = cell_count<0>(mw[g]) * sm.exp_of(d[4 * g + 0]);
+                p[4 * g + 1] = cell_count<1>(mw[g]) * sm.exp_of(d[4 * g + 1]);
+                p[4 * g + 2] = cell_count<2>(mw[g]) * sm.exp_of(d[4 * g + 2]);
+                p[4 * g + 3] = cell_count<3>(mw[g]) * sm.exp_of(d[4 * g + 3]);
+                rs += (p[4 * g] + p[4 * g + 1]) + (p[4 * g + 2] + p[4 * g + 3]);
             }
 #pragma unroll
-            for (int ks = 0; ks < MA_KS; ks++) {
+            for (int s2 = 0; s2 < 2; s2++) {
+                const Frag pf = split8(p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3],
+                                       p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]);
 #pragma unroll
-                for (int u = 0; u < SUB; u++)
-                    d[u] = mma3(read_rows(buf + u * MA_IMG + MA_KH, buf + u * MA_IMG + MA_KL, lane, ks),
-                                qf[ks], d[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < SUB; u++) {
-                // cells: this lane holds row i0 + c32, keys 32t + acc_row(r, h); byte 4g + u of
-                // the cell word is the multiplicity of register 4g + u
-                const uint4 mm = ct.words(mcur[u], t0 + u, lane);
-                const unsigned mw[4] = {lv[u] ? mm.x : 0u, lv[u] ? mm.y : 0u,
-                                        lv[u] ? mm.z : 0u, lv[u] ? mm.w : 0u};
-                float p[16];
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    p[4 * g + 0] = cell_count<0>(mw[g]) * sm.exp_of(d[u][4 * g + 0]);
-                    p[4 * g + 1] = cell_count<1>(mw[g]) * sm.exp_of(d[u][4 * g + 1]);
-                    p[4 * g + 2] = cell_count<2>(mw[g]) * sm.exp_of(d[u][4 * g + 2]);
-                    p[4 * g + 3] = cell_count<3>(mw[g]) * sm.exp_of(d[u][4 * g + 3]);
-                    rs += (p[4 * g] + p[4 * g + 1]) + (p[4 * g + 2] + p[4 * g + 3]);
-                }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; s2++) {
-                    const Frag pf = split8(p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3],
-                                           p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]);
-#pragma unroll
-                    for (int eh = 0; eh < MA_ET; eh++)
-                        yacc[eh] = mma3(pf, read_cols_tr(buf + u * MA_IMG + MA_VH, buf + u * MA_IMG + MA_VL,
-                                                         32 * eh, lane, s2), yacc[eh]);
-                }
+                for (int eh = 0; eh < MA_ET; eh++)
+                    yacc[eh] = mm<2, PI>(pf, read_cols_tr<PI>(buf + MA_VH, buf + MA_VL, 32 * eh, lane, s2),
+                                         yacc[eh]);
             }
         }
-        if (it + 1 < NIT) {
-#pragma unroll
-            for (int u = 0; u < SUB; u++)
-                stager.store(img + (((it + 1) & 1) * SUB + u) * MA_IMG, nxt[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < SUB; u++) mcur[u] = mnxt[u];
-#ifdef MA_STAMP
-        {
-            const float now = (float)(__builtin_amdgcn_s_memtime() - st_t0);
-#pragma unroll
-            for (int i = 0; i < 16; i++) st_it[i] = (i == it) ? now : st_it[i];
-        }
-#endif
+        if (t + 1 < T_) stager.store(img + ((t + 1) & 1) * MA_IMG, nxt);
+        mcur = mnxt;
         __syncthreads();
     }
-#ifdef MA_STAMP
-    st_it[16] = (float)(__builtin_amdgcn_s_memtime() - st_t0);
-#endif
 
     // ---- rows: 1 / max(1e-9, sum); the two lane halves hold disjoint keys of the same row ----
     rs += __shfl_xor(rs, 32, SPT_WAVE);
@@ -776,7 +715,7 @@ void attention_mfma_forward_kernel(
         if (i0 + c32 < S) row_sum[(size_t)b * S + i0 + c32] = rs;
     }
     wave_lds_fence();
-    float *y_b = y + (size_t)b * S * MA_E;
+    T *y_b = y + (size_t)b * S * MA_E;
     if (i0 < S) {
         if (!YT) {
 #pragma unroll
@@ -786,7 +725,7 @@ void attention_mfma_forward_kernel(
                 if (i0 + il < S) {
 #pragma unroll
                     for (int eh = 0; eh < MA_ET; eh++)
-                        y_b[(size_t)(i0 + il) * MA_E + 32 * eh + c32] = yacc[eh][r] * sc;
+                        st1(y_b + (size_t)(i0 + il) * MA_E + 32 * eh + c32, yacc[eh][r] * sc);
                 }
             }
         } else {
@@ -810,31 +749,20 @@ void attention_mfma_forward_kernel(
                 for (int k4 = 0; k4 < 4; k4++) {
                     const int el = (lane >> 3) + 8 * k4, i4 = (lane & 7) * 4;
                     const float4 o = *reinterpret_cast<const float4 *>(tile + el * MA_TLD + i4);
-                    float *dst = y_b + (size_t)(el + 32 * eh) * S + i0 + i4;
+                    T *dst = y_b + (size_t)(el + 32 * eh) * S + i0 + i4;
                     if (i0 + i4 + 3 < S && (S & 3) == 0) {
-                        *reinterpret_cast<float4 *>(dst) = o;
+                        st4(dst, o);
                     } else {
                         const float ov[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
                         for (int u = 0; u < 4; u++)
-                            if (i0 + i4 + u < S) dst[u] = ov[u];
+                            if (i0 + i4 + u < S) st1(dst + u, ov[u]);
                     }
                 }
                 wave_lds_fence();
             }
         }
     }
-#ifdef MA_STAMP
-    // (after everything else: the stamps overwrite row sums of batch slices 0 and 1)
-    __syncthreads();
-    if (bid < 2 && lane == 0) {
-        float *out = row_sum + (size_t)bid * 160 + wave * 20;
-        for (int i = 0; i < 17; i++) out[i] = st_it[i];
-        out[17] = (float)(__builtin_amdgcn_s_memtime() - st_t0);
-        out[18] = (float)T;
-        out[19] = (float)(i0 / 32);
-    }
-#endif
 }
 
 // ===================================== backward ============================================
@@ -848,88 +776,43 @@ void attention_mfma_forward_kernel(
 //   grad_q[i] = sum_j dS[i, j] k[j]     grad_k[j] = sum_i dS[i, j] q[i]     (kernels/sddmm.py)
 //   grad_v[j] = sum_i P[i, j] dY[i]     dP[i, j]  = dY[i] . v[j]            (kernels/spmm.py)
 
-// ---- row-owned: same skeleton as the forward; images K rows | V rows (the K rows image also
-// feeds grad_q = dS^T K through the transposing read) ----
-constexpr int MR_KR = 0, MR_VR = 2 * MA_RIMG, MR_IMG = 4 * MA_RIMG;         // 18432 B
-struct RowsStager : TileStager {
-    using TileStager::TileStager;
-    __device__ __forceinline__ void store(char *buf, const TileRegs &r) const {
-#pragma unroll
-        for (int u = 0; u < MA_RPT; u++) {
-            const int row = jl + MA_RPP * u;
-            put4_along_e<true, false>(buf + MR_KR, nullptr, row, e4, r.kf[u]);
-            put4_along_e<true, false>(buf + MR_VR, nullptr, row, e4, r.vf[u]);
-        }
-    }
-};
-
+// ---- row-owned: same skeleton as the forward and the same images, K rows | V rows (the K
+// rows image also feeds grad_q = dS^T K through the transposing read).
+// Measured by compiling phases out (80 us whole): without the tile arithmetic 54 us (prologue --
+// dY, Y, Q: 100 MB -- 23, the loop's loads 23, epilogue 6, image stores 2, barriers 0); WITH the
+// arithmetic but without the loop's loads, stores and barriers 75 us.  So the loop's memory
+// traffic hides behind the arithmetic, and the arithmetic (46 us for 16 us of MFMA-pipe time) is
+// one wave per SIMD running its MFMA and VALU phases one after the other: at 187 VGPRs a CU holds
+// one workgroup, and half of its waves (the short row tiles) finish early. ----
 // GT: grad_y and y arrive as [batch, E, S] (the transposed forward output and its gradient)
-template <bool GT>
+template <typename T, bool GT>
 __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_ROWS_WAVES_PER_EU, MA_ROWS_WAVES_PER_EU)))
 void attention_mfma_backward_rows_kernel(
     const unsigned long long *__restrict__ masks, const unsigned char *__restrict__ cells,
     const unsigned char *__restrict__ pool,
-    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
-    const float *__restrict__ gy, const float *__restrict__ y,
-    const float *__restrict__ row_sum, float *__restrict__ grad_q, float *__restrict__ delta,
+    const T *__restrict__ q, const T *__restrict__ k, const T *__restrict__ v,
+    const T *__restrict__ gy, const T *__restrict__ y,
+    const float *__restrict__ row_sum, T *__restrict__ grad_q, float *__restrict__ delta,
     int S, float scale, float clampv, int heads, int blocks_per_batch, int half) {
+    constexpr int PI = Elem<T>::PARTS;                  // parts of the K / V images
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *img = smem;                                   // [2][MR_IMG]
+    char *img = smem;                                   // [2][MA_IMG]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c32 = lane & 31;
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int b = bid / blocks_per_batch;
-    constexpr bool PAIRED = MR_PAIRED;
-    constexpr int HALFW = MA_WAVES / 2;
-    const int hf = wave / HALFW;                // which of a pair's two waves
     const DenseView dv = dense_view(b, S, MA_E, heads);
     const int RT = (S + MA_WROWS - 1) / MA_WROWS;
     const ScoreMap sm(scale, clampv);
-#ifdef MA_STAMP
-    // diagnostic build only: workgroup 0's waves record the shader clock at the marks below
-    // (R_STAMP), written over grad_q rows 0..3 of head 0 at the end
-    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
-    float st_v[32];
-    int st_n = 0;
-#pragma unroll
-    for (int i = 0; i < 32; i++) st_v[i] = 0.f;
-#define R_STAMP()                                                                   \
-    do {                                                                            \
-        const float now_ = (float)(__builtin_amdgcn_s_memtime() - st_t0);           \
-        _Pragma("unroll") for (int i_ = 0; i_ < 32; i_++) st_v[i_] = (i_ == st_n) ? now_ : st_v[i_]; \
-        st_n++;                                                                     \
-    } while (0)
-#else
-#define R_STAMP()
-#endif
-  for (int pass = 0; pass < (PAIRED ? 2 : 1); pass++) {
-    // the row tile this wave works on in this pass, and the last one any wave of the block does
-    const int own = PAIRED ? (pass == 0 ? HALFW + wave % HALFW : wave % HALFW) : wave;
-    const int i0 = MA_WROWS * folded_row_tile(bid % blocks_per_batch, blocks_per_batch, own);
+    const int i0 = MA_WROWS * folded_row_tile(bid % blocks_per_batch, blocks_per_batch, wave);
     const CellTiles ct(masks, cells, pool, b, RT, i0 / MA_WROWS, i0 < S);
-    const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch,
-                                          PAIRED && pass == 1 ? HALFW - 1 : MA_WAVES - 1);
-    const int T = min(RT, last_tile + 1);
-    // An iteration = MR_SUB key tiles.  Measured by compiling phases out (80 us whole): without
-    // the tile arithmetic 54 us (prologue -- dY, Y, Q: 100 MB -- 23, the loop's loads 23,
-    // epilogue 6, image stores 2, barriers 0); WITH the arithmetic but without the loop's
-    // loads, stores and barriers 75 us.  So the loop's memory traffic hides behind the
-    // arithmetic, and the arithmetic (46 us for 16 us of MFMA-pipe time) is one wave per SIMD
-    // running its MFMA and VALU phases one after the other: at 187 VGPRs a CU holds one
-    // workgroup, and half of its waves (the short row tiles) finish early.  That is why two
-    // tiles per iteration, a second tile in flight, 16-byte own-row accesses and 8x smaller
-    // cell tiles all measured the same.
-    constexpr int SUB = PAIRED ? 2 : MR_SUB;
-    const RowsStager stager(k + dv.base, v + dv.base, dv.ld, S, tid);
-    TileRegs nxt[SUB];
-    uint4 mcur[SUB], mnxt[SUB];
-#pragma unroll
-    for (int u = 0; u < SUB; u++) {
-        nxt[u] = stager.load(min(u, T - 1));
-        mcur[u] = ct.load(u, lane);
-    }
+    const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch, MA_WAVES - 1);
+    const int T_ = min(RT, last_tile + 1);
+    const TileStager<T> stager(k + dv.base, v + dv.base, dv.ld, S, tid);
+    TileRegs<T> nxt = stager.load(0);
+    uint4 mcur = ct.load(0, lane), mnxt;
     // own rows: dY (B operand of dP = V dY^T), delta = max(1e-9, dY . Y), Q (B operand of D)
     Frag gf[MA_KS], qf[MA_KS];
     float delta_i;
@@ -938,20 +821,19 @@ void attention_mfma_backward_rows_kernel(
     {
         float xr[MA_E / 2], yr[MA_E / 2], xq[MA_E / 2];
         const size_t ob = (size_t)b * S * MA_E;
-        load_own_rows_raw<false>(xq, q + dv.base, dv.ld, S, i0, lane);
+        load_own_rows_raw(xq, q + dv.base, dv.ld, S, i0, lane);
         if (GT) {
-            // [E][S] operands: 16-byte loads through the wave's LDS tile (the image buffers
+            // [E][S] operands: wide loads through the wave's LDS tile (the image buffers
             // are free until the first key tile is staged)
             float *tile = reinterpret_cast<float *>(img) + wave * (32 * MA_TLD);
             load_own_rows_transposed(xr, gy + ob, S, i0, tile, lane);
             load_own_rows_transposed(yr, y + ob, S, i0, tile, lane);
             __syncthreads();
         } else {
-            load_own_rows_raw<false>(xr, gy + ob, MA_E, S, i0, lane);
-            load_own_rows_raw<false>(yr, y + ob, MA_E, S, i0, lane);
+            load_own_rows_raw(xr, gy + ob, MA_E, S, i0, lane);
+            load_own_rows_raw(yr, y + ob, MA_E, S, i0, lane);
         }
-#pragma unroll
-        for (int u = 0; u < SUB; u++) stager.store(img + u * MR_IMG, nxt[u]);
+        stager.store(img, nxt);
         float dl = 0.f;
 #pragma unroll
         for (int x = 0; x < MA_E / 2; x++) dl = fmaf(xr[x], yr[x], dl);
@@ -962,12 +844,10 @@ void attention_mfma_backward_rows_kernel(
         const float pscale = scale / fmaxf(1e-9f, rsum);
         split_own_rows(gf, xr, pscale);
         split_own_rows(qf, xq, sm.sl2);
-        if (h == 0 && row < S && half == 0 && (!PAIRED || hf == 0))
-            delta[(size_t)b * S + row] = delta_i;
+        if (h == 0 && row < S && half == 0) delta[(size_t)b * S + row] = delta_i;
         delta_i *= pscale;
     }
     __syncthreads();
-    R_STAMP();                                   // prologue done
 
     f32x16 qacc[MR_QTILES];
 #pragma unroll
@@ -975,31 +855,21 @@ void attention_mfma_backward_rows_kernel(
 #pragma unroll
         for (int r = 0; r < 16; r++) qacc[e][r] = 0.f;
 
-    const int NIT = (T + SUB - 1) / SUB;
-    for (int it = 0; it < NIT; it++) {
-        const int t0 = it * SUB;
-        const char *stage = img + (it & 1) * SUB * MR_IMG;
-        bool lv[SUB];
-#pragma unroll
-        for (int u = 0; u < SUB; u++) {
-            nxt[u] = stager.load(min(t0 + SUB + u, T - 1));
-            mnxt[u] = ct.load(t0 + SUB + u, lane);
-            lv[u] = t0 + u < T && ct.live(t0 + u) && (!PAIRED || u == hf);
-        }
-#pragma unroll
-        for (int u = 0; u < SUB; u++) {
-            if (!lv[u]) continue;
-            const char *buf = stage + u * MR_IMG;
+    for (int t = 0; t < T_; t++) {
+        const char *buf = img + (t & 1) * MA_IMG;
+        nxt = stager.load(min(t + 1, T_ - 1));
+        mnxt = ct.load(t + 1, lane);
+        if (ct.live(t)) {
             f32x16 d, dp;
 #pragma unroll
             for (int r = 0; r < 16; r++) d[r] = dp[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < MA_KS; ks++) {
-                d = mma3(read_rows(buf + MR_KR, buf + MR_KR + MA_RIMG, lane, ks), qf[ks], d);
-                dp = mma3(read_rows(buf + MR_VR, buf + MR_VR + MA_RIMG, lane, ks), gf[ks], dp);
+                d = mm<PI, 2>(read_rows<PI>(buf + MA_KH, buf + MA_KL, lane, ks), qf[ks], d);
+                dp = mm<PI, 2>(read_rows<PI>(buf + MA_VH, buf + MA_VL, lane, ks), gf[ks], dp);
             }
-            const uint4 mm = ct.words(mcur[u], t0 + u, lane);
-            const unsigned mw[4] = {mm.x, mm.y, mm.z, mm.w};
+            const uint4 mm4 = ct.words(mcur, t, lane);
+            const unsigned mw[4] = {mm4.x, mm4.y, mm4.z, mm4.w};
             float ds[16];
 #pragma unroll
             for (int g = 0; g < 4; g++) {
@@ -1018,60 +888,22 @@ void attention_mfma_backward_rows_kernel(
                                        ds[8 * s2 + 4], ds[8 * s2 + 5], ds[8 * s2 + 6], ds[8 * s2 + 7]);
 #pragma unroll
                 for (int eh = 0; eh < MR_QTILES; eh++)
-                    qacc[eh] = mma3(sf, read_cols_tr(buf + MR_KR, buf + MR_KR + MA_RIMG,
-                                                     32 * MR_QTILES * half + 32 * eh, lane, s2),
-                                    qacc[eh]);
+                    qacc[eh] = mm<2, PI>(sf, read_cols_tr<PI>(buf + MA_KH, buf + MA_KL,
+                                                              32 * MR_QTILES * half + 32 * eh, lane, s2),
+                                         qacc[eh]);
             }
         }
-        if (it + 1 < NIT) {
-#pragma unroll
-            for (int u = 0; u < SUB; u++)
-                stager.store(img + (((it + 1) & 1) * SUB + u) * MR_IMG, nxt[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < SUB; u++) mcur[u] = mnxt[u];
-        R_STAMP();                               // iteration's work done (before its barrier)
+        if (t + 1 < T_) stager.store(img + ((t + 1) & 1) * MA_IMG, nxt);
+        mcur = mnxt;
         __syncthreads();
     }
-    R_STAMP();                                   // loop done
-    if (PAIRED) {
-        // (the loop's last barrier freed the images) partner's partial sums: register layout,
-        // lane-contiguous, behind the eight waves' transpose tiles
-        float *xch = reinterpret_cast<float *>(img) + MA_WAVES * (32 * MA_TLD) +
-                     (wave % HALFW) * (MR_QTILES * 16 * 64);
-        if (hf == 1) {
-#pragma unroll
-            for (int eh = 0; eh < MR_QTILES; eh++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) xch[(eh * 16 + r) * 64 + lane] = qacc[eh][r];
-        }
-        __syncthreads();
-        if (hf == 0) {
-#pragma unroll
-            for (int eh = 0; eh < MR_QTILES; eh++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) qacc[eh][r] += xch[(eh * 16 + r) * 64 + lane];
-        }
-    }
-    if (i0 < S && (!PAIRED || hf == 0)) {
+    if (i0 < S) {
         float *tile = reinterpret_cast<float *>(img) + wave * (32 * MA_TLD);
-        float *gq_b = grad_q + dv.base + (size_t)i0 * dv.ld + 32 * MR_QTILES * half;
+        T *gq_b = grad_q + dv.base + (size_t)i0 * dv.ld + 32 * MR_QTILES * half;
 #pragma unroll
         for (int eh = 0; eh < MR_QTILES; eh++)
             store_acc_half(qacc[eh], 1.0f, tile, gq_b + 32 * eh, dv.ld, S - i0, lane);
     }
-    R_STAMP();                                   // pass done
-    if (PAIRED && pass == 0) __syncthreads();      // the next pass stages into the same LDS
-  }
-#ifdef MA_STAMP
-    __syncthreads();
-    if (bid == 0 && lane == 0) {
-        for (int i = 0; i < 32; i++) {
-            const int idx = wave * 32 + i;
-            grad_q[dv.base + (size_t)(idx / 64) * dv.ld + idx % 64] = st_v[i];
-        }
-    }
-#endif
 }
 
 // ---- key-owned: a wave owns 32 keys (K, V fragments and the grad_k, grad_v accumulators in
@@ -1086,11 +918,16 @@ void attention_mfma_backward_rows_kernel(
 constexpr int MK_GSLOT = MA_CIMG > MA_RIMG ? MA_CIMG : MA_RIMG;           // either orientation
 constexpr int MK_QR = 0, MK_G = 2 * MA_RIMG, MK_ST = 2 * MA_RIMG + 2 * MK_GSLOT,
               MK_IMG = MK_ST + MA_WROWS * 4;                                // 18560 B at E = 64
-template <bool GT>
+template <typename T, bool GT>
 struct KeysStager {
-    const float *q_b, *gy_b, *rs_b, *dl_b;
+    const T *q_b, *gy_b;
+    const float *rs_b, *dl_b;
     int ld, S, tid;
-    struct Regs { float4 qf[MA_RPT], gf[MA_RPT], rs[MA_RPT]; float st_rs, st_dl; };
+    struct Regs {
+        typename Elem<T>::raw4 qf[MA_RPT], gf[MA_RPT];
+        float4 rs[MA_RPT];
+        float st_rs, st_dl;
+    };
     // unconditional, clamped loads (see TileStager::load); rows >= S are given weight 0 by
     // store(), so whatever finite data the clamped rows hold never counts.  Raw values only:
     // arithmetic on them here would wait for the loads at the top of the iteration.
@@ -1102,14 +939,14 @@ struct KeysStager {
         for (int u = 0; u < MA_RPT; u++) {
             const int il = tid / MA_EQ + MA_RPP * u;
             const int row = min(i0 + il, S - 1);
-            r.qf[u] = *reinterpret_cast<const float4 *>(q_b + (size_t)row * ld + e4);
+            r.qf[u] = ld_raw4(q_b + (size_t)row * ld + e4);
             if (!GT) {
-                r.gf[u] = *reinterpret_cast<const float4 *>(gy_b + (size_t)row * MA_E + e4);
+                r.gf[u] = ld_raw4(gy_b + (size_t)row * MA_E + e4);
                 r.rs[u] = make_float4(rs_b[row], 0.f, 0.f, 0.f);
             } else {        // [E][S]: four consecutive rows of one e (S % 4 == 0)
                 const int e = (tid >> 3) + (MA_THREADS / 8) * u;
                 const int i4 = min(i0 + (tid & 7) * 4, S - 4);
-                r.gf[u] = *reinterpret_cast<const float4 *>(gy_b + (size_t)e * S + i4);
+                r.gf[u] = ld_raw4(gy_b + (size_t)e * S + i4);
                 r.rs[u] = *reinterpret_cast<const float4 *>(rs_b + i4);
             }
         }
@@ -1119,7 +956,8 @@ struct KeysStager {
         return r;
     }
     // 1 / row_sum is a per-row factor of both P (grad_v) and dS (grad_k): dY is staged
-    // pre-multiplied by it, rows >= S by 0, and the rows' delta likewise
+    // pre-multiplied by it (an fp32 product: two parts whatever the storage type), rows >= S
+    // by 0, and the rows' delta likewise
     __device__ __forceinline__ void store(char *buf, const Regs &r, int rt) const {
         const int i0 = rt * MA_WROWS;
         const int e4 = (tid % MA_EQ) * 4;
@@ -1129,20 +967,18 @@ struct KeysStager {
 #pragma unroll
         for (int u = 0; u < MA_RPT; u++) {
             const int il = tid / MA_EQ + MA_RPP * u;
-            put4_along_e<true, false>(buf + MK_QR, nullptr, il, e4, r.qf[u]);
+            put_rows4(buf + MK_QR, il, e4, r.qf[u]);
+            const float4 g = Elem<T>::f4(r.gf[u]);
             if (!GT) {
                 const float w = weight(r.rs[u].x, i0 + il);
-                put4_along_e<true, false>(
-                    buf + MK_G, nullptr, il, e4,
-                    make_float4(w * r.gf[u].x, w * r.gf[u].y, w * r.gf[u].z, w * r.gf[u].w));
+                put_rows4(buf + MK_G, il, e4, make_float4(w * g.x, w * g.y, w * g.z, w * g.w));
             } else {
                 const int i4 = (tid & 7) * 4;
-                put4_along_r<false, true>(
-                    nullptr, buf + MK_G, (tid >> 3) + (MA_THREADS / 8) * u, i4,
-                    make_float4(weight(r.rs[u].x, i0 + i4) * r.gf[u].x,
-                                weight(r.rs[u].y, i0 + i4 + 1) * r.gf[u].y,
-                                weight(r.rs[u].z, i0 + i4 + 2) * r.gf[u].z,
-                                weight(r.rs[u].w, i0 + i4 + 3) * r.gf[u].w));
+                put_cols4(buf + MK_G, (tid >> 3) + (MA_THREADS / 8) * u, i4,
+                          make_float4(weight(r.rs[u].x, i0 + i4) * g.x,
+                                      weight(r.rs[u].y, i0 + i4 + 1) * g.y,
+                                      weight(r.rs[u].z, i0 + i4 + 2) * g.z,
+                                      weight(r.rs[u].w, i0 + i4 + 3) * g.w));
             }
         }
         if (tid < MA_WROWS)
@@ -1155,16 +991,17 @@ struct KeysStager {
 // tile arithmetic (the combined kernel spilled 41-60 registers: 281 us per launch), so there
 // MODE 1: grad_v alone, all 128 columns (needs P only: no V fragments, no dP, no delta);
 // MODE 2: grad_k alone, 64 columns per launch.
-template <bool GT, int MODE>
+template <typename T, bool GT, int MODE>
 __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_KEYS_WAVES_PER_EU, MA_KEYS_WAVES_PER_EU)))
 void attention_mfma_backward_keys_kernel(
     const unsigned long long *__restrict__ masks, const unsigned char *__restrict__ cells_t,
     const unsigned char *__restrict__ pool_t,
-    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
-    const float *__restrict__ gy, const float *__restrict__ row_sum,
-    const float *__restrict__ delta, float *__restrict__ grad_k, float *__restrict__ grad_v,
+    const T *__restrict__ q, const T *__restrict__ k, const T *__restrict__ v,
+    const T *__restrict__ gy, const float *__restrict__ row_sum,
+    const float *__restrict__ delta, T *__restrict__ grad_k, T *__restrict__ grad_v,
     int S, float scale, float clampv, int heads, int blocks_per_batch, int half) {
+    constexpr int PI = Elem<T>::PARTS;                  // parts of the Q image and of the V fragments
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *img = smem;                                   // [2][MK_IMG]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1184,12 +1021,12 @@ void attention_mfma_backward_keys_kernel(
     Frag kf[MA_KS], vf[WANT_K ? MA_KS : 1];
     {
         float xk[MA_E / 2];
-        load_own_rows_raw<false>(xk, k + dv.base, dv.ld, S, j0, lane);
+        load_own_rows_raw(xk, k + dv.base, dv.ld, S, j0, lane);
         split_own_rows(kf, xk, sm.sl2);     // the score scale (log2 domain) folded into K
         if constexpr (WANT_K) {             // V only feeds dP, which only dS needs
             float xv[MA_E / 2];
-            load_own_rows_raw<false>(xv, v + dv.base, dv.ld, S, j0, lane);
-            split_own_rows(vf, xv);
+            load_own_rows_raw(xv, v + dv.base, dv.ld, S, j0, lane);
+            split_own_rows(vf, xv);         // (stored bf16: the lo parts are zero and unused)
         }
     }
     // the slice's row-tile masks live in registers (lane rt: mask of row tile rt), so that the
@@ -1224,8 +1061,8 @@ void attention_mfma_backward_keys_kernel(
     };
 
     const int rt0 = (MA_WAVES / 2) * g;                 // the first row tile any wave needs
-    const KeysStager<GT> stager{q + dv.base, gy + (size_t)b * S * MA_E, row_sum + (size_t)b * S,
-                                delta + (size_t)b * S, dv.ld, S, tid};
+    const KeysStager<T, GT> stager{q + dv.base, gy + (size_t)b * S * MA_E, row_sum + (size_t)b * S,
+                                   delta + (size_t)b * S, dv.ld, S, tid};
     stager.store(img, stager.load(min(rt0, RT - 1)), rt0);
     unsigned long long mcur_mask = mask_of(rt0);
     uint4 mcur = cell_load(rt0);
@@ -1243,7 +1080,7 @@ void attention_mfma_backward_keys_kernel(
 
     for (int rt = rt0; rt < RT; rt++) {
         const char *buf = img + ((rt - rt0) & 1) * MK_IMG;
-        const typename KeysStager<GT>::Regs nxt = stager.load(min(rt + 1, RT - 1));
+        const typename KeysStager<T, GT>::Regs nxt = stager.load(min(rt + 1, RT - 1));
         const unsigned long long mnxt_mask = mask_of(rt + 1);
         const uint4 mnxt = cell_load(rt + 1);
         if (live(mcur_mask, rt)) {
@@ -1252,16 +1089,16 @@ void attention_mfma_backward_keys_kernel(
             for (int r = 0; r < 16; r++) d[r] = dp[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < MA_KS; ks++) {
-                d = mma3(read_rows(buf + MK_QR, buf + MK_QR + MA_RIMG, lane, ks), kf[ks], d);
+                d = mm<PI, 2>(read_rows<PI>(buf + MK_QR, buf + MK_QR + MA_RIMG, lane, ks), kf[ks], d);
                 if constexpr (WANT_K)
-                    dp = mma3(GT ? read_rows_tr(buf + MK_G, buf + MK_G + MA_CIMG, lane, ks)
-                                 : read_rows(buf + MK_G, buf + MK_G + MA_RIMG, lane, ks),
-                              vf[ks], dp);
+                    dp = mm<2, PI>(GT ? read_rows_tr(buf + MK_G, buf + MK_G + MA_CIMG, lane, ks)
+                                      : read_rows<2>(buf + MK_G, buf + MK_G + MA_RIMG, lane, ks),
+                                   vf[ks], dp);
             }
             // this lane: key j0 + c32, rows 8g + 4h + u of the tile in register 4g + u
             const float *st = reinterpret_cast<const float *>(buf + MK_ST);
-            const uint4 mm = cell_words(mcur, multi_of(rt), lane);
-            const unsigned mw[4] = {mm.x, mm.y, mm.z, mm.w};
+            const uint4 mm4 = cell_words(mcur, multi_of(rt), lane);
+            const unsigned mw[4] = {mm4.x, mm4.y, mm4.z, mm4.w};
             float p[16], ds[16];
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
@@ -1289,18 +1126,18 @@ void attention_mfma_backward_keys_kernel(
 #pragma unroll
                     for (int eh = 0; eh < NVT; eh++) {
                         const int col0 = (MODE == 1 ? 0 : 64 * half) + 32 * eh;
-                        vacc[eh] = mma3(pf, GT ? read_cols(buf + MK_G, buf + MK_G + MA_CIMG,
-                                                           c32 + col0, h, s2)
-                                               : read_cols_tr(buf + MK_G, buf + MK_G + MA_RIMG,
-                                                              col0, lane, s2), vacc[eh]);
+                        vacc[eh] = mm<2, 2>(pf, GT ? read_cols(buf + MK_G, buf + MK_G + MA_CIMG,
+                                                               c32 + col0, h, s2)
+                                                   : read_cols_tr<2>(buf + MK_G, buf + MK_G + MA_RIMG,
+                                                                     col0, lane, s2), vacc[eh]);
                     }
                 }
                 if constexpr (WANT_K) {
 #pragma unroll
                     for (int eh = 0; eh < MK_KTILES; eh++)
-                        kacc[eh] = mma3(sf, read_cols_tr(buf + MK_QR, buf + MK_QR + MA_RIMG,
-                                                         32 * MK_KTILES * half + 32 * eh, lane, s2),
-                                        kacc[eh]);
+                        kacc[eh] = mm<2, PI>(sf, read_cols_tr<PI>(buf + MK_QR, buf + MK_QR + MA_RIMG,
+                                                                  32 * MK_KTILES * half + 32 * eh, lane, s2),
+                                             kacc[eh]);
                 }
             }
         }
@@ -1312,13 +1149,13 @@ void attention_mfma_backward_keys_kernel(
     if (have) {
         float *tile = reinterpret_cast<float *>(img) + wave * (32 * MA_TLD);
         if constexpr (WANT_K) {
-            float *gk_b = grad_k + dv.base + (size_t)j0 * dv.ld + 32 * MK_KTILES * half;
+            T *gk_b = grad_k + dv.base + (size_t)j0 * dv.ld + 32 * MK_KTILES * half;
 #pragma unroll
             for (int eh = 0; eh < MK_KTILES; eh++)
                 store_acc_half(kacc[eh], scale, tile, gk_b + 32 * eh, dv.ld, S - j0, lane);
         }
         if constexpr (WANT_V) {
-            float *gv_b = grad_v + dv.base + (size_t)j0 * dv.ld + (MODE == 1 ? 0 : 64 * half);
+            T *gv_b = grad_v + dv.base + (size_t)j0 * dv.ld + (MODE == 1 ? 0 : 64 * half);
 #pragma unroll
             for (int eh = 0; eh < NVT; eh++)
                 store_acc_half(vacc[eh], 1.0f, tile, gv_b + 32 * eh, dv.ld, S - j0, lane);
@@ -1327,54 +1164,53 @@ void attention_mfma_backward_keys_kernel(
 }
 
 static size_t mfma_forward_lds() {
-    return 2 * MA_SUB * MA_IMG + (size_t)MA_WAVES * MA_WROWS * sizeof(float);
+    return 2 * MA_IMG + (size_t)MA_WAVES * MA_WROWS * sizeof(float);
 }
 
 // ---- launchers of this head dimension (the d_head 64 unit dispatches to spt::e128's) ----
-int launch_forward(const unsigned long long *masks, const unsigned char *cells,
-                   const unsigned char *pool, const float *q,
-                   const float *k, const float *v, float *y, float *row_sum, int batch_size,
-                   int S, float scale, float clamp, int heads, int y_transposed, hipStream_t s) {
+template <typename T>
+static int launch_forward_t(const unsigned long long *masks, const unsigned char *cells,
+                            const unsigned char *pool, const T *q, const T *k, const T *v, T *y,
+                            float *row_sum, int batch_size, int S, float scale, float clamp,
+                            int heads, int y_transposed, hipStream_t s) {
     const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
     const size_t lds = mfma_forward_lds();
     const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
     SPT_HIP_TRY(hipFuncSetAttribute(
-        y_transposed ? (const void *)attention_mfma_forward_kernel<true>
-                     : (const void *)attention_mfma_forward_kernel<false>,
+        y_transposed ? (const void *)attention_mfma_forward_kernel<T, true>
+                     : (const void *)attention_mfma_forward_kernel<T, false>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (y_transposed)
-        hipLaunchKernelGGL(attention_mfma_forward_kernel<true>, grid, block, lds, s, masks, cells,
-                           pool, q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
+        hipLaunchKernelGGL((attention_mfma_forward_kernel<T, true>), grid, block, lds, s, masks,
+                           cells, pool, q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
     else
-        hipLaunchKernelGGL(attention_mfma_forward_kernel<false>, grid, block, lds, s, masks, cells,
-                           pool, q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
+        hipLaunchKernelGGL((attention_mfma_forward_kernel<T, false>), grid, block, lds, s, masks,
+                           cells, pool, q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }
 
-int launch_backward(const unsigned long long *masks, const unsigned char *cells,
-                    const unsigned char *cells_t, const unsigned char *pool,
-                    const unsigned char *pool_t, const float *q, const float *k, const float *v,
-                    const float *y, const float *grad_y, const float *row_sum, float *delta,
-                    float *grad_q, float *grad_k, float *grad_v, int batch_size, int S,
-                    float scale, float clamp, int heads, int transposed, hipStream_t s) {
+template <typename T>
+static int launch_backward_t(const unsigned long long *masks, const unsigned char *cells,
+                             const unsigned char *cells_t, const unsigned char *pool,
+                             const unsigned char *pool_t, const T *q, const T *k, const T *v,
+                             const T *y, const T *grad_y, const float *row_sum, float *delta,
+                             T *grad_q, T *grad_k, T *grad_v, int batch_size, int S,
+                             float scale, float clamp, int heads, int transposed, hipStream_t s) {
     const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
     const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
-    const size_t lds_r = 2 * (MR_PAIRED ? 2 : MR_SUB) * MR_IMG, lds_k = 2 * MK_IMG;
-    static_assert(!MR_PAIRED || (size_t)MA_WAVES * 32 * MA_TLD * 4 + 4 * MR_QTILES * 16 * 64 * 4 <=
-                                    (size_t)4 * MR_IMG, "paired exchange area fits the images");
+    const size_t lds_r = 2 * MA_IMG, lds_k = 2 * MK_IMG;
     // 64 gradient columns per launch (the accumulators of 128 would not fit the registers
     // beside the operands' fragments): d_head 128 runs each kernel twice
 #define SPT_MB(GT)                                                                              \
     do {                                                                                        \
         SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
-            (const void *)attention_mfma_backward_rows_kernel<GT>,                              \
+            (const void *)attention_mfma_backward_rows_kernel<T, GT>,                           \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));                           \
         for (int half = 0; half < MA_ET / MR_QTILES; half++)                                    \
-            hipLaunchKernelGGL(attention_mfma_backward_rows_kernel<GT>, grid, block, lds_r, s,  \
-                               masks, cells, pool, q, k, v, grad_y, y, row_sum, grad_q, delta,  \
-                               S,                                                               \
-                               scale, clamp, heads, bpb, half);                                 \
+            hipLaunchKernelGGL((attention_mfma_backward_rows_kernel<T, GT>), grid, block, lds_r, \
+                               s, masks, cells, pool, q, k, v, grad_y, y, row_sum, grad_q,      \
+                               delta, S, scale, clamp, heads, bpb, half);                       \
         if (MA_BH == 1) {                                                                       \
             SPT_KEYS(GT, 0, 0);                                                                 \
         } else {                                                                                \
@@ -1385,11 +1221,11 @@ int launch_backward(const unsigned long long *masks, const unsigned char *cells,
 #define SPT_KEYS(GT, MODE, HALF)                                                                \
     do {                                                                                        \
         SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
-            (const void *)attention_mfma_backward_keys_kernel<GT, MODE>,                        \
+            (const void *)attention_mfma_backward_keys_kernel<T, GT, MODE>,                     \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));                           \
-        hipLaunchKernelGGL((attention_mfma_backward_keys_kernel<GT, MODE>), grid, block, lds_k, \
-                           s, masks, cells_t, pool_t, q, k, v, grad_y, row_sum, delta, grad_k,  \
-                           grad_v, S, scale, clamp, heads, bpb, HALF);                          \
+        hipLaunchKernelGGL((attention_mfma_backward_keys_kernel<T, GT, MODE>), grid, block,     \
+                           lds_k, s, masks, cells_t, pool_t, q, k, v, grad_y, row_sum, delta,   \
+                           grad_k, grad_v, S, scale, clamp, heads, bpb, HALF);                  \
     } while (0)
     if (transposed) SPT_MB(true);
     else SPT_MB(false);
@@ -1399,17 +1235,50 @@ int launch_backward(const unsigned long long *masks, const unsigned char *cells,
     return SPT_OK;
 }
 
+// dtype: SPT_F32 (float tensors) or SPT_BF16 (bf16 storage; row_sum and delta stay fp32)
+int launch_forward(const unsigned long long *masks, const unsigned char *cells,
+                   const unsigned char *pool, int dtype, const void *q, const void *k,
+                   const void *v, void *y, float *row_sum, int batch_size, int S, float scale,
+                   float clamp, int heads, int y_transposed, hipStream_t s) {
+    if (dtype == SPT_BF16)
+        return launch_forward_t<bf16_t>(masks, cells, pool, (const bf16_t *)q, (const bf16_t *)k,
+                                        (const bf16_t *)v, (bf16_t *)y, row_sum, batch_size, S,
+                                        scale, clamp, heads, y_transposed, s);
+    return launch_forward_t<float>(masks, cells, pool, (const float *)q, (const float *)k,
+                                   (const float *)v, (float *)y, row_sum, batch_size, S, scale,
+                                   clamp, heads, y_transposed, s);
+}
+
+int launch_backward(const unsigned long long *masks, const unsigned char *cells,
+                    const unsigned char *cells_t, const unsigned char *pool,
+                    const unsigned char *pool_t, int dtype, const void *q, const void *k,
+                    const void *v, const void *y, const void *grad_y, const float *row_sum,
+                    float *delta, void *grad_q, void *grad_k, void *grad_v, int batch_size, int S,
+                    float scale, float clamp, int heads, int transposed, hipStream_t s) {
+    if (dtype == SPT_BF16)
+        return launch_backward_t<bf16_t>(masks, cells, cells_t, pool, pool_t, (const bf16_t *)q,
+                                         (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)y,
+                                         (const bf16_t *)grad_y, row_sum, delta, (bf16_t *)grad_q,
+                                         (bf16_t *)grad_k, (bf16_t *)grad_v, batch_size, S, scale,
+                                         clamp, heads, transposed, s);
+    return launch_backward_t<float>(masks, cells, cells_t, pool, pool_t, (const float *)q,
+                                    (const float *)k, (const float *)v, (const float *)y,
+                                    (const float *)grad_y, row_sum, delta, (float *)grad_q,
+                                    (float *)grad_k, (float *)grad_v, batch_size, S, scale, clamp,
+                                    heads, transposed, s);
+}
+
 #if MA_E_VALUE == 64
 namespace e128 {
 int launch_forward(const unsigned long long *masks, const unsigned char *cells,
-                   const unsigned char *pool, const float *q,
-                   const float *k, const float *v, float *y, float *row_sum, int batch_size,
-                   int S, float scale, float clamp, int heads, int y_transposed, hipStream_t s);
+                   const unsigned char *pool, int dtype, const void *q, const void *k,
+                   const void *v, void *y, float *row_sum, int batch_size, int S, float scale,
+                   float clamp, int heads, int y_transposed, hipStream_t s);
 int launch_backward(const unsigned long long *masks, const unsigned char *cells,
                     const unsigned char *cells_t, const unsigned char *pool,
-                    const unsigned char *pool_t, const float *q, const float *k, const float *v,
-                    const float *y, const float *grad_y, const float *row_sum, float *delta,
-                    float *grad_q, float *grad_k, float *grad_v, int batch_size, int S,
+                    const unsigned char *pool_t, int dtype, const void *q, const void *k,
+                    const void *v, const void *y, const void *grad_y, const float *row_sum,
+                    float *delta, void *grad_q, void *grad_k, void *grad_v, int batch_size, int S,
                     float scale, float clamp, int heads, int transposed, hipStream_t s);
 }  // namespace e128
 
@@ -1498,11 +1367,10 @@ extern "C" int spt_attention_mfma_prepare(const int32_t *indices, void *tiles, i
     return SPT_OK;
 }
 
-extern "C" int spt_attention_mfma_forward(const void *tiles, int layout, const float *q,
-                                          const float *k, const float *v, float *y,
-                                          float *row_sum, int batch_size, int seq_length,
-                                          int d_head, int nnz, float scale, float clamp, int heads,
-                                          int y_transposed, void *stream) {
+static int mfma_forward_any(const void *tiles, int layout, int dtype, const void *q,
+                            const void *k, const void *v, void *y, float *row_sum,
+                            int batch_size, int seq_length, int d_head, int nnz, float scale,
+                            float clamp, int heads, int y_transposed, void *stream) {
     using namespace spt;
     if (!tiles || !q || !k || !v || !y || !row_sum) return SPT_EINVAL;
     if (batch_size <= 0 || heads < 0) return SPT_EINVAL;
@@ -1512,19 +1380,17 @@ extern "C" int spt_attention_mfma_forward(const void *tiles, int layout, const f
     const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length, layout);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return d_head == 64
-               ? launch_forward(ts.masks, ts.cells, ts.pool, q, k, v, y, row_sum, batch_size,
-                                seq_length, scale, clamp, heads, y_transposed, s)
-               : e128::launch_forward(ts.masks, ts.cells, ts.pool, q, k, v, y, row_sum, batch_size,
-                                      seq_length, scale, clamp, heads, y_transposed, s);
+               ? launch_forward(ts.masks, ts.cells, ts.pool, dtype, q, k, v, y, row_sum,
+                                batch_size, seq_length, scale, clamp, heads, y_transposed, s)
+               : e128::launch_forward(ts.masks, ts.cells, ts.pool, dtype, q, k, v, y, row_sum,
+                                      batch_size, seq_length, scale, clamp, heads, y_transposed, s);
 }
 
-extern "C" int spt_attention_mfma_backward(const void *tiles, int layout, const float *q,
-                                           const float *k, const float *v, const float *y,
-                                           const float *grad_y, const float *row_sum, float *delta,
-                                           float *grad_q, float *grad_k, float *grad_v,
-                                           int batch_size, int seq_length, int d_head, int nnz,
-                                           float scale, float clamp, int heads, int transposed,
-                                           void *stream) {
+static int mfma_backward_any(const void *tiles, int layout, int dtype, const void *q,
+                             const void *k, const void *v, const void *y, const void *grad_y,
+                             const float *row_sum, float *delta, void *grad_q, void *grad_k,
+                             void *grad_v, int batch_size, int seq_length, int d_head, int nnz,
+                             float scale, float clamp, int heads, int transposed, void *stream) {
     using namespace spt;
     if (!tiles || !q || !k || !v || !y || !grad_y || !row_sum || !delta || !grad_q || !grad_k ||
         !grad_v)
@@ -1537,11 +1403,54 @@ extern "C" int spt_attention_mfma_backward(const void *tiles, int layout, const 
     const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length, layout);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return d_head == 64
-               ? launch_backward(ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, q, k, v, y,
-                                 grad_y, row_sum, delta, grad_q, grad_k, grad_v, batch_size,
+               ? launch_backward(ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, dtype, q, k,
+                                 v, y, grad_y, row_sum, delta, grad_q, grad_k, grad_v, batch_size,
                                  seq_length, scale, clamp, heads, transposed, s)
-               : e128::launch_backward(ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, q, k, v,
-                                       y, grad_y, row_sum, delta, grad_q, grad_k, grad_v,
+               : e128::launch_backward(ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, dtype,
+                                       q, k, v, y, grad_y, row_sum, delta, grad_q, grad_k, grad_v,
                                        batch_size, seq_length, scale, clamp, heads, transposed, s);
+}
+
+extern "C" int spt_attention_mfma_forward(const void *tiles, int layout, const float *q,
+                                          const float *k, const float *v, float *y,
+                                          float *row_sum, int batch_size, int seq_length,
+                                          int d_head, int nnz, float scale, float clamp, int heads,
+                                          int y_transposed, void *stream) {
+    return mfma_forward_any(tiles, layout, SPT_F32, q, k, v, y, row_sum, batch_size, seq_length,
+                            d_head, nnz, scale, clamp, heads, y_transposed, stream);
+}
+
+extern "C" int spt_attention_mfma_backward(const void *tiles, int layout, const float *q,
+                                           const float *k, const float *v, const float *y,
+                                           const float *grad_y, const float *row_sum, float *delta,
+                                           float *grad_q, float *grad_k, float *grad_v,
+                                           int batch_size, int seq_length, int d_head, int nnz,
+                                           float scale, float clamp, int heads, int transposed,
+                                           void *stream) {
+    return mfma_backward_any(tiles, layout, SPT_F32, q, k, v, y, grad_y, row_sum, delta, grad_q,
+                             grad_k, grad_v, batch_size, seq_length, d_head, nnz, scale, clamp,
+                             heads, transposed, stream);
+}
+
+extern "C" int spt_attention_mfma_forward_bf16(const void *tiles, int layout, const uint16_t *q,
+                                               const uint16_t *k, const uint16_t *v, uint16_t *y,
+                                               float *row_sum, int batch_size, int seq_length,
+                                               int d_head, int nnz, float scale, float clamp,
+                                               int heads, int y_transposed, void *stream) {
+    return mfma_forward_any(tiles, layout, SPT_BF16, q, k, v, y, row_sum, batch_size, seq_length,
+                            d_head, nnz, scale, clamp, heads, y_transposed, stream);
+}
+
+extern "C" int spt_attention_mfma_backward_bf16(const void *tiles, int layout, const uint16_t *q,
+                                                const uint16_t *k, const uint16_t *v,
+                                                const uint16_t *y, const uint16_t *grad_y,
+                                                const float *row_sum, float *delta,
+                                                uint16_t *grad_q, uint16_t *grad_k,
+                                                uint16_t *grad_v, int batch_size, int seq_length,
+                                                int d_head, int nnz, float scale, float clamp,
+                                                int heads, int transposed, void *stream) {
+    return mfma_backward_any(tiles, layout, SPT_BF16, q, k, v, y, grad_y, row_sum, delta, grad_q,
+                             grad_k, grad_v, batch_size, seq_length, d_head, nnz, scale, clamp,
+                             heads, transposed, stream);
 }
 #endif

@@ -24,6 +24,9 @@
         if (e__ != hipSuccess) return (int)e__;    \
     } while (0)
 
+// element type of the dense attention operands (mfma_attention.hip)
+enum { SPT_F32 = 0, SPT_BF16 = 1 };
+
 namespace spt {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (SPT_WAVE - 1); }

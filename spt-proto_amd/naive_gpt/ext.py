@@ -35,6 +35,7 @@ _PROTOTYPES = {
     'spt_cdist_backward': ([_c_ptr] * 6 + [_c_int] * 4 + [_c_ptr], _c_int),
     'spt_lookup_forward': ([_c_ptr] * 3 + [_c_int] * 4 + [_c_ptr], _c_int),
     'spt_pq_encode_heads': ([_c_ptr] * 3 + [_c_int] * 6 + [_c_ptr], _c_int),
+    'spt_pq_encode_heads_bf16': ([_c_ptr] * 3 + [_c_int] * 6 + [_c_ptr], _c_int),
     'spt_pq_loss_workspace_bytes': ([ctypes.c_int64] + [_c_int] * 3, ctypes.c_int64),
     'spt_pq_loss_forward': ([_c_ptr] * 4 + [ctypes.c_int64] + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_pq_loss_backward': ([_c_ptr] * 6 + [ctypes.c_int64] + [_c_int] * 3 + [_c_ptr], _c_int),
@@ -60,6 +61,10 @@ _PROTOTYPES = {
                                    [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int),
     'spt_attention_mfma_backward': ([_c_ptr, _c_int] + [_c_ptr] * 10 + [_c_int] * 4 +
                                     [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int),
+    'spt_attention_mfma_forward_bf16': ([_c_ptr, _c_int] + [_c_ptr] * 5 + [_c_int] * 4 +
+                                        [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int),
+    'spt_attention_mfma_backward_bf16': ([_c_ptr, _c_int] + [_c_ptr] * 10 + [_c_int] * 4 +
+                                         [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int),
     'spt_grouped_gemm_fused': ([_c_ptr, _c_ptr], _c_int),
     'spt_grouped_gemm_pdot_width': ([_c_int], _c_int),
     'spt_grouped_gemm_image_path': ([_c_ptr], _c_int),
@@ -72,7 +77,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _lib = None
 
@@ -278,10 +283,11 @@ def head_layout_supported(S: int, E: int, B: int) -> bool:
 
 
 def pq_encode_heads(z: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
-    """z [N, S, H, E] fp32 -> PQ codes [N * H, S, M] int32 (``spt_pq_encode_heads``)."""
+    """z [N, S, H, E] fp32 (or bf16 storage: widened exactly, same arithmetic) -> PQ codes
+    [N * H, S, M] int32 (``spt_pq_encode_heads`` / ``_bf16``)."""
     _check_dim(z, 4, 'z')
     _check_dim(table, 3, 'table')
-    _check_type(z, torch.float32, 'z')
+    _require(z.dtype in (torch.float32, torch.bfloat16), 'z: float32 or bfloat16')
     _check_type(table, torch.float32, 'table')
     dev = _same_device(z, table)
     N, S, H, E = z.shape
@@ -290,8 +296,8 @@ def pq_encode_heads(z: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
     lib = load_library()
     with torch.cuda.device(dev):
         codes = torch.empty([N * H, S, M], dtype=torch.int32, device=dev)
-        rc = lib.spt_pq_encode_heads(z.data_ptr(), table.data_ptr(), codes.data_ptr(),
-                                     N, S, H, M, C, D, _stream(dev))
+        fn = lib.spt_pq_encode_heads if z.dtype == torch.float32 else lib.spt_pq_encode_heads_bf16
+        rc = fn(z.data_ptr(), table.data_ptr(), codes.data_ptr(), N, S, H, M, C, D, _stream(dev))
     if rc != 0:
         _raise(lib, rc, 'pq_encode_heads')
     return codes
@@ -497,7 +503,8 @@ def attention_mfma_forward(tiles, q: torch.Tensor, k: torch.Tensor, v: torch.Ten
     (``y_transposed``) ``[N*H, E, S]`` and the softmax denominators ``[N*H, S]`` the backward
     needs; no ``[N*H, nnz]`` array is produced."""
     _check_dim(q, 4, 'q')
-    _check_type(q, torch.float32, 'q')
+    _require(q.dtype in (torch.float32, torch.bfloat16), 'q: float32 or bfloat16 (bf16 storage)')
+    _require(q.dtype == k.dtype == v.dtype, 'q, k, v: same dtype')
     _require(q.shape == k.shape == v.shape, 'q, k, v: same shape')
     _require(q.is_contiguous() and k.is_contiguous() and v.is_contiguous(), 'contiguous operands')
     N, S, H, E = q.shape
@@ -509,9 +516,11 @@ def attention_mfma_forward(tiles, q: torch.Tensor, k: torch.Tensor, v: torch.Ten
     dev = _same_device(tiles.buffer, q, k, v)
     lib = load_library()
     with torch.cuda.device(dev):
-        y = torch.empty([B, E, S] if y_transposed else [B, S, E], dtype=torch.float32, device=dev)
+        y = torch.empty([B, E, S] if y_transposed else [B, S, E], dtype=q.dtype, device=dev)
         row_sum = torch.empty([B, S], dtype=torch.float32, device=dev)
-        rc = lib.spt_attention_mfma_forward(
+        fn = (lib.spt_attention_mfma_forward if q.dtype == torch.float32
+              else lib.spt_attention_mfma_forward_bf16)
+        rc = fn(
             tiles.buffer.data_ptr(), tiles.layout, q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(),
             row_sum.data_ptr(), B, S, E, tiles.nnz, float(scale), float(clamp), H,
             int(bool(y_transposed)), _stream(dev))
@@ -528,7 +537,9 @@ def attention_mfma_backward(tiles: MfmaTiles, q: torch.Tensor, k: torch.Tensor, 
     y, grad_y: the forward's output and its gradient, ``[N*H, S, E]`` or (``transposed``)
     ``[N*H, E, S]``.  Returns ``(grad_q, grad_k, grad_v)``, each ``[N, S, H, E]``."""
     _check_dim(q, 4, 'q')
-    _check_type(q, torch.float32, 'q')
+    _require(q.dtype in (torch.float32, torch.bfloat16), 'q: float32 or bfloat16 (bf16 storage)')
+    _require(q.dtype == k.dtype == v.dtype == y.dtype == grad_y.dtype, 'q, k, v, y, grad_y: same dtype')
+    _check_type(row_sum, torch.float32, 'row_sum')
     _require(q.shape == k.shape == v.shape, 'q, k, v: same shape')
     for t in (q, k, v, y, grad_y, row_sum):
         _require(t.is_contiguous(), 'contiguous operands')
@@ -542,7 +553,9 @@ def attention_mfma_backward(tiles: MfmaTiles, q: torch.Tensor, k: torch.Tensor, 
     with torch.cuda.device(dev):
         grad_q, grad_k, grad_v = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         delta = torch.empty([B, S], dtype=torch.float32, device=dev)
-        rc = lib.spt_attention_mfma_backward(
+        fn = (lib.spt_attention_mfma_backward if q.dtype == torch.float32
+              else lib.spt_attention_mfma_backward_bf16)
+        rc = fn(
             tiles.buffer.data_ptr(), tiles.layout, q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(),
             grad_y.data_ptr(), row_sum.data_ptr(), delta.data_ptr(), grad_q.data_ptr(),
             grad_k.data_ptr(), grad_v.data_ptr(), B, S, E, tiles.nnz, float(scale), float(clamp),

@@ -94,6 +94,128 @@ def test_mfma_backward_matches_oracle_chain(N, H, S, Z, E, gt):
             (name, err, want.abs().max().item())
 
 
+BF16_SHAPES = [                        # (N, H, S, Z, d_head): bf16 storage (BASELINE configs[1] "bf16")
+    (2, 16, 512, 64, 64), (1, 4, 80, 8, 64), (1, 2, 2048, 256, 64),
+    (2, 8, 512, 64, 128), (1, 2, 1024, 128, 128),
+]
+# Tolerances of the bf16-storage path.  The kernels compute on the widened inputs exactly as the
+# fp32 path does (stored values are their own matrix-core operands; everything computed on the way
+# is fp32 split in two), so BEFORE the store the result is within the fp32 path's 1e-3 of the
+# oracle run on the bf16-rounded inputs; the store rounds once to nearest-even bf16, a relative
+# 2^-9 per element.  Bar: |got - want| <= 1e-3 max|want| + 2^-8 |want|.
+BF16_ULP = 2.0 ** -8
+
+
+def _close_bf16(got, want, name):
+    got = got.float().cpu()
+    bound = 1e-3 * want.abs().max() + BF16_ULP * want.abs()
+    err = (got - want).abs()
+    assert (err <= bound).all(), (name, (err - bound).max().item(), want.abs().max().item())
+
+
+@pytest.mark.parametrize('yt', [False, True])
+@pytest.mark.parametrize('N,H,S,Z,E', BF16_SHAPES)
+def test_mfma_forward_bf16_storage_matches_oracle_on_rounded_inputs(N, H, S, Z, E, yt):
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(N * S + Z + 1)
+    q, k, v = [torch.randn([N, S, H, E], generator=gen) for _ in range(3)]
+    q = q * 3.0                                    # some scores beyond the clamp
+    q, k, v = [t.bfloat16() for t in (q, k, v)]
+    indices = causal_indices(N * H, S, Z, gen)
+    scale = E ** -0.5
+    want_scores, _, want_y = oracle_chain(indices, q.float(), k.float(), v.float(), scale)
+    y, row_sum = ext.attention_mfma_forward(indices.cuda(), q.cuda(), k.cuda(), v.cuda(),
+                                            scale, CLAMP, y_transposed=yt)
+    assert y.dtype == torch.bfloat16 and row_sum.dtype == torch.float32
+    if yt:
+        assert y.shape == (N * H, E, S)
+        y = y.transpose(1, 2)
+    rows = torch.arange(S).view(1, S, 1)
+    live = (indices.view(N * H, S, Z) <= rows).float()
+    want_sum = (want_scores.view(N * H, S, Z).exp() * live).sum(-1)
+    # a row that is column 0 Z = 256 times (row 0; row 1 when both of its draws are 0): the
+    # byte-sized cell count saturates at 255 (include/spt_hip.h), the row sum is 255 / 256 of exact
+    full = (indices.view(N * H, S, Z) == 0).sum(-1) > 255
+    want_sum = torch.where(full, want_sum * (255 / 256), want_sum)
+    assert torch.allclose(row_sum.cpu(), want_sum, rtol=1e-4)
+    _close_bf16(y, want_y, 'y')
+    # and the fp32 kernels on the widened inputs give the same values before the store's rounding
+    y32, rs32 = ext.attention_mfma_forward(indices.cuda(), q.float().cuda(), k.float().cuda(),
+                                           v.float().cuda(), scale, CLAMP, y_transposed=yt)
+    if yt:
+        y32 = y32.transpose(1, 2)
+    assert torch.allclose(row_sum, rs32, rtol=1e-5)
+    assert ((y.float() - y32).abs() <= BF16_ULP * y32.abs() + 5e-5 * y32.abs().max()).all()
+
+
+@pytest.mark.parametrize('gt', [False, True])
+@pytest.mark.parametrize('N,H,S,Z,E', BF16_SHAPES)
+def test_mfma_backward_bf16_storage_matches_oracle_on_rounded_inputs(N, H, S, Z, E, gt):
+    import numpy as np
+    from oracle import ext_stub
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(7 * N + S + Z + 1)
+    B = N * H
+    q, k, v = [torch.randn([N, S, H, E], generator=gen) for _ in range(3)]
+    q = q * 3.0
+    gy = torch.randn([B, S, E], generator=gen)
+    q, k, v, gy = [t.bfloat16() for t in (q, k, v, gy)]
+    indices = causal_indices(B, S, Z, gen)
+    scale = E ** -0.5
+    tiles = ext.attention_mfma_prepare(indices.cuda(), S)
+    y, row_sum = ext.attention_mfma_forward(tiles, q.cuda(), k.cuda(), v.cuda(), scale, CLAMP,
+                                            y_transposed=gt)
+    gy_in = gy.transpose(1, 2).contiguous() if gt else gy
+    gq, gk, gv = ext.attention_mfma_backward(tiles, q.cuda(), k.cuda(), v.cuda(), y, gy_in.cuda(),
+                                             row_sum, scale, CLAMP, transposed=gt)
+    assert gq.dtype == gk.dtype == gv.dtype == torch.bfloat16
+    # oracle on the widened inputs.  delta = dY . Y uses the y the backward is GIVEN (the stored,
+    # bf16-rounded one), as autograd would hand it over: the oracle's softmax backward forms the
+    # same sum from P and dP, i.e. from the unrounded y -- the difference is one more 2^-9-relative
+    # perturbation of delta, inside the bar below
+    qf, kf, vf, gyf = q.float(), k.float(), v.float(), gy.float()
+    scores, attn, _ = oracle_chain(indices, qf, kf, vf, scale)
+    flat = lambda t: t.transpose(1, 2).contiguous().view(B, S, E)       # noqa: E731
+    heads = lambda t: t.view(N, H, S, E).transpose(1, 2)                  # noqa: E731
+    indptr = torch.arange(0, S * Z + 1, Z, dtype=torch.int32)
+    f, t = torch.scalar_tensor(False), torch.scalar_tensor(True)
+    dp = ext_stub.sddmm_forward_cuda(f, t, indptr, indices, gyf, flat(vf))
+    ds = ext_stub.softmax_backward_cuda(indptr, indices, attn, dp)
+    raw = torch.where(scores.abs() < CLAMP, ds * np.float32(scale), torch.zeros_like(ds))
+    want_q = heads(ext_stub.spmm_forward_cuda(f, f, indptr, indices, raw, flat(kf)))
+    want_k = heads(ext_stub.spmm_forward_cuda(t, f, indptr, indices, raw, flat(qf)))
+    want_v = heads(ext_stub.spmm_forward_cuda(t, f, indptr, indices, attn, gyf))
+    for got, want, name in ((gq, want_q, 'grad_q'), (gk, want_k, 'grad_k'), (gv, want_v, 'grad_v')):
+        got = got.float().cpu()
+        bound = 4e-3 * want.abs().max() + BF16_ULP * want.abs()
+        err = (got - want).abs()
+        assert (err <= bound).all(), (name, (err - bound).max().item(), want.abs().max().item())
+    # sharper: against the fp32 kernels on the widened inputs AND the widened stored y
+    y32 = y.float()
+    g32 = ext.attention_mfma_backward(tiles, qf.cuda(), kf.cuda(), vf.cuda(), y32, gy_in.float().cuda(),
+                                      row_sum, scale, CLAMP, transposed=gt)
+    for got, ref, name in zip((gq, gk, gv), g32, ('grad_q', 'grad_k', 'grad_v')):
+        assert ((got.float() - ref).abs() <= BF16_ULP * ref.abs() + 5e-5 * ref.abs().max()).all(), name
+
+
+def test_bf16_storage_codes_equal_the_codes_of_the_widened_values():
+    """PQ codes from bf16 storage are those of the fp32 operator on the widened values, bit for
+    bit (and those of the oracle on them)."""
+    import numpy as np
+    from oracle import oracle as O
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(5)
+    N, S, H, E, M, C = 2, 128, 4, 64, 8, 16
+    z = torch.randn([N, S, H, E], generator=gen).bfloat16()
+    table = torch.randn([M, C, E // M], generator=gen)
+    got = ext.pq_encode_heads(z.cuda(), table.cuda())
+    ref = ext.pq_encode_heads(z.float().cuda(), table.cuda())
+    assert torch.equal(got, ref)
+    zq = z.float().permute(0, 2, 1, 3).reshape(N * H * S, M, E // M).permute(1, 0, 2).contiguous().numpy()
+    _, codes = O.cdist_forward(zq, table.numpy())
+    assert np.array_equal(got.cpu().numpy().reshape(N * H * S, M), codes.T)
+
+
 def test_mfma_forward_masks_columns_beyond_the_row():
     from naive_gpt import ext
     gen = torch.Generator().manual_seed(4)
