@@ -318,16 +318,19 @@ def block_record(tuning, args, dev):
 
 
 # ------------------------------------------------------------- configs[1]: attention only
-def attention_record(args, dev):
+def attention_record(args, dev, dtype=torch.float32):
     """BASELINE.json configs[1]: `SparseVanillaAttentionV2` fwd + bwd on randn[N, S, H, E]
     (cdist / lookup / sddmm / softmax / spmm), its dominant kernel against the HBM roofline,
-    dense causal attention beside it."""
+    dense causal attention beside it.  dtype bfloat16: q, k, v (and y, the gradients) stored
+    bf16, both for the sparse layer and for its dense counterpart."""
     from naive_gpt import ext, layers
     N = args.batch
     torch.manual_seed(0)
     attn = layers.SparseVanillaAttentionV2(d_head=E, d_codeword=D, n_codewords=C,
                                            p_dropout=0.0).to(dev)
-    q, k, v = [torch.randn([N, S, H, E], device=dev, requires_grad=True) for _ in range(3)]
+    q, k, v = [torch.randn([N, S, H, E], device=dev).to(dtype).requires_grad_(True) for _ in range(3)]
+    eb = 2 if dtype == torch.bfloat16 else 4
+    name = 'bf16 storage' if dtype == torch.bfloat16 else 'fp32'
 
     events = []
     orig_bwd = ext.attention_mfma_backward
@@ -354,19 +357,20 @@ def attention_record(args, dev):
     timed_loop(step, 50, 0, 1)
     ext.attention_mfma_backward = orig_bwd
     B = N * H
-    rec = {'workload': 'BASELINE.json configs[1]: BERT-large sparse-MHA only, fwd+bwd, fp32',
+    rec = {'workload': 'BASELINE.json configs[1]: BERT-large sparse-MHA only, fwd+bwd, ' + name,
+           'dtype': 'bf16' if dtype == torch.bfloat16 else 'f32',
            'value': N * S * steps / dt, 'unit': 'tokens/s', 'ms_per_step': 1e3 * dt / steps,
            'peak_hbm_gb': peak}
     if events:
         us = 1e3 * float(np.mean([a.elapsed_time(b) for a, b in events]))
-        nbytes = (8 * S * E * 4 + S * Z * 4) * B       # q k v dY y read, 3 gradients written, CSR
+        nbytes = (8 * S * E * eb + S * Z * 4) * B      # q k v dY y read, 3 gradients written, CSR
         rec['roofline'] = {'kernel': 'attention_mfma_backward (two launches)', 'bound': 'hbm',
                            'achieved': nbytes / (us * 1e-6) / 1e9, 'peak': HBM_PEAK_GBS,
                            'unit': 'GB/s', 'frac': nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                            'avg_us': us, 'bytes_per_launch': nbytes}
     del attn
     dense = layers.VanillaAttention(d_head=E, p_dropout=0.0).to(dev)
-    mask = torch.full([S, S], float('-inf'), device=dev).triu(1)
+    mask = torch.full([S, S], float('-inf'), device=dev, dtype=dtype).triu(1)
 
     def dense_step():
         for t in (q, k, v):
@@ -570,6 +574,10 @@ def main():
         result['block'] = blk
     if single and not args.no_attention:
         result['attention'] = attention_record(args, dev)
+        try:          # the same workload with bf16 storage (configs[1] "fp32 and bf16")
+            result['attention_bf16'] = attention_record(args, dev, torch.bfloat16)
+        except Exception as exc:
+            result['attention_bf16'] = {'error': repr(exc)}
     if single and not args.no_graph:
         # the HIP-graph records come last (a captured graph's memory pool outlives its record)
         # and must never cost the line

@@ -237,8 +237,11 @@ class _SparseCore:
         n, s, h, e = t.shape
         # (n * h >= 32 as for the other head-layout kernels: below that the launch cannot fill
         # the GPU, and small direct calls of _get_attn keep returning the reference's triple)
-        return (t.is_cuda and t.dtype == torch.float32 and s % 4 == 0 and s % SPARSE_COEFF == 0
-                and n * h >= 32 and ext.attention_mfma_supported(s, e, s * (s // SPARSE_COEFF)))
+        # bf16: the bf16-storage build of the same kernels (BASELINE configs[1] "bf16"); it is the
+        # only path that takes bf16 tensors, so there the shape must fit or the layer raises
+        return (t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and s % 4 == 0
+                and s % SPARSE_COEFF == 0 and (n * h >= 32 or t.dtype == torch.bfloat16)
+                and ext.attention_mfma_supported(s, e, s * (s // SPARSE_COEFF)))
 
     @staticmethod
     def _head_layout_ok(t: torch.Tensor) -> bool:
@@ -254,8 +257,9 @@ class _SparseCore:
         q, k = q.contiguous(), k.contiguous()
         if self._take_trigger():
             # the PQ loss is a mean over all sub-vectors: the head layout holds the same set
-            loss_q = self.quantizer.train_loss(q)
-            loss_k = self.quantizer.train_loss(k)
+            # (bf16 storage: the loss is formed in fp32 from the widened values)
+            loss_q = self.quantizer.train_loss(q.float())
+            loss_k = self.quantizer.train_loss(k.float())
             self.register_buffer('loss', loss_q + loss_k, persistent=False)
         table = self.quantizer.weight.detach()
         q_c = ext.pq_encode_heads(q.detach(), table)
@@ -278,6 +282,9 @@ class _SparseCore:
         assert q.size() == k.size()
         if self._head_layout_ok(q) and self.quantizer.method == 'v2':
             return self._sparse_attn_heads(q, k)
+        if q.dtype != torch.float32:
+            raise RuntimeError('sparse attention: {} tensors only on the matrix-core path (cuda, '
+                               'PQ v2, d_head 64 / 128, S <= 2048, S % 32 == 0)'.format(q.dtype))
         seq_length = q.size(1)
         q = q.transpose(1, 2).contiguous()
         k = k.transpose(1, 2).contiguous()

@@ -318,6 +318,48 @@ def test_layer_through_mfma_kernels_equals_separate_operators(kind, monkeypatch)
         assert torch.allclose(a, b, rtol=1e-3, atol=2e-4 * b.abs().max().item()), name
 
 
+@pytest.mark.parametrize('kind', ['vanilla', 'rotary'])
+def test_layer_with_bf16_storage_equals_the_fp32_layer_on_the_widened_values(kind):
+    """BASELINE configs[1] "bf16": q, k, v stored bf16.  PQ codes and the CSR structure are those
+    of the fp32 layer on the widened values bit for bit; y and the gradients agree to the
+    rounding of the stored results (the rotary variant rotates q, k in bf16 first: compared
+    after that step, on what the sparse core is given)."""
+    from naive_gpt import layers
+    torch.manual_seed(0)
+    cls = layers.SparseVanillaAttentionV2 if kind == 'vanilla' else layers.SparseRotaryAttentionV2
+    attn = cls(d_head=64, d_codeword=8, n_codewords=16, p_dropout=0.0).cuda()
+    N, S, H = 2, 256, 16
+    q, k, v, w = [torch.randn([N, S, H, 64], device='cuda').bfloat16() for _ in range(4)]
+    got_attn = attn._sparse_attn(q, k)
+    want_attn = attn._sparse_attn(q.float(), k.float())
+    assert got_attn[0] == want_attn[0] == 'mfma'
+    assert torch.equal(got_attn[2], want_attn[2])                 # CSR column indices, bit-exact
+    if kind == 'rotary':
+        return
+
+    def run(cast):
+        qi, ki, vi = [cast(t).clone().requires_grad_(True) for t in (q, k, v)]
+        y = attn(qi, ki, vi, attn_mask=None)
+        (y * cast(w)).sum().backward()
+        return y.detach(), qi.grad, ki.grad, vi.grad
+
+    low, full = run(lambda t: t), run(lambda t: t.float())
+    assert low[0].dtype == torch.bfloat16 and low[1].dtype == torch.bfloat16
+    for a, b, name in zip(low, full, ['y', 'grad_q', 'grad_k', 'grad_v']):
+        # (the bf16 backward is handed the ROUNDED y and a bf16 grad_y = w: 4e-3 as in the
+        # operator test above)
+        bound = 4e-3 * b.abs().max() + BF16_ULP * b.abs()
+        assert ((a.float() - b).abs() <= bound).all(), name
+
+
+def test_bf16_storage_outside_the_matrix_core_path_is_refused():
+    from naive_gpt import layers
+    attn = layers.SparseVanillaAttentionV2(d_head=32, d_codeword=8, n_codewords=16, p_dropout=0.0).cuda()
+    q = torch.randn([2, 128, 16, 32], device='cuda').bfloat16()
+    with pytest.raises(RuntimeError):
+        attn(q, q, q, attn_mask=None)
+
+
 def test_host_side_arming_equals_the_reference_protocol():
     """module.arm() (no device read-back in the next forward) against the reference's
     `module.trigger.fill_(True)`: same loss buffer, trigger disarmed afterwards, one-shot."""
