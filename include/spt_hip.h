@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 19
+#define SPT_ABI_VERSION 20
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -454,6 +454,21 @@ int spt_grouped_gemm_image_path(const SptGroupedGemm *desc);
 size_t spt_split_bf16_bytes(long long rows, int cols);
 int spt_split_bf16(const float *src, void *image, long long rows, int cols, long long ld,
                    void *stream);
+
+/*
+ * The rank-r down product of the LoRA adapters (naive_gpt/layers/tuning/lora.py:70-80,
+ * lora_ffn.py:87-111) as a single pass over the tall activation (lora_side.hip):
+ *   spt_lora_down  u[rows, n] = x[rows, k] . l[k, n]   (x row stride ldx floats; l, u contiguous;
+ *                  u_block_major != 0: u is n / 16 matrices [rows, 16] one after the other --
+ *                  several adapters' tables side by side in l, each adapter's u contiguous);
+ *                  optional by-products of the same read: `image` (spt_split_bf16's layout,
+ *                  spt_split_bf16_bytes(rows, k) bytes) and `norms` [rows] (row 2-norms) -- NULL
+ *                  to skip.  k % 1024 == 0, n in {16, 32, 48, 64}: SPT_EUNSUP otherwise (callers
+ *                  then use a library GEMM).
+ * Split-bf16 matrix-core products as in spt_grouped_gemm: <= 2^-16 relative per product.
+ */
+int spt_lora_down(const float *x, long long ldx, long long rows, int k, const float *l, int n,
+                  float *u, int u_block_major, void *image, float *norms, void *stream);
 
 /*
  * Bucketing for the routed FFN: the k largest of the n_blocks router probabilities of every

@@ -71,13 +71,15 @@ _PROTOTYPES = {
     'spt_split_bf16_bytes': ([ctypes.c_longlong, _c_int], ctypes.c_size_t),
     'spt_split_bf16': ([_c_ptr, _c_ptr, ctypes.c_longlong, _c_int, ctypes.c_longlong, _c_ptr], _c_int),
     'spt_rows_combine': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_lora_down': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_int,
+                       _c_ptr, _c_int] + [_c_ptr] * 3, _c_int),
     'spt_route_topk': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_forward': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_backward': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _lib = None
 
@@ -863,6 +865,30 @@ def image_of(x: torch.Tensor, owner: torch.Tensor = None) -> SplitImage:
     return img
 
 
+def cached_image(x: torch.Tensor, owner: torch.Tensor = None):
+    """The cached image `image_of(x, owner)` would return, or None."""
+    owner = x if owner is None else owner
+    if owner.is_inference():
+        return None
+    hit = _IMAGE_CACHE.get(id(owner))
+    if hit is not None and hit[0]() is owner and hit[1] == (owner._version, tuple(x.shape)):
+        return hit[2]
+    return None
+
+
+def put_image(x: torch.Tensor, owner: torch.Tensor, img: SplitImage) -> None:
+    """Hand the cache an image made elsewhere (``lora_down(..., want_image=True)``)."""
+    owner = x if owner is None else owner
+    if owner.is_inference():
+        return
+    key = id(owner)
+    _IMAGE_CACHE[key] = (weakref.ref(owner, lambda _, k=key: _IMAGE_CACHE.pop(k, None)),
+                         (owner._version, tuple(x.shape)), img)
+    _IMAGE_CACHE.move_to_end(key)
+    while len(_IMAGE_CACHE) > IMAGE_CACHE_ENTRIES:
+        _IMAGE_CACHE.popitem(last=False)
+
+
 def drop_images():
     _IMAGE_CACHE.clear()
     _WEIGHT_IMAGES.clear()
@@ -1067,6 +1093,45 @@ def rows_combine(rows: torch.Tensor, pos: torch.Tensor, bias: torch.Tensor = Non
             if rc != 0:
                 _raise(lib, rc, 'rows_combine')
     return out
+
+
+def lora_down_supported(x: torch.Tensor, table: torch.Tensor) -> bool:
+    """Shapes ``spt_lora_down`` takes: a CUDA fp32 matrix with unit inner stride and 16-byte
+    aligned rows, K a multiple of 1024, 16 / 32 / 48 / 64 table columns."""
+    return (x.is_cuda and x.dtype == torch.float32 and table.dtype == torch.float32
+            and x.dim() == 2 and table.dim() == 2 and x.size(0) > 0
+            and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and x.size(1) == table.size(0) and x.size(1) % 1024 == 0
+            and table.size(1) % 16 == 0 and 0 < table.size(1) <= 64)
+
+
+def lora_down(x: torch.Tensor, table: torch.Tensor, want_image: bool = False,
+              want_norms: bool = False, block_major: bool = False):
+    """u = x @ table for a tall x [rows, K] and a table [K, n] of a few columns, as ONE pass over x
+    (``spt_lora_down``); the same pass can also leave x's split image (:class:`SplitImage`) and its
+    row 2-norms.  Returns u, or (u, image | None, norms | None) when a by-product is asked for.
+    ``block_major``: u as [n / 16, rows, 16] (tables of several rank-16 adapters side by side:
+    each adapter's product contiguous)."""
+    _require(lora_down_supported(x, table), 'lora_down: see lora_down_supported')
+    table = table.contiguous()
+    rows, k = x.shape
+    n = table.size(1)
+    dev = _same_device(x, table)
+    lib = load_library()
+    with torch.cuda.device(dev):
+        u = torch.empty([n // 16, rows, 16] if block_major else [rows, n], dtype=torch.float32, device=dev)
+        image = norms = None
+        if want_image:
+            image = SplitImage(torch.empty([lib.spt_split_bf16_bytes(rows, k)], dtype=torch.uint8,
+                                           device=dev), rows, k)
+        if want_norms:
+            norms = torch.empty([rows], dtype=torch.float32, device=dev)
+        rc = lib.spt_lora_down(x.data_ptr(), x.stride(0), rows, k, table.data_ptr(), n, u.data_ptr(),
+                               int(bool(block_major)), image.buffer.data_ptr() if want_image else None,
+                               _ptr(norms), _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'lora_down')
+    return (u, image, norms) if (want_image or want_norms) else u
 
 
 def softmax_backward_clamped(indptr: torch.Tensor, indices: torch.Tensor,

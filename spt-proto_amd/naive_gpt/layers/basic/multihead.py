@@ -10,6 +10,10 @@ def project_heads(module, q, k, v, attn_mask):
     ``[N,S,d] -> [N,S,H,E]``, run the attention core, merge, project out."""
     assert q.size(0) == k.size(0) == v.size(0)
     n_heads = module.n_heads
+    if q is k and k is v:
+        # self-attention: adapters on the three projections share one pass over the input
+        from ..tuning import lora
+        lora.prepare_shared(q, (module.linear_q, module.linear_k, module.linear_v))
     q = module.linear_q(q)
     k = module.linear_k(k)
     v = module.linear_v(v)

@@ -172,6 +172,17 @@ def _block_cat(table: torch.Tensor, n_blocks: int) -> torch.Tensor:
     return table.view(n_blocks, bs, -1).permute(1, 0, 2).reshape(bs, -1)
 
 
+def _down(a: torch.Tensor, table: torch.Tensor, want_image: bool, want_norms: bool):
+    """(a @ table, split image of a | None, row norms of a | None): one pass over `a`
+    (ext.lora_down) where its shapes allow, else the separate operators."""
+    if ext.lora_down_supported(a, table):
+        if want_image or want_norms:
+            return ext.lora_down(a, table, want_image=want_image, want_norms=want_norms)
+        return ext.lora_down(a, table), None, None
+    return (torch.matmul(a, table), ext.split_bf16(a) if want_image else None,
+            ext.row_norms(a) if want_norms else None)
+
+
 def _tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     from naive_gpt.layers.tuning.lora import tall_tn
     return tall_tn(a, b)
@@ -200,27 +211,26 @@ class RoutedLoRAFFN(torch.autograd.Function):
         d_ff, d = w1.shape
         bs, rank, rows = d_ff // nb, l1.size(1), bk.token.numel()
         x, coeff = x.contiguous(), coeff.contiguous()
-        u = torch.matmul(x, l1)                                              # [T, r]
-        # Both block GEMMs run from pre-split images (ext.split_bf16): the weights' are kept
-        # with the frozen parameters, x's and h's cost one pass each.  In front of a ReLU the
-        # kernel also wants the row norms of both operands (include/spt_hip.h: a_norm).
+        # Both block GEMMs run from pre-split images: the weights' are made from the frozen
+        # parameters, x's and h's cost one pass each -- the pass that also forms the LoRA down
+        # product and, in front of a ReLU, the row norms the kernel wants (include/spt_hip.h:
+        # a_norm): ext.lora_down, one read of the activation for all three.
         relu = act == ext.ACT_RELU
         imgs = _images_usable(x, w1, w2, d, bs)
+        u, x_img, x_norm = _down(x, l1, imgs, relu)                          # [T, r]
         h, s = ext.grouped_gemm_fused(
             x, w1, bk.offsets, nb, n=bs, k=d, w_group_stride=bs * d, w_ldn=d, w_ldk=1,
             n_rows=rows, gather=bk.token, bias=b1, rowscale=coeff,
             a2=u, gather2=bk.token, b2=r1, b2_group_stride=bs * rank,
             epilogue=ext.EPI_ACT, activation=act, keep_preact=not relu,
-            a_image=ext.split_bf16(x) if imgs else None,
-            w_image=ext.weight_image(w1) if imgs else None,
-            a_norm=ext.row_norms(x) if relu else None,
-            w_norm=ext.weight_row_norms(w1) if relu else None)
-        z = _own_block(torch.matmul(h, _block_cat(l2, nb)), bk.block, nb).contiguous()   # [P, r]
+            a_image=x_img, w_image=ext.weight_image(w1) if imgs else None,
+            a_norm=x_norm, w_norm=ext.weight_row_norms(w1) if relu else None)
+        zw, h_img, _ = _down(h, _block_cat(l2, nb), imgs, False)
+        z = _own_block(zw, bk.block, nb).contiguous()                        # [P, r]
         ys = ext.grouped_gemm_fused(
             h, w2, bk.offsets, nb, n=d, k=bs, w_group_stride=bs, w_ldn=d_ff, w_ldk=1,
             n_rows=rows, rowscale=coeff, a2=z, b2=r2, b2_group_stride=0,
-            a_image=ext.split_bf16(h) if imgs else None,
-            w_image=ext.weight_image(w2) if imgs else None)
+            a_image=h_img, w_image=ext.weight_image(w2) if imgs else None)
         y = ext.rows_combine(ys, bk.pos, bias=b2)
         ctx.bk, ctx.act = bk, act
         # x is a norm output the block can recompute: keep its origin instead (tuning/recompute.py)
@@ -240,15 +250,14 @@ class RoutedLoRAFFN(torch.autograd.Function):
         bs, rank, rows = d_ff // nb, l1.size(1), bk.token.numel()
         pos = bk.pos.long()
         dy = dy.contiguous()
-        dzt = torch.matmul(dy, r2)                                           # [T, r]
         imgs = _images_usable(dy, w1, w2, d, bs)
+        dzt, dy_img, _ = _down(dy, r2, imgs, False)                          # [T, r]
         ds, dot_main, dot_act = ext.grouped_gemm_fused(
             dy, w2, bk.offsets, nb, n=bs, k=d, w_group_stride=bs, w_ldn=1, w_ldk=d_ff,
             n_rows=rows, gather=bk.token, rowscale=coeff,
             a2=dzt, gather2=bk.token, b2=l2, b2_group_stride=bs * rank,
             epilogue=ext.EPI_DACT, activation=act, h_in=h, s_in=s,
-            a_image=ext.split_bf16(dy) if imgs else None,
-            w_image=ext.weight_image(w2) if imgs else None)
+            a_image=dy_img, w_image=ext.weight_image(w2) if imgs else None)
         du = _own_block(torch.matmul(ds, _block_cat(r1, nb)), bk.block, nb).contiguous()  # [P, r]
         u_rows = u.index_select(0, bk.token_long)
         # d/dc = <dy W2_g^T, h> + <ds, x W1_g^T + b1_g>.  The kernel's dot_main = <v, h> with
@@ -314,10 +323,16 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
         d_ff, d = wg.shape
         bs, rank, rows = d_ff // nb, lg.size(1), bk.token.numel()
         x, coeff = x.contiguous(), coeff.contiguous()
-        ug, us = torch.matmul(x, lg), torch.matmul(x, ls)                      # [T, r]
-
         imgs = _images_usable(x, wg, wd, d, bs)
-        x_image = ext.split_bf16(x) if imgs else None        # read by both up projections
+        # one pass over x: both adapters' down products and the image both up projections read
+        table = torch.cat([lg, ls], dim=1)
+        if rank == 16 and ext.lora_down_supported(x, table):
+            ugs, x_image, _ = ext.lora_down(x, table, want_image=True, block_major=True) if imgs \
+                else (ext.lora_down(x, table, block_major=True), None, None)
+            ug, us = ugs[0], ugs[1]                                               # [T, r]
+        else:
+            ug, us = torch.matmul(x, lg), torch.matmul(x, ls)
+            x_image = ext.split_bf16(x) if imgs else None
 
         def up(w, u, r_table):
             return ext.grouped_gemm_fused(
@@ -328,13 +343,13 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
 
         g, sd = up(wg, ug, rg), up(ws, us, rs)
         h = activation(g) * sd
-        z = _own_block(torch.matmul(h, _block_cat(ld, nb)), bk.block, nb).contiguous()
+        zw, h_img, _ = _down(h, _block_cat(ld, nb), imgs, False)
+        z = _own_block(zw, bk.block, nb).contiguous()
         ys = ext.grouped_gemm_fused(
             h, wd, bk.offsets, nb, n=d, k=bs, w_group_stride=bs, w_ldn=d_ff, w_ldk=1,
             n_rows=rows, rowscale=coeff, a2=z, b2=rd, b2_group_stride=0,
-            a_image=ext.split_bf16(h) if imgs else None,
-            w_image=ext.weight_image(wd) if imgs else None)
-        del x_image
+            a_image=h_img, w_image=ext.weight_image(wd) if imgs else None)
+        del x_image, h_img
         y = ext.rows_combine(ys, bk.pos)
         ctx.bk, ctx.activation = bk, activation
         ctx.origin_module = origin_module
@@ -353,15 +368,15 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
         bs, rank, rows = d_ff // nb, lg.size(1), bk.token.numel()
         pos = bk.pos.long()
         dy = dy.contiguous()
-        dzt = torch.matmul(dy, rd)                                            # [T, r]
-        dz_rows = dzt.index_select(0, bk.token_long)
         imgs = _images_usable(dy, wg, wd, d, bs)
+        dzt, dy_img, _ = _down(dy, rd, imgs, False)                           # [T, r]
+        dz_rows = dzt.index_select(0, bk.token_long)
         dh = ext.grouped_gemm_fused(
             dy, wd, bk.offsets, nb, n=bs, k=d, w_group_stride=bs, w_ldn=1, w_ldk=d_ff,
             n_rows=rows, gather=bk.token, rowscale=coeff, a2=dzt, gather2=bk.token, b2=ld,
             b2_group_stride=bs * rank,
-            a_image=ext.split_bf16(dy) if imgs else None,
-            w_image=ext.weight_image(wd) if imgs else None)
+            a_image=dy_img, w_image=ext.weight_image(wd) if imgs else None)
+        del dy_img
         grad_coeff = ((dh * h).sum(dim=-1) - (dz_rows * z).sum(dim=-1)) / _floor(coeff)
         # through h = act(g) * sd
         with torch.enable_grad():

@@ -6,6 +6,8 @@ path lives in ``lora.left.weight [in, r]`` and ``lora.right.weight [out, r]`` (t
 id).  ``right`` starts at zero, so a fresh adapter is the identity.  No 1/r scaling
 is applied (``scaling`` is stored but unused, as in the reference).
 """
+import weakref
+
 import torch
 from torch import nn
 
@@ -98,6 +100,59 @@ def _mfma_gemm(a, weight, n, k, ldn, ldk, bias=None, a2=None, b2=None, images=Fa
                                   rows, bias=bias, a2=a2, b2=b2, a_image=a_image, w_image=w_image)
 
 
+# ---- the down products u = x L of adapters that share an input -------------------------------
+# The q / k / v projections read the same tensor: their three tables go side by side through ONE
+# pass over it (ext.lora_down: u for each adapter, plus the split image the three GEMMs read).
+# `prepare_shared` is called by the attention module in front of the three linear layers; each
+# layer then finds its u here.  One entry, alive as long as the input tensor is.
+_SHARED = {}
+
+
+def prepare_shared(x: torch.Tensor, linears) -> None:
+    from naive_gpt import ext
+    _SHARED.clear()
+    if not (x.is_cuda and x.dim() >= 2 and not x.is_inference()):
+        return
+    if not all(isinstance(m, LoRALinear) and m._frozen() for m in linears):
+        return
+    lefts = [m.lora.left.weight for m in linears]
+    x2 = x.reshape(-1, x.size(-1))
+    if any(l.size(1) != 16 for l in lefts) or len(lefts) > 4:
+        return
+    if not all(_mfma_linear_usable(x2, m.weight, 16) for m in linears):
+        return
+    with torch.no_grad():
+        table = torch.cat(lefts, dim=1)
+        if not ext.lora_down_supported(x2, table):
+            return
+        u, image, _ = ext.lora_down(x2, table, want_image=True, block_major=True)
+    ext.put_image(x2, x, image)
+    _SHARED[id(x)] = (weakref.ref(x, lambda _, k=id(x): _SHARED.pop(k, None)), x._version,
+                      {id(l): u[i] for i, l in enumerate(lefts)})
+
+
+def _shared_u(x: torch.Tensor, left: torch.Tensor):
+    hit = _SHARED.get(id(x))
+    if hit is None or hit[0]() is not x or hit[1] != x._version:
+        return None
+    return hit[2].get(id(left))
+
+
+def _down(x: torch.Tensor, x2: torch.Tensor, left: torch.Tensor, images: bool):
+    """u = x2 @ left: found (prepare_shared), or one pass that also leaves x2's split image when
+    the GEMM behind it wants one and none is cached, or the library product."""
+    from naive_gpt import ext
+    u = _shared_u(x, left)
+    if u is not None:
+        return u
+    if images and ext.lora_down_supported(x2, left) and x2.size(1) % 32 == 0:
+        if ext.cached_image(x2, x) is None and not x.is_inference():
+            u, image, _ = ext.lora_down(x2, left, want_image=True)
+            ext.put_image(x2, x, image)
+            return u
+    return torch.matmul(x2, left)
+
+
 class _FrozenLoRALinear(torch.autograd.Function):
     """y = x W^T + b + (x L) R^T with W, b frozen (the reference's forward,
     lora.py:70-80, differentiated by hand): the side product is accumulated into the base
@@ -107,9 +162,9 @@ class _FrozenLoRALinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, left, right):
         x2 = x.reshape(-1, x.size(-1))
-        u = torch.matmul(x2, left)                                   # [T, r]
         n, k = weight.shape
         ctx.mfma = _mfma_linear_usable(x2, weight, left.size(1))
+        u = _down(x, x2, left, ctx.mfma and x2.is_contiguous())      # [T, r]
         if ctx.mfma:
             # one launch: base product, bias and the side product (the K extension) together
             y = _mfma_gemm(x2, weight, n, k, k, 1, bias=None if bias is None else bias.view(1, n),
@@ -163,9 +218,11 @@ class LoRALinear(nn.Linear):
                            bias=source.bias is not None)
         return _load_base(model, source)
 
+    def _frozen(self) -> bool:
+        return not self.weight.requires_grad and (self.bias is None or not self.bias.requires_grad)
+
     def forward(self, x: torch.Tensor):
-        frozen = not self.weight.requires_grad and (self.bias is None
-                                                    or not self.bias.requires_grad)
+        frozen = self._frozen()
         if frozen and x.is_cuda and x.dim() >= 2:
             return _FrozenLoRALinear.apply(x, self.weight, self.bias,
                                            self.lora.left.weight, self.lora.right.weight)
