@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 20
+#define SPT_ABI_VERSION 21
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -436,6 +436,9 @@ typedef struct SptGroupedGemm {
      * one after another (~2 us each).  16-byte aligned; contents on return are unspecified. */
     void *relu_queue;
     int64_t relu_queue_bytes;
+    int64_t ldo;               /* row stride (floats) of out, out2, h_in, s_in; 0: n.  A padded
+                                  stride keeps the rows of a ragged n (a vocabulary of 30522)
+                                  16-byte aligned for the kernels that read them next */
 } SptGroupedGemm;
 int spt_grouped_gemm_fused(const SptGroupedGemm *desc, void *stream);
 int spt_grouped_gemm_pdot_width(int n);
@@ -469,6 +472,20 @@ int spt_split_bf16(const float *src, void *image, long long rows, int cols, long
  */
 int spt_lora_down(const float *x, long long ldx, long long rows, int k, const float *l, int n,
                   float *u, int u_block_major, void *image, float *norms, void *stream);
+
+/*
+ * Softmax cross-entropy of the language-model head (script/4-sparse-tuning-0.py:45-59:
+ * nn.CrossEntropyLoss() on logits [rows, n_classes]), loss and gradient in one pass, IN PLACE:
+ *   loss[i]      = log(sum_j exp(z[i, j])) - z[i, target[i]]           (0 for an ignored row)
+ *   z[i, j]     <- (softmax(z[i, :])[j] - [j == target[i]]) * *scale   (0 for an ignored row)
+ * z has row stride ld >= n_classes (ld % 4 == 0, 16-byte aligned); columns n_classes .. ld-1 are
+ * written as zeros.  target: int64 [rows]; a row whose target equals ignore_index (or lies
+ * outside [0, n_classes)) is ignored.  scale: one DEVICE float (1 / number of counted rows for
+ * the mean reduction); loss: [rows] -- the mean is sum(loss) * scale.
+ */
+int spt_cross_entropy_grad(float *logits, long long ld, long long rows, int n_classes,
+                           const long long *target, const float *scale, float *loss,
+                           long long ignore_index, void *stream);
 
 /*
  * Bucketing for the routed FFN: the k largest of the n_blocks router probabilities of every

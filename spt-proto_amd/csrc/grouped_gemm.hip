@@ -103,6 +103,7 @@ struct GroupedArgs {
     float *out;             // [P, N] row-major
     int P, K, N, G;
     int lda;
+    long long ldo;          // row stride of out / out2 / h_in / s_in (>= N; launch_grouped: 0 -> N)
     long long gstride;
     int ldn, ldk;
     // K extension (the LoRA side product), added AFTER rowscale / bias:
@@ -229,6 +230,7 @@ __device__ __forceinline__ void gg_epilogue(const GroupedArgs &g, float *smem,
     const float *sh = (EPI == EPI_DACT) ? (g.s_in ? g.s_in : g.h_in) : nullptr;
     const int n = col_tile * GG_BN + wn + rcol;
     const bool vec = (g.N & 3) == 0;
+    const bool vec_row = (g.ldo & 3) == 0;        // 16-byte aligned pieces of the N-wide rows
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias) {
         const float *bp = g.bias + (size_t)bucket * g.N + n;
@@ -269,11 +271,11 @@ __device__ __forceinline__ void gg_epilogue(const GroupedArgs &g, float *smem,
             float c[4] = {c4.x, c4.y, c4.z, c4.w};
             const float b[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
             const float rs = (live && g.rowscale) ? g.rowscale[p] : 1.0f;
-            const size_t at = (size_t)p * g.N + n;
+            const size_t at = (size_t)p * g.ldo + n;
             float sv[4] = {0.f, 0.f, 0.f, 0.f};
             if (EPI == EPI_DACT && live) {
-                if (vec) {
-                    if (n < g.N) {
+                if (vec_row && n + 3 < g.N) {
+                    {
                         const float4 t4 = *reinterpret_cast<const float4 *>(sh + at);
                         sv[0] = t4.x; sv[1] = t4.y; sv[2] = t4.z; sv[3] = t4.w;
                     }
@@ -351,8 +353,8 @@ __device__ __forceinline__ void gg_epilogue(const GroupedArgs &g, float *smem,
                 }
             }
             if (live) {
-                if (vec) {
-                    if (n < g.N) {
+                if (vec_row && n + 3 < g.N) {
+                    {
                         *reinterpret_cast<float4 *>(g.out + at) = make_float4(c[0], c[1], c[2], c[3]);
                         if (EPI == EPI_ACT && g.out2)
                             *reinterpret_cast<float4 *>(g.out2 + at) =
@@ -998,8 +1000,8 @@ __global__ __launch_bounds__(256) void relu_fix_kernel(GroupedArgs g) {
         const int p = q.x, n = q.y & 0xFFFFFF, bucket = (unsigned)q.y >> 24;
         const float exact = gg_exact_preact(g, bucket, p, n, lane);
         if (lane == 0) {
-            g.out[(size_t)p * g.N + n] = act_forward(g.act, exact);
-            if (g.out2) g.out2[(size_t)p * g.N + n] = exact;
+            g.out[(size_t)p * g.ldo + n] = act_forward(g.act, exact);
+            if (g.out2) g.out2[(size_t)p * g.ldo + n] = exact;
         }
     }
 }
@@ -1056,6 +1058,8 @@ static bool image_path(GroupedArgs &g, int epilogue) {
 static int launch_grouped(GroupedArgs g, int epilogue, void *stream) {
     if ((!g.a && !g.a_img) || (!g.w && !g.w_img) || !g.offsets || !g.out) return SPT_EINVAL;
     if (g.P <= 0 || g.K <= 0 || g.N <= 0 || g.G <= 0 || g.lda < g.K) return SPT_EINVAL;
+    if (g.ldo == 0) g.ldo = g.N;
+    if (g.ldo < g.N) return SPT_EINVAL;
     if (g.K % 4 != 0 || g.lda % 4 != 0) return SPT_ESHAPE;       // float4 rows of A
     if (g.ldk != 1 && g.ldn != 1) return SPT_EUNSUP;
     if (g.ldk == 1 && (g.ldn % 4 != 0 || g.gstride % 4 != 0)) return SPT_ESHAPE;
@@ -1157,6 +1161,7 @@ extern "C" int spt_grouped_gemm_fused(const SptGroupedGemm *d, void *stream) {
     g.a_img = reinterpret_cast<const char *>(d->a_image);
     g.w_img = reinterpret_cast<const char *>(d->w_image);
     g.a_norm = d->a_norm; g.w_norm = d->w_norm;
+    g.ldo = d->ldo;
     const long long header = GG_FIX_SEGS * 64;
     if (d->relu_queue && d->relu_queue_bytes >= header + GG_FIX_SEGS * 8) {
         g.fix_count = reinterpret_cast<unsigned *>(d->relu_queue);

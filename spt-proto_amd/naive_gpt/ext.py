@@ -71,6 +71,8 @@ _PROTOTYPES = {
     'spt_split_bf16_bytes': ([ctypes.c_longlong, _c_int], ctypes.c_size_t),
     'spt_split_bf16': ([_c_ptr, _c_ptr, ctypes.c_longlong, _c_int, ctypes.c_longlong, _c_ptr], _c_int),
     'spt_rows_combine': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_cross_entropy_grad': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_ptr,
+                                _c_ptr, ctypes.c_longlong, _c_ptr], _c_int),
     'spt_lora_down': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_int,
                        _c_ptr, _c_int] + [_c_ptr] * 3, _c_int),
     'spt_route_topk': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
@@ -79,7 +81,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _lib = None
 
@@ -795,7 +797,7 @@ class _GroupedDesc(ctypes.Structure):
         ('out2', _c_ptr), ('h_in', _c_ptr), ('s_in', _c_ptr),
         ('pdot_main', _c_ptr), ('pdot_act', _c_ptr), ('pdot_ld', ctypes.c_int32),
         ('a_image', _c_ptr), ('w_image', _c_ptr), ('a_norm', _c_ptr), ('w_norm', _c_ptr),
-        ('relu_queue', _c_ptr), ('relu_queue_bytes', ctypes.c_int64),
+        ('relu_queue', _c_ptr), ('relu_queue_bytes', ctypes.c_int64), ('ldo', ctypes.c_int64),
     ]
 
 
@@ -963,13 +965,14 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                        keep_preact: bool = False, h_in=None, s_in=None,
                        a_image: SplitImage = None, w_image: SplitImage = None,
                        a_norm: torch.Tensor = None, w_norm: torch.Tensor = None,
-                       relu_queue_entries: int = None):
+                       relu_queue_entries: int = None, out: torch.Tensor = None):
     """``spt_grouped_gemm_fused``: the block GEMM of a routed FFN with its LoRA side
     product, rowscale / bias, and the activation (EPI_ACT) or its derivative plus the two
     row dots of the coefficient gradient (EPI_DACT) folded in (include/spt_hip.h).
 
     Returns ``out`` (EPI_PLAIN), ``(out, preact | None)`` (EPI_ACT) or
-    ``(out, dot_main [P], dot_act [P])`` (EPI_DACT)."""
+    ``(out, dot_main [P], dot_act [P])`` (EPI_DACT).  ``out``: a buffer [n_rows, >= n] to write
+    into (EPI_PLAIN; its row stride may exceed n: ``ldo`` of include/spt_hip.h)."""
     for t, name in ((a, 'a'), (weight, 'weight')):
         _check_type(t, torch.float32, name)
     _check_type(offsets, torch.int32, 'offsets')
@@ -1005,7 +1008,13 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                  'w_image: the image of the weight with rows of w_ldn (w_ldk) elements')
     lib = load_library()
     with torch.cuda.device(dev):
-        out = torch.empty([n_rows, n], dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty([n_rows, n], dtype=torch.float32, device=dev)
+        else:
+            _check_type(out, torch.float32, 'out')
+            _require(epilogue == EPI_PLAIN and out.is_cuda and out.dim() == 2 and out.stride(1) == 1
+                     and out.size(0) == n_rows and out.size(1) >= n and out.stride(0) >= out.size(1),
+                     'out: [n_rows, >= n] fp32 with unit inner stride (EPI_PLAIN only)')
         preact = dot_main = dot_act = None
         if epilogue == EPI_ACT and keep_preact:
             preact = torch.empty_like(out)
@@ -1035,7 +1044,7 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                 a_image=a_image.buffer.data_ptr() if images else None,
                 w_image=w_image.buffer.data_ptr() if images else None,
                 a_norm=_ptr(a_norm), w_norm=_ptr(w_norm), relu_queue=_ptr(queue),
-                relu_queue_bytes=queue.numel() if queue is not None else 0)
+                relu_queue_bytes=queue.numel() if queue is not None else 0, ldo=out.stride(0))
             global LAST_GEMM_USED_IMAGES
             LAST_GEMM_USED_IMAGES = bool(lib.spt_grouped_gemm_image_path(ctypes.byref(desc)))
             rc = lib.spt_grouped_gemm_fused(ctypes.byref(desc), _stream(dev))
@@ -1132,6 +1141,33 @@ def lora_down(x: torch.Tensor, table: torch.Tensor, want_image: bool = False,
     if rc != 0:
         _raise(lib, rc, 'lora_down')
     return (u, image, norms) if (want_image or want_norms) else u
+
+
+def cross_entropy_grad_(logits: torch.Tensor, n_classes: int, target: torch.Tensor,
+                        scale: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """``spt_cross_entropy_grad``: per-row losses [rows] of softmax cross-entropy, and `logits`
+    [rows, ld >= n_classes] OVERWRITTEN with (softmax - onehot) * scale (pad columns: zeros).
+    `scale`: a one-element device tensor (1 / number of counted targets for the mean)."""
+    _check_type(logits, torch.float32, 'logits')
+    _check_type(target, torch.int64, 'target')
+    _check_type(scale, torch.float32, 'scale')
+    _require(logits.is_cuda and logits.dim() == 2 and logits.stride(1) == 1
+             and logits.stride(0) % 4 == 0 and logits.stride(0) >= logits.size(1) >= n_classes
+             and logits.data_ptr() % 16 == 0, 'logits: [rows, ld >= n_classes], 16-byte aligned rows')
+    _require(target.is_contiguous() and target.numel() == logits.size(0) and scale.numel() == 1,
+             'target: one int64 per row; scale: one float')
+    dev = _same_device(logits, target, scale)
+    rows = logits.size(0)
+    lib = load_library()
+    with torch.cuda.device(dev):
+        loss = torch.empty([rows], dtype=torch.float32, device=dev)
+        if rows > 0:
+            rc = lib.spt_cross_entropy_grad(logits.data_ptr(), logits.stride(0), rows, n_classes,
+                                            target.data_ptr(), scale.data_ptr(), loss.data_ptr(),
+                                            ignore_index, _stream(dev))
+            if rc != 0:
+                _raise(lib, rc, 'cross_entropy_grad')
+    return loss
 
 
 def softmax_backward_clamped(indptr: torch.Tensor, indices: torch.Tensor,

@@ -42,12 +42,16 @@ class DecoderLM(nn.Module):
             h = h + self.learned_pe(positions + self.position_offset).unsqueeze(0)
         return h
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """tokens [batch, seq] (integer) -> logits [batch, seq, vocab]."""
+    def hidden(self, x: torch.Tensor) -> torch.Tensor:
+        """tokens [batch, seq] -> the LM head's input [batch, seq, d_model]."""
         assert x.dim() == 2
         seq_length = x.size(-1)
         mask = self.attn_mask[:seq_length, :seq_length]
         h = self.embed(x)
         for block in self.decoders:
             h = block(h, attn_mask=mask)
-        return self.lm_output(self.final_norm(h))
+        return self.final_norm(h)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """tokens [batch, seq] (integer) -> logits [batch, seq, vocab]."""
+        return self.lm_output(self.hidden(x))

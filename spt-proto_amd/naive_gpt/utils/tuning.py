@@ -101,6 +101,21 @@ class SparseTuner:
         loss = self.loss_fn(output.flatten(end_dim=-2), target=target.flatten())
         return output, loss
 
+    def step_loss(self, src: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """`shared_step(...)[-1]` without materialising what only the loss needs: a frozen LoRA
+        head and `nn.CrossEntropyLoss()` go through one fused function
+        (layers/tuning/head_loss.py: logits written once, turned into their gradient in place)."""
+        from naive_gpt.layers.tuning import head_loss
+        model, fn = self.model, self.loss_fn
+        plain = (type(fn) is nn.CrossEntropyLoss and fn.weight is None and fn.reduction == 'mean'
+                 and fn.label_smoothing == 0.0)
+        if plain and hasattr(model, 'hidden') and hasattr(model, 'lm_output') and torch.is_grad_enabled():
+            h = model.hidden(src)
+            if head_loss.fused_usable(model.lm_output, h):
+                return head_loss.lm_head_loss(model.lm_output, h, target, fn.ignore_index)
+            return fn(model.lm_output(h).flatten(end_dim=-2), target=target.flatten())
+        return self.shared_step(src, target)[-1]
+
     def training_step(self, batch: torch.Tensor, pq_loss: bool = True) -> torch.Tensor:
         """One micro-batch: forward, backward; every ``n_accumulate``-th call also
         exchanges, clips and applies the gradients.  Returns the (detached) loss.
@@ -117,7 +132,7 @@ class SparseTuner:
         self.model.train()
         if pq_loss:
             self.arm_triggers()
-        loss = self.shared_step(batch[:, 1:-1], target=batch[:, 2:])[-1]
+        loss = self.step_loss(batch[:, 1:-1], target=batch[:, 2:])
         if pq_loss:
             loss = loss + self.aux_weight * self.aux_loss()
         (loss / self.n_accumulate).backward()

@@ -1,0 +1,100 @@
+"""The LM head's loss as one function (layers/tuning/head_loss.py, csrc/head_loss.hip) against the
+op-by-op composition of the reference's step (script/4-sparse-tuning-0.py:45-59:
+nn.CrossEntropyLoss() on the LoRA head's logits)."""
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('rows,V,ld', [(300, 1000, 1024), (64, 30522, 30528), (33, 30522, 30528),
+                                       (16, 50272, 50272), (8, 40000, 40032), (5, 7, 8)])
+def test_cross_entropy_grad_in_place(rows, V, ld):
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(rows + V)
+    z = (3.0 * torch.randn([rows, V], generator=gen)).cuda()
+    target = torch.randint(0, V, [rows], generator=gen).cuda()
+    target[::5] = -100                                         # ignored rows
+    zr = z.clone().requires_grad_(True)
+    want = nn.functional.cross_entropy(zr, target)
+    want.backward()
+    buf = torch.full([rows, ld], 7.0, device='cuda')
+    buf[:, :V] = z
+    count = (target != -100).sum()
+    scale = (1.0 / count.float()).reshape(1)
+    loss_rows = ext.cross_entropy_grad_(buf, V, target, scale)
+    assert torch.allclose(loss_rows.sum() * scale[0], want.detach(), rtol=1e-5)
+    assert (loss_rows[::5] == 0).all()
+    assert torch.allclose(buf[:, :V], zr.grad, rtol=1e-4, atol=1e-9)
+    assert (buf[:, V:] == 0).all()                             # pad columns: zeros
+
+
+def _head(d, V, rank=16):
+    from naive_gpt import layers
+    torch.manual_seed(0)
+    head = layers.LoRALinear.from_pretrained(rank, nn.Linear(d, V, bias=False)).cuda()
+    with torch.no_grad():
+        head.lora.right.weight.normal_(0.0, 0.05)              # a fresh adapter is the identity
+    return head
+
+
+@pytest.mark.parametrize('d,V', [(256, 1000), (1024, 3002)])
+def test_fused_head_loss_equals_cross_entropy_of_the_lora_head(d, V):
+    from naive_gpt.layers.tuning import head_loss
+    head = _head(d, V)
+    before = head.weight.detach().clone()
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn([4, 512, d], generator=gen).cuda()
+    target = torch.randint(0, V, [4, 512], generator=gen).cuda()
+    target[0, :7] = -100
+    w = 0.37                                                    # an upstream factor, as loss / n_accumulate
+
+    def run(fused):
+        xi = x.clone().requires_grad_(True)
+        for p in head.parameters():
+            p.grad = None
+        if fused:
+            assert head_loss.fused_usable(head, xi)
+            loss = head_loss.lm_head_loss(head, xi, target)
+        else:
+            loss = nn.functional.cross_entropy(head(xi).flatten(end_dim=-2), target.flatten())
+        (w * loss).backward()
+        return loss.detach(), xi.grad, head.lora.left.weight.grad.clone(), head.lora.right.weight.grad.clone()
+
+    got, want = run(True), run(False)
+    assert torch.allclose(got[0], want[0], rtol=1e-5)
+    for a, b, name in zip(got[1:], want[1:], ['grad_x', 'grad_left', 'grad_right']):
+        assert torch.allclose(a, b, rtol=1e-3, atol=2e-5 * b.abs().max().item()), \
+            (name, (a - b).abs().max().item(), b.abs().max().item())
+    # the weight was re-homed into zero-padded storage: same values, same shape, same state_dict key
+    assert torch.equal(head.weight.detach(), before) and head.weight.shape == (V, d)
+    assert 'weight' in head.state_dict() and head.state_dict()['weight'].shape == (V, d)
+    assert head.weight.is_contiguous() and not head.weight.requires_grad
+
+
+def test_fused_head_loss_is_what_the_tuner_steps_on():
+    """SparseTuner.step_loss takes the fused path for an upgraded model and gives the loss (and,
+    through backward, the gradients) of the plain composition."""
+    from naive_gpt import models, utils
+    torch.manual_seed(0)
+    with torch.device('cuda'):
+        model = models.OPTModel(d_model=256, n_heads=4, n_layers=1, max_length=512, vocab_size=1000,
+                                d_feedforward=1024, p_dropout=0.0)
+        model = utils.upgrade_sparse(model, d_lora=16, stages=('lora',))
+    with torch.no_grad():
+        model.lm_output.lora.right.weight.normal_(0.0, 0.05)
+    tuner = utils.SparseTuner(model)
+    batch = torch.randint(3, 1000, [4, 514], device='cuda')
+    src, target = batch[:, 1:-1], batch[:, 2:]
+    loss = tuner.step_loss(src, target)
+    assert loss.grad_fn is not None and 'HeadLoss' in type(loss.grad_fn).__name__
+    loss.backward()
+    got = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    want_loss = tuner.shared_step(src, target)[-1]
+    want_loss.backward()
+    assert torch.allclose(loss.detach(), want_loss.detach(), rtol=1e-5)
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.allclose(got[n], p.grad, rtol=2e-3, atol=2e-5 * p.grad.abs().max().item()), n
