@@ -27,6 +27,39 @@ import torch
 from .lora import LoRALinear, _down, _mfma_linear_usable, _one_group, tall_tn
 
 _PADDED = {}
+_SPLIT = 3            # parts of the vocabulary in the head's backward GEMM
+_PAD = 32 * _SPLIT    # rows of the padded weight / columns of the padded logits: whole k-steps per part
+_INDEX = {}
+
+
+def _index(kind: str, T: int, device):
+    key = (T, str(device))
+    hit = _INDEX.get(key)
+    if hit is None:
+        with torch.inference_mode(False):
+            t = torch.arange(T, dtype=torch.int32, device=device)
+            hit = {
+                'offsets': torch.arange(0, (_SPLIT + 1) * T, T, dtype=torch.int32, device=device),
+                # row p = g * T + t of the parts reads buffer row t * _SPLIT + g
+                'gather': torch.cat([t * _SPLIT + g for g in range(_SPLIT)]).contiguous(),
+                # token t sums rows t, T + t, 2 T + t of the parts
+                'pos': torch.stack([t + g * T for g in range(_SPLIT)], dim=1).contiguous(),
+            }
+        _INDEX.clear()                  # one token count at a time
+        _INDEX[key] = hit
+    return hit[kind]
+
+
+def _split_offsets(T, device):
+    return _index('offsets', T, device)
+
+
+def _split_gather(T, device):
+    return _index('gather', T, device)
+
+
+def _split_pos(T, device):
+    return _index('pos', T, device)
 
 
 def _pad_rows(weight: torch.Tensor, rows: int) -> None:
@@ -49,7 +82,7 @@ class _FrozenLoRAHeadLoss(torch.autograd.Function):
         V, d = weight.shape
         x2 = x.reshape(-1, d)
         T = x2.size(0)
-        Vp = (V + 31) // 32 * 32
+        Vp = (V + _PAD - 1) // _PAD * _PAD
         _pad_rows(weight, Vp)
         one = _one_group(T, x2.device)
         u = _down(x, x2, left, d % 32 == 0)                            # [T, r]
@@ -67,9 +100,19 @@ class _FrozenLoRAHeadLoss(torch.autograd.Function):
         # buf now holds d loss / d logits (pad columns zero).  Everything that needs it, now:
         dl = buf[:, :V]
         du = torch.matmul(dl, right)                                   # [T, r]
-        k4 = (V + 3) // 4 * 4                                          # (weight rows >= V: zeros)
-        grad_x = ext.grouped_gemm_fused(buf, weight, one, 1, d, k4, 0, 1, d, T,
-                                        a2=du.contiguous(), b2=left.contiguous())
+        # dX = dl W, a contraction over the (padded) vocabulary: [T / 128] x [d / 128] tiles with a
+        # 30k-long k-loop fill a third of the GPU's workgroup slots.  Split in _SPLIT parts over
+        # the vocabulary instead -- row t of part g is row t * _SPLIT + g of the SAME buffer seen as
+        # [T * _SPLIT, Vp / _SPLIT], part g's weights are rows g Vp / _SPLIT .. of W: the grouped
+        # GEMM's own row gather and group stride -- and the parts summed in a fixed order.
+        kc = Vp // _SPLIT
+        parts = ext.grouped_gemm_fused(
+            buf.view(T * _SPLIT, kc), weight, _split_offsets(T, x2.device), _SPLIT, n=d, k=kc,
+            w_group_stride=kc * d, w_ldn=1, w_ldk=d, n_rows=T * _SPLIT,
+            gather=_split_gather(T, x2.device))
+        grad_x = ext.rows_combine(parts, _split_pos(T, x2.device))
+        del parts
+        grad_x.addmm_(du, left.t())
         grad_right = torch.matmul(dl.t(), u)                           # [V, r]
         grad_left = tall_tn(x2, du)
         del buf, dl
