@@ -5,12 +5,13 @@
 // over the blocks with boolean masks (`x[mask]`, one device->host sync per block).  The
 // grouped GEMMs want the (token, block) pairs sorted by block instead, stable in the token id
 // (= the order of `x[mask]`).  With torch ops that is topk + argsort + bincount + cumsum +
-// gathers, ~15 launches and ~130 us at T = 8192; here it is a counting sort in one workgroup:
+// gathers, ~15 launches and ~130 us at T = 8192; here it is a counting sort in one launch:
 //
-//   pass 1  every thread selects the k largest of the G probabilities of its (contiguous)
-//           tokens and counts its selections per block;
-//   scan    exclusive prefix of the G counters over the 1024 threads (DPP wave scan + LDS);
-//   pass 2  position of (token, block) = offsets[block] + prefix + running count.
+//   select  a thread per token picks the k largest of its G probabilities (a bit mask);
+//   count   ballots per block give the selections per wave; the sort position of a selection =
+//           (selections of lower blocks) + (same block, earlier tokens) -- a function of the masks
+//           of the earlier tokens alone, which every workgroup derives for itself (below);
+//   place   token / block / pos written at that position.
 //
 // Selection order: larger probability first (NaN above every number, as torch.topk ranks it),
 // ties to the lower block index (a total order; torch.topk leaves ties unspecified).  G <= 8, T <= 65536 (64 tokens per thread); bigger
@@ -19,7 +20,6 @@
 
 namespace spt {
 
-constexpr int RT_THREADS = 1024;
 constexpr int RT_MAXG = 8;
 
 // Orderable key of a probability: ascending unsigned order == ascending float order, -0 == +0,
@@ -33,103 +33,114 @@ __device__ __forceinline__ unsigned order_key(float x) {
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
-__device__ __forceinline__ unsigned select_topk(const float (&v)[RT_MAXG], int G, int k) {
-    unsigned key[RT_MAXG];
+template <int MG>
+__device__ __forceinline__ unsigned select_topk(const float (&v)[MG], int G, int k) {
+    unsigned key[MG];
 #pragma unroll
-    for (int j = 0; j < RT_MAXG; j++) key[j] = order_key(v[j]);
+    for (int j = 0; j < MG; j++) key[j] = order_key(v[j]);
     unsigned mask = 0u;
 #pragma unroll
-    for (int j = 0; j < RT_MAXG; j++) {
+    for (int j = 0; j < MG; j++) {
         int rank = 0;
 #pragma unroll
-        for (int i = 0; i < RT_MAXG; i++)
+        for (int i = 0; i < MG; i++)
             rank += (i < G) && (key[i] > key[j] || (key[i] == key[j] && i < j));
         if (j < G && rank < k) mask |= 1u << j;
     }
     return mask;
 }
 
-__global__ __launch_bounds__(RT_THREADS) void route_topk_kernel(
+// A workgroup places the selections of its own 256 tokens (a thread per token); what it needs
+// of the other tokens -- how many selections per block precede its own -- it counts itself, from
+// the probabilities: every workgroup ballots through ALL chunks (110 instructions per chunk and
+// thread, 4 KiB of loads), which costs less than any exchange between workgroups would (a second
+// launch, or a scratch buffer the C ABI would have to carry) and keeps the result a pure function
+// of the input.  History: one workgroup of 1024 threads, 8 tokens per thread, selections parked in
+// LDS: 39 us at T = 8192 (a single CU's latency chain).
+// (MG = 4 or 8 block slots compiled in: the selection is a rank over MG x MG comparisons, and
+// it is what the redundant counting repeats.)
+constexpr int RT_CHUNK = 256;
+template <int MG>
+__global__ __launch_bounds__(RT_CHUNK) void route_topk_kernel(
     const float *__restrict__ prob, int32_t *__restrict__ token, int32_t *__restrict__ block,
     int32_t *__restrict__ offsets, int32_t *__restrict__ pos, int T, int G, int k) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint8_t *sel = reinterpret_cast<uint8_t *>(smem);          // [T] selection masks
-    __shared__ int wave_tot[RT_THREADS / 64][RT_MAXG];
-    __shared__ int base[RT_MAXG + 1];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int tpt = (T + RT_THREADS - 1) / RT_THREADS;
-    const int t0 = min(T, tid * tpt), t1 = min(T, t0 + tpt);
-
-    // pass 1: selections (kept in LDS for pass 2) and per-thread counts.  The probabilities
-    // of 8 tokens are requested before the first is used: a single workgroup has nothing
-    // else to hide the load latency behind.
-    int cnt[RT_MAXG];
+    __shared__ int wave_before[RT_CHUNK / 64][MG];   // selections in chunks before mine, by wave
+    __shared__ int wave_total[RT_CHUNK / 64][MG];    // ... in all chunks
+    __shared__ int wave_mine[RT_CHUNK / 64][MG];     // ... in my chunk
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mine = blockIdx.x, nchunks = (T + RT_CHUNK - 1) / RT_CHUNK;
+    auto load = [&](int c, float (&v)[MG]) {
+        const int t = min(c * RT_CHUNK + tid, T - 1);           // (clamped: masked below)
+        if (MG == 4 && G == 4) {
+            const float4 q = *reinterpret_cast<const float4 *>(prob + (size_t)t * 4);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
 #pragma unroll
-    for (int g = 0; g < RT_MAXG; g++) cnt[g] = 0;
-    for (int tb = t0; tb < t1; tb += 8) {
-        float v[8][RT_MAXG];
+            for (int j = 0; j < MG; j++) v[j] = j < G ? prob[(size_t)t * G + j] : 0.0f;
+        }
+    };
+    int before[MG], total[MG], own[MG], rank[MG];   // wave-uniform counters
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int t = min(tb + u, t1 - 1);
-            if (G == 4) {
-                const float4 q = *reinterpret_cast<const float4 *>(prob + (size_t)t * 4);
-                v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
+    for (int g = 0; g < MG; g++) before[g] = total[g] = own[g] = rank[g] = 0;
+    unsigned my_mask = 0u;
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    constexpr int AHEAD = 4;                  // chunks whose loads are in flight together
+    for (int c0 = 0; c0 < nchunks; c0 += AHEAD) {
+        float v[AHEAD][MG];
 #pragma unroll
-                for (int j = 4; j < RT_MAXG; j++) v[u][j] = 0.0f;
-            } else {
+        for (int u = 0; u < AHEAD; u++) load(min(c0 + u, nchunks - 1), v[u]);
 #pragma unroll
-                for (int j = 0; j < RT_MAXG; j++) v[u][j] = j < G ? prob[(size_t)t * G + j] : 0.0f;
+        for (int u = 0; u < AHEAD; u++) {
+            const int c = c0 + u;
+            if (c >= nchunks) break;
+            const unsigned m = (c * RT_CHUNK + tid < T) ? select_topk(v[u], G, k) : 0u;
+            if (c == mine) my_mask = m;
+#pragma unroll
+            for (int g = 0; g < MG; g++) {
+                const unsigned long long b = __ballot((m >> g) & 1u);
+                const int n = __popcll(b);
+                total[g] += n;
+                if (c < mine) before[g] += n;
+                if (c == mine) {
+                    own[g] = n;
+                    rank[g] = __popcll(b & lower);
+                }
             }
         }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            if (tb + u < t1) {
-                const unsigned m = select_topk(v[u], G, k);
-                sel[tb + u] = (uint8_t)m;
-#pragma unroll
-                for (int g = 0; g < RT_MAXG; g++) cnt[g] += (m >> g) & 1u;
-            }
-        }
     }
-    // exclusive prefix over threads, per block
-    int pre[RT_MAXG];
+    if (lane == 0) {
 #pragma unroll
-    for (int g = 0; g < RT_MAXG; g++) {
-        int inc = cnt[g];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += o;
+        for (int g = 0; g < MG; g++) {
+            wave_before[wave][g] = before[g];
+            wave_total[wave][g] = total[g];
+            wave_mine[wave][g] = own[g];
         }
-        pre[g] = inc - cnt[g];
-        if (lane == 63) wave_tot[wave][g] = inc;
     }
     __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int g = 0; g < G; g++) {
-            base[g] = run;
-            for (int w = 0; w < RT_THREADS / 64; w++) run += wave_tot[w][g];
-        }
-        base[G] = run;
-        for (int g = 0; g <= G; g++) offsets[g] = base[g];
-    }
-    __syncthreads();
+    // position of this token's selection of block g: all selections of lower blocks, then those of
+    // block g in earlier chunks, in lower waves of this chunk, in lower lanes of this wave
+    int run = 0, place[MG];
 #pragma unroll
-    for (int g = 0; g < RT_MAXG; g++) {
-        int before = g < G ? base[g] : 0;
-        for (int w = 0; w < wave; w++) before += wave_tot[w][g];
-        pre[g] += before;
+    for (int g = 0; g < MG; g++) {
+        int tot = 0, bef = 0;
+#pragma unroll
+        for (int w = 0; w < RT_CHUNK / 64; w++) {
+            tot += wave_total[w][g];
+            bef += wave_before[w][g] + (w < wave ? wave_mine[w][g] : 0);
+        }
+        place[g] = run + bef + rank[g];
+        if (mine == 0 && tid == 0 && g < G) offsets[g] = run;
+        run += g < G ? tot : 0;
     }
-    // pass 2: placement (a thread only reads the selections it wrote)
-    for (int t = t0; t < t1; t++) {
-        const unsigned m = sel[t];
+    if (mine == 0 && tid == 0) offsets[G] = run;
+    const int t = mine * RT_CHUNK + tid;
+    if (t < T) {
         int j = 0;
 #pragma unroll
-        for (int g = 0; g < RT_MAXG; g++) {
-            if ((m >> g) & 1u) {
-                const int r = pre[g]++;
+        for (int g = 0; g < MG; g++) {
+            if ((my_mask >> g) & 1u) {
+                const int r = place[g];
                 token[r] = t;
                 block[r] = g;
                 pos[(size_t)t * k + j] = r;
@@ -148,13 +159,14 @@ extern "C" int spt_route_topk(const float *prob, int32_t *token, int32_t *block,
                               int k, void *stream) {
     if (!prob || !token || !block || !offsets || !pos) return SPT_EINVAL;
     if (n_tokens <= 0 || n_blocks <= 0 || k <= 0 || k > n_blocks) return SPT_EINVAL;
-    if (n_blocks > RT_MAXG || n_tokens > 64 * RT_THREADS) return SPT_EUNSUP;
-    const size_t lds = ((size_t)n_tokens + 15) & ~(size_t)15;
-    if (lds > 64 * 1024)
-        SPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&route_topk_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(route_topk_kernel, dim3(1), dim3(RT_THREADS), lds, (hipStream_t)stream,
-                       prob, token, block, offsets, pos, n_tokens, n_blocks, k);
+    if (n_blocks > RT_MAXG || n_tokens > 65536) return SPT_EUNSUP;
+    const dim3 grid((n_tokens + RT_CHUNK - 1) / RT_CHUNK), threads(RT_CHUNK);
+    if (n_blocks <= 4)
+        hipLaunchKernelGGL(route_topk_kernel<4>, grid, threads, 0, (hipStream_t)stream, prob, token,
+                           block, offsets, pos, n_tokens, n_blocks, k);
+    else
+        hipLaunchKernelGGL(route_topk_kernel<RT_MAXG>, grid, threads, 0, (hipStream_t)stream, prob, token,
+                           block, offsets, pos, n_tokens, n_blocks, k);
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }

@@ -662,7 +662,12 @@ def test_norm_outputs_are_recomputed_not_kept(monkeypatch):
     assert torch.equal(y1, y0) and torch.equal(gx1, gx0)
     assert set(g0) == set(g1)
     for n in g0:
-        assert torch.equal(g1[n], g0[n]), n
+        if n.startswith('ffd.router') and n.endswith('weight'):
+            # the recomputing router forms its weight gradient split over the tokens (tall_tn):
+            # another summation order than autograd's single GEMM
+            assert torch.allclose(g1[n], g0[n], rtol=1e-5, atol=1e-6 * g0[n].abs().max().item()), n
+        else:
+            assert torch.equal(g1[n], g0[n]), n
     act = N * S * d * 4
     assert held0 - held1 >= 1.9 * act, (held0, held1, act)     # both norm outputs are gone
 
