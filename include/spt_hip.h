@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 21
+#define SPT_ABI_VERSION 22
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -486,6 +486,24 @@ int spt_lora_down(const float *x, long long ldx, long long rows, int k, const fl
 int spt_cross_entropy_grad(float *logits, long long ld, long long rows, int n_classes,
                            const long long *target, const float *scale, float *loss,
                            long long ignore_index, void *stream);
+
+/*
+ * LayerNorm of the residual stream with the additions around it (the pre-norm wiring of
+ * naive_gpt/layers/basic/transformer.py:46-52; nn.LayerNorm arithmetic: biased variance, eps
+ * inside the root).  rows x d fp32, contiguous; d in {256, 512, 1024, 2048} (SPT_EUNSUP else).
+ *   forward   s = x + r (r, s may be NULL: s = x, nothing written);  y = LN(s) gamma + beta;
+ *             mean, rstd [rows] for the backward.
+ *   backward  dx = dLN(dy) (+ dskip, may be NULL: the gradient arriving over the skip path);
+ *             dgamma, dbeta = ONE buffer [2, d] (dbeta == dgamma + d); `partial`:
+ *             spt_layernorm_partial_rows(rows) x 2 d floats of scratch.  Fixed summation order.
+ */
+int spt_layernorm_partial_rows(long long rows);
+int spt_add_layernorm_forward(const float *x, const float *r, const float *gamma, const float *beta,
+                              float *s, float *y, float *mean, float *rstd, long long rows, int d,
+                              float eps, void *stream);
+int spt_layernorm_backward(const float *s, const float *dy, const float *gamma, const float *mean,
+                           const float *rstd, const float *dskip, float *dx, float *dgamma,
+                           float *dbeta, float *partial, long long rows, int d, void *stream);
 
 /*
  * Bucketing for the routed FFN: the k largest of the n_blocks router probabilities of every

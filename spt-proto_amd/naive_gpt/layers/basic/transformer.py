@@ -9,6 +9,7 @@ import copy
 import torch
 from torch import nn
 
+from . import fused_norm
 from .multihead import project_heads
 from ..tuning import recompute
 
@@ -42,13 +43,22 @@ class TransformerBlock(nn.Module):
         self.norm1 = copy.deepcopy(layernorm_fn)
         self.norm2 = copy.deepcopy(layernorm_fn)
 
+    def forward_pair(self, x: torch.Tensor, pending, attn_mask: torch.Tensor = None):
+        """The pre-norm block on (residual stream, addend not yet added): returns the same pair --
+        every addition of the stream then sits in front of a norm and is fused with it
+        (fused_norm.py).  forward(x) == x' + pending' of forward_pair(x, None)."""
+        assert x.dim() == 3 and self.pre_norm
+        # (the norm outputs are tagged so that the LoRA layers behind them can recompute
+        # them in the backward instead of keeping them: layers/tuning/recompute.py)
+        x, h = fused_norm.add_norm(self.norm1, x, pending)
+        h = recompute.tag(h, self.norm1, x)
+        x, h = fused_norm.add_norm(self.norm2, x, self.mha(h, h, h, attn_mask=attn_mask))
+        return x, self.ffd(recompute.tag(h, self.norm2, x))
+
     def forward(self, x: torch.Tensor, attn_mask: torch.Tensor = None):
         assert x.dim() == 3
         if self.pre_norm:
-            # (the norm outputs are tagged so that the LoRA layers behind them can recompute
-            # them in the backward instead of keeping them: layers/tuning/recompute.py)
-            h = recompute.tag(self.norm1(x), self.norm1, x)
-            x = x + self.mha(h, h, h, attn_mask=attn_mask)
-            return x + self.ffd(recompute.tag(self.norm2(x), self.norm2, x))
+            x, pending = self.forward_pair(x, None, attn_mask=attn_mask)
+            return x + pending
         x = self.norm1(x + self.mha(x, x, x, attn_mask=attn_mask))
         return self.norm2(x + self.ffd(x))

@@ -59,7 +59,9 @@ def output(module: nn.Module, input: torch.Tensor) -> torch.Tensor:
     if _last[0] == key:
         return _last[1]
     with torch.no_grad():
-        out = module(input)
+        # the same kernel as the forward took (basic/fused_norm.py), so the same bits
+        from ..basic import fused_norm
+        out = fused_norm.add_norm(module, input, None)[1]
     _last[0], _last[1] = key, out
     return out
 

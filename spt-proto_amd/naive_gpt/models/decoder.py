@@ -48,6 +48,15 @@ class DecoderLM(nn.Module):
         seq_length = x.size(-1)
         mask = self.attn_mask[:seq_length, :seq_length]
         h = self.embed(x)
+        if all(getattr(block, 'pre_norm', False) and hasattr(block, 'forward_pair')
+               for block in self.decoders):
+            # pre-norm stack as (stream, pending addend) pairs: each residual addition is fused
+            # with the norm behind it, the last one with the final norm (layers/basic/fused_norm.py)
+            from naive_gpt.layers.basic import fused_norm
+            pending = None
+            for block in self.decoders:
+                h, pending = block.forward_pair(h, pending, attn_mask=mask)
+            return fused_norm.add_norm(self.final_norm, h, pending)[1]
         for block in self.decoders:
             h = block(h, attn_mask=mask)
         return self.final_norm(h)
