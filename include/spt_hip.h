@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 22
+#define SPT_ABI_VERSION 23
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -439,6 +439,8 @@ typedef struct SptGroupedGemm {
     int64_t ldo;               /* row stride (floats) of out, out2, h_in, s_in; 0: n.  A padded
                                   stride keeps the rows of a ragged n (a vocabulary of 30522)
                                   16-byte aligned for the kernels that read them next */
+    int32_t accumulate;        /* != 0 (SPT_EPI_PLAIN only): out += the product instead of out = --
+                                  the sum of several products (dX of q / k / v) without a pass of its own */
 } SptGroupedGemm;
 int spt_grouped_gemm_fused(const SptGroupedGemm *desc, void *stream);
 int spt_grouped_gemm_pdot_width(int n);

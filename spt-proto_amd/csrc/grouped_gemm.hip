@@ -104,6 +104,7 @@ struct GroupedArgs {
     int P, K, N, G;
     int lda;
     long long ldo;          // row stride of out / out2 / h_in / s_in (>= N; launch_grouped: 0 -> N)
+    int accumulate;         // EPI_PLAIN: out += result (the sum of several products in one buffer)
     long long gstride;
     int ldn, ldk;
     // K extension (the LoRA side product), added AFTER rowscale / bias:
@@ -350,6 +351,16 @@ __device__ __forceinline__ void gg_epilogue(const GroupedArgs &g, float *smem,
                         cand &= ~(1u << e);
                     }
                     todo = __ballot(cand != 0);
+                }
+            }
+            if (EPI == EPI_PLAIN && g.accumulate && live) {
+                if (vec_row && n + 3 < g.N) {
+                    const float4 o4 = *reinterpret_cast<const float4 *>(g.out + at);
+                    c[0] += o4.x; c[1] += o4.y; c[2] += o4.z; c[3] += o4.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (n + e < g.N) c[e] += g.out[at + e];
                 }
             }
             if (live) {
@@ -1060,6 +1071,7 @@ static int launch_grouped(GroupedArgs g, int epilogue, void *stream) {
     if (g.P <= 0 || g.K <= 0 || g.N <= 0 || g.G <= 0 || g.lda < g.K) return SPT_EINVAL;
     if (g.ldo == 0) g.ldo = g.N;
     if (g.ldo < g.N) return SPT_EINVAL;
+    if (g.accumulate && epilogue != EPI_PLAIN) return SPT_EUNSUP;
     if (g.K % 4 != 0 || g.lda % 4 != 0) return SPT_ESHAPE;       // float4 rows of A
     if (g.ldk != 1 && g.ldn != 1) return SPT_EUNSUP;
     if (g.ldk == 1 && (g.ldn % 4 != 0 || g.gstride % 4 != 0)) return SPT_ESHAPE;
@@ -1162,6 +1174,7 @@ extern "C" int spt_grouped_gemm_fused(const SptGroupedGemm *d, void *stream) {
     g.w_img = reinterpret_cast<const char *>(d->w_image);
     g.a_norm = d->a_norm; g.w_norm = d->w_norm;
     g.ldo = d->ldo;
+    g.accumulate = d->accumulate;
     const long long header = GG_FIX_SEGS * 64;
     if (d->relu_queue && d->relu_queue_bytes >= header + GG_FIX_SEGS * 8) {
         g.fix_count = reinterpret_cast<unsigned *>(d->relu_queue);

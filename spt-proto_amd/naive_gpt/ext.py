@@ -84,7 +84,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _lib = None
 
@@ -801,6 +801,7 @@ class _GroupedDesc(ctypes.Structure):
         ('pdot_main', _c_ptr), ('pdot_act', _c_ptr), ('pdot_ld', ctypes.c_int32),
         ('a_image', _c_ptr), ('w_image', _c_ptr), ('a_norm', _c_ptr), ('w_norm', _c_ptr),
         ('relu_queue', _c_ptr), ('relu_queue_bytes', ctypes.c_int64), ('ldo', ctypes.c_int64),
+        ('accumulate', ctypes.c_int32),
     ]
 
 
@@ -968,14 +969,16 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                        keep_preact: bool = False, h_in=None, s_in=None,
                        a_image: SplitImage = None, w_image: SplitImage = None,
                        a_norm: torch.Tensor = None, w_norm: torch.Tensor = None,
-                       relu_queue_entries: int = None, out: torch.Tensor = None):
+                       relu_queue_entries: int = None, out: torch.Tensor = None,
+                       accumulate: bool = False):
     """``spt_grouped_gemm_fused``: the block GEMM of a routed FFN with its LoRA side
     product, rowscale / bias, and the activation (EPI_ACT) or its derivative plus the two
     row dots of the coefficient gradient (EPI_DACT) folded in (include/spt_hip.h).
 
     Returns ``out`` (EPI_PLAIN), ``(out, preact | None)`` (EPI_ACT) or
     ``(out, dot_main [P], dot_act [P])`` (EPI_DACT).  ``out``: a buffer [n_rows, >= n] to write
-    into (EPI_PLAIN; its row stride may exceed n: ``ldo`` of include/spt_hip.h)."""
+    into (EPI_PLAIN; its row stride may exceed n: ``ldo`` of include/spt_hip.h); with
+    ``accumulate`` the product is ADDED to what `out` holds."""
     for t, name in ((a, 'a'), (weight, 'weight')):
         _check_type(t, torch.float32, name)
     _check_type(offsets, torch.int32, 'offsets')
@@ -1011,6 +1014,7 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                  'w_image: the image of the weight with rows of w_ldn (w_ldk) elements')
     lib = load_library()
     with torch.cuda.device(dev):
+        _require(not accumulate or out is not None, 'accumulate: needs `out`')
         if out is None:
             out = torch.empty([n_rows, n], dtype=torch.float32, device=dev)
         else:
@@ -1047,7 +1051,8 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                 a_image=a_image.buffer.data_ptr() if images else None,
                 w_image=w_image.buffer.data_ptr() if images else None,
                 a_norm=_ptr(a_norm), w_norm=_ptr(w_norm), relu_queue=_ptr(queue),
-                relu_queue_bytes=queue.numel() if queue is not None else 0, ldo=out.stride(0))
+                relu_queue_bytes=queue.numel() if queue is not None else 0, ldo=out.stride(0),
+                accumulate=int(bool(accumulate)))
             global LAST_GEMM_USED_IMAGES
             LAST_GEMM_USED_IMAGES = bool(lib.spt_grouped_gemm_image_path(ctypes.byref(desc)))
             rc = lib.spt_grouped_gemm_fused(ctypes.byref(desc), _stream(dev))

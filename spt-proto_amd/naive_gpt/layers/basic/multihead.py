@@ -10,13 +10,20 @@ def project_heads(module, q, k, v, attn_mask):
     ``[N,S,d] -> [N,S,H,E]``, run the attention core, merge, project out."""
     assert q.size(0) == k.size(0) == v.size(0)
     n_heads = module.n_heads
+    fused = False
     if q is k and k is v:
-        # self-attention: adapters on the three projections share one pass over the input
+        # self-attention: frozen projections with adapters run as one function of the shared input
         from ..tuning import lora
-        lora.prepare_shared(q, (module.linear_q, module.linear_k, module.linear_v))
-    q = module.linear_q(q)
-    k = module.linear_k(k)
-    v = module.linear_v(v)
+        linears = (module.linear_q, module.linear_k, module.linear_v)
+        if lora.qkv_usable(q, linears):
+            q, k, v = lora.qkv(q, linears)
+            fused = True
+        else:
+            lora.prepare_shared(q, linears)      # (at least one pass for the three down products)
+    if not fused:
+        q = module.linear_q(q)
+        k = module.linear_k(k)
+        v = module.linear_v(v)
     q = q.view([q.size(0), q.size(1), n_heads, -1])
     k = k.view([k.size(0), k.size(1), n_heads, -1])
     v = v.view([v.size(0), v.size(1), n_heads, -1])

@@ -202,6 +202,96 @@ class _FrozenLoRALinear(torch.autograd.Function):
         return grad_x, None, None, grad_left, grad_right
 
 
+class _FrozenLoRAQKV(torch.autograd.Function):
+    """The three projections of a self-attention input as ONE function: q, k, v = x W_g^T + b_g +
+    (x L_g) R_g^T (three `_FrozenLoRALinear`s, reference lora.py:70-80 called three times from
+    multihead.py:13-15).  What sharing buys: one pass over x for the three down products and the
+    operand image (forward); in the backward dX = sum_g dY_g W_g accumulates in one buffer (the
+    GEMM's `accumulate`: no elementwise sums) and the three `left` gradients are one product
+    x^T [dU_q | dU_k | dU_v]."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        from naive_gpt import ext
+        weights, biases = params[0:3], params[3:6]
+        lefts, rights = params[6:9], params[9:12]
+        x2 = x.reshape(-1, x.size(-1))
+        n, k = weights[0].shape
+        u3, image, _ = ext.lora_down(x2, torch.cat(lefts, dim=1), want_image=True, block_major=True)
+        one = _one_group(x2.size(0), x2.device)
+        outs = []
+        for g in range(3):
+            y = ext.grouped_gemm_fused(
+                x2, weights[g], one, 1, n, k, 0, k, 1, x2.size(0),
+                bias=None if biases[g] is None else biases[g].view(1, n),
+                a2=u3[g], b2=rights[g].contiguous(), a_image=image,
+                w_image=ext.weight_image(weights[g]))
+            outs.append(y.view(*x.shape[:-1], n))
+        origin = recompute.origin_of(x)
+        ctx.origin_module = origin.module if origin is not None else None
+        ctx.save_for_backward(origin.input if origin is not None else x2, u3, *weights, *lefts, *rights)
+        ctx.x_shape = x.shape
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        from naive_gpt import ext
+        saved = ctx.saved_tensors
+        x2, u3 = saved[0], saved[1]
+        weights, lefts, rights = saved[2:5], saved[5:8], saved[8:11]
+        n, k = weights[0].shape
+        if ctx.origin_module is not None:
+            x2 = recompute.output(ctx.origin_module, x2).reshape(-1, k)
+        rows = x2.size(0)
+        one = _one_group(rows, x2.device)
+        dy2 = [None if d is None else d.reshape(-1, n).contiguous() for d in dys]
+        dus = [None if d is None else torch.matmul(d, rights[g]) for g, d in enumerate(dy2)]
+        grad_x = None
+        if ctx.needs_input_grad[0]:
+            for g in range(3):
+                if dy2[g] is None:
+                    continue
+                # dX (+)= dY_g W_g + dU_g L_g^T
+                grad_x = ext.grouped_gemm_fused(
+                    dy2[g], weights[g], one, 1, k, n, 0, 1, k, rows, a2=dus[g].contiguous(),
+                    b2=lefts[g].contiguous(), out=grad_x, accumulate=grad_x is not None)
+            if grad_x is not None:
+                grad_x = grad_x.view(ctx.x_shape)
+        live = [g for g in range(3) if dy2[g] is not None]
+        grad_lefts, grad_rights = [None] * 3, [None] * 3
+        if live:
+            gl = tall_tn(x2, torch.cat([dus[g] for g in live], dim=1))        # [k, 16 * len(live)]
+            r = lefts[0].size(1)
+            for i, g in enumerate(live):
+                grad_lefts[g] = gl[:, i * r:(i + 1) * r]
+                grad_rights[g] = tall_tn(dy2[g], u3[g])
+        return (grad_x, None, None, None, None, None, None, *grad_lefts, *grad_rights)
+
+
+def qkv_usable(x: torch.Tensor, linears) -> bool:
+    from naive_gpt import ext
+    if not (x.is_cuda and x.dim() >= 2 and x.dtype == torch.float32 and not x.is_inference()):
+        return False
+    if not all(isinstance(m, LoRALinear) and m._frozen() for m in linears):
+        return False
+    w = linears[0].weight
+    if any(m.weight.shape != w.shape or (m.bias is None) != (linears[0].bias is None)
+           or m.lora.left.weight.size(1) != 16 for m in linears):
+        return False
+    x2 = x.reshape(-1, x.size(-1))
+    n, k = w.shape
+    return (x2.is_contiguous() and _mfma_linear_usable(x2, w, 16) and _mfma_linear_usable(x2, w, 16, False)
+            and k % 1024 == 0 and n % 32 == 0
+            and all(m.lora.left.weight.requires_grad and m.lora.right.weight.requires_grad for m in linears))
+
+
+def qkv(x: torch.Tensor, linears):
+    """(linear_q(x), linear_k(x), linear_v(x)) as one autograd function (see _FrozenLoRAQKV)."""
+    args = ([m.weight for m in linears] + [m.bias for m in linears]
+            + [m.lora.left.weight for m in linears] + [m.lora.right.weight for m in linears])
+    return _FrozenLoRAQKV.apply(x, *args)
+
+
 class LoRALinear(nn.Linear):
     def __init__(self, d_lora: int, in_features: int, out_features: int,
                  bias: bool = True, *args, **kwargs):

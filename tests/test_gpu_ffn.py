@@ -748,3 +748,45 @@ def test_recomputed_norm_output_is_never_stale_across_steps():
     fresh = grads(xs[1], keep=False)
     for n in fresh:
         assert torch.equal(second[n], fresh[n]), n
+
+
+def test_joint_qkv_projection_equals_three_lora_linears():
+    """lora.qkv (one function for the three projections of a self-attention input: shared down
+    product and operand image, dX accumulated in the GEMM, one product for the three `left`
+    gradients) against linear_q(x), linear_k(x), linear_v(x)."""
+    from naive_gpt import layers
+    from naive_gpt.layers.tuning import lora
+    torch.manual_seed(0)
+    d = 1024
+    linears = [layers.LoRALinear.from_pretrained(16, nn.Linear(d, d)).cuda() for _ in range(3)]
+    for m in linears:
+        m.lora.right.weight.data.normal_(0, 0.02)
+    x0 = torch.randn([4, 512, d], device='cuda')
+    ws = [torch.randn([4, 512, d], device='cuda') for _ in range(3)]
+
+    def run(joint):
+        x = x0.clone().requires_grad_(True)
+        for m in linears:
+            m.zero_grad()
+        if joint:
+            assert lora.qkv_usable(x, linears)
+            outs = lora.qkv(x, linears)
+        else:
+            outs = [m(x) for m in linears]
+        sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+        grads = [x.grad] + [m.lora.left.weight.grad.clone() for m in linears] \
+            + [m.lora.right.weight.grad.clone() for m in linears]
+        return [o.detach() for o in outs] + grads
+
+    for a, b in zip(run(True), run(False)):
+        assert torch.allclose(a, b, rtol=1e-3, atol=2e-5 * b.abs().max().item())
+    # only two of the three outputs used downstream: the unused one contributes nothing
+    x = x0.clone().requires_grad_(True)
+    q, k, v = lora.qkv(x, linears)
+    for m in linears:
+        m.zero_grad()
+    ((q * ws[0]).sum() + (v * ws[2]).sum()).backward()
+    xr = x0.clone().requires_grad_(True)
+    ((linears[0](xr) * ws[0]).sum() + (linears[2](xr) * ws[2]).sum()).backward()
+    assert torch.allclose(x.grad, xr.grad, rtol=1e-3, atol=2e-5 * xr.grad.abs().max().item())
+    assert linears[1].lora.left.weight.grad is None or not linears[1].lora.left.weight.grad.any()
