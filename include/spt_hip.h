@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 23
+#define SPT_ABI_VERSION 24
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -94,6 +94,13 @@ int64_t spt_pq_loss_workspace_bytes(int64_t n_vectors, int n_subspaces, int n_co
 int spt_pq_loss_forward(const float *z, const float *table, float *loss, void *workspace,
                         int64_t n_vectors, int n_subspaces, int n_codewords, int d_code,
                         void *stream);
+/* The same forward with the PQ codes as a by-product: z [batch, seq, heads, M * D] (the attention
+ * layout) -> loss as above and codes [batch * heads, seq, M] -- bit for bit those of
+ * spt_pq_encode_heads (the loss's argmin is the code): a training step that arms the loss needs no
+ * encode pass. */
+int spt_pq_loss_forward_codes(const float *z, const float *table, float *loss, void *workspace,
+                              int32_t *codes, int batch, int seq_length, int n_heads,
+                              int n_subspaces, int n_codewords, int d_code, void *stream);
 int spt_pq_loss_backward(const float *z, const float *table, const float *grad_loss,
                          float *grad_z, float *grad_table, void *workspace,
                          int64_t n_vectors, int n_subspaces, int n_codewords, int d_code,

@@ -122,7 +122,7 @@ __device__ __forceinline__ void pq_stage_table(const float *__restrict__ table, 
 template <int D>
 __global__ __launch_bounds__(PQL_THREADS) void pq_loss_forward_kernel(
     const float *__restrict__ z, const float *__restrict__ table, float *__restrict__ partial,
-    int total, int M) {
+    int total, int M, int32_t *__restrict__ codes, int S, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *tab = reinterpret_cast<float *>(smem);
     constexpr int CD = PQL_C * D;
@@ -136,6 +136,14 @@ __global__ __launch_bounds__(PQL_THREADS) void pq_loss_forward_kernel(
     for (int j = first; j < total; j += gridDim.x * PQL_THREADS) {
         PQSub<D> s;
         pq_sub_forward<D>(z + (size_t)j * D, tm, s);
+        if (codes) {
+            // the argmin IS the PQ code (same distances, same scan as pq_encode_heads_kernel):
+            // z [N, S, H, M D] -> codes [N H, S, M], the input of lookup
+            const int vec = j / M, m = j - vec * M;
+            const int ns = vec / H, h = vec - ns * H;
+            const int n = ns / S, sq = ns - n * S;
+            codes[((size_t)(n * H + h) * S + sq) * M + m] = s.best;
+        }
 #pragma unroll
         for (int i = 0; i < D; i++) {
             const float e1 = s.zw[i] - s.zq[i];
@@ -427,12 +435,14 @@ extern "C" int64_t spt_pq_loss_workspace_bytes(int64_t n_vectors, int n_subspace
     return (int64_t)nblk * n_subspaces * n_codewords * d_code * (int64_t)sizeof(float);
 }
 
-extern "C" int spt_pq_loss_forward(const float *z, const float *table, float *loss,
-                                   void *workspace, int64_t n_vectors, int n_subspaces,
-                                   int n_codewords, int d_code, void *stream) {
+static int pq_loss_forward_any(const float *z, const float *table, float *loss, void *workspace,
+                               int64_t n_vectors, int n_subspaces, int n_codewords, int d_code,
+                               int32_t *codes, int seq_length, int n_heads, void *stream) {
     if (!z || !table || !loss || !workspace) return SPT_EINVAL;
     if (n_vectors <= 0 || n_subspaces <= 0 || n_codewords <= 0 || d_code <= 0) return SPT_EINVAL;
     if (!pq_loss_shape_ok(n_vectors, n_subspaces, n_codewords, d_code)) return SPT_EUNSUP;
+    if (codes && (seq_length <= 0 || n_heads <= 0 || n_vectors % ((int64_t)seq_length * n_heads) != 0))
+        return SPT_ESHAPE;
     const int total = (int)(n_vectors * n_subspaces);
     const int nblk = pq_loss_blocks(total);
     const size_t lds = (size_t)n_subspaces * (n_codewords * d_code + 4) * sizeof(float);
@@ -441,15 +451,31 @@ extern "C" int spt_pq_loss_forward(const float *z, const float *table, float *lo
     hipStream_t s = (hipStream_t)stream;
     if (d_code == 4)
         hipLaunchKernelGGL((pq_loss_forward_kernel<4>), dim3(nblk), dim3(PQL_THREADS), lds, s, z,
-                           table, partial, total, n_subspaces);
+                           table, partial, total, n_subspaces, codes, seq_length, n_heads);
     else
         hipLaunchKernelGGL((pq_loss_forward_kernel<8>), dim3(nblk), dim3(PQL_THREADS), lds, s, z,
-                           table, partial, total, n_subspaces);
+                           table, partial, total, n_subspaces, codes, seq_length, n_heads);
     SPT_LAUNCH_CHECK();
     hipLaunchKernelGGL(pq_loss_finish_kernel, dim3(1), dim3(64), 0, s, partial, loss, nblk,
                        inv_count);
     SPT_LAUNCH_CHECK();
     return SPT_OK;
+}
+
+extern "C" int spt_pq_loss_forward(const float *z, const float *table, float *loss,
+                                   void *workspace, int64_t n_vectors, int n_subspaces,
+                                   int n_codewords, int d_code, void *stream) {
+    return pq_loss_forward_any(z, table, loss, workspace, n_vectors, n_subspaces, n_codewords,
+                               d_code, nullptr, 0, 0, stream);
+}
+
+extern "C" int spt_pq_loss_forward_codes(const float *z, const float *table, float *loss,
+                                         void *workspace, int32_t *codes, int batch,
+                                         int seq_length, int n_heads, int n_subspaces,
+                                         int n_codewords, int d_code, void *stream) {
+    if (!codes || batch <= 0 || seq_length <= 0 || n_heads <= 0) return SPT_EINVAL;
+    return pq_loss_forward_any(z, table, loss, workspace, (int64_t)batch * seq_length * n_heads,
+                               n_subspaces, n_codewords, d_code, codes, seq_length, n_heads, stream);
 }
 
 extern "C" int spt_pq_loss_backward(const float *z, const float *table, const float *grad_loss,

@@ -38,6 +38,7 @@ _PROTOTYPES = {
     'spt_pq_encode_heads_bf16': ([_c_ptr] * 3 + [_c_int] * 6 + [_c_ptr], _c_int),
     'spt_pq_loss_workspace_bytes': ([ctypes.c_int64] + [_c_int] * 3, ctypes.c_int64),
     'spt_pq_loss_forward': ([_c_ptr] * 4 + [ctypes.c_int64] + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_pq_loss_forward_codes': ([_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr], _c_int),
     'spt_pq_loss_backward': ([_c_ptr] * 6 + [ctypes.c_int64] + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_sddmm_forward': (
         [_c_ptr] * 5 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int
@@ -84,7 +85,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _lib = None
 
@@ -335,17 +336,26 @@ def _pq_loss_args(z: torch.Tensor, table: torch.Tensor):
     return lib, dev, n_vectors, (M, C, D), nbytes
 
 
-def pq_loss_forward(z: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
-    """-> 0-dim loss of ``PQBase.forward('train', z)`` (quantizer.py:80-111)."""
+def pq_loss_forward(z: torch.Tensor, table: torch.Tensor, want_codes: bool = False):
+    """-> 0-dim loss of ``PQBase.forward('train', z)`` (quantizer.py:80-111); with ``want_codes``
+    (z [N, S, H, E]) also the PQ codes [N * H, S, M] of ``pq_encode_heads``, from the same pass."""
     lib, dev, n_vectors, (M, C, D), nbytes = _pq_loss_args(z, table)
     with torch.cuda.device(dev):
         loss = torch.empty([], dtype=torch.float32, device=dev)
         scratch = torch.empty([nbytes // 4], dtype=torch.float32, device=dev)
-        rc = lib.spt_pq_loss_forward(z.data_ptr(), table.data_ptr(), loss.data_ptr(),
-                                     scratch.data_ptr(), n_vectors, M, C, D, _stream(dev))
+        if want_codes:
+            _check_dim(z, 4, 'z')
+            N, S, H, _ = z.shape
+            codes = torch.empty([N * H, S, M], dtype=torch.int32, device=dev)
+            rc = lib.spt_pq_loss_forward_codes(z.data_ptr(), table.data_ptr(), loss.data_ptr(),
+                                               scratch.data_ptr(), codes.data_ptr(), N, S, H, M, C, D,
+                                               _stream(dev))
+        else:
+            rc = lib.spt_pq_loss_forward(z.data_ptr(), table.data_ptr(), loss.data_ptr(),
+                                         scratch.data_ptr(), n_vectors, M, C, D, _stream(dev))
     if rc != 0:
         _raise(lib, rc, 'pq_loss_forward')
-    return loss
+    return (loss, codes) if want_codes else loss
 
 
 def pq_loss_backward(z: torch.Tensor, table: torch.Tensor, grad_loss: torch.Tensor):

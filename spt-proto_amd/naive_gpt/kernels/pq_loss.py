@@ -12,17 +12,26 @@ from naive_gpt import ext
 
 class PQLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z: torch.Tensor, table: torch.Tensor):
+    def forward(ctx, z: torch.Tensor, table: torch.Tensor, want_codes: bool = False):
         z, table = z.contiguous(), table.contiguous()
         ctx.save_for_backward(z, table)
+        if want_codes:
+            loss, codes = ext.pq_loss_forward(z, table, want_codes=True)
+            ctx.mark_non_differentiable(codes)
+            return loss, codes
         return ext.pq_loss_forward(z, table)
 
     @staticmethod
-    def backward(ctx, grad_loss: torch.Tensor):
+    def backward(ctx, grad_loss: torch.Tensor, *unused):
         z, table = ctx.saved_tensors
         grad_z, grad_table = ext.pq_loss_backward(z, table, grad_loss.contiguous())
-        return grad_z, grad_table
+        return grad_z, grad_table, None
 
 
 def pq_loss(z: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
     return PQLoss.apply(z, table)
+
+
+def pq_loss_and_codes(z: torch.Tensor, table: torch.Tensor):
+    """(loss, codes [N * H, S, M]) for z [N, S, H, E]: the loss's argmin is the PQ code."""
+    return PQLoss.apply(z, table, True)

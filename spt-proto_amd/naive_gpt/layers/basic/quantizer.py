@@ -63,6 +63,13 @@ class PQBase(nn.Module):
             return kernels.pq_loss(z, self.weight)
         return self('train', z=z)[-1]
 
+    def train_loss_and_codes(self, z: torch.Tensor):
+        """(``self('train', z)[-1]``, PQ codes [N * H, S, M]) of z [N, S, H, E] in one pass where
+        the fused operator applies (its argmin is the code), else (loss, None)."""
+        if self.method == 'v2' and z.dim() == 4 and ext.pq_loss_supported(z, self.weight):
+            return kernels.pq_loss_and_codes(z, self.weight)
+        return self.train_loss(z), None
+
     def forward(self, mode: str, z: torch.Tensor):
         assert mode in _MODES
         assert z.dim() > 1

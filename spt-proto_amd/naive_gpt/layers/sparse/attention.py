@@ -255,15 +255,19 @@ class _SparseCore:
         """MI355X fast path: no layout copies (see module docstring)."""
         seq_length, heads = q.size(1), q.size(2)
         q, k = q.contiguous(), k.contiguous()
+        q_c = k_c = None
         if self._take_trigger():
             # the PQ loss is a mean over all sub-vectors: the head layout holds the same set
-            # (bf16 storage: the loss is formed in fp32 from the widened values)
-            loss_q = self.quantizer.train_loss(q.float())
-            loss_k = self.quantizer.train_loss(k.float())
+            # (bf16 storage: the loss is formed in fp32 from the widened values); its argmin is
+            # the PQ code, so an armed step needs no encode pass
+            loss_q, q_c = self.quantizer.train_loss_and_codes(q.float())
+            loss_k, k_c = self.quantizer.train_loss_and_codes(k.float())
             self.register_buffer('loss', loss_q + loss_k, persistent=False)
         table = self.quantizer.weight.detach()
-        q_c = ext.pq_encode_heads(q.detach(), table)
-        k_c = ext.pq_encode_heads(k.detach(), table)
+        if q_c is None:
+            q_c = ext.pq_encode_heads(q.detach(), table)
+        if k_c is None:
+            k_c = ext.pq_encode_heads(k.detach(), table)
         topk_indices = kernels.lookup(q_c, k_c, sparse_coeff=SPARSE_COEFF)
         csr_indices = topk_indices.flatten(start_dim=1)
         indptr = self._uniform_indptr(seq_length, q.device)

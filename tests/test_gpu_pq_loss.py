@@ -154,3 +154,25 @@ def test_unsupported_shapes_fall_back_and_raise():
     loss = pq.train_loss(z.requires_grad_(True))           # composed path
     loss.backward()
     assert torch.isfinite(loss)
+
+
+def test_loss_forward_leaves_the_pq_codes_of_the_encode_pass():
+    """spt_pq_loss_forward_codes: the loss of the plain forward and, bit for bit, the codes of
+    spt_pq_encode_heads (the loss's argmin is the code)."""
+    from naive_gpt import ext, kernels
+    gen = torch.Generator().manual_seed(11)
+    N, S, H, M, C, D = 2, 256, 16, 8, 16, 8
+    z = torch.randn([N, S, H, M * D], generator=gen).cuda()
+    table = torch.randn([M, C, D], generator=gen).cuda()
+    loss, codes = ext.pq_loss_forward(z, table, want_codes=True)
+    assert torch.equal(loss, ext.pq_loss_forward(z, table))
+    assert torch.equal(codes, ext.pq_encode_heads(z, table))
+    zr = z.clone().requires_grad_(True)
+    tr = table.clone().requires_grad_(True)
+    l2, c2 = kernels.pq_loss_and_codes(zr, tr)
+    assert not c2.requires_grad and torch.equal(c2, codes)
+    l2.backward()
+    z0 = z.clone().requires_grad_(True)
+    t0 = table.clone().requires_grad_(True)
+    kernels.pq_loss(z0, t0).backward()
+    assert torch.equal(zr.grad, z0.grad) and torch.equal(tr.grad, t0.grad)
