@@ -400,8 +400,19 @@ __global__ __launch_bounds__(1024) void pq_loss_table_reduce_kernel(
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     float acc = 0.0f;
-    if (e < elems)
-        for (int b = grp; b < nblk; b += 16) acc += partial[(size_t)b * elems + e];
+    if (e < elems) {
+        // four loads in flight per thread (one dependent chain of 32 loads was the kernel's time)
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int b = grp;
+        for (; b + 48 < nblk; b += 64) {
+            a0 += partial[(size_t)b * elems + e];
+            a1 += partial[(size_t)(b + 16) * elems + e];
+            a2 += partial[(size_t)(b + 32) * elems + e];
+            a3 += partial[(size_t)(b + 48) * elems + e];
+        }
+        for (; b < nblk; b += 16) a0 += partial[(size_t)b * elems + e];
+        acc = (a0 + a1) + (a2 + a3);
+    }
     red[grp][lane] = acc;
     __syncthreads();
     if (grp == 0 && e < elems) {
