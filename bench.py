@@ -487,6 +487,10 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='skip the HIP-graph records')
     ap.add_argument('--no-gemm-events', action='store_true')
     ap.add_argument('--only', action='store_true', help='the headline step alone')
+    ap.add_argument('--backend', default='nccl', help="process-group backend (nccl = RCCL)")
+    ap.add_argument('--one-device', action='store_true',
+                    help='rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0 '
+                         '(use with --backend gloo); not a measurement')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--cpu-seqs', type=int, default=16)
     args = ap.parse_args()
@@ -497,11 +501,16 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'launch {} ranks for --gpus {}'.format(args.gpus, args.gpus)
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from naive_gpt import ext
     ext.load_library()        # fail loudly when the HIP library is missing
