@@ -14,19 +14,26 @@ sys.path.insert(0, os.path.join(ROOT, 'spt-proto_amd'))
 import torch
 from naive_gpt import models, utils
 
-CONFIG = dict(d_model=1024, n_heads=16, n_layers=int(os.environ.get('LAYERS', 24)), max_length=512,
-              vocab_size=30522, d_feedforward=4096, p_dropout=0.0)
-N, S = int(os.environ.get('BATCH', 16)), 512
+# other configurations by environment, e.g. BASELINE configs[4] (LLaMA-7B dims):
+#   FAMILY=llama D_MODEL=4096 N_HEADS=32 D_FF=11008 LAYERS=32 SEQ=2048 VOCAB=32000 BATCH=1
+FAMILY = os.environ.get('FAMILY', 'opt')
+S = int(os.environ.get('SEQ', 512))
+CONFIG = dict(d_model=int(os.environ.get('D_MODEL', 1024)), n_heads=int(os.environ.get('N_HEADS', 16)),
+              n_layers=int(os.environ.get('LAYERS', 24)), max_length=S,
+              vocab_size=int(os.environ.get('VOCAB', 30522)),
+              d_feedforward=int(os.environ.get('D_FF', 4096)), p_dropout=0.0)
+N = int(os.environ.get('BATCH', 16))
 dev = 'cuda'
 
 
 def build(tuning):
     torch.manual_seed(0)
-    model = models.OPTModel(**CONFIG)
-    if tuning == 'lora':
-        model = utils.upgrade_sparse(model, d_lora=16, stages=('lora',))
-    elif tuning == 'sparse':
-        model = utils.upgrade_sparse(model, d_lora=16)
+    with torch.device(dev):           # (a 7B model is built on the GPU, not copied to it)
+        model = (models.LLaMAModel if FAMILY == 'llama' else models.OPTModel)(**CONFIG)
+        if tuning == 'lora':
+            model = utils.upgrade_sparse(model, d_lora=16, stages=('lora',))
+        elif tuning == 'sparse':
+            model = utils.upgrade_sparse(model, d_lora=16)
     return model.to(dev)
 
 
@@ -57,7 +64,7 @@ def run(tuning, steps=int(os.environ.get('STEPS', 8)), warmup=3):
     return res
 
 
-out = {'config': dict(CONFIG, batch=N, seq=S, dtype='f32',
+out = {'config': dict(CONFIG, family=FAMILY, batch=N, seq=S, dtype='f32',
                       what='SparseTuner.training_step: fwd + bwd + clip + AdamW')}
 tunings = os.environ.get('TUNINGS', 'full,lora,sparse').split(',')
 for tuning in tunings:
