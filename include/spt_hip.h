@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 24
+#define SPT_ABI_VERSION 25
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -526,6 +526,19 @@ int spt_layernorm_backward(const float *s, const float *dy, const float *gamma, 
  */
 int spt_route_topk(const float *prob, int32_t *token, int32_t *block, int32_t *offsets,
                    int32_t *pos, int n_tokens, int n_blocks, int k, void *stream);
+
+/*
+ * Router-coefficient gradient of the routed LoRA FFN's backward (layers/sparse/grouped.py; the
+ * reference differentiates c * (x W^T + b) by autograd, lora_ffn.py:96-98):
+ *   out[p] = (sum_j dot_main[p, j] + sum_j dot_act[p, j] - <du[p], u[token[p]]> - <dzt[token[p]], z[p]>)
+ *            / max(coeff[p], floor_value)
+ * dot_main, dot_act [n_rows, width]: SptGroupedGemm.pdot_main / pdot_act of the EPI_DACT GEMM;
+ * du, z [n_rows, rank]; u, dzt [tokens, rank]; rank % 4 == 0.
+ */
+int spt_ffn_coeff_grad(const float *dot_main, const float *dot_act, int width, const float *du,
+                       const float *u, const float *dzt, const float *z, const int32_t *token,
+                       const float *coeff, float floor_value, float *out, int n_rows, int rank,
+                       void *stream);
 
 /*
  * Un-bucketing: out[t, :] = bias + sum_{j < k} rows[pos[t * k + j], :] (bias may be NULL).

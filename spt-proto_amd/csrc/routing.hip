@@ -150,6 +150,37 @@ __global__ __launch_bounds__(RT_CHUNK) void route_topk_kernel(
     }
 }
 
+
+// The router-coefficient gradient of the routed LoRA FFN's backward (layers/sparse/grouped.py):
+//   out[p] = (sum_j dot_main[p, j] + sum_j dot_act[p, j] - <du[p], u[token[p]]> - <dzt[token[p]], z[p]>)
+//            / max(coeff[p], floor)
+// dot_main / dot_act: the EPI_DACT epilogue's per-column-tile partial row dots [P, w]; du, z [P, r];
+// u, dzt [T, r].  As torch operators: two reductions, two gathers' worth of products, seven
+// elementwise kernels on 16384-element vectors -- ~40 us of launches for 2 MB of data.
+__global__ __launch_bounds__(256) void ffn_coeff_grad_kernel(
+    const float *__restrict__ dot_main, const float *__restrict__ dot_act, int w,
+    const float *__restrict__ du, const float *__restrict__ u, const float *__restrict__ dzt,
+    const float *__restrict__ z, const int32_t *__restrict__ token, const float *__restrict__ coeff,
+    float floor_value, float *__restrict__ out, int P, int r) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    float acc = 0.0f;
+    for (int j = 0; j < w; j++) acc += dot_main[(size_t)p * w + j];
+    float acc2 = 0.0f;
+    for (int j = 0; j < w; j++) acc2 += dot_act[(size_t)p * w + j];
+    const int t = token[p];
+    float d1 = 0.0f, d2 = 0.0f;
+    for (int j = 0; j < r; j += 4) {
+        const float4 a = *reinterpret_cast<const float4 *>(du + (size_t)p * r + j);
+        const float4 b = *reinterpret_cast<const float4 *>(u + (size_t)t * r + j);
+        const float4 c = *reinterpret_cast<const float4 *>(dzt + (size_t)t * r + j);
+        const float4 e = *reinterpret_cast<const float4 *>(z + (size_t)p * r + j);
+        d1 += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+        d2 += (c.x * e.x + c.y * e.y) + (c.z * e.z + c.w * e.w);
+    }
+    out[p] = (((acc + acc2) - d1) - d2) / fmaxf(coeff[p], floor_value);
+}
+
 }  // namespace spt
 
 using namespace spt;
@@ -167,6 +198,20 @@ extern "C" int spt_route_topk(const float *prob, int32_t *token, int32_t *block,
     else
         hipLaunchKernelGGL(route_topk_kernel<RT_MAXG>, grid, threads, 0, (hipStream_t)stream, prob, token,
                            block, offsets, pos, n_tokens, n_blocks, k);
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
+extern "C" int spt_ffn_coeff_grad(const float *dot_main, const float *dot_act, int width,
+                                  const float *du, const float *u, const float *dzt, const float *z,
+                                  const int32_t *token, const float *coeff, float floor_value,
+                                  float *out, int n_rows, int rank, void *stream) {
+    if (!dot_main || !dot_act || !du || !u || !dzt || !z || !token || !coeff || !out) return SPT_EINVAL;
+    if (n_rows <= 0 || width <= 0 || rank <= 0) return SPT_EINVAL;
+    if (rank % 4 != 0) return SPT_ESHAPE;
+    hipLaunchKernelGGL(ffn_coeff_grad_kernel, dim3((n_rows + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, dot_main, dot_act, width, du, u, dzt, z, token, coeff,
+                       floor_value, out, n_rows, rank);
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }

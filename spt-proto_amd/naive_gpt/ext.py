@@ -72,6 +72,8 @@ _PROTOTYPES = {
     'spt_split_bf16_bytes': ([ctypes.c_longlong, _c_int], ctypes.c_size_t),
     'spt_split_bf16': ([_c_ptr, _c_ptr, ctypes.c_longlong, _c_int, ctypes.c_longlong, _c_ptr], _c_int),
     'spt_rows_combine': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_ffn_coeff_grad': ([_c_ptr, _c_ptr, _c_int] + [_c_ptr] * 6 + [_c_f32, _c_ptr, _c_int, _c_int, _c_ptr],
+                           _c_int),
     'spt_layernorm_partial_rows': ([ctypes.c_longlong], _c_int),
     'spt_add_layernorm_forward': ([_c_ptr] * 8 + [ctypes.c_longlong, _c_int, _c_f32, _c_ptr], _c_int),
     'spt_layernorm_backward': ([_c_ptr] * 10 + [ctypes.c_longlong, _c_int, _c_ptr], _c_int),
@@ -85,7 +87,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 _lib = None
 
@@ -980,7 +982,7 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                        a_image: SplitImage = None, w_image: SplitImage = None,
                        a_norm: torch.Tensor = None, w_norm: torch.Tensor = None,
                        relu_queue_entries: int = None, out: torch.Tensor = None,
-                       accumulate: bool = False):
+                       accumulate: bool = False, raw_dots: bool = False):
     """``spt_grouped_gemm_fused``: the block GEMM of a routed FFN with its LoRA side
     product, rowscale / bias, and the activation (EPI_ACT) or its derivative plus the two
     row dots of the coefficient gradient (EPI_DACT) folded in (include/spt_hip.h).
@@ -1073,6 +1075,8 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
         LAST_RELU_QUEUE = queue
         return out, preact
     if epilogue == EPI_DACT:
+        if raw_dots:            # [P, width] partial row dots per column tile (ffn_coeff_grad sums them)
+            return out, dot_main, dot_act
         return out, dot_main.sum(dim=-1), dot_act.sum(dim=-1)
     return out
 
@@ -1244,6 +1248,32 @@ def layernorm_backward(s: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, m
     if rc != 0:
         _raise(lib, rc, 'layernorm_backward')
     return dx, dparam[0], dparam[1]
+
+
+def ffn_coeff_grad(dot_main: torch.Tensor, dot_act: torch.Tensor, du: torch.Tensor, u: torch.Tensor,
+                   dzt: torch.Tensor, z: torch.Tensor, token: torch.Tensor, coeff: torch.Tensor,
+                   floor_value: float) -> torch.Tensor:
+    """``spt_ffn_coeff_grad``: (sum dot_main + sum dot_act - <du, u[token]> - <dzt[token], z>) /
+    max(coeff, floor) per row, one launch (the routed FFN's router-coefficient gradient)."""
+    for t in (dot_main, dot_act, du, u, dzt, z, coeff):
+        _check_type(t, torch.float32, 'ffn_coeff_grad operand')
+        _require(t.is_cuda and t.is_contiguous(), 'ffn_coeff_grad: contiguous CUDA operands')
+    _check_type(token, torch.int32, 'token')
+    P, r = du.shape
+    _require(dot_main.shape == dot_act.shape and dot_main.size(0) == P and z.shape == (P, r)
+             and u.size(1) == r and dzt.shape == u.shape and token.numel() == P and coeff.numel() == P
+             and r % 4 == 0, 'ffn_coeff_grad: shapes')
+    dev = _same_device(dot_main, du, u, token, coeff)
+    lib = load_library()
+    with torch.cuda.device(dev):
+        out = torch.empty([P], dtype=torch.float32, device=dev)
+        rc = lib.spt_ffn_coeff_grad(dot_main.data_ptr(), dot_act.data_ptr(), dot_main.size(1),
+                                    du.data_ptr(), u.data_ptr(), dzt.data_ptr(), z.data_ptr(),
+                                    token.data_ptr(), coeff.data_ptr(), float(floor_value),
+                                    out.data_ptr(), P, r, _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'ffn_coeff_grad')
+    return out
 
 
 def softmax_backward_clamped(indptr: torch.Tensor, indices: torch.Tensor,

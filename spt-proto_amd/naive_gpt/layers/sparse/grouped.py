@@ -248,7 +248,6 @@ class RoutedLoRAFFN(torch.autograd.Function):
         nb = bk.n_blocks
         d_ff, d = w1.shape
         bs, rank, rows = d_ff // nb, l1.size(1), bk.token.numel()
-        pos = bk.pos.long()
         dy = dy.contiguous()
         imgs = _images_usable(dy, w1, w2, d, bs)
         dzt, dy_img, _ = _down(dy, r2, imgs, False)                          # [T, r]
@@ -257,7 +256,7 @@ class RoutedLoRAFFN(torch.autograd.Function):
             n_rows=rows, gather=bk.token, rowscale=coeff,
             a2=dzt, gather2=bk.token, b2=l2, b2_group_stride=bs * rank,
             epilogue=ext.EPI_DACT, activation=act, h_in=h, s_in=s,
-            a_image=dy_img, w_image=ext.weight_image(w2) if imgs else None)
+            a_image=dy_img, w_image=ext.weight_image(w2) if imgs else None, raw_dots=True)
         du = _own_block(torch.matmul(ds, _block_cat(r1, nb)), bk.block, nb).contiguous()  # [P, r]
         u_rows = u.index_select(0, bk.token_long)
         # d/dc = <dy W2_g^T, h> + <ds, x W1_g^T + b1_g>.  The kernel's dot_main = <v, h> with
@@ -265,15 +264,15 @@ class RoutedLoRAFFN(torch.autograd.Function):
         # s = c (x W1^T + b1) + u R1^T; the LoRA parts of both are [*, r] dots:
         # <dzt L2_g^T, h> = <dzt, z> and <ds, u R1_g^T> = <du, u>
         dz_rows = dzt.index_select(0, bk.token_long)
-        grad_coeff = (dot_main + dot_act - (du * u_rows).sum(dim=-1)
-                      - (dz_rows * z).sum(dim=-1)) / _floor(coeff)
+        # (dot_main + dot_act - <du, u_rows> - <dz_rows, z>) / _floor(coeff), one launch
+        grad_coeff = ext.ffn_coeff_grad(dot_main, dot_act, du, u, dzt, z, bk.token, coeff, COEFF_FLOOR)
         # LoRA tables (before the last GEMM: ds [P, bs] is released as soon as that has read it --
         # the step's peak memory is here, with h, ds, dxs and grad_x alive)
-        du_tok = du[pos].sum(dim=1)                                          # [T, r]
+        du_tok = ext.rows_combine(du, bk.pos)                                # [T, r]: du[pos].sum(1)
         grad_l1 = _tn(x, du_tok)
         grad_r1 = _block_major(_tn(ds, _in_own_block(u_rows, bk.block, nb)), nb)
         grad_l2 = _block_major(_tn(h, _in_own_block(dz_rows, bk.block, nb)), nb)
-        grad_r2 = _tn(dy, z[pos].sum(dim=1))
+        grad_r2 = _tn(dy, ext.rows_combine(z, bk.pos))
         del dot_main, dot_act, u_rows, dz_rows, du_tok, dzt
         dxs = ext.grouped_gemm_fused(
             ds, w1, bk.offsets, nb, n=d, k=bs, w_group_stride=bs * d, w_ldn=1, w_ldk=d,
@@ -366,7 +365,6 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
         nb = bk.n_blocks
         d_ff, d = wg.shape
         bs, rank, rows = d_ff // nb, lg.size(1), bk.token.numel()
-        pos = bk.pos.long()
         dy = dy.contiguous()
         imgs = _images_usable(dy, wg, wd, d, bs)
         dzt, dy_img, _ = _down(dy, rd, imgs, False)                           # [T, r]
@@ -394,7 +392,7 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
             dxs = ext.grouped_gemm_fused(
                 dpre, w, bk.offsets, nb, n=d, k=bs, w_group_stride=bs * d, w_ldn=1, w_ldk=d,
                 n_rows=rows, rowscale=coeff, a2=du, b2=l_table, b2_group_stride=0)
-            grad_l = _tn(x, du[pos].sum(dim=1))
+            grad_l = _tn(x, ext.rows_combine(du, bk.pos))
             grad_r = _block_major(_tn(dpre, _in_own_block(u_rows, bk.block, nb)), nb)
             return dxs, dc, grad_l, grad_r
 
@@ -408,7 +406,7 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
         del dxs_g
         grad_coeff = grad_coeff + dc_g + dc_s
         grad_ld = _block_major(_tn(h, _in_own_block(dz_rows, bk.block, nb)), nb)
-        grad_rd = _tn(dy, z[pos].sum(dim=1))
+        grad_rd = _tn(dy, ext.rows_combine(z, bk.pos))
         return (grad_x, grad_coeff, grad_lg, grad_rg, grad_ls, grad_rs, grad_ld, grad_rd,
                 None, None, None, None, None, None, None)
 
