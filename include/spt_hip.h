@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 25
+#define SPT_ABI_VERSION 26
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -499,7 +499,9 @@ int spt_cross_entropy_grad(float *logits, long long ld, long long rows, int n_cl
 /*
  * LayerNorm of the residual stream with the additions around it (the pre-norm wiring of
  * naive_gpt/layers/basic/transformer.py:46-52; nn.LayerNorm arithmetic: biased variance, eps
- * inside the root).  rows x d fp32, contiguous; d in {256, 512, 1024, 2048} (SPT_EUNSUP else).
+ * inside the root), or -- rms != 0 -- LLaMA's RMSNorm (utils.py:22-37: no mean, no beta; beta may be
+ * NULL, mean is written as 0, dbeta as 0).  rows x d fp32, contiguous; d in {256, 512, 1024, 2048},
+ * RMSNorm also 4096 (SPT_EUNSUP else).
  *   forward   s = x + r (r, s may be NULL: s = x, nothing written);  y = LN(s) gamma + beta;
  *             mean, rstd [rows] for the backward.
  *   backward  dx = dLN(dy) (+ dskip, may be NULL: the gradient arriving over the skip path);
@@ -509,10 +511,10 @@ int spt_cross_entropy_grad(float *logits, long long ld, long long rows, int n_cl
 int spt_layernorm_partial_rows(long long rows);
 int spt_add_layernorm_forward(const float *x, const float *r, const float *gamma, const float *beta,
                               float *s, float *y, float *mean, float *rstd, long long rows, int d,
-                              float eps, void *stream);
+                              float eps, int rms, void *stream);
 int spt_layernorm_backward(const float *s, const float *dy, const float *gamma, const float *mean,
                            const float *rstd, const float *dskip, float *dx, float *dgamma,
-                           float *dbeta, float *partial, long long rows, int d, void *stream);
+                           float *dbeta, float *partial, long long rows, int d, int rms, void *stream);
 
 /*
  * Bucketing for the routed FFN: the k largest of the n_blocks router probabilities of every

@@ -3,7 +3,7 @@
 //
 // Reference: the pre-norm wiring of naive_gpt/layers/basic/transformer.py:46-52
 //     x = x + mha(norm1(x));  x = x + ffd(norm2(x))
-// with nn.LayerNorm prototypes (models/opt.py).  Each norm sits between two elementwise
+// with nn.LayerNorm prototypes (models/opt.py) or LLaMA's RMSNorm (models/llama.py; the RMS flag).  Each norm sits between two elementwise
 // additions -- forward: the sum it normalises; backward: the skip path's gradient joining the
 // norm's -- and all of it is HBM-bound traffic over [tokens, d_model] fp32 tensors (33 MB each at
 // BERT-large): as library operators 17 us forward, 35 + 21 us backward and 11 us per addition,
@@ -34,20 +34,25 @@ __device__ __forceinline__ float ln_wave_sum(float v) {
     return v;
 }
 
-// NV = d / 256: float4 per lane
-template <int NV, bool ADD>
+// NV = d / 256: float4 per lane.  RMS: LLaMA's RMSNorm (naive_gpt/layers/basic/utils.py:22-37 of the
+// reference): no mean, no beta -- y = s rsqrt(mean(s^2) + eps) gamma.  GREG: gamma (and beta) held in
+// registers across the rows a wave walks (d <= 2048); re-read per row from L1 above that.
+template <int NV, bool ADD, bool RMS>
 __global__ __launch_bounds__(LN_THREADS) void add_layernorm_forward_kernel(
     const float *__restrict__ x, const float *__restrict__ r, const float *__restrict__ gamma,
     const float *__restrict__ beta, float *__restrict__ s, float *__restrict__ y,
     float *__restrict__ mean, float *__restrict__ rstd, long long rows, float eps) {
     constexpr int D = NV * 256;
+    constexpr bool GREG = NV <= 8;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4 gm[NV], bt[NV];
+    float4 gm[GREG ? NV : 1], bt[GREG && !RMS ? NV : 1];
+    if (GREG) {
 #pragma unroll
-    for (int j = 0; j < NV; j++) {
-        gm[j] = reinterpret_cast<const float4 *>(gamma)[lane + 64 * j];
-        bt[j] = reinterpret_cast<const float4 *>(beta)[lane + 64 * j];
+        for (int j = 0; j < NV; j++) {
+            gm[j] = reinterpret_cast<const float4 *>(gamma)[lane + 64 * j];
+            if (!RMS) bt[j] = reinterpret_cast<const float4 *>(beta)[lane + 64 * j];
+        }
     }
     for (long long row = (long long)blockIdx.x * LN_WAVES + wave; row < rows;
          row += (long long)gridDim.x * LN_WAVES) {
@@ -66,10 +71,13 @@ __global__ __launch_bounds__(LN_THREADS) void add_layernorm_forward_kernel(
 #pragma unroll
             for (int j = 0; j < NV; j++) sp[lane + 64 * j] = v[j];
         }
-        float sum = 0.f;
+        float mu = 0.f;
+        if (!RMS) {
+            float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < NV; j++) sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-        const float mu = ln_wave_sum(sum) * (1.0f / D);
+            for (int j = 0; j < NV; j++) sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            mu = ln_wave_sum(sum) * (1.0f / D);
+        }
         float sq = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; j++) {
@@ -80,11 +88,14 @@ __global__ __launch_bounds__(LN_THREADS) void add_layernorm_forward_kernel(
         float4 *yp = reinterpret_cast<float4 *>(y + row * D);
 #pragma unroll
         for (int j = 0; j < NV; j++) {
+            const float4 g4 = GREG ? gm[j] : reinterpret_cast<const float4 *>(gamma)[lane + 64 * j];
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!RMS) b4 = GREG ? bt[j] : reinterpret_cast<const float4 *>(beta)[lane + 64 * j];
             float4 o;
-            o.x = fmaf((v[j].x - mu) * rs, gm[j].x, bt[j].x);
-            o.y = fmaf((v[j].y - mu) * rs, gm[j].y, bt[j].y);
-            o.z = fmaf((v[j].z - mu) * rs, gm[j].z, bt[j].z);
-            o.w = fmaf((v[j].w - mu) * rs, gm[j].w, bt[j].w);
+            o.x = fmaf((v[j].x - mu) * rs, g4.x, b4.x);
+            o.y = fmaf((v[j].y - mu) * rs, g4.y, b4.y);
+            o.z = fmaf((v[j].z - mu) * rs, g4.z, b4.z);
+            o.w = fmaf((v[j].w - mu) * rs, g4.w, b4.w);
             yp[lane + 64 * j] = o;
         }
         if (lane == 0) {
@@ -94,78 +105,96 @@ __global__ __launch_bounds__(LN_THREADS) void add_layernorm_forward_kernel(
     }
 }
 
-// partial: [gridDim.x][2][D] (dgamma row, dbeta row) per workgroup
-template <int NV, bool SKIP>
+// partial: [gridDim.x][2][D] (dgamma row, dbeta row -- zeros for RMS) per workgroup
+template <int NV, bool SKIP, bool RMS>
 __global__ __launch_bounds__(LN_THREADS) void layernorm_backward_kernel(
     const float *__restrict__ s, const float *__restrict__ dy, const float *__restrict__ gamma,
     const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ dskip, float *__restrict__ dx, float *__restrict__ partial,
     long long rows) {
     constexpr int D = NV * 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *acc = reinterpret_cast<float4 *>(smem);           // [LN_WAVES][2][D / 4]
+    constexpr bool GREG = NV <= 8;
+    __shared__ float4 acc[LN_WAVES][2][64];          // one 64-lane piece of the rows at a time
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4 gm[NV], dg[NV], db[NV];
+    float4 gm[GREG ? NV : 1], dg[NV], db[RMS ? 1 : NV];
 #pragma unroll
     for (int j = 0; j < NV; j++) {
-        gm[j] = reinterpret_cast<const float4 *>(gamma)[lane + 64 * j];
+        if (GREG) gm[j] = reinterpret_cast<const float4 *>(gamma)[lane + 64 * j];
         dg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        db[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!RMS) db[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (long long row = (long long)blockIdx.x * LN_WAVES + wave; row < rows;
          row += (long long)gridDim.x * LN_WAVES) {
         const float4 *sp = reinterpret_cast<const float4 *>(s + row * D);
         const float4 *gp = reinterpret_cast<const float4 *>(dy + row * D);
-        float4 xh[NV], g[NV], sk[NV];
-#pragma unroll
-        for (int j = 0; j < NV; j++) {
-            xh[j] = sp[lane + 64 * j];
-            g[j] = gp[lane + 64 * j];
-            if (SKIP) sk[j] = reinterpret_cast<const float4 *>(dskip + row * D)[lane + 64 * j];
-        }
-        const float mu = mean[row], rs = rstd[row];
+        const float mu = RMS ? 0.0f : mean[row], rs = rstd[row];
         float c1 = 0.f, c2 = 0.f;
+        // d <= 2048: the row's s and dy stay in registers between the reductions and the write;
+        // above that (128 registers of row data beside the 64 of dgamma spill) they are read a
+        // second time -- the row was just read, the second read is an L2 hit.
+        constexpr bool KEEP = NV <= 8;
+        float4 xh[KEEP ? NV : 1], g[KEEP ? NV : 1];
 #pragma unroll
         for (int j = 0; j < NV; j++) {
-            xh[j].x = (xh[j].x - mu) * rs; xh[j].y = (xh[j].y - mu) * rs;
-            xh[j].z = (xh[j].z - mu) * rs; xh[j].w = (xh[j].w - mu) * rs;
+            float4 x4 = sp[lane + 64 * j], g4r = gp[lane + 64 * j];
+            const float4 gm4 = GREG ? gm[j] : reinterpret_cast<const float4 *>(gamma)[lane + 64 * j];
+            x4.x = (x4.x - mu) * rs; x4.y = (x4.y - mu) * rs; x4.z = (x4.z - mu) * rs; x4.w = (x4.w - mu) * rs;
             // parameter gradients take dy itself, the input gradient dy * gamma
-            dg[j].x = fmaf(g[j].x, xh[j].x, dg[j].x); dg[j].y = fmaf(g[j].y, xh[j].y, dg[j].y);
-            dg[j].z = fmaf(g[j].z, xh[j].z, dg[j].z); dg[j].w = fmaf(g[j].w, xh[j].w, dg[j].w);
-            db[j].x += g[j].x; db[j].y += g[j].y; db[j].z += g[j].z; db[j].w += g[j].w;
-            g[j].x *= gm[j].x; g[j].y *= gm[j].y; g[j].z *= gm[j].z; g[j].w *= gm[j].w;
-            c1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
-            c2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+            dg[j].x = fmaf(g4r.x, x4.x, dg[j].x); dg[j].y = fmaf(g4r.y, x4.y, dg[j].y);
+            dg[j].z = fmaf(g4r.z, x4.z, dg[j].z); dg[j].w = fmaf(g4r.w, x4.w, dg[j].w);
+            if (!RMS) { db[j].x += g4r.x; db[j].y += g4r.y; db[j].z += g4r.z; db[j].w += g4r.w; }
+            g4r.x *= gm4.x; g4r.y *= gm4.y; g4r.z *= gm4.z; g4r.w *= gm4.w;
+            if (!RMS) c1 += (g4r.x + g4r.y) + (g4r.z + g4r.w);
+            c2 += (g4r.x * x4.x + g4r.y * x4.y) + (g4r.z * x4.z + g4r.w * x4.w);
+            if (KEEP) { xh[j] = x4; g[j] = g4r; }
+            // (wide rows: keep the compiler from hoisting all 32 loads of the unrolled loop -- 128
+            // registers -- in front of the arithmetic)
+            if (!KEEP && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        c1 = ln_wave_sum(c1) * (1.0f / D);
+        if (!RMS) c1 = ln_wave_sum(c1) * (1.0f / D);
         c2 = ln_wave_sum(c2) * (1.0f / D);
         float4 *op = reinterpret_cast<float4 *>(dx + row * D);
 #pragma unroll
         for (int j = 0; j < NV; j++) {
+            float4 x4, g4r;
+            if (KEEP) {
+                x4 = xh[j]; g4r = g[j];
+            } else {
+                x4 = sp[lane + 64 * j]; g4r = gp[lane + 64 * j];
+                const float4 gm4 = reinterpret_cast<const float4 *>(gamma)[lane + 64 * j];
+                x4.x = (x4.x - mu) * rs; x4.y = (x4.y - mu) * rs; x4.z = (x4.z - mu) * rs; x4.w = (x4.w - mu) * rs;
+                g4r.x *= gm4.x; g4r.y *= gm4.y; g4r.z *= gm4.z; g4r.w *= gm4.w;
+            }
             float4 o;
-            o.x = rs * (g[j].x - c1 - xh[j].x * c2); o.y = rs * (g[j].y - c1 - xh[j].y * c2);
-            o.z = rs * (g[j].z - c1 - xh[j].z * c2); o.w = rs * (g[j].w - c1 - xh[j].w * c2);
-            if (SKIP) { o.x += sk[j].x; o.y += sk[j].y; o.z += sk[j].z; o.w += sk[j].w; }
+            o.x = rs * (g4r.x - c1 - x4.x * c2); o.y = rs * (g4r.y - c1 - x4.y * c2);
+            o.z = rs * (g4r.z - c1 - x4.z * c2); o.w = rs * (g4r.w - c1 - x4.w * c2);
+            if (SKIP) {
+                const float4 k4 = reinterpret_cast<const float4 *>(dskip + row * D)[lane + 64 * j];
+                o.x += k4.x; o.y += k4.y; o.z += k4.z; o.w += k4.w;
+            }
             op[lane + 64 * j] = o;
+            if (!KEEP && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // the workgroup's eight waves -> one partial row pair, in a fixed order
+    // the workgroup's eight waves -> one partial row pair, in a fixed order, a 64-lane piece at a time
+    float4 *out = reinterpret_cast<float4 *>(partial + (size_t)blockIdx.x * 2 * D);
 #pragma unroll
     for (int j = 0; j < NV; j++) {
-        acc[(wave * 2 + 0) * (D / 4) + lane + 64 * j] = dg[j];
-        acc[(wave * 2 + 1) * (D / 4) + lane + 64 * j] = db[j];
-    }
-    __syncthreads();
-    float4 *out = reinterpret_cast<float4 *>(partial + (size_t)blockIdx.x * 2 * D);
-    for (int i = threadIdx.x; i < 2 * D / 4; i += LN_THREADS) {
-        float4 t = acc[i];
+        acc[wave][0][lane] = dg[j];
+        acc[wave][1][lane] = RMS ? make_float4(0.f, 0.f, 0.f, 0.f) : db[RMS ? 0 : j];
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6, l = threadIdx.x & 63;
+            float4 t = acc[0][which][l];
 #pragma unroll
-        for (int w = 1; w < LN_WAVES; w++) {
-            const float4 u = acc[w * 2 * (D / 4) + i];
-            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            for (int w = 1; w < LN_WAVES; w++) {
+                const float4 u = acc[w][which][l];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            out[which * (D / 4) + l + 64 * j] = t;
         }
-        out[i] = t;
+        __syncthreads();
     }
 }
 
@@ -205,29 +234,40 @@ static int ln_blocks(long long rows) {
 
 extern "C" int spt_layernorm_partial_rows(long long rows) { return rows > 0 ? ln_blocks(rows) : 0; }
 
+static bool ln_width_ok(int d, int rms) {
+    return d == 256 || d == 512 || d == 1024 || d == 2048 || (rms && d == 4096);
+}
+
 extern "C" int spt_add_layernorm_forward(const float *x, const float *r, const float *gamma,
                                          const float *beta, float *s, float *y, float *mean,
-                                         float *rstd, long long rows, int d, float eps,
+                                         float *rstd, long long rows, int d, float eps, int rms,
                                          void *stream) {
-    if (!x || !gamma || !beta || !y || !mean || !rstd || (r && !s)) return SPT_EINVAL;
+    if (!x || !gamma || (!rms && !beta) || !y || !mean || !rstd || (r && !s)) return SPT_EINVAL;
     if (rows <= 0 || d <= 0) return SPT_EINVAL;
-    if (d != 1024 && d != 2048 && d != 512 && d != 256) return SPT_EUNSUP;
+    if (!ln_width_ok(d, rms)) return SPT_EUNSUP;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ln_blocks(rows)), block(LN_THREADS);
-#define SPT_LNF(NV)                                                                              \
+#define SPT_LNF2(NV, RMS)                                                                        \
     do {                                                                                         \
-        if (r) hipLaunchKernelGGL((add_layernorm_forward_kernel<NV, true>), grid, block, 0, st, x, r, \
-                                  gamma, beta, s, y, mean, rstd, rows, eps);                      \
-        else hipLaunchKernelGGL((add_layernorm_forward_kernel<NV, false>), grid, block, 0, st, x, r, \
-                                gamma, beta, s, y, mean, rstd, rows, eps);                        \
+        if (r) hipLaunchKernelGGL((add_layernorm_forward_kernel<NV, true, RMS>), grid, block, 0, st, \
+                                  x, r, gamma, beta, s, y, mean, rstd, rows, eps);               \
+        else hipLaunchKernelGGL((add_layernorm_forward_kernel<NV, false, RMS>), grid, block, 0, st, \
+                                x, r, gamma, beta, s, y, mean, rstd, rows, eps);                 \
+    } while (0)
+#define SPT_LNF(NV)                                  \
+    do {                                             \
+        if (rms) SPT_LNF2(NV, true);                 \
+        else SPT_LNF2(NV, false);                    \
     } while (0)
     switch (d / 256) {
         case 1: SPT_LNF(1); break;
         case 2: SPT_LNF(2); break;
         case 4: SPT_LNF(4); break;
-        default: SPT_LNF(8); break;
+        case 8: SPT_LNF(8); break;
+        default: SPT_LNF2(16, true); break;
     }
 #undef SPT_LNF
+#undef SPT_LNF2
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }
@@ -235,37 +275,36 @@ extern "C" int spt_add_layernorm_forward(const float *x, const float *r, const f
 extern "C" int spt_layernorm_backward(const float *s, const float *dy, const float *gamma,
                                       const float *mean, const float *rstd, const float *dskip,
                                       float *dx, float *dgamma, float *dbeta, float *partial,
-                                      long long rows, int d, void *stream) {
+                                      long long rows, int d, int rms, void *stream) {
     if (!s || !dy || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !partial)
         return SPT_EINVAL;
     if (rows <= 0 || d <= 0) return SPT_EINVAL;
-    if (d != 1024 && d != 2048 && d != 512 && d != 256) return SPT_EUNSUP;
+    if (!ln_width_ok(d, rms)) return SPT_EUNSUP;
     if (dbeta != dgamma + d) return SPT_EINVAL;        // one [2, d] buffer: reduced in one launch
     hipStream_t st = (hipStream_t)stream;
     const int nblk = ln_blocks(rows);
     const dim3 grid(nblk), block(LN_THREADS);
-    const size_t lds = (size_t)LN_WAVES * 2 * d * sizeof(float);
-#define SPT_LNB(NV)                                                                              \
+#define SPT_LNB2(NV, RMS)                                                                        \
     do {                                                                                         \
-        if (dskip) {                                                                             \
-            SPT_HIP_TRY(hipFuncSetAttribute((const void *)layernorm_backward_kernel<NV, true>,   \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL((layernorm_backward_kernel<NV, true>), grid, block, lds, st, s, dy, \
-                               gamma, mean, rstd, dskip, dx, partial, rows);                     \
-        } else {                                                                                 \
-            SPT_HIP_TRY(hipFuncSetAttribute((const void *)layernorm_backward_kernel<NV, false>,  \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL((layernorm_backward_kernel<NV, false>), grid, block, lds, st, s, dy, \
-                               gamma, mean, rstd, dskip, dx, partial, rows);                     \
-        }                                                                                        \
+        if (dskip) hipLaunchKernelGGL((layernorm_backward_kernel<NV, true, RMS>), grid, block, 0, st, \
+                                      s, dy, gamma, mean, rstd, dskip, dx, partial, rows);       \
+        else hipLaunchKernelGGL((layernorm_backward_kernel<NV, false, RMS>), grid, block, 0, st, \
+                                s, dy, gamma, mean, rstd, dskip, dx, partial, rows);             \
+    } while (0)
+#define SPT_LNB(NV)                                  \
+    do {                                             \
+        if (rms) SPT_LNB2(NV, true);                 \
+        else SPT_LNB2(NV, false);                    \
     } while (0)
     switch (d / 256) {
         case 1: SPT_LNB(1); break;
         case 2: SPT_LNB(2); break;
         case 4: SPT_LNB(4); break;
-        default: SPT_LNB(8); break;
+        case 8: SPT_LNB(8); break;
+        default: SPT_LNB2(16, true); break;
     }
 #undef SPT_LNB
+#undef SPT_LNB2
     SPT_LAUNCH_CHECK();
     hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((2 * d + 15) / 16), dim3(256), 0, st,
                        partial, dgamma, 2 * d, nblk);

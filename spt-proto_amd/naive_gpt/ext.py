@@ -75,8 +75,8 @@ _PROTOTYPES = {
     'spt_ffn_coeff_grad': ([_c_ptr, _c_ptr, _c_int] + [_c_ptr] * 6 + [_c_f32, _c_ptr, _c_int, _c_int, _c_ptr],
                            _c_int),
     'spt_layernorm_partial_rows': ([ctypes.c_longlong], _c_int),
-    'spt_add_layernorm_forward': ([_c_ptr] * 8 + [ctypes.c_longlong, _c_int, _c_f32, _c_ptr], _c_int),
-    'spt_layernorm_backward': ([_c_ptr] * 10 + [ctypes.c_longlong, _c_int, _c_ptr], _c_int),
+    'spt_add_layernorm_forward': ([_c_ptr] * 8 + [ctypes.c_longlong, _c_int, _c_f32, _c_int, _c_ptr], _c_int),
+    'spt_layernorm_backward': ([_c_ptr] * 10 + [ctypes.c_longlong, _c_int, _c_int, _c_ptr], _c_int),
     'spt_cross_entropy_grad': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_ptr,
                                 _c_ptr, ctypes.c_longlong, _c_ptr], _c_int),
     'spt_lora_down': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_int,
@@ -87,7 +87,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _lib = None
 
@@ -1195,42 +1195,46 @@ def cross_entropy_grad_(logits: torch.Tensor, n_classes: int, target: torch.Tens
 LAYERNORM_WIDTHS = (256, 512, 1024, 2048)
 
 
-def layernorm_supported(x: torch.Tensor, d: int) -> bool:
-    return (x.is_cuda and x.dtype == torch.float32 and x.size(-1) == d and d in LAYERNORM_WIDTHS
-            and x.numel() > 0)
+def layernorm_supported(x: torch.Tensor, d: int, rms: bool = False) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.size(-1) == d and x.numel() > 0
+            and (d in LAYERNORM_WIDTHS or (rms and d == 4096)))
 
 
-def add_layernorm_forward(x: torch.Tensor, r, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
+def add_layernorm_forward(x: torch.Tensor, r, gamma: torch.Tensor, beta, eps: float, rms: bool = False):
     """``spt_add_layernorm_forward``: (s, y, mean, rstd) with s = x + r (s is x itself when r is
-    None) and y = LayerNorm(s); x, r [..., d] contiguous."""
+    None) and y = LayerNorm(s) -- or, ``rms``, RMSNorm(s) (beta None); x, r [..., d] contiguous."""
     d = x.size(-1)
-    _require(layernorm_supported(x, d) and x.is_contiguous() and gamma.is_contiguous()
-             and beta.is_contiguous() and gamma.numel() == d and beta.numel() == d,
-             'add_layernorm: contiguous CUDA fp32 [..., d], d in {256, 512, 1024, 2048}')
+    _require(layernorm_supported(x, d, rms) and x.is_contiguous() and gamma.is_contiguous()
+             and gamma.numel() == d and gamma.dtype == torch.float32,
+             'add_layernorm: contiguous CUDA fp32 [..., d], d in {256, 512, 1024, 2048} (RMS: also 4096)')
+    if not rms:
+        _require(beta is not None and beta.is_contiguous() and beta.numel() == d, 'beta: [d]')
     if r is not None:
         _require(r.shape == x.shape and r.is_contiguous() and r.dtype == torch.float32, 'r: like x')
     rows = x.numel() // d
-    dev = _same_device(x, gamma, beta)
+    dev = _same_device(x, gamma)
     lib = load_library()
     with torch.cuda.device(dev):
         s = torch.empty_like(x) if r is not None else x
         y = torch.empty_like(x)
         mean = torch.empty([rows], dtype=torch.float32, device=dev)
         rstd = torch.empty([rows], dtype=torch.float32, device=dev)
-        rc = lib.spt_add_layernorm_forward(x.data_ptr(), _ptr(r), gamma.data_ptr(), beta.data_ptr(),
+        rc = lib.spt_add_layernorm_forward(x.data_ptr(), _ptr(r), gamma.data_ptr(),
+                                           None if rms else beta.data_ptr(),
                                            s.data_ptr() if r is not None else None, y.data_ptr(),
                                            mean.data_ptr(), rstd.data_ptr(), rows, d, float(eps),
-                                           _stream(dev))
+                                           int(bool(rms)), _stream(dev))
     if rc != 0:
         _raise(lib, rc, 'add_layernorm_forward')
     return s, y, mean, rstd
 
 
 def layernorm_backward(s: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor,
-                       rstd: torch.Tensor, dskip=None):
-    """``spt_layernorm_backward``: (dx, dgamma, dbeta); dx includes `dskip` when given."""
+                       rstd: torch.Tensor, dskip=None, rms: bool = False):
+    """``spt_layernorm_backward``: (dx, dgamma, dbeta); dx includes `dskip` when given (``rms``:
+    dbeta is zeros)."""
     d = s.size(-1)
-    _require(layernorm_supported(s, d) and s.is_contiguous() and dy.is_contiguous()
+    _require(layernorm_supported(s, d, rms) and s.is_contiguous() and dy.is_contiguous()
              and dy.shape == s.shape and dy.dtype == torch.float32, 'layernorm_backward: s, dy [..., d]')
     if dskip is not None:
         _require(dskip.shape == s.shape and dskip.is_contiguous() and dskip.dtype == torch.float32,
@@ -1244,7 +1248,8 @@ def layernorm_backward(s: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, m
         partial = torch.empty([lib.spt_layernorm_partial_rows(rows), 2 * d], dtype=torch.float32, device=dev)
         rc = lib.spt_layernorm_backward(s.data_ptr(), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                         rstd.data_ptr(), _ptr(dskip), dx.data_ptr(), dparam.data_ptr(),
-                                        dparam[1].data_ptr(), partial.data_ptr(), rows, d, _stream(dev))
+                                        dparam[1].data_ptr(), partial.data_ptr(), rows, d,
+                                        int(bool(rms)), _stream(dev))
     if rc != 0:
         _raise(lib, rc, 'layernorm_backward')
     return dx, dparam[0], dparam[1]

@@ -11,8 +11,8 @@ addition of the residual stream sits directly in front of a norm::
 
 so the forward reads the two summands once and writes the sum and the normalised row, and the
 backward's ``d_sum = d_stream + dLN(d_h)`` is one kernel whose result is the gradient of BOTH
-summands.  Modules other than a plain affine ``nn.LayerNorm`` (LLaMA's RMSNorm), widths the kernels
-do not take and CPU tensors run the same expression op by op.
+summands.  A plain affine ``nn.LayerNorm`` and LLaMA's ``LlamaRMSNorm`` take the kernels; other modules, widths
+the kernels do not take and CPU tensors run the same expression op by op.
 """
 import torch
 from torch import nn
@@ -20,10 +20,11 @@ from torch import nn
 
 class _AddLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, eps: float):
+    def forward(ctx, x, r, gamma, beta, eps: float, rms: bool):
         from naive_gpt import ext
-        s, y, mean, rstd = ext.add_layernorm_forward(x.contiguous(), r.contiguous(), gamma, beta, eps)
+        s, y, mean, rstd = ext.add_layernorm_forward(x.contiguous(), r.contiguous(), gamma, beta, eps, rms)
         ctx.save_for_backward(s, gamma, mean, rstd)
+        ctx.rms = rms
         return s, y
 
     @staticmethod
@@ -31,42 +32,56 @@ class _AddLayerNorm(torch.autograd.Function):
         from naive_gpt import ext
         s, gamma, mean, rstd = ctx.saved_tensors
         if dy is None:                                   # (the normalised output was not used)
-            return ds, ds, None, None, None
+            return ds, ds, None, None, None, None
         dx, dgamma, dbeta = ext.layernorm_backward(s, dy.contiguous(), gamma, mean, rstd,
-                                                   dskip=None if ds is None else ds.contiguous())
-        return dx, dx, dgamma, dbeta, None
+                                                   dskip=None if ds is None else ds.contiguous(),
+                                                   rms=ctx.rms)
+        return dx, dx, dgamma, None if ctx.rms else dbeta, None, None
 
 
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps: float):
+    def forward(ctx, x, gamma, beta, eps: float, rms: bool):
         from naive_gpt import ext
         x = x.contiguous()
-        _, y, mean, rstd = ext.add_layernorm_forward(x, None, gamma, beta, eps)
+        _, y, mean, rstd = ext.add_layernorm_forward(x, None, gamma, beta, eps, rms)
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.rms = rms
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from naive_gpt import ext
         x, gamma, mean, rstd = ctx.saved_tensors
-        dx, dgamma, dbeta = ext.layernorm_backward(x, dy.contiguous(), gamma, mean, rstd)
-        return dx, dgamma, dbeta, None
+        dx, dgamma, dbeta = ext.layernorm_backward(x, dy.contiguous(), gamma, mean, rstd, rms=ctx.rms)
+        return dx, dgamma, None if ctx.rms else dbeta, None, None
+
+
+def _kind(norm: nn.Module):
+    """(gamma, beta | None, eps, rms) of a norm the kernels implement, else None."""
+    from .utils import LlamaRMSNorm
+    if type(norm) is nn.LayerNorm and norm.elementwise_affine and norm.bias is not None \
+            and len(norm.normalized_shape) == 1:
+        return norm.weight, norm.bias, norm.eps, False
+    if type(norm) is LlamaRMSNorm and norm.weight.dtype == torch.float32:
+        return norm.weight, None, norm.variance_epsilon, True
+    return None
 
 
 def usable(norm: nn.Module, x: torch.Tensor) -> bool:
-    if not (type(norm) is nn.LayerNorm and norm.elementwise_affine and norm.bias is not None
-            and len(norm.normalized_shape) == 1):
+    kind = _kind(norm)
+    if kind is None:
         return False
     from naive_gpt import ext
-    return ext.layernorm_supported(x, norm.normalized_shape[0]) and not x.is_inference()
+    return ext.layernorm_supported(x, kind[0].numel(), kind[3]) and not x.is_inference()
 
 
 def add_norm(norm: nn.Module, x: torch.Tensor, r):
     """(x + r, norm(x + r)); r None: (x, norm(x))."""
     if usable(norm, x):
+        gamma, beta, eps, rms = _kind(norm)
         if r is None:
-            return x, _LayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
-        return _AddLayerNorm.apply(x, r, norm.weight, norm.bias, norm.eps)
+            return x, _LayerNorm.apply(x, gamma, beta, eps, rms)
+        return _AddLayerNorm.apply(x, r, gamma, beta, eps, rms)
     s = x if r is None else x + r
     return s, norm(s)

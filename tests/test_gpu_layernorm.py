@@ -50,7 +50,6 @@ def test_add_layernorm_forward_backward(rows, d, add):
 
 
 def test_other_norms_and_widths_run_op_by_op():
-    from naive_gpt import layers
     from naive_gpt.layers.basic import fused_norm
     x = torch.randn([4, 8, 96], device='cuda')
     r = torch.randn([4, 8, 96], device='cuda')
@@ -58,11 +57,42 @@ def test_other_norms_and_widths_run_op_by_op():
     assert not fused_norm.usable(norm, x)
     s, y = fused_norm.add_norm(norm, x, r)
     assert torch.equal(s, x + r) and torch.equal(y, norm(x + r))
-    rms = layers.LlamaRMSNorm(1024).cuda()
-    x = torch.randn([2, 4, 1024], device='cuda')
-    assert not fused_norm.usable(rms, x)
-    s, y = fused_norm.add_norm(rms, x, None)
-    assert s is x and torch.equal(y, rms(x))
+    plain = nn.LayerNorm(1024, elementwise_affine=False).cuda()
+    assert not fused_norm.usable(plain, torch.randn([2, 4, 1024], device='cuda'))
+
+
+@pytest.mark.parametrize('rows,d', [(2048, 4096), (777, 1024), (33, 2048)])
+@pytest.mark.parametrize('add', [False, True])
+def test_rmsnorm_forward_backward(rows, d, add):
+    """LLaMA's RMSNorm (reference utils.py:22-37) through the same kernels (rms flag)."""
+    from naive_gpt import layers
+    from naive_gpt.layers.basic import fused_norm
+    gen = torch.Generator().manual_seed(rows + d + 1)
+    norm = layers.LlamaRMSNorm(d).cuda()
+    with torch.no_grad():
+        norm.weight.copy_(1.0 + 0.1 * torch.randn([d], generator=gen))
+    x = (2.0 * torch.randn([rows, d], generator=gen) + 0.5).cuda()
+    r = torch.randn([rows, d], generator=gen).cuda() if add else None
+    ws, wy = [torch.randn([rows, d], generator=gen).cuda() for _ in range(2)]
+
+    def run(fused):
+        xi = x.clone().requires_grad_(True)
+        ri = r.clone().requires_grad_(True) if add else None
+        norm.zero_grad()
+        if fused:
+            assert fused_norm.usable(norm, xi)
+            s, y = fused_norm.add_norm(norm, xi, ri)
+        else:
+            s = xi + ri if add else xi
+            y = norm(s)
+        ((s * ws).sum() + (y * wy).sum()).backward()
+        return s.detach(), y.detach(), xi.grad, ri.grad if add else None, norm.weight.grad.clone()
+
+    for a, b, name in zip(run(True), run(False), ['s', 'y', 'grad_x', 'grad_r', 'grad_gamma']):
+        if b is None:
+            continue
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * b.abs().max().item()), \
+            (name, (a - b).abs().max().item(), b.abs().max().item())
 
 
 def test_block_as_pairs_equals_the_reference_wiring():
