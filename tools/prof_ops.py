@@ -55,13 +55,30 @@ for _ in range(reps):
         ext.sparse_attention_backward_rows(idx, yt.view(B, S, E), q4, q4, sc, at, 0.125, 10.0, grad_y_transposed=False, causal=True)
     if 'mfma' in ops:
         q4 = q.view(N, H, S, E).transpose(1, 2).contiguous()
-        tiles = ext.attention_mfma_prepare(idx, S)
+        tiles = ext.attention_mfma_prepare(idx, S, lookup_pattern=True)      # (the layers' compact tiles)
         yt, rs = ext.attention_mfma_forward(tiles, q4, q4, q4, 0.125, 10.0, y_transposed=True)
         ext.attention_mfma_backward(tiles, q4, q4, q4, yt, yt, rs, 0.125, 10.0, transposed=True)
+        qb = q4.bfloat16()                                                    # bf16 storage build
+        yb, rsb = ext.attention_mfma_forward(tiles, qb, qb, qb, 0.125, 10.0, y_transposed=True)
+        ext.attention_mfma_backward(tiles, qb, qb, qb, yb, yb, rsb, 0.125, 10.0, transposed=True)
     if 'pq_loss' in ops:
         zh = q.view(N, H, S, E)
         ext.pq_encode_heads(zh, table)
         ext.pq_loss_forward(q, table)
         ext.pq_loss_backward(q, table, torch.ones([], device=dev))
+    if 'norm' in ops:          # LayerNorm + residual additions (BERT-large stream: [8192, 1024])
+        x2, r2 = torch.randn([8192, 1024], device=dev), torch.randn([8192, 1024], device=dev)
+        gam, bet = torch.ones([1024], device=dev), torch.zeros([1024], device=dev)
+        s2, y2, mu, rs2 = ext.add_layernorm_forward(x2, r2, gam, bet, 1e-5)
+        ext.layernorm_backward(s2, y2, gam, mu, rs2, dskip=x2)
+    if 'lora' in ops:          # LoRA down product + operand image (+ row norms)
+        x2 = torch.randn([8192, 1024], device=dev)
+        ext.lora_down(x2, torch.randn([1024, 16], device=dev), want_image=True)
+        ext.lora_down(x2, torch.randn([1024, 48], device=dev), want_image=True)
+        ext.lora_down(x2, torch.randn([1024, 16], device=dev), want_image=True, want_norms=True)
+    if 'ce' in ops:            # LM head loss in place on padded logits
+        z2 = torch.randn([8192, 30528], device=dev)
+        ext.cross_entropy_grad_(z2, 30522, torch.randint(0, 30522, [8192], device=dev),
+                                torch.full([1], 1.0 / 8192, device=dev))
 torch.cuda.synchronize()
 print('done')
