@@ -477,7 +477,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=16, help='micro-batch per GPU')
     ap.add_argument('--layers', type=int, default=LAYERS)
     ap.add_argument('--no-baselines', action='store_true', help='skip full / lora')
