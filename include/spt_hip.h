@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 26
+#define SPT_ABI_VERSION 27
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -88,6 +88,8 @@ int spt_pq_encode_heads_bf16(const uint16_t *z, const float *table, int32_t *cod
  * the shape of z, grad_table the shape of table.  Supported: C == 16, D in {4, 8}, M a
  * power of two <= 32 (SPT_EUNSUP otherwise: callers compose the loss from spt_cdist_*).
  * workspace: spt_pq_loss_workspace_bytes() bytes, used by both passes.
+ * backward, accumulate != 0: grad_z += the gradient (grad_z already holds what reached z over another
+ * path -- the attention's grad_q / grad_k -- and no elementwise sum is needed).
  */
 int64_t spt_pq_loss_workspace_bytes(int64_t n_vectors, int n_subspaces, int n_codewords,
                                     int d_code);
@@ -104,7 +106,7 @@ int spt_pq_loss_forward_codes(const float *z, const float *table, float *loss, v
 int spt_pq_loss_backward(const float *z, const float *table, const float *grad_loss,
                          float *grad_z, float *grad_table, void *workspace,
                          int64_t n_vectors, int n_subspaces, int n_codewords, int d_code,
-                         void *stream);
+                         int accumulate, void *stream);
 
 /*
  * cdist_backward_cuda(query, table, grad_output) -> [grad_query, grad_table]

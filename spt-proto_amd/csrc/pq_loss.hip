@@ -190,7 +190,7 @@ template <int D>
 __global__ __launch_bounds__(PQL_THREADS, 2) void pq_loss_backward_kernel(
     const float *__restrict__ z, const float *__restrict__ table,
     const float *__restrict__ grad_loss, float *__restrict__ grad_z,
-    float *__restrict__ partial, int total, int M, float inv_count) {
+    float *__restrict__ partial, int total, int M, float inv_count, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *tab = reinterpret_cast<float *>(smem);
     constexpr int CD = PQL_C * D;
@@ -357,13 +357,23 @@ __global__ __launch_bounds__(PQL_THREADS, 2) void pq_loss_backward_kernel(
 #pragma unroll
         for (int i = 0; i < D; i++) gz[i] += pair_other(gz[i]);
         float *gp = grad_z + (size_t)j * D + half * (D / 2);
+        // accumulate: grad_z already holds the gradient that reached z over another path (the
+        // attention's grad_q / grad_k): added here instead of by an elementwise pass of its own
         if constexpr (D == 8) {
-            *reinterpret_cast<float4 *>(gp) =
-                half == 0 ? make_float4(gz[0], gz[1], gz[2], gz[3])
-                          : make_float4(gz[4], gz[5], gz[6], gz[7]);
+            float4 o = half == 0 ? make_float4(gz[0], gz[1], gz[2], gz[3])
+                                 : make_float4(gz[4], gz[5], gz[6], gz[7]);
+            if (accumulate) {
+                const float4 b = *reinterpret_cast<const float4 *>(gp);
+                o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+            }
+            *reinterpret_cast<float4 *>(gp) = o;
         } else {
-            *reinterpret_cast<float2 *>(gp) =
-                half == 0 ? make_float2(gz[0], gz[1]) : make_float2(gz[2], gz[3]);
+            float2 o = half == 0 ? make_float2(gz[0], gz[1]) : make_float2(gz[2], gz[3]);
+            if (accumulate) {
+                const float2 b = *reinterpret_cast<const float2 *>(gp);
+                o.x += b.x; o.y += b.y;
+            }
+            *reinterpret_cast<float2 *>(gp) = o;
         }
     }
 
@@ -492,7 +502,7 @@ extern "C" int spt_pq_loss_forward_codes(const float *z, const float *table, flo
 extern "C" int spt_pq_loss_backward(const float *z, const float *table, const float *grad_loss,
                                     float *grad_z, float *grad_table, void *workspace,
                                     int64_t n_vectors, int n_subspaces, int n_codewords,
-                                    int d_code, void *stream) {
+                                    int d_code, int accumulate, void *stream) {
     if (!z || !table || !grad_loss || !grad_z || !grad_table || !workspace) return SPT_EINVAL;
     if (n_vectors <= 0 || n_subspaces <= 0 || n_codewords <= 0 || d_code <= 0) return SPT_EINVAL;
     if (!pq_loss_shape_ok(n_vectors, n_subspaces, n_codewords, d_code)) return SPT_EUNSUP;
@@ -507,10 +517,10 @@ extern "C" int spt_pq_loss_backward(const float *z, const float *table, const fl
     hipStream_t s = (hipStream_t)stream;
     if (d_code == 4)
         hipLaunchKernelGGL((pq_loss_backward_kernel<4>), dim3(nblk), dim3(PQL_THREADS), lds, s, z,
-                           table, grad_loss, grad_z, partial, total, n_subspaces, inv_count);
+                           table, grad_loss, grad_z, partial, total, n_subspaces, inv_count, accumulate);
     else
         hipLaunchKernelGGL((pq_loss_backward_kernel<8>), dim3(nblk), dim3(PQL_THREADS), lds, s, z,
-                           table, grad_loss, grad_z, partial, total, n_subspaces, inv_count);
+                           table, grad_loss, grad_z, partial, total, n_subspaces, inv_count, accumulate);
     SPT_LAUNCH_CHECK();
     const int elems = n_subspaces * CD;
     hipLaunchKernelGGL(pq_loss_table_reduce_kernel, dim3((elems + 63) / 64), dim3(1024), 0, s,

@@ -39,7 +39,7 @@ _PROTOTYPES = {
     'spt_pq_loss_workspace_bytes': ([ctypes.c_int64] + [_c_int] * 3, ctypes.c_int64),
     'spt_pq_loss_forward': ([_c_ptr] * 4 + [ctypes.c_int64] + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_pq_loss_forward_codes': ([_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr], _c_int),
-    'spt_pq_loss_backward': ([_c_ptr] * 6 + [ctypes.c_int64] + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_pq_loss_backward': ([_c_ptr] * 6 + [ctypes.c_int64] + [_c_int] * 4 + [_c_ptr], _c_int),
     'spt_sddmm_forward': (
         [_c_ptr] * 5 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int
     ),
@@ -87,7 +87,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _lib = None
 
@@ -360,18 +360,26 @@ def pq_loss_forward(z: torch.Tensor, table: torch.Tensor, want_codes: bool = Fal
     return (loss, codes) if want_codes else loss
 
 
-def pq_loss_backward(z: torch.Tensor, table: torch.Tensor, grad_loss: torch.Tensor):
-    """-> (grad_z, grad_table) for a 0-dim device ``grad_loss`` (no host read)."""
+def pq_loss_backward(z: torch.Tensor, table: torch.Tensor, grad_loss: torch.Tensor,
+                     accumulate_into: torch.Tensor = None):
+    """-> (grad_z, grad_table) for a 0-dim device ``grad_loss`` (no host read).  With
+    ``accumulate_into`` (fp32, z's shape, contiguous) the gradient is ADDED to that tensor, which
+    is returned as grad_z."""
     lib, dev, n_vectors, (M, C, D), nbytes = _pq_loss_args(z, table)
     _check_type(grad_loss, torch.float32, 'grad_loss')
     _require(grad_loss.numel() == 1 and grad_loss.device == z.device, 'grad_loss: device scalar')
+    if accumulate_into is not None:
+        _require(accumulate_into.dtype == torch.float32 and accumulate_into.shape == z.shape
+                 and accumulate_into.is_contiguous() and accumulate_into.device == z.device,
+                 'accumulate_into: contiguous fp32 tensor of z\'s shape')
     with torch.cuda.device(dev):
-        grad_z = torch.empty_like(z)
+        grad_z = torch.empty_like(z) if accumulate_into is None else accumulate_into
         grad_table = torch.empty_like(table)
         scratch = torch.empty([nbytes // 4], dtype=torch.float32, device=dev)
         rc = lib.spt_pq_loss_backward(z.data_ptr(), table.data_ptr(), grad_loss.data_ptr(),
                                       grad_z.data_ptr(), grad_table.data_ptr(),
-                                      scratch.data_ptr(), n_vectors, M, C, D, _stream(dev))
+                                      scratch.data_ptr(), n_vectors, M, C, D,
+                                      int(accumulate_into is not None), _stream(dev))
     if rc != 0:
         _raise(lib, rc, 'pq_loss_backward')
     return grad_z, grad_table

@@ -154,7 +154,8 @@ class _MfmaAttention(torch.autograd.Function):
     tiles in two launches (grad_q; grad_k and grad_v)."""
 
     @staticmethod
-    def forward(ctx, indices, q, k, v, scale: float):
+    def forward(ctx, indices, q, k, v, scale: float, armed: bool = False):
+        ctx.armed = armed
         # `indices` come straight from kernels.lookup: only its padding column 0 repeats in a
         # row, which is what the compact tile layout needs (70 -> 17 MB per BERT-large layer)
         tiles = ext.attention_mfma_prepare(indices, q.size(1), lookup_pattern=True)
@@ -169,7 +170,12 @@ class _MfmaAttention(torch.autograd.Function):
         grad_q, grad_k, grad_v = ext.attention_mfma_backward(
             ctx.tiles, q, k, v, y, grad_out.contiguous(), row_sum, ctx.scale, CLAMP,
             transposed=True)
-        return None, grad_q, grad_k, grad_v, None
+        if ctx.armed:
+            # the PQ loss of the same q / k adds its gradient into these (kernels/pq_loss.py)
+            from naive_gpt.kernels.pq_loss import pending_gradient
+            pending_gradient(q, grad_q)
+            pending_gradient(k, grad_k)
+        return None, grad_q, grad_k, grad_v, None, None
 
 
 class _SparseCore:
@@ -256,7 +262,11 @@ class _SparseCore:
         seq_length, heads = q.size(1), q.size(2)
         q, k = q.contiguous(), k.contiguous()
         q_c = k_c = None
-        if self._take_trigger():
+        armed = self._take_trigger()
+        self.__dict__['_armed_now'] = armed          # (read by _sparse_apply of the same forward)
+        if armed:
+            from naive_gpt.kernels.pq_loss import drop_pending_gradients
+            drop_pending_gradients()                 # nothing of an earlier backward survives
             # the PQ loss is a mean over all sub-vectors: the head layout holds the same set
             # (bf16 storage: the loss is formed in fp32 from the widened values); its argmin is
             # the PQ code, so an armed step needs no encode pass
@@ -312,7 +322,8 @@ class _SparseCore:
         if len(attn) == 5:
             kind, indptr, indices, q, k = attn
             if kind == 'mfma':
-                return _MfmaAttention.apply(indices, q, k, v.contiguous(), self.scaling)
+                return _MfmaAttention.apply(indices, q, k, v.contiguous(), self.scaling,
+                                            bool(self.__dict__.pop('_armed_now', False)))
             return _FusedAttention.apply(indptr, indices, q, k, v.contiguous(), self.scaling)
         if len(attn) == 4:
             indptr, indices, values, heads = attn

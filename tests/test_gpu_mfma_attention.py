@@ -360,6 +360,36 @@ def test_bf16_storage_outside_the_matrix_core_path_is_refused():
         attn(q, q, q, attn_mask=None)
 
 
+def test_pq_loss_gradient_joins_the_attention_gradient_in_place(monkeypatch):
+    """An armed layer: the PQ loss's gradient of q / k is added into the attention's gradient
+    tensors by the loss's backward kernel (kernels/pq_loss.py: pending_gradient) instead of by
+    autograd's elementwise sum -- same numbers."""
+    from naive_gpt import layers
+    import importlib
+    pq = importlib.import_module('naive_gpt.kernels.pq_loss')
+    torch.manual_seed(0)
+    attn = layers.SparseVanillaAttentionV2(d_head=64, d_codeword=8, n_codewords=16, p_dropout=0.0).cuda()
+    q, k, v, w = [torch.randn([2, 256, 16, 64], device='cuda') for _ in range(4)]
+
+    def run():
+        qi, ki, vi = [t.clone().requires_grad_(True) for t in (q, k, v)]
+        attn.zero_grad()
+        attn.arm()
+        y = attn(qi, ki, vi, attn_mask=None)
+        ((y * w).sum() + 3.0 * attn.loss).backward()
+        return qi.grad, ki.grad, vi.grad, attn.quantizer.weight.grad.clone()
+
+    used = []
+    orig = pq.take_pending_gradient
+    monkeypatch.setattr(pq, 'take_pending_gradient', lambda z: used.append(1) or orig(z))
+    joined = run()
+    assert len(used) == 2 and not pq._PENDING                  # q and k: both taken
+    monkeypatch.setattr(pq, 'pending_gradient', lambda z, g: None)
+    plain = run()
+    for a, b in zip(joined, plain):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * b.abs().max().item())
+
+
 def test_host_side_arming_equals_the_reference_protocol():
     """module.arm() (no device read-back in the next forward) against the reference's
     `module.trigger.fill_(True)`: same loss buffer, trigger disarmed afterwards, one-shot."""
