@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 27
+#define SPT_ABI_VERSION 28
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -530,6 +530,22 @@ int spt_layernorm_backward(const float *s, const float *dy, const float *gamma, 
  */
 int spt_route_topk(const float *prob, int32_t *token, int32_t *block, int32_t *offsets,
                    int32_t *pos, int n_tokens, int n_blocks, int k, void *stream);
+
+/*
+ * The same launch with the by-products the routed LoRA FFN needs next (lora_ffn.py:87-98 reads
+ * them off `topk` / boolean masks): token64 / block64 = token / block as int64 (torch's gather /
+ * scatter index type), coeff[p] = scale * prob[token[p], block[p]] (the row's router coefficient;
+ * the reference's `2.0 * prob` is scale = 2).  All three required.
+ * spt_route_coeff_backward: the adjoint of `coeff`,
+ *   dprob[t, g] = scale * dcoeff[p] if row p is token t's selection of block g, else 0
+ * (dprob [n_tokens, n_blocks] is written whole).
+ */
+int spt_route_topk_coeff(const float *prob, int32_t *token, int32_t *block, int32_t *offsets,
+                         int32_t *pos, long long *token64, long long *block64, float *coeff,
+                         float scale, int n_tokens, int n_blocks, int k, void *stream);
+int spt_route_coeff_backward(const float *dcoeff, const int32_t *pos, const int32_t *block,
+                             float scale, float *dprob, int n_tokens, int n_blocks, int k,
+                             void *stream);
 
 /*
  * Router-coefficient gradient of the routed LoRA FFN's backward (layers/sparse/grouped.py; the

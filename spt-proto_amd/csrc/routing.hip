@@ -63,7 +63,9 @@ constexpr int RT_CHUNK = 256;
 template <int MG>
 __global__ __launch_bounds__(RT_CHUNK) void route_topk_kernel(
     const float *__restrict__ prob, int32_t *__restrict__ token, int32_t *__restrict__ block,
-    int32_t *__restrict__ offsets, int32_t *__restrict__ pos, int T, int G, int k) {
+    int32_t *__restrict__ offsets, int32_t *__restrict__ pos, int T, int G, int k,
+    long long *__restrict__ token64, long long *__restrict__ block64, float *__restrict__ coeff,
+    float scale) {
     __shared__ int wave_before[RT_CHUNK / 64][MG];   // selections in chunks before mine, by wave
     __shared__ int wave_total[RT_CHUNK / 64][MG];    // ... in all chunks
     __shared__ int wave_mine[RT_CHUNK / 64][MG];     // ... in my chunk
@@ -84,6 +86,9 @@ __global__ __launch_bounds__(RT_CHUNK) void route_topk_kernel(
 #pragma unroll
     for (int g = 0; g < MG; g++) before[g] = total[g] = own[g] = rank[g] = 0;
     unsigned my_mask = 0u;
+    float my_v[MG];
+#pragma unroll
+    for (int g = 0; g < MG; g++) my_v[g] = 0.0f;
     const unsigned long long lower = (1ull << lane) - 1ull;
     constexpr int AHEAD = 4;                  // chunks whose loads are in flight together
     for (int c0 = 0; c0 < nchunks; c0 += AHEAD) {
@@ -95,7 +100,11 @@ __global__ __launch_bounds__(RT_CHUNK) void route_topk_kernel(
             const int c = c0 + u;
             if (c >= nchunks) break;
             const unsigned m = (c * RT_CHUNK + tid < T) ? select_topk(v[u], G, k) : 0u;
-            if (c == mine) my_mask = m;
+            if (c == mine) {
+                my_mask = m;
+#pragma unroll
+                for (int g = 0; g < MG; g++) my_v[g] = v[u][g];
+            }
 #pragma unroll
             for (int g = 0; g < MG; g++) {
                 const unsigned long long b = __ballot((m >> g) & 1u);
@@ -144,6 +153,10 @@ __global__ __launch_bounds__(RT_CHUNK) void route_topk_kernel(
                 token[r] = t;
                 block[r] = g;
                 pos[(size_t)t * k + j] = r;
+                // (optional by-products: what the routed FFN otherwise derives with six more launches)
+                if (token64) token64[r] = t;
+                if (block64) block64[r] = g;
+                if (coeff) coeff[r] = scale * my_v[g];
                 j++;
             }
         }
@@ -157,6 +170,29 @@ __global__ __launch_bounds__(RT_CHUNK) void route_topk_kernel(
 // dot_main / dot_act: the EPI_DACT epilogue's per-column-tile partial row dots [P, w]; du, z [P, r];
 // u, dzt [T, r].  As torch operators: two reductions, two gathers' worth of products, seven
 // elementwise kernels on 16384-element vectors -- ~40 us of launches for 2 MB of data.
+// Adjoint of the `coeff` by-product of route_topk_kernel: d prob[t, g] = scale * d coeff[p] where row
+// p is token t's selection of block g, zero for the blocks t did not select.  A thread per token.
+__global__ __launch_bounds__(256) void route_coeff_backward_kernel(
+    const float *__restrict__ dcoeff, const int32_t *__restrict__ pos, const int32_t *__restrict__ block,
+    float scale, float *__restrict__ dprob, int T, int G, int k) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    float out[RT_MAXG];
+#pragma unroll
+    for (int g = 0; g < RT_MAXG; g++) out[g] = 0.0f;
+    for (int j = 0; j < k; j++) {
+        const int p = pos[(size_t)t * k + j];
+        const int b = block[p];
+        const float v = scale * dcoeff[p];
+#pragma unroll
+        for (int g = 0; g < RT_MAXG; g++)
+            if (g == b) out[g] = v;
+    }
+#pragma unroll
+    for (int g = 0; g < RT_MAXG; g++)
+        if (g < G) dprob[(size_t)t * G + g] = out[g];
+}
+
 __global__ __launch_bounds__(256) void ffn_coeff_grad_kernel(
     const float *__restrict__ dot_main, const float *__restrict__ dot_act, int w,
     const float *__restrict__ du, const float *__restrict__ u, const float *__restrict__ dzt,
@@ -185,19 +221,47 @@ __global__ __launch_bounds__(256) void ffn_coeff_grad_kernel(
 
 using namespace spt;
 
-extern "C" int spt_route_topk(const float *prob, int32_t *token, int32_t *block,
-                              int32_t *offsets, int32_t *pos, int n_tokens, int n_blocks,
-                              int k, void *stream) {
+static int route_topk_any(const float *prob, int32_t *token, int32_t *block, int32_t *offsets,
+                          int32_t *pos, long long *token64, long long *block64, float *coeff,
+                          float scale, int n_tokens, int n_blocks, int k, void *stream) {
     if (!prob || !token || !block || !offsets || !pos) return SPT_EINVAL;
     if (n_tokens <= 0 || n_blocks <= 0 || k <= 0 || k > n_blocks) return SPT_EINVAL;
     if (n_blocks > RT_MAXG || n_tokens > 65536) return SPT_EUNSUP;
     const dim3 grid((n_tokens + RT_CHUNK - 1) / RT_CHUNK), threads(RT_CHUNK);
     if (n_blocks <= 4)
         hipLaunchKernelGGL(route_topk_kernel<4>, grid, threads, 0, (hipStream_t)stream, prob, token,
-                           block, offsets, pos, n_tokens, n_blocks, k);
+                           block, offsets, pos, n_tokens, n_blocks, k, token64, block64, coeff, scale);
     else
         hipLaunchKernelGGL(route_topk_kernel<RT_MAXG>, grid, threads, 0, (hipStream_t)stream, prob, token,
-                           block, offsets, pos, n_tokens, n_blocks, k);
+                           block, offsets, pos, n_tokens, n_blocks, k, token64, block64, coeff, scale);
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
+extern "C" int spt_route_topk(const float *prob, int32_t *token, int32_t *block,
+                              int32_t *offsets, int32_t *pos, int n_tokens, int n_blocks,
+                              int k, void *stream) {
+    return route_topk_any(prob, token, block, offsets, pos, nullptr, nullptr, nullptr, 1.0f,
+                          n_tokens, n_blocks, k, stream);
+}
+
+extern "C" int spt_route_topk_coeff(const float *prob, int32_t *token, int32_t *block,
+                                    int32_t *offsets, int32_t *pos, long long *token64,
+                                    long long *block64, float *coeff, float scale, int n_tokens,
+                                    int n_blocks, int k, void *stream) {
+    if (!token64 || !block64 || !coeff) return SPT_EINVAL;
+    return route_topk_any(prob, token, block, offsets, pos, token64, block64, coeff, scale,
+                          n_tokens, n_blocks, k, stream);
+}
+
+extern "C" int spt_route_coeff_backward(const float *dcoeff, const int32_t *pos, const int32_t *block,
+                                        float scale, float *dprob, int n_tokens, int n_blocks,
+                                        int k, void *stream) {
+    if (!dcoeff || !pos || !block || !dprob) return SPT_EINVAL;
+    if (n_tokens <= 0 || n_blocks <= 0 || k <= 0 || k > n_blocks) return SPT_EINVAL;
+    if (n_blocks > RT_MAXG) return SPT_EUNSUP;
+    hipLaunchKernelGGL(route_coeff_backward_kernel, dim3((n_tokens + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, dcoeff, pos, block, scale, dprob, n_tokens, n_blocks, k);
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }

@@ -82,12 +82,14 @@ _PROTOTYPES = {
     'spt_lora_down': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_int,
                        _c_ptr, _c_int] + [_c_ptr] * 3, _c_int),
     'spt_route_topk': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_route_topk_coeff': ([_c_ptr] * 8 + [_c_f32] + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_route_coeff_backward': ([_c_ptr] * 3 + [_c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_forward': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_backward': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _lib = None
 
@@ -155,7 +157,31 @@ def _same_device(*tensors):
 
 
 def _stream(dev) -> int:
-    return torch.cuda.current_stream(dev).cuda_stream
+    # torch's current stream on `dev` as the raw hipStream_t (the C call behind
+    # torch.cuda.current_stream(dev).cuda_stream, without the Stream object: ~0.3 us against 4 --
+    # a fine-tune step makes ~600 of these calls)
+    idx = dev.index
+    return torch._C._cuda_getCurrentRawStream(idx if idx is not None else torch._C._cuda_getDevice())
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on(dev):
+    """`torch.cuda.device(dev)` only when `dev` is not already the current device (the guard's
+    enter / exit cost ~5 us of host time per call; allocations and launches below go to `dev`)."""
+    idx = dev.index
+    if idx is None or idx == torch._C._cuda_getDevice():
+        return _NO_GUARD
+    return torch.cuda.device(dev)
 
 
 def _flag(t) -> bool:
@@ -175,7 +201,7 @@ def cdist_forward_cuda(query: torch.Tensor, table: torch.Tensor):
     M, NQ, D = query.shape
     C = table.size(1)
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         distance = torch.empty([M, NQ, C], dtype=torch.float32, device=dev)
         indices = torch.empty([M, NQ], dtype=torch.int32, device=dev)
         rc = lib.spt_cdist_forward(
@@ -198,7 +224,7 @@ def cdist_encode(query: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
     dev = _same_device(query, table)
     M, NQ, D = query.shape
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         indices = torch.empty([M, NQ], dtype=torch.int32, device=dev)
         rc = lib.spt_cdist_forward(
             query.data_ptr(), table.data_ptr(), None, indices.data_ptr(),
@@ -228,7 +254,7 @@ def cdist_backward_cuda(query: torch.Tensor, table: torch.Tensor,
     M, NQ, D = query.shape
     C = table.size(1)
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         grad_query = torch.empty_like(query)
         grad_table = torch.empty_like(table)
         nbytes = lib.spt_cdist_backward_workspace_bytes(M, NQ, C, D)
@@ -259,7 +285,7 @@ def lookup_forward_cuda(config: torch.Tensor, query: torch.Tensor,
     Z = S // sparsity
     _require(Z % 16 == 0, 'nonzeros % BLOCK_SIZE == 0')
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         output = torch.empty([B, S, Z], dtype=torch.int32, device=dev)
         rc = lib.spt_lookup_forward(
             query.data_ptr(), key.data_ptr(), output.data_ptr(),
@@ -304,7 +330,7 @@ def pq_encode_heads(z: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
     M, C, D = table.shape
     _require(E == M * D, 'z.size(-1) == n_subspaces * d_codeword')
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         codes = torch.empty([N * H, S, M], dtype=torch.int32, device=dev)
         fn = lib.spt_pq_encode_heads if z.dtype == torch.float32 else lib.spt_pq_encode_heads_bf16
         rc = fn(z.data_ptr(), table.data_ptr(), codes.data_ptr(), N, S, H, M, C, D, _stream(dev))
@@ -342,7 +368,7 @@ def pq_loss_forward(z: torch.Tensor, table: torch.Tensor, want_codes: bool = Fal
     """-> 0-dim loss of ``PQBase.forward('train', z)`` (quantizer.py:80-111); with ``want_codes``
     (z [N, S, H, E]) also the PQ codes [N * H, S, M] of ``pq_encode_heads``, from the same pass."""
     lib, dev, n_vectors, (M, C, D), nbytes = _pq_loss_args(z, table)
-    with torch.cuda.device(dev):
+    with _on(dev):
         loss = torch.empty([], dtype=torch.float32, device=dev)
         scratch = torch.empty([nbytes // 4], dtype=torch.float32, device=dev)
         if want_codes:
@@ -372,7 +398,7 @@ def pq_loss_backward(z: torch.Tensor, table: torch.Tensor, grad_loss: torch.Tens
         _require(accumulate_into.dtype == torch.float32 and accumulate_into.shape == z.shape
                  and accumulate_into.is_contiguous() and accumulate_into.device == z.device,
                  'accumulate_into: contiguous fp32 tensor of z\'s shape')
-    with torch.cuda.device(dev):
+    with _on(dev):
         grad_z = torch.empty_like(z) if accumulate_into is None else accumulate_into
         grad_table = torch.empty_like(table)
         scratch = torch.empty([nbytes // 4], dtype=torch.float32, device=dev)
@@ -404,7 +430,7 @@ def sddmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,
     nnz = indices.size(-1)
     _require(indptr.size(-1) == S + 1, 'indptr.size(-1) == seq_length + 1')
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         output = torch.empty([B, nnz], dtype=torch.float32, device=dev)
         rc = lib.spt_sddmm_forward(
             indptr.data_ptr(), indices.data_ptr(), query.data_ptr(),
@@ -463,7 +489,7 @@ def sparse_attention_forward(indices: torch.Tensor, q: torch.Tensor, k: torch.Te
     B, nnz = N * H, indices.size(-1)
     _require(indices.dim() == 2 and indices.size(0) == B, 'indices: [N * H, nnz]')
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         scores = torch.empty([B, nnz], dtype=torch.float32, device=dev)
         attn = torch.empty([B, nnz], dtype=torch.float32, device=dev)
         y = torch.empty([B, E, S] if y_transposed else [B, S, E], dtype=torch.float32, device=dev)
@@ -512,7 +538,7 @@ def attention_mfma_prepare(indices: torch.Tensor, seq_length: int,
     lib = load_library()
     size = lib.spt_attention_mfma_tiles_bytes(B, int(seq_length), nnz, layout)
     _require(size > 0, 'attention_mfma: unsupported shape (d_head 64, Z <= 256, Z % 4 == 0, S <= 2048)')
-    with torch.cuda.device(dev):
+    with _on(dev):
         buf = torch.empty([size], dtype=torch.uint8, device=dev)
         rc = lib.spt_attention_mfma_prepare(indices.data_ptr(), buf.data_ptr(), B, int(seq_length),
                                             nnz, layout, _stream(dev))
@@ -542,7 +568,7 @@ def attention_mfma_forward(tiles, q: torch.Tensor, k: torch.Tensor, v: torch.Ten
     _require(tiles.batch == B and tiles.seq == S, 'tiles: prepared for [N * H, nnz] indices at S')
     dev = _same_device(tiles.buffer, q, k, v)
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         y = torch.empty([B, E, S] if y_transposed else [B, S, E], dtype=q.dtype, device=dev)
         row_sum = torch.empty([B, S], dtype=torch.float32, device=dev)
         fn = (lib.spt_attention_mfma_forward if q.dtype == torch.float32
@@ -577,7 +603,7 @@ def attention_mfma_backward(tiles: MfmaTiles, q: torch.Tensor, k: torch.Tensor, 
     _require(row_sum.numel() == B * S, 'row_sum: [N * H, S]')
     dev = _same_device(tiles.buffer, q, k, v, y, grad_y, row_sum)
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         grad_q, grad_k, grad_v = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         delta = torch.empty([B, S], dtype=torch.float32, device=dev)
         fn = (lib.spt_attention_mfma_backward if q.dtype == torch.float32
@@ -613,7 +639,7 @@ def sparse_attention_backward_rows(indices: torch.Tensor, grad_y: torch.Tensor, 
     _require(grad_y.numel() == B * S * E, 'grad_y: N * H * S * E elements')
     _require(scores.shape == attn.shape == indices.shape, 'scores, attn: the shape of indices')
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         grad_raw = torch.empty([B, nnz], dtype=torch.float32, device=dev)
         grad_q = torch.empty_like(v)
         rows = torch.empty([B, S, E], dtype=torch.float32, device=dev) if grad_y_transposed \
@@ -638,7 +664,7 @@ def csr_transpose(indptr: torch.Tensor, indices: torch.Tensor, d_head: int = 64)
     B, nnz = indices.shape
     S = indptr.size(-1) - 1
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         nbytes = lib.spt_csr_transpose_workspace_bytes(B, S, nnz, int(d_head))
         buf = torch.empty([max(int(nbytes), 16)], dtype=torch.uint8, device=dev)
         if nnz > 0:
@@ -671,7 +697,7 @@ def spmm_transposed(transposed: torch.Tensor, indptr: torch.Tensor,
     dev, B, S, E = _check_spmm(indptr, indices, values, x, x_heads)
     nnz = indices.size(-1)
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         output = _alloc_dense(B, S, E, y_heads, dev)
         if nnz == 0:
             return output.zero_()
@@ -696,7 +722,7 @@ def spmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,
     trans = int(_flag(trans_lhs))
     nnz = indices.size(-1)
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         output = _alloc_dense(B, S, E, y_heads, dev)
         if nnz == 0:
             return output.zero_()
@@ -726,7 +752,7 @@ def softmax_forward_cuda(indptr: torch.Tensor, indices: torch.Tensor,
     B, nnz = indices.shape
     S = indptr.size(-1) - 1
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         output = torch.empty_like(values)
         rc = lib.spt_softmax_forward(
             indptr.data_ptr(), indices.data_ptr(), values.data_ptr(),
@@ -753,7 +779,7 @@ def softmax_backward_cuda(indptr: torch.Tensor, indices: torch.Tensor,
     B, nnz = indices.shape
     S = indptr.size(-1) - 1
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         grad_values = torch.empty_like(output)
         rc = lib.spt_softmax_backward(
             indptr.data_ptr(), indices.data_ptr(), output.data_ptr(),
@@ -789,7 +815,7 @@ def grouped_gemm(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Tensor,
     if gather is not None:
         _check_type(gather, torch.int32, 'gather')
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty([n_rows, n], dtype=torch.float32, device=dev)
         if n_rows == 0:
             return out
@@ -852,7 +878,7 @@ def split_bf16(x: torch.Tensor) -> SplitImage:
     rows, cols = x.shape
     lib = load_library()
     dev = x.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         buf = torch.empty([lib.spt_split_bf16_bytes(rows, cols)], dtype=torch.uint8, device=dev)
         if rows > 0:
             rc = lib.spt_split_bf16(x.data_ptr(), buf.data_ptr(), rows, cols, x.stride(0),
@@ -1033,7 +1059,7 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                  and w_image.cols == (w_ldn if w_ldk == 1 else w_ldk),
                  'w_image: the image of the weight with rows of w_ldn (w_ldk) elements')
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         _require(not accumulate or out is not None, 'accumulate: needs `out`')
         if out is None:
             out = torch.empty([n_rows, n], dtype=torch.float32, device=dev)
@@ -1102,7 +1128,7 @@ def route_topk(prob: torch.Tensor, k: int):
     _require(0 < k <= G, 'route_topk: 0 < k <= n_blocks')
     dev = prob.device
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         token = torch.empty([T * k], dtype=torch.int32, device=dev)
         block = torch.empty([T * k], dtype=torch.int32, device=dev)
         offsets = torch.empty([G + 1], dtype=torch.int32, device=dev)
@@ -1112,6 +1138,53 @@ def route_topk(prob: torch.Tensor, k: int):
     if rc != 0:
         _raise(lib, rc, 'route_topk')
     return token, block, offsets, pos
+
+
+def route_topk_coeff(prob: torch.Tensor, k: int, scale: float):
+    """``spt_route_topk_coeff``: `route_topk` plus, from the same launch, token / block as int64
+    and coeff[p] = scale * prob[token[p], block[p]].
+    -> (token, block, offsets, pos, token64, block64, coeff)."""
+    _check_dim(prob, 2, 'prob')
+    _check_type(prob, torch.float32, 'prob')
+    _require(prob.is_cuda and prob.is_contiguous(), 'route_topk_coeff: contiguous CUDA prob')
+    T, G = prob.shape
+    _require(0 < k <= G, 'route_topk: 0 < k <= n_blocks')
+    dev = prob.device
+    lib = load_library()
+    with _on(dev):
+        ints = torch.empty([3 * T * k + G + 1], dtype=torch.int32, device=dev)
+        token, block, pos = ints[:T * k], ints[T * k:2 * T * k], ints[2 * T * k:3 * T * k].view(T, k)
+        offsets = ints[3 * T * k:]
+        longs = torch.empty([2, T * k], dtype=torch.int64, device=dev)
+        coeff = torch.empty([T * k], dtype=torch.float32, device=dev)
+        rc = lib.spt_route_topk_coeff(prob.data_ptr(), token.data_ptr(), block.data_ptr(),
+                                      offsets.data_ptr(), pos.data_ptr(), longs[0].data_ptr(),
+                                      longs[1].data_ptr(), coeff.data_ptr(), float(scale), T, G, k,
+                                      _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'route_topk_coeff')
+    return token, block, offsets, pos, longs[0], longs[1], coeff
+
+
+def route_coeff_backward(dcoeff: torch.Tensor, pos: torch.Tensor, block: torch.Tensor,
+                         scale: float, n_blocks: int) -> torch.Tensor:
+    """``spt_route_coeff_backward``: d prob [T, n_blocks] from d coeff [T * k]."""
+    _check_type(dcoeff, torch.float32, 'dcoeff')
+    _check_type(pos, torch.int32, 'pos')
+    _check_type(block, torch.int32, 'block')
+    _require(dcoeff.is_cuda and dcoeff.is_contiguous() and pos.is_contiguous() and block.is_contiguous()
+             and pos.dim() == 2 and dcoeff.numel() == pos.numel() == block.numel(),
+             'route_coeff_backward: dcoeff [T * k], pos [T, k], block [T * k], contiguous')
+    T, k = pos.shape
+    dev = _same_device(dcoeff, pos, block)
+    lib = load_library()
+    with _on(dev):
+        dprob = torch.empty([T, n_blocks], dtype=torch.float32, device=dev)
+        rc = lib.spt_route_coeff_backward(dcoeff.data_ptr(), pos.data_ptr(), block.data_ptr(),
+                                          float(scale), dprob.data_ptr(), T, n_blocks, k, _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'route_coeff_backward')
+    return dprob
 
 
 def rows_combine(rows: torch.Tensor, pos: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
@@ -1124,7 +1197,7 @@ def rows_combine(rows: torch.Tensor, pos: torch.Tensor, bias: torch.Tensor = Non
     T, k = pos.shape
     d = rows.size(1)
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty([T, d], dtype=torch.float32, device=dev)
         if T > 0:
             rc = lib.spt_rows_combine(rows.data_ptr(), pos.data_ptr(), _ptr(bias), out.data_ptr(),
@@ -1157,7 +1230,7 @@ def lora_down(x: torch.Tensor, table: torch.Tensor, want_image: bool = False,
     n = table.size(1)
     dev = _same_device(x, table)
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         u = torch.empty([n // 16, rows, 16] if block_major else [rows, n], dtype=torch.float32, device=dev)
         image = norms = None
         if want_image:
@@ -1189,7 +1262,7 @@ def cross_entropy_grad_(logits: torch.Tensor, n_classes: int, target: torch.Tens
     dev = _same_device(logits, target, scale)
     rows = logits.size(0)
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         loss = torch.empty([rows], dtype=torch.float32, device=dev)
         if rows > 0:
             rc = lib.spt_cross_entropy_grad(logits.data_ptr(), logits.stride(0), rows, n_classes,
@@ -1222,7 +1295,7 @@ def add_layernorm_forward(x: torch.Tensor, r, gamma: torch.Tensor, beta, eps: fl
     rows = x.numel() // d
     dev = _same_device(x, gamma)
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         s = torch.empty_like(x) if r is not None else x
         y = torch.empty_like(x)
         mean = torch.empty([rows], dtype=torch.float32, device=dev)
@@ -1250,7 +1323,7 @@ def layernorm_backward(s: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, m
     rows = s.numel() // d
     dev = _same_device(s, dy, gamma, mean, rstd)
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         dx = torch.empty_like(s)
         dparam = torch.empty([2, d], dtype=torch.float32, device=dev)
         partial = torch.empty([lib.spt_layernorm_partial_rows(rows), 2 * d], dtype=torch.float32, device=dev)
@@ -1278,7 +1351,7 @@ def ffn_coeff_grad(dot_main: torch.Tensor, dot_act: torch.Tensor, du: torch.Tens
              and r % 4 == 0, 'ffn_coeff_grad: shapes')
     dev = _same_device(dot_main, du, u, token, coeff)
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty([P], dtype=torch.float32, device=dev)
         rc = lib.spt_ffn_coeff_grad(dot_main.data_ptr(), dot_act.data_ptr(), dot_main.size(1),
                                     du.data_ptr(), u.data_ptr(), dzt.data_ptr(), z.data_ptr(),
@@ -1305,7 +1378,7 @@ def softmax_backward_clamped(indptr: torch.Tensor, indices: torch.Tensor,
     B, nnz = indices.shape
     S = indptr.size(-1) - 1
     lib = load_library()
-    with torch.cuda.device(dev):
+    with _on(dev):
         grad = torch.empty_like(output)
         rc = lib.spt_softmax_backward_clamped(
             indptr.data_ptr(), indices.data_ptr(), output.data_ptr(),

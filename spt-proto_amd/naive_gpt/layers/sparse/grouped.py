@@ -29,15 +29,36 @@ class Buckets(NamedTuple):
     pos: torch.Tensor       # [T, k] int32: the rows of each token (inverse of `token`)
 
 
-def make_buckets(prob: torch.Tensor, k: int) -> Buckets:
-    """prob [T, G] router probabilities -> block-sorted (token, block) rows."""
+class _RouteTopK(torch.autograd.Function):
+    """prob [T, G] -> the block-sorted rows AND their coefficients scale * prob[token, block], one
+    launch (routing.hip); backward: the coefficients' gradient scattered back, one launch.
+    (As torch operators: two int64 copies, two index computations, a gather and a product
+    forward; a product, a zero fill and an index_add backward -- x 24 layers.)"""
+
+    @staticmethod
+    def forward(ctx, prob, k, scale):
+        token, block, offsets, pos, token_long, block_long, coeff = \
+            ext.route_topk_coeff(prob.contiguous(), k, scale)
+        ctx.save_for_backward(pos, block)
+        ctx.scale, ctx.n_blocks = scale, prob.size(1)
+        ctx.mark_non_differentiable(token, block, offsets, pos, token_long, block_long)
+        return token, block, offsets, pos, token_long, block_long, coeff
+
+    @staticmethod
+    def backward(ctx, *grads):
+        pos, block = ctx.saved_tensors
+        return ext.route_coeff_backward(grads[6].contiguous(), pos, block, ctx.scale,
+                                        ctx.n_blocks), None, None
+
+
+def make_buckets(prob: torch.Tensor, k: int, scale: float = 1.0) -> Buckets:
+    """prob [T, G] router probabilities -> block-sorted (token, block) rows; `coeff` =
+    scale * the rows' probabilities."""
     n_tokens, n_blocks = prob.shape
     if prob.is_cuda and prob.dtype == torch.float32 \
             and ext.route_topk_supported(n_tokens, n_blocks):
         # one launch (routing.hip) instead of topk + argsort + bincount + cumsum + gathers
-        token, block, offsets, pos = ext.route_topk(prob.detach().contiguous(), k)
-        token_long, block_long = token.long(), block.long()
-        coeff = prob.reshape(-1).index_select(0, token_long * n_blocks + block_long)
+        token, _, offsets, pos, token_long, block_long, coeff = _RouteTopK.apply(prob, k, float(scale))
         return Buckets(token=token, token_long=token_long, block=block_long, offsets=offsets,
                        coeff=coeff, n_blocks=n_blocks, pos=pos)
     indices = torch.topk(prob, k=k, dim=-1, sorted=False).indices       # [T, k]
@@ -49,6 +70,8 @@ def make_buckets(prob: torch.Tensor, k: int) -> Buckets:
     offsets = torch.zeros([n_blocks + 1], dtype=torch.int32, device=prob.device)
     offsets[1:] = torch.cumsum(counts, dim=0)
     coeff = prob.reshape(-1).index_select(0, token_long * n_blocks + block_sorted)
+    if scale != 1.0:
+        coeff = scale * coeff
     # row p holds the flat (token, choice) pair order[p]: invert the permutation
     pos = torch.empty_like(order)
     pos[order] = torch.arange(order.numel(), device=order.device)

@@ -63,8 +63,8 @@ class LoRARoutedFFN(layers.RoutedFFN):
         matmuls on the same row space.  No host synchronisation."""
         nb, bs, d, r = self.n_blocks, self.block_size, self.d_model, self.fc1.lora.left.weight.size(1)
         prob = self._router(x, origin)
-        bk = grouped.make_buckets(prob, k=nb // 2)
-        coeff = (2.0 * bk.coeff).contiguous()
+        bk = grouped.make_buckets(prob, k=nb // 2, scale=2.0)       # coeff = 2 prob (lora_ffn.py:96)
+        coeff = bk.coeff
         act = grouped.activation_code(self.activation)
         if act is not None and grouped.fused_usable(r) and self.fc2.bias is not None \
                 and not self.fc2.bias.requires_grad:
@@ -152,8 +152,8 @@ class LoRARoutedLLaMaFFN(layers.RoutedLLaMaFFN):
         """MI355X path, see LoRARoutedFFN._forward_grouped."""
         nb, bs, d, r = self.n_blocks, self.block_size, self.d_model, self.gate.lora.left.weight.size(1)
         prob = self._router(x, origin)
-        bk = grouped.make_buckets(prob, k=nb // 2)
-        coeff = (2.0 * bk.coeff).contiguous()
+        bk = grouped.make_buckets(prob, k=nb // 2, scale=2.0)       # coeff = 2 prob (lora_ffn.py:96)
+        coeff = bk.coeff
         if grouped.fused_usable(r):
             # three fused block GEMMs forward (layers/sparse/grouped.py: RoutedLoRALLaMAFFN)
             return grouped.routed_lora_llama_ffn(

@@ -532,6 +532,28 @@ def test_route_topk_is_the_stable_block_sort_of_topk(T, G, k):
     assert torch.equal(block.long()[pos.long()], sel)
 
 
+@pytest.mark.parametrize('T,G,k', [(8192, 4, 2), (1000, 8, 4), (77, 4, 2), (300, 6, 3)])
+def test_route_topk_coeff_by_products_and_their_adjoint(T, G, k):
+    """spt_route_topk_coeff: the same rows as spt_route_topk, their int64 copies and
+    coeff = 2 prob[token, block] from one launch -- bit for bit the torch composition -- and
+    spt_route_coeff_backward = autograd of that composition (a gather's adjoint: exact)."""
+    from naive_gpt import ext
+    from naive_gpt.layers.sparse import grouped
+    gen = torch.Generator().manual_seed(3 * T + G)
+    prob = torch.rand([T, G], generator=gen).cuda().requires_grad_(True)
+    token, block, offsets, pos = ext.route_topk(prob.detach(), k)
+    bk = grouped.make_buckets(prob, k, scale=2.0)
+    assert torch.equal(bk.token, token) and torch.equal(bk.offsets, offsets) and torch.equal(bk.pos, pos)
+    assert bk.token_long.dtype == torch.int64 and torch.equal(bk.token_long, token.long())
+    assert bk.block.dtype == torch.int64 and torch.equal(bk.block, block.long())
+    ref = 2.0 * prob.reshape(-1).index_select(0, token.long() * G + block.long())
+    assert torch.equal(bk.coeff, ref.detach())
+    w = torch.randn([T * k], generator=gen).cuda()
+    (g_new,) = torch.autograd.grad(bk.coeff, prob, w)
+    (g_ref,) = torch.autograd.grad(ref, prob, w)
+    assert torch.equal(g_new, g_ref)
+
+
 def test_route_topk_ties_go_to_the_lower_block():
     from naive_gpt import ext
     prob = torch.tensor([[0.5, 0.5, 0.5, 0.5], [0.1, 0.9, 0.9, 0.1], [1.0, 0.0, 1.0, 1.0]]).cuda()

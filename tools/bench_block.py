@@ -46,7 +46,7 @@ def build(tuning):
 def run(tuning, steps=10, warmup=5):
     model = build(tuning)
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = optim.AdamW(params, lr=1e-4, weight_decay=1e-2)
+    opt = optim.AdamW(params, lr=1e-4, weight_decay=1e-2, fused=True)
     mask = None if tuning == 'sparse' else torch.full([S, S], float('-inf'), device=dev).triu(1)
 
     def step():

@@ -21,7 +21,7 @@ with contextlib.redirect_stdout(io.StringIO()):
         model = utils.ModuleUpgrader(utils.SparseLoRAHandler(d_lora=16, stage=stage)).visit(model)
 model = model.to(dev)
 params = [p for p in model.parameters() if p.requires_grad]
-opt = optim.AdamW(params, lr=1e-4, weight_decay=1e-2)
+opt = optim.AdamW(params, lr=1e-4, weight_decay=1e-2, fused=True)
 param_ptrs = {p.untyped_storage().data_ptr() for p in model.parameters()}
 param_ptrs |= {b.untyped_storage().data_ptr() for b in model.buffers()}
 
