@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 28
+#define SPT_ABI_VERSION 29
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -472,7 +472,8 @@ int spt_split_bf16(const float *src, void *image, long long rows, int cols, long
 /*
  * The rank-r down product of the LoRA adapters (naive_gpt/layers/tuning/lora.py:70-80,
  * lora_ffn.py:87-111) as a single pass over the tall activation (lora_side.hip):
- *   spt_lora_down  u[rows, n] = x[rows, k] . l[k, n]   (x row stride ldx floats; l, u contiguous;
+ *   spt_lora_down  u[rows, n] = x[rows, k] . l[k, n]   (x row stride ldx floats; l contiguous; u
+ *                  with row stride ldu floats, 0 = n: a column slice of a wider matrix;
  *                  u_block_major != 0: u is n / 16 matrices [rows, 16] one after the other --
  *                  several adapters' tables side by side in l, each adapter's u contiguous);
  *                  optional by-products of the same read: `image` (spt_split_bf16's layout,
@@ -482,7 +483,7 @@ int spt_split_bf16(const float *src, void *image, long long rows, int cols, long
  * Split-bf16 matrix-core products as in spt_grouped_gemm: <= 2^-16 relative per product.
  */
 int spt_lora_down(const float *x, long long ldx, long long rows, int k, const float *l, int n,
-                  float *u, int u_block_major, void *image, float *norms, void *stream);
+                  float *u, long long ldu, int u_block_major, void *image, float *norms, void *stream);
 
 /*
  * Softmax cross-entropy of the language-model head (script/4-sparse-tuning-0.py:45-59:
@@ -517,6 +518,24 @@ int spt_add_layernorm_forward(const float *x, const float *r, const float *gamma
 int spt_layernorm_backward(const float *s, const float *dy, const float *gamma, const float *mean,
                            const float *rstd, const float *dskip, float *dx, float *dgamma,
                            float *dbeta, float *partial, long long rows, int d, int rms, void *stream);
+
+/*
+ * The LoRA table gradients (autograd of lora.py:70-80 and of the per-block side products of
+ * lora_ffn.py:87-111): out = wide^T . narrow for a tall activation (or activation gradient)
+ * wide [rows, width] and the rank-sized side narrow [*, n], n = 4, 16 or 48,
+ *   out[g][w][j] = sum over the rows r of group g of wide[r, w] * narrow[gather ? gather[r] : r, j]
+ * plain fp32 FMAs (exact products), fixed summation order (chunks of 64 rows, then the chunks in
+ * order: reproducible).  offsets == NULL: one group of all rows (n_groups must be 1); else
+ * offsets [n_groups + 1] int32 on the device, rows offsets[g] .. offsets[g + 1] - 1 form group g
+ * (rows sorted by block: the routed FFN's row space).  transposed != 0 writes out[g][j][w].
+ * out: n_groups * width * n floats, written whole.  workspace: spt_tall_tn_workspace_bytes(rows,
+ * n_groups, width, n) bytes of device scratch.  width, ldw even; wide 8-byte aligned; ldn a
+ * multiple of 4 and narrow 16-byte aligned.
+ */
+long long spt_tall_tn_workspace_bytes(long long rows, int n_groups, int width, int n);
+int spt_tall_tn(const float *wide, long long ldw, const float *narrow, long long ldn,
+                const int32_t *gather, const int32_t *offsets, int n_groups, long long rows,
+                int width, int n, float *out, int transposed, void *workspace, void *stream);
 
 /*
  * Bucketing for the routed FFN: the k largest of the n_blocks router probabilities of every

@@ -153,8 +153,8 @@ using namespace spt;
 static bool ls_aligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int spt_lora_down(const float *x, long long ldx, long long rows, int k, const float *l,
-                             int n, float *u, int u_block_major, void *image, float *norms,
-                             void *stream) {
+                             int n, float *u, long long ldu, int u_block_major, void *image,
+                             float *norms, void *stream) {
     if (!x || !l || !u) return SPT_EINVAL;
     if (rows <= 0 || k <= 0 || n <= 0 || ldx < k) return SPT_EINVAL;
     if (k % (4 * 32 * LS_CH) != 0 || n % 16 != 0 || n > 64) return SPT_EUNSUP;
@@ -164,7 +164,8 @@ extern "C" int spt_lora_down(const float *x, long long ldx, long long rows, int 
     hipStream_t s = (hipStream_t)stream;
     char *img = static_cast<char *>(image);
     // u [rows, n], or (u_block_major) n / 16 contiguous matrices [rows, 16]: one per adapter
-    const long long u_ld = u_block_major ? 16 : n, u_block = u_block_major ? rows * 16 : 16;
+    if (ldu != 0 && (ldu < n || u_block_major)) return SPT_EINVAL;
+    const long long u_ld = u_block_major ? 16 : (ldu ? ldu : n), u_block = u_block_major ? rows * 16 : 16;
 #define SPT_LD(NB, IM, NO)                                                                      \
     hipLaunchKernelGGL((lora_down_kernel<NB, IM, NO>), dim3((unsigned)nblk), dim3(256), 0, s, x, \
                        ldx, rows, k, l, n, u, u_ld, u_block, img, norms)
@@ -183,6 +184,222 @@ extern "C" int spt_lora_down(const float *x, long long ldx, long long rows, int 
     }
 #undef SPT_LD_NB
 #undef SPT_LD
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
+// ---- out = wide^T . narrow (the LoRA table gradients) ----------------------------------------
+// Reference: autograd of lora.py:70-80 / lora_ffn.py:87-111 -- every table gradient is
+//   out[w, j] = sum_r wide[r, w] * narrow[r, j]     wide [R, W] an activation or its gradient
+//                                                    (W = 1024 ...), narrow [R, n] the rank-r side
+// 2 R W n flops on R W 4 bytes: HBM-bound for n <= 48 on plain fp32 FMAs (exact fp32 products, no
+// split).  A lane owns two adjacent columns of `wide` and streams rows of them (coalesced rows,
+// UNROLL loads in flight); narrow[r, :] is the same for the whole wave, so it arrives through the
+// scalar cache and enters the FMAs as an SGPR operand: no cross-lane traffic.  The problem is small
+// (8 M elements = 8 K per SIMD), so what matters is latency: a workgroup is 8 waves on the same
+// 128 columns, 16 rows each (two workgroups per CU = 4 waves per SIMD, each with one or two
+// batches of loads), added through LDS in wave order; the chunks' sums (TN_RC = 128 rows) go to
+// `workspace` and a second launch adds them in chunk order (deterministic throughout).
+// History: one wave per SIMD with 64-row chunks per wave: 26 us (16384 x 1024 x 16: 34) where
+// the library's batched product takes 11-13.
+//   grouped form (offsets != null): rows offsets[g] .. offsets[g + 1] - 1 contribute to out[g]
+//   (the routed FFN's per-block tables: rows are sorted by block) -- the torch composition
+//   scatters `narrow` into a [R, G n] matrix of mostly zeros first.
+//   gather != null: narrow row = gather[r] (rows of a per-token matrix picked per (token, block) row).
+namespace spt {
+
+constexpr int TN_WAVES = 8;
+constexpr int TN_RW = 16;                      // rows per wave
+constexpr int TN_RC = TN_WAVES * TN_RW;        // rows per chunk
+constexpr int TN_COLS = 128;                   // columns per workgroup (two per lane)
+
+// chunk c -> (group, first row, rows): groups' chunk ranges are consecutive
+__device__ __forceinline__ void tn_chunk(const int32_t *offsets, int G, long long R, int c, int &g,
+                                         long long &row0, int &rows) {
+    if (!offsets) { g = 0; row0 = (long long)c * TN_RC; rows = (int)min((long long)TN_RC, R - row0); return; }
+    int base = 0;
+    g = -1; row0 = 0; rows = 0;
+    for (int i = 0; i < G; i++) {
+        const int lo = offsets[i], hi = offsets[i + 1];
+        const int nc = (hi - lo + TN_RC - 1) / TN_RC;
+        if (g < 0 && c < base + nc) {
+            g = i; row0 = lo + (long long)(c - base) * TN_RC;
+            rows = (int)min((long long)TN_RC, hi - row0);
+        }
+        base += nc;
+    }
+}
+
+template <int N, int UNROLL, bool GATHER>
+__global__ __launch_bounds__(64 * TN_WAVES, 2) void tall_tn_partial_kernel(
+    const float *__restrict__ wide, long long ldw, const float *__restrict__ narrow, long long ldn,
+    const int32_t *__restrict__ gather, const int32_t *__restrict__ offsets, int G, long long R, int W,
+    float *__restrict__ partial) {
+    constexpr int JB = N < 16 ? N : 16;                      // table columns per reduction pass
+    __shared__ float2 red[TN_WAVES][JB][64];
+    int g, rows; long long row0;
+    tn_chunk(offsets, G, R, blockIdx.x, g, row0, rows);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col0 = blockIdx.y * TN_COLS;
+    const int col = min(col0 + 2 * lane, W - 2);             // (clamped lanes are never stored)
+    float acc[2][N];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int j = 0; j < N; j++) acc[c][j] = 0.0f;
+    // the chunk's rows of `narrow` -> LDS (the memory of `red`, free until the sums are formed):
+    // read from there as wave-wide broadcasts.  (As scalar loads every row was a miss of the
+    // scalar cache -- a 64-byte line used once -- in the middle of the FMA chain: 12 us for 33 MB.)
+    float *nar = reinterpret_cast<float *>(&red[0][0][0]);   // [rows][N]
+    static_assert(sizeof(red) >= (size_t)TN_RC * N * sizeof(float), "narrow chunk fits in red");
+    for (int i = threadIdx.x; i < rows * (N / 4); i += 64 * TN_WAVES) {
+        const int r = i / (N / 4), q = i - r * (N / 4);
+        const long long src = GATHER ? (long long)gather[row0 + r] : row0 + r;
+        reinterpret_cast<float4 *>(nar)[i] = *reinterpret_cast<const float4 *>(narrow + src * ldn + 4 * q);
+    }
+    __syncthreads();
+    const int wr0 = wave * TN_RW;                            // this wave's rows of the chunk
+    const int wrows = min(TN_RW, rows - wr0);                // (<= 0: nothing, g < 0: rows = 0)
+    if (wrows > 0) {
+        const long long base = row0 + wr0;
+        const float *wp = wide + base * ldw + col;
+        // the next batch of rows is requested before the current one is used: a wave has only one
+        // to four batches, and without this its loads and its FMAs (0.4 us per batch) alternate
+        float2 vn[UNROLL];
+        auto request = [&](int r0) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++)                 // rows past the end: clamped, weight 0
+                vn[u] = *reinterpret_cast<const float2 *>(wp + (long long)min(r0 + u, wrows - 1) * ldw);
+        };
+        request(0);
+        for (int r0 = 0; r0 < wrows; r0 += UNROLL) {
+            float2 v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) v[u] = vn[u];
+            if (r0 + UNROLL < wrows) request(r0 + UNROLL);
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                if (r0 + u >= wrows) v[u] = make_float2(0.0f, 0.0f);
+                const float4 *np = reinterpret_cast<const float4 *>(nar + (wr0 + min(r0 + u, wrows - 1)) * N);
+#pragma unroll
+                for (int j4 = 0; j4 < N / 4; j4++) {
+                    const float4 b = np[j4];                 // the same address in every lane
+                    acc[0][4 * j4 + 0] = fmaf(v[u].x, b.x, acc[0][4 * j4 + 0]);
+                    acc[1][4 * j4 + 0] = fmaf(v[u].y, b.x, acc[1][4 * j4 + 0]);
+                    acc[0][4 * j4 + 1] = fmaf(v[u].x, b.y, acc[0][4 * j4 + 1]);
+                    acc[1][4 * j4 + 1] = fmaf(v[u].y, b.y, acc[1][4 * j4 + 1]);
+                    acc[0][4 * j4 + 2] = fmaf(v[u].x, b.z, acc[0][4 * j4 + 2]);
+                    acc[1][4 * j4 + 2] = fmaf(v[u].y, b.z, acc[1][4 * j4 + 2]);
+                    acc[0][4 * j4 + 3] = fmaf(v[u].x, b.w, acc[0][4 * j4 + 3]);
+                    acc[1][4 * j4 + 3] = fmaf(v[u].y, b.w, acc[1][4 * j4 + 3]);
+                }
+            }
+        }
+    }
+    __syncthreads();                                         // `nar` is read: `red` may be written
+    // the eight waves' sums through LDS, JB table columns at a time; partial [chunk][N][W]
+    float *pp = partial + (size_t)blockIdx.x * N * W;
+#pragma unroll
+    for (int jb = 0; jb < N; jb += JB) {
+        if (jb) __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < JB; jj++) red[wave][jj][lane] = make_float2(acc[0][jb + jj], acc[1][jb + jj]);
+        __syncthreads();
+        for (int o = threadIdx.x; o < JB * 64; o += 64 * TN_WAVES) {
+            const int jj = o >> 6, pair = o & 63;
+            float2 t = red[0][jj][pair];
+#pragma unroll
+            for (int w = 1; w < TN_WAVES; w++) { t.x += red[w][jj][pair].x; t.y += red[w][jj][pair].y; }
+            const int c = col0 + 2 * pair;
+            if (c < W) *reinterpret_cast<float2 *>(pp + (size_t)(jb + jj) * W + c) = t;
+        }
+    }
+}
+
+// out[g][w][j] (or transposed: out[g][j][w]) = sum over the chunks of group g.  A workgroup = 64
+// elements x 4 slices of the chunk range (consecutive quarters), the slices added in order: fixed
+// summation tree.  (One thread per element: 16 K threads on 64 CUs, 8 us for 4 MB.)
+__global__ __launch_bounds__(256) void tall_tn_reduce_kernel(
+    const float *__restrict__ partial, const int32_t *__restrict__ offsets, int G, int W, int n,
+    int nchunks, float *__restrict__ out, int transposed) {
+    __shared__ float slice_sum[4][64];
+    const int g = blockIdx.y;
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;                    // element (j, w) of the group's table
+    int first = 0, count;
+    if (!offsets) {
+        count = nchunks;
+    } else {
+        for (int i = 0; i < g; i++) first += (offsets[i + 1] - offsets[i] + TN_RC - 1) / TN_RC;
+        count = (offsets[g + 1] - offsets[g] + TN_RC - 1) / TN_RC;
+    }
+    const int per = (count + 3) / 4;
+    const int c0 = min(slice * per, count), c1 = min(c0 + per, count);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e < W * n) {
+        const size_t step = (size_t)W * n;
+        const float *p = partial + (size_t)first * step + e;
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {                        // eight loads in flight
+            float t[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) t[i] = p[(size_t)(c + i) * step];
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i & 3] += t[i];
+        }
+        for (; c < c1; c++) a[0] += p[(size_t)c * step];
+    }
+    slice_sum[slice][lane] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    if (slice == 0 && e < W * n) {
+        const float v = (slice_sum[0][lane] + slice_sum[1][lane]) + (slice_sum[2][lane] + slice_sum[3][lane]);
+        const int j = e / W, w = e - j * W;
+        out[(size_t)g * W * n + (transposed ? (size_t)e : (size_t)w * n + j)] = v;
+    }
+}
+
+}  // namespace spt
+
+extern "C" long long spt_tall_tn_workspace_bytes(long long rows, int n_groups, int width, int n) {
+    if (rows <= 0 || n_groups <= 0 || width <= 0 || n <= 0) return 0;
+    const long long nchunks = (rows + TN_RC - 1) / TN_RC + n_groups;
+    return nchunks * width * n * (long long)sizeof(float);
+}
+
+extern "C" int spt_tall_tn(const float *wide, long long ldw, const float *narrow, long long ldn,
+                           const int32_t *gather, const int32_t *offsets, int n_groups,
+                           long long rows, int width, int n, float *out, int transposed,
+                           void *workspace, void *stream) {
+    if (!wide || !narrow || !out || !workspace) return SPT_EINVAL;
+    if (rows <= 0 || width <= 0 || n <= 0 || n_groups <= 0 || ldw < width || ldn < n) return SPT_EINVAL;
+    if (!offsets && n_groups != 1) return SPT_EINVAL;
+    if (n != 4 && n != 16 && n != 48) return SPT_EUNSUP;
+    if (n_groups > 64 || rows > 0x7FFFFFFFll) return SPT_EUNSUP;
+    if (width % 2 != 0 || ldw % 2 != 0 || (reinterpret_cast<uintptr_t>(wide) & 7) != 0) return SPT_ESHAPE;
+    if (ldn % 4 != 0 || !ls_aligned(narrow)) return SPT_ESHAPE;
+    // (upper bound of the chunk count: each group ends with at most one short chunk; chunks past a
+    // group's rows find no group and write zeros that the reduction never reads)
+    const int nchunks = (int)((rows + TN_RC - 1) / TN_RC) + (offsets ? n_groups : 0);
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = static_cast<float *>(workspace);
+    const dim3 grid(nchunks, (width + TN_COLS - 1) / TN_COLS);
+#define SPT_TN(N, U)                                                                              \
+    do {                                                                                          \
+        if (gather)                                                                               \
+            hipLaunchKernelGGL((tall_tn_partial_kernel<N, U, true>), grid, dim3(64 * TN_WAVES), 0, s, \
+                               wide, ldw, narrow, ldn, gather, offsets, n_groups, rows, width, partial); \
+        else                                                                                      \
+            hipLaunchKernelGGL((tall_tn_partial_kernel<N, U, false>), grid, dim3(64 * TN_WAVES), 0, s, \
+                               wide, ldw, narrow, ldn, gather, offsets, n_groups, rows, width, partial); \
+    } while (0)
+    if (n == 4) SPT_TN(4, 8);
+    else if (n == 16) SPT_TN(16, 8);
+    else SPT_TN(48, 4);
+#undef SPT_TN
+    SPT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tall_tn_reduce_kernel, dim3((width * n + 63) / 64, n_groups), dim3(256), 0, s,
+                       partial, offsets, n_groups, width, n, nchunks, out, transposed);
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }

@@ -80,7 +80,10 @@ _PROTOTYPES = {
     'spt_cross_entropy_grad': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_ptr,
                                 _c_ptr, ctypes.c_longlong, _c_ptr], _c_int),
     'spt_lora_down': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_int,
-                       _c_ptr, _c_int] + [_c_ptr] * 3, _c_int),
+                       _c_ptr, ctypes.c_longlong, _c_int] + [_c_ptr] * 3, _c_int),
+    'spt_tall_tn_workspace_bytes': ([ctypes.c_longlong, _c_int, _c_int, _c_int], ctypes.c_longlong),
+    'spt_tall_tn': ([_c_ptr, ctypes.c_longlong, _c_ptr, ctypes.c_longlong, _c_ptr, _c_ptr, _c_int,
+                     ctypes.c_longlong, _c_int, _c_int, _c_ptr, _c_int, _c_ptr, _c_ptr], _c_int),
     'spt_route_topk': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_route_topk_coeff': ([_c_ptr] * 8 + [_c_f32] + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_route_coeff_backward': ([_c_ptr] * 3 + [_c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr], _c_int),
@@ -89,7 +92,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 _lib = None
 
@@ -1034,9 +1037,12 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
     for t, name in ((gather, 'gather'), (gather2, 'gather2')):
         if t is not None:
             _check_type(t, torch.int32, name)
-    for t in (gather, bias, rowscale, a2, gather2, b2, h_in, s_in):
+    for t in (gather, bias, rowscale, gather2, b2, h_in, s_in):
         if t is not None:
             _require(t.is_cuda and t.is_contiguous(), 'grouped_gemm_fused: contiguous CUDA operands')
+    if a2 is not None:      # [rows, r]: may be a column slice of a wider matrix (lda2 = its row stride)
+        _require(a2.is_cuda and a2.dim() == 2 and a2.stride(1) == 1 and a2.stride(0) % 4 == 0
+                 and a2.data_ptr() % 16 == 0, 'a2: [rows, r] fp32, unit inner stride, 16-byte aligned rows')
     if epilogue == EPI_ACT and activation == ACT_RELU:
         # pre-activations within the split's error of zero are recomputed in fp32: the kernel
         # finds them from the row norms of both operands (include/spt_hip.h)
@@ -1140,6 +1146,44 @@ def route_topk(prob: torch.Tensor, k: int):
     return token, block, offsets, pos
 
 
+def tall_tn_supported(wide: torch.Tensor, narrow: torch.Tensor) -> bool:
+    return (wide.is_cuda and wide.dtype == torch.float32 and narrow.dtype == torch.float32
+            and wide.dim() == 2 and narrow.dim() == 2 and wide.stride(1) == 1 and narrow.stride(1) == 1
+            and narrow.size(1) in (4, 16, 48) and wide.size(1) % 2 == 0 and wide.stride(0) % 2 == 0
+            and wide.data_ptr() % 8 == 0 and wide.size(0) > 0
+            and narrow.stride(0) % 4 == 0 and narrow.data_ptr() % 16 == 0)
+
+
+def tall_tn(wide: torch.Tensor, narrow: torch.Tensor, gather: torch.Tensor = None,
+            offsets: torch.Tensor = None, transposed: bool = False) -> torch.Tensor:
+    """``spt_tall_tn``: wide^T . narrow -> [G, width, n] (``transposed``: [G, n, width]); G = 1
+    without ``offsets``, else the row groups offsets[g] .. offsets[g + 1] (device int32).
+    ``gather`` [rows] int32 picks the row of ``narrow`` for every row of ``wide``."""
+    _require(tall_tn_supported(wide, narrow), 'tall_tn: fp32 CUDA [rows, even width] x [*, 4 | 16 | 48]')
+    rows, width = wide.shape
+    n = narrow.size(1)
+    G = 1 if offsets is None else offsets.numel() - 1
+    if gather is not None:
+        _check_type(gather, torch.int32, 'gather')
+        _require(gather.is_contiguous() and gather.numel() == rows, 'gather: one int32 per row of wide')
+    else:
+        _require(narrow.size(0) == rows, 'narrow: one row per row of wide')
+    if offsets is not None:
+        _check_type(offsets, torch.int32, 'offsets')
+        _require(offsets.is_contiguous() and G >= 1, 'offsets: [G + 1] int32')
+    dev = wide.device
+    lib = load_library()
+    with _on(dev):
+        out = torch.empty([G, n, width] if transposed else [G, width, n], dtype=torch.float32, device=dev)
+        work = torch.empty([lib.spt_tall_tn_workspace_bytes(rows, G, width, n)], dtype=torch.uint8, device=dev)
+        rc = lib.spt_tall_tn(wide.data_ptr(), wide.stride(0), narrow.data_ptr(), narrow.stride(0),
+                             _ptr(gather), _ptr(offsets), G, rows, width, n, out.data_ptr(),
+                             int(transposed), work.data_ptr(), _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'tall_tn')
+    return out
+
+
 def route_topk_coeff(prob: torch.Tensor, k: int, scale: float):
     """``spt_route_topk_coeff``: `route_topk` plus, from the same launch, token / block as int64
     and coeff[p] = scale * prob[token[p], block[p]].
@@ -1218,12 +1262,13 @@ def lora_down_supported(x: torch.Tensor, table: torch.Tensor) -> bool:
 
 
 def lora_down(x: torch.Tensor, table: torch.Tensor, want_image: bool = False,
-              want_norms: bool = False, block_major: bool = False):
+              want_norms: bool = False, block_major: bool = False, out: torch.Tensor = None):
     """u = x @ table for a tall x [rows, K] and a table [K, n] of a few columns, as ONE pass over x
     (``spt_lora_down``); the same pass can also leave x's split image (:class:`SplitImage`) and its
     row 2-norms.  Returns u, or (u, image | None, norms | None) when a by-product is asked for.
     ``block_major``: u as [n / 16, rows, 16] (tables of several rank-16 adapters side by side:
-    each adapter's product contiguous)."""
+    each adapter's product contiguous).  ``out``: a [rows, n] view to write u into (unit inner
+    stride, any row stride: a column slice of a wider matrix)."""
     _require(lora_down_supported(x, table), 'lora_down: see lora_down_supported')
     table = table.contiguous()
     rows, k = x.shape
@@ -1231,7 +1276,13 @@ def lora_down(x: torch.Tensor, table: torch.Tensor, want_image: bool = False,
     dev = _same_device(x, table)
     lib = load_library()
     with _on(dev):
-        u = torch.empty([n // 16, rows, 16] if block_major else [rows, n], dtype=torch.float32, device=dev)
+        if out is not None:
+            _check_type(out, torch.float32, 'out')
+            _require(not block_major and out.is_cuda and out.shape == (rows, n) and out.stride(1) == 1
+                     and out.stride(0) >= n, 'lora_down: out [rows, n] with unit inner stride')
+            u = out
+        else:
+            u = torch.empty([n // 16, rows, 16] if block_major else [rows, n], dtype=torch.float32, device=dev)
         image = norms = None
         if want_image:
             image = SplitImage(torch.empty([lib.spt_split_bf16_bytes(rows, k)], dtype=torch.uint8,
@@ -1239,6 +1290,7 @@ def lora_down(x: torch.Tensor, table: torch.Tensor, want_image: bool = False,
         if want_norms:
             norms = torch.empty([rows], dtype=torch.float32, device=dev)
         rc = lib.spt_lora_down(x.data_ptr(), x.stride(0), rows, k, table.data_ptr(), n, u.data_ptr(),
+                               0 if block_major else u.stride(0),
                                int(bool(block_major)), image.buffer.data_ptr() if want_image else None,
                                _ptr(norms), _stream(dev))
     if rc != 0:

@@ -211,6 +211,18 @@ def _tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return tall_tn(a, b)
 
 
+def _tn_blocks(wide: torch.Tensor, per_token: torch.Tensor, bk: Buckets) -> torch.Tensor:
+    """The gradient of a per-block LoRA table [nb * bs, r]: for block g, wide[rows of g]^T .
+    per_token[token of those rows] -- rows are sorted by block, so it is a grouped product
+    (spt_tall_tn with the bucket offsets and the rows' token ids as the gather) instead of a
+    [P, nb * r] matrix of mostly zeros times wide."""
+    nb = bk.n_blocks
+    if ext.tall_tn_supported(wide, per_token):
+        return ext.tall_tn(wide, per_token, gather=bk.token, offsets=bk.offsets).view(nb * wide.size(1), -1)
+    rows = per_token.index_select(0, bk.token_long)
+    return _block_major(_tn(wide, _in_own_block(rows, bk.block, nb)), nb)
+
+
 class RoutedLoRAFFN(torch.autograd.Function):
     """y = LoRARoutedFFN(x) for frozen base weights (reference formula:
     naive_gpt/layers/tuning/lora_ffn.py:87-111), as four fused block GEMMs:
@@ -281,22 +293,20 @@ class RoutedLoRAFFN(torch.autograd.Function):
             epilogue=ext.EPI_DACT, activation=act, h_in=h, s_in=s,
             a_image=dy_img, w_image=ext.weight_image(w2) if imgs else None, raw_dots=True)
         du = _own_block(torch.matmul(ds, _block_cat(r1, nb)), bk.block, nb).contiguous()  # [P, r]
-        u_rows = u.index_select(0, bk.token_long)
         # d/dc = <dy W2_g^T, h> + <ds, x W1_g^T + b1_g>.  The kernel's dot_main = <v, h> with
         # v = c (dy W2_g^T) + dzt L2_g^T (the value before act'), dot_act = <ds, s> with
         # s = c (x W1^T + b1) + u R1^T; the LoRA parts of both are [*, r] dots:
         # <dzt L2_g^T, h> = <dzt, z> and <ds, u R1_g^T> = <du, u>
-        dz_rows = dzt.index_select(0, bk.token_long)
-        # (dot_main + dot_act - <du, u_rows> - <dz_rows, z>) / _floor(coeff), one launch
+        # (dot_main + dot_act - <du, u[token]> - <dzt[token], z>) / _floor(coeff), one launch
         grad_coeff = ext.ffn_coeff_grad(dot_main, dot_act, du, u, dzt, z, bk.token, coeff, COEFF_FLOOR)
         # LoRA tables (before the last GEMM: ds [P, bs] is released as soon as that has read it --
         # the step's peak memory is here, with h, ds, dxs and grad_x alive)
         du_tok = ext.rows_combine(du, bk.pos)                                # [T, r]: du[pos].sum(1)
         grad_l1 = _tn(x, du_tok)
-        grad_r1 = _block_major(_tn(ds, _in_own_block(u_rows, bk.block, nb)), nb)
-        grad_l2 = _block_major(_tn(h, _in_own_block(dz_rows, bk.block, nb)), nb)
+        grad_r1 = _tn_blocks(ds, u, bk)
+        grad_l2 = _tn_blocks(h, dzt, bk)
         grad_r2 = _tn(dy, ext.rows_combine(z, bk.pos))
-        del dot_main, dot_act, u_rows, dz_rows, du_tok, dzt
+        del dot_main, dot_act, du_tok, dzt
         dxs = ext.grouped_gemm_fused(
             ds, w1, bk.offsets, nb, n=d, k=bs, w_group_stride=bs * d, w_ldn=1, w_ldk=d,
             n_rows=rows, rowscale=coeff, a2=du, b2=l1, b2_group_stride=0)
@@ -416,7 +426,7 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
                 dpre, w, bk.offsets, nb, n=d, k=bs, w_group_stride=bs * d, w_ldn=1, w_ldk=d,
                 n_rows=rows, rowscale=coeff, a2=du, b2=l_table, b2_group_stride=0)
             grad_l = _tn(x, ext.rows_combine(du, bk.pos))
-            grad_r = _block_major(_tn(dpre, _in_own_block(u_rows, bk.block, nb)), nb)
+            grad_r = _tn_blocks(dpre, u, bk)
             return dxs, dc, grad_l, grad_r
 
         dxs_g, dc_g, grad_lg, grad_rg = down(dg, g, wg, ug, lg, rg)
@@ -428,7 +438,7 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
         grad_x = ext.rows_combine(dxs_g, bk.pos)
         del dxs_g
         grad_coeff = grad_coeff + dc_g + dc_s
-        grad_ld = _block_major(_tn(h, _in_own_block(dz_rows, bk.block, nb)), nb)
+        grad_ld = _tn_blocks(h, dzt, bk)
         grad_rd = _tn(dy, ext.rows_combine(z, bk.pos))
         return (grad_x, grad_coeff, grad_lg, grad_rg, grad_ls, grad_rs, grad_ld, grad_rd,
                 None, None, None, None, None, None, None)

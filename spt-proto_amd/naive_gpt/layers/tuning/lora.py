@@ -49,6 +49,15 @@ def tall_tn(a: torch.Tensor, b: torch.Tensor, chunk: int = 256) -> torch.Tensor:
     1024 x 64 x 16384 measured); split over R into a batched product plus a sum it fills
     the chip.  Falls back to one matmul for short or ragged R."""
     rows = a.size(0)
+    if a.is_cuda and rows >= 512:
+        # one call of libspt_hip (lora_side.hip: spt_tall_tn) -- the same HBM-bound pass as the
+        # library's batched product + sum, at a quarter of their host time (the step makes ~260
+        # of these products and is within 10 % of being host-bound)
+        from naive_gpt import ext
+        if a.size(1) >= b.size(1) and ext.tall_tn_supported(a, b):
+            return ext.tall_tn(a, b)[0]
+        if a.size(1) < b.size(1) and ext.tall_tn_supported(b, a):
+            return ext.tall_tn(b, a, transposed=True)[0]
     if not a.is_cuda or rows % chunk != 0 or rows < 8 * chunk:
         return torch.matmul(a.t(), b)
     parts = rows // chunk
@@ -153,6 +162,20 @@ def _down(x: torch.Tensor, x2: torch.Tensor, left: torch.Tensor, images: bool):
     return torch.matmul(x2, left)
 
 
+def _down_grad(dy2: torch.Tensor, right: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """dU = dY R [T, r] of a LoRA layer's backward: the same tall-times-narrow pass as the forward's
+    x L (spt_lora_down; a library GEMM costs the host four times as much per call), optionally
+    into a column slice `out` of a wider matrix."""
+    from naive_gpt import ext
+    if ext.lora_down_supported(dy2, right):
+        return ext.lora_down(dy2, right, out=out)
+    du = torch.matmul(dy2, right)
+    if out is None:
+        return du
+    out.copy_(du)
+    return out
+
+
 class _FrozenLoRALinear(torch.autograd.Function):
     """y = x W^T + b + (x L) R^T with W, b frozen (the reference's forward,
     lora.py:70-80, differentiated by hand): the side product is accumulated into the base
@@ -185,7 +208,7 @@ class _FrozenLoRALinear(torch.autograd.Function):
         if ctx.origin_module is not None:
             x2 = recompute.output(ctx.origin_module, x2).reshape(-1, weight.size(1))
         dy2 = dy.reshape(-1, dy.size(-1))
-        du = torch.matmul(dy2, right)                                # [T, r]
+        du = _down_grad(dy2, right)                                  # [T, r]
         grad_x = None
         if ctx.needs_input_grad[0]:
             n, k = weight.shape
@@ -245,7 +268,13 @@ class _FrozenLoRAQKV(torch.autograd.Function):
         rows = x2.size(0)
         one = _one_group(rows, x2.device)
         dy2 = [None if d is None else d.reshape(-1, n).contiguous() for d in dys]
-        dus = [None if d is None else torch.matmul(d, rights[g]) for g, d in enumerate(dy2)]
+        live = [g for g in range(3) if dy2[g] is not None]
+        r = lefts[0].size(1)
+        # the live dU_g = dY_g R_g side by side in one matrix: the operand of the joint `left` gradient
+        du_cat = torch.empty([rows, r * len(live)], dtype=x2.dtype, device=x2.device)
+        dus = [None] * 3
+        for i, g in enumerate(live):
+            dus[g] = _down_grad(dy2[g], rights[g], out=du_cat[:, i * r:(i + 1) * r])
         grad_x = None
         if ctx.needs_input_grad[0]:
             for g in range(3):
@@ -253,15 +282,13 @@ class _FrozenLoRAQKV(torch.autograd.Function):
                     continue
                 # dX (+)= dY_g W_g + dU_g L_g^T
                 grad_x = ext.grouped_gemm_fused(
-                    dy2[g], weights[g], one, 1, k, n, 0, 1, k, rows, a2=dus[g].contiguous(),
+                    dy2[g], weights[g], one, 1, k, n, 0, 1, k, rows, a2=dus[g],
                     b2=lefts[g].contiguous(), out=grad_x, accumulate=grad_x is not None)
             if grad_x is not None:
                 grad_x = grad_x.view(ctx.x_shape)
-        live = [g for g in range(3) if dy2[g] is not None]
         grad_lefts, grad_rights = [None] * 3, [None] * 3
         if live:
-            gl = tall_tn(x2, torch.cat([dus[g] for g in live], dim=1))        # [k, 16 * len(live)]
-            r = lefts[0].size(1)
+            gl = tall_tn(x2, du_cat)                                          # [k, 16 * len(live)]
             for i, g in enumerate(live):
                 grad_lefts[g] = gl[:, i * r:(i + 1) * r]
                 grad_rights[g] = tall_tn(dy2[g], u3[g])

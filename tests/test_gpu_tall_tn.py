@@ -1,0 +1,79 @@
+"""spt_tall_tn (lora_side.hip): the LoRA table gradients wide^T . narrow, plain and grouped,
+against the torch composition they replace (fp32; tolerance 1e-5 of the result's scale: both
+sides are fp32 sums of the same exact-ish products in different orders)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=2e-5):
+    scale = max(float(b.abs().max()), 1e-20)
+    assert float((a - b).abs().max()) <= tol * scale, float((a - b).abs().max()) / scale
+
+
+@pytest.mark.parametrize('rows,width,n', [(8192, 1024, 16), (8192, 1024, 48), (8192, 1024, 4),
+                                          (1000, 514, 16), (70, 64, 4), (16384, 4096, 16), (513, 2, 48)])
+def test_plain_product_and_its_transposed_form(rows, width, n):
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(rows + n)
+    wide = torch.randn([rows, width], generator=gen).cuda()
+    narrow = torch.randn([rows, n], generator=gen).cuda()
+    ref = torch.matmul(wide.double().t(), narrow.double()).float()
+    out = ext.tall_tn(wide, narrow)
+    assert out.shape == (1, width, n)
+    _close(out[0], ref)
+    _close(ext.tall_tn(wide, narrow, transposed=True)[0], ref.t())
+    # deterministic: the same bits twice
+    assert torch.equal(out, ext.tall_tn(wide, narrow))
+
+
+def test_strided_operands_and_the_layer_level_helper():
+    from naive_gpt import ext
+    from naive_gpt.layers.tuning import lora
+    gen = torch.Generator().manual_seed(5)
+    big = torch.randn([4096, 1100], generator=gen).cuda()
+    cat = torch.randn([4096, 48], generator=gen).cuda()
+    wide, narrow = big[:, 4:1028], cat[:, 16:32]                     # row strides 1100 / 48
+    _close(ext.tall_tn(wide, narrow)[0], torch.matmul(wide.double().t(), narrow.double()).float())
+    a, b = wide.contiguous(), narrow.contiguous()
+    _close(lora.tall_tn(a, b), torch.matmul(a.double().t(), b.double()).float())
+    _close(lora.tall_tn(b, a), torch.matmul(b.double().t(), a.double()).float())     # [16, 1024]
+    odd = torch.randn([4096, 24], generator=gen).cuda()               # a rank the kernel does not take
+    _close(lora.tall_tn(a, odd), torch.matmul(a.double().t(), odd.double()).float())
+
+
+@pytest.mark.parametrize('sizes', [[4100, 4000, 4200, 4084], [0, 16384, 0, 0], [1, 63, 64, 65, 129, 0, 7, 5000]])
+def test_grouped_product_with_a_gather(sizes):
+    """Rows sorted by block, narrow picked per row through `gather`: block g's table gradient is
+    wide[rows of g]^T . per_token[gather[rows of g]] -- against the scatter-into-zeros composition
+    of layers/sparse/grouped.py (_in_own_block + one product + _block_major)."""
+    from naive_gpt import ext
+    from naive_gpt.layers.sparse import grouped
+    gen = torch.Generator().manual_seed(len(sizes))
+    P, G, bs, r, T = sum(sizes), len(sizes), 256, 16, 3000
+    wide = torch.randn([P, bs], generator=gen).cuda()
+    per_token = torch.randn([T, r], generator=gen).cuda()
+    token = torch.randint(0, T, [P], generator=gen).int().cuda()
+    offsets = torch.tensor([0] + sizes).cumsum(0).int().cuda()
+    block = torch.repeat_interleave(torch.arange(G), torch.tensor(sizes)).cuda()
+    out = ext.tall_tn(wide, per_token, gather=token, offsets=offsets)
+    assert out.shape == (G, bs, r)
+    rows = per_token.index_select(0, token.long())
+    ref = grouped._block_major(
+        torch.matmul(wide.double().t(), grouped._in_own_block(rows, block, G).double()).float(), G)
+    _close(out.view(G * bs, r), ref)
+    for g, size in enumerate(sizes):
+        if size == 0:
+            assert float(out[g].abs().max()) == 0.0
+
+
+def test_bad_arguments_are_refused():
+    from naive_gpt import ext
+    wide = torch.randn([1024, 64]).cuda()
+    with pytest.raises(Exception):
+        ext.tall_tn(wide, torch.randn([1024, 24]).cuda())             # rank not compiled in
+    with pytest.raises(Exception):
+        ext.tall_tn(wide, torch.randn([1000, 16]).cuda())             # rows disagree
+    with pytest.raises(Exception):
+        ext.tall_tn(wide[:, :63], torch.randn([1024, 16]).cuda())      # odd width
