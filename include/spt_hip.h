@@ -527,7 +527,8 @@ int spt_layernorm_backward(const float *s, const float *dy, const float *gamma, 
  * plain fp32 FMAs (exact products), fixed summation order (chunks of 64 rows, then the chunks in
  * order: reproducible).  offsets == NULL: one group of all rows (n_groups must be 1); else
  * offsets [n_groups + 1] int32 on the device, rows offsets[g] .. offsets[g + 1] - 1 form group g
- * (rows sorted by block: the routed FFN's row space).  transposed != 0 writes out[g][j][w].
+ * (rows sorted by block: the routed FFN's row space).  transposed: 0 out[g][w][j], 1 out[g][j][w],
+ * 2 out[g][j / 16][w][j % 16] (n / 16 rank-16 tables side by side in narrow: each its own matrix).
  * out: n_groups * width * n floats, written whole.  workspace: spt_tall_tn_workspace_bytes(rows,
  * n_groups, width, n) bytes of device scratch.  width, ldw even; wide 8-byte aligned; ldn a
  * multiple of 4 and narrow 16-byte aligned.

@@ -355,7 +355,11 @@ __global__ __launch_bounds__(256) void tall_tn_reduce_kernel(
     if (slice == 0 && e < W * n) {
         const float v = (slice_sum[0][lane] + slice_sum[1][lane]) + (slice_sum[2][lane] + slice_sum[3][lane]);
         const int j = e / W, w = e - j * W;
-        out[(size_t)g * W * n + (transposed ? (size_t)e : (size_t)w * n + j)] = v;
+        // layout 0: [w][j]; 1: [j][w]; 2: [j / 16][w][16] (rank-16 tables side by side: each its own matrix)
+        const size_t at = transposed == 1 ? (size_t)e
+                        : transposed == 2 ? ((size_t)(j >> 4) * W + w) * 16 + (j & 15)
+                                          : (size_t)w * n + j;
+        out[(size_t)g * W * n + at] = v;
     }
 }
 
@@ -375,6 +379,7 @@ extern "C" int spt_tall_tn(const float *wide, long long ldw, const float *narrow
     if (rows <= 0 || width <= 0 || n <= 0 || n_groups <= 0 || ldw < width || ldn < n) return SPT_EINVAL;
     if (!offsets && n_groups != 1) return SPT_EINVAL;
     if (n != 4 && n != 16 && n != 48) return SPT_EUNSUP;
+    if (transposed < 0 || transposed > 2 || (transposed == 2 && n % 16 != 0)) return SPT_EINVAL;
     if (n_groups > 64 || rows > 0x7FFFFFFFll) return SPT_EUNSUP;
     if (width % 2 != 0 || ldw % 2 != 0 || (reinterpret_cast<uintptr_t>(wide) & 7) != 0) return SPT_ESHAPE;
     if (ldn % 4 != 0 || !ls_aligned(narrow)) return SPT_ESHAPE;

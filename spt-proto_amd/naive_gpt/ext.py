@@ -1155,10 +1155,12 @@ def tall_tn_supported(wide: torch.Tensor, narrow: torch.Tensor) -> bool:
 
 
 def tall_tn(wide: torch.Tensor, narrow: torch.Tensor, gather: torch.Tensor = None,
-            offsets: torch.Tensor = None, transposed: bool = False) -> torch.Tensor:
-    """``spt_tall_tn``: wide^T . narrow -> [G, width, n] (``transposed``: [G, n, width]); G = 1
+            offsets: torch.Tensor = None, transposed: bool = False, split16: bool = False) -> torch.Tensor:
+    """``spt_tall_tn``: wide^T . narrow -> [G, width, n] (``transposed``: [G, n, width];
+    ``split16``: [G, n / 16, width, 16], one contiguous matrix per rank-16 table); G = 1
     without ``offsets``, else the row groups offsets[g] .. offsets[g + 1] (device int32).
     ``gather`` [rows] int32 picks the row of ``narrow`` for every row of ``wide``."""
+    _require(not (transposed and split16), 'tall_tn: transposed or split16')
     _require(tall_tn_supported(wide, narrow), 'tall_tn: fp32 CUDA [rows, even width] x [*, 4 | 16 | 48]')
     rows, width = wide.shape
     n = narrow.size(1)
@@ -1174,11 +1176,12 @@ def tall_tn(wide: torch.Tensor, narrow: torch.Tensor, gather: torch.Tensor = Non
     dev = wide.device
     lib = load_library()
     with _on(dev):
-        out = torch.empty([G, n, width] if transposed else [G, width, n], dtype=torch.float32, device=dev)
+        shape = [G, n, width] if transposed else [G, n // 16, width, 16] if split16 else [G, width, n]
+        out = torch.empty(shape, dtype=torch.float32, device=dev)
         work = torch.empty([lib.spt_tall_tn_workspace_bytes(rows, G, width, n)], dtype=torch.uint8, device=dev)
         rc = lib.spt_tall_tn(wide.data_ptr(), wide.stride(0), narrow.data_ptr(), narrow.stride(0),
                              _ptr(gather), _ptr(offsets), G, rows, width, n, out.data_ptr(),
-                             int(transposed), work.data_ptr(), _stream(dev))
+                             2 if split16 else int(transposed), work.data_ptr(), _stream(dev))
     if rc != 0:
         _raise(lib, rc, 'tall_tn')
     return out

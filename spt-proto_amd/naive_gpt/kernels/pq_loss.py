@@ -18,11 +18,14 @@ class PQLoss(torch.autograd.Function):
         if want_codes:
             loss, codes = ext.pq_loss_forward(z, table, want_codes=True)
             ctx.mark_non_differentiable(codes)
+            ctx.set_materialize_grads(False)     # no zero tensor (4 MB) for the codes' "gradient"
             return loss, codes
         return ext.pq_loss_forward(z, table)
 
     @staticmethod
     def backward(ctx, grad_loss: torch.Tensor, *unused):
+        if grad_loss is None:
+            return None, None, None
         z, table = ctx.saved_tensors
         # z usually has a second consumer, the attention core, whose gradient for it may exist
         # already (`pending_gradient`): the loss's gradient is then added INTO that tensor by the

@@ -42,10 +42,14 @@ class _RouteTopK(torch.autograd.Function):
         ctx.save_for_backward(pos, block)
         ctx.scale, ctx.n_blocks = scale, prob.size(1)
         ctx.mark_non_differentiable(token, block, offsets, pos, token_long, block_long)
+        # (or autograd hands the backward a zero tensor for each of the six index outputs: six fills)
+        ctx.set_materialize_grads(False)
         return token, block, offsets, pos, token_long, block_long, coeff
 
     @staticmethod
     def backward(ctx, *grads):
+        if grads[6] is None:
+            return None, None, None
         pos, block = ctx.saved_tensors
         return ext.route_coeff_backward(grads[6].contiguous(), pos, block, ctx.scale,
                                         ctx.n_blocks), None, None

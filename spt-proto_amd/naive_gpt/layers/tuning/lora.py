@@ -288,9 +288,12 @@ class _FrozenLoRAQKV(torch.autograd.Function):
                 grad_x = grad_x.view(ctx.x_shape)
         grad_lefts, grad_rights = [None] * 3, [None] * 3
         if live:
-            gl = tall_tn(x2, du_cat)                                          # [k, 16 * len(live)]
+            if r == 16 and ext.tall_tn_supported(x2, du_cat) and x2.size(0) >= 512:
+                gl = ext.tall_tn(x2, du_cat, split16=True)[0]                  # [len(live), k, 16]
+            else:
+                gl = tall_tn(x2, du_cat).view(x2.size(1), len(live), r).permute(1, 0, 2)
             for i, g in enumerate(live):
-                grad_lefts[g] = gl[:, i * r:(i + 1) * r]
+                grad_lefts[g] = gl[i]
                 grad_rights[g] = tall_tn(dy2[g], u3[g])
         return (grad_x, None, None, None, None, None, None, *grad_lefts, *grad_rights)
 

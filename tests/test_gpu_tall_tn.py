@@ -24,6 +24,10 @@ def test_plain_product_and_its_transposed_form(rows, width, n):
     assert out.shape == (1, width, n)
     _close(out[0], ref)
     _close(ext.tall_tn(wide, narrow, transposed=True)[0], ref.t())
+    if n % 16 == 0:      # one contiguous [width, 16] matrix per rank-16 table
+        split = ext.tall_tn(wide, narrow, split16=True)
+        assert split.shape == (1, n // 16, width, 16)
+        assert torch.equal(split[0].permute(1, 0, 2).reshape(width, n), out[0])
     # deterministic: the same bits twice
     assert torch.equal(out, ext.tall_tn(wide, narrow))
 
