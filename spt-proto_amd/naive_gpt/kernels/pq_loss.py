@@ -49,13 +49,15 @@ class PQLoss(torch.autograd.Function):
 _PENDING = {}
 
 
-def pending_gradient(z: torch.Tensor, grad: torch.Tensor) -> None:
-    if grad.dtype == torch.float32 and grad.is_contiguous() and grad.shape == z.shape:
-        _PENDING[(z.data_ptr(), tuple(z.shape))] = grad
+def pending_gradient(z: torch.Tensor, grad: torch.Tensor, tag=None) -> None:
+    """`grad` is the gradient some backward has just produced for a consumer of `z` (`tag`: which
+    tensor derived from z, when it is not z itself); a later backward may add its own into it."""
+    if grad.dtype == torch.float32 and grad.is_contiguous() and (tag is not None or grad.shape == z.shape):
+        _PENDING[(z.data_ptr(), tuple(z.shape), tag)] = grad
 
 
-def take_pending_gradient(z: torch.Tensor):
-    return _PENDING.pop((z.data_ptr(), tuple(z.shape)), None)
+def take_pending_gradient(z: torch.Tensor, tag=None):
+    return _PENDING.pop((z.data_ptr(), tuple(z.shape), tag), None)
 
 
 def drop_pending_gradients() -> None:

@@ -227,6 +227,14 @@ def _tn_blocks(wide: torch.Tensor, per_token: torch.Tensor, bk: Buckets) -> torc
     return _block_major(_tn(wide, _in_own_block(rows, bk.block, nb)), nb)
 
 
+def _offer(ctx, grad_x: torch.Tensor) -> None:
+    """The FFN's input gradient, offered to the router's backward (the same norm output's other
+    consumer, which runs next: tuning/recompute.py RecomputedLinear) to add its own into."""
+    if ctx.origin_module is not None:
+        from naive_gpt.kernels.pq_loss import pending_gradient
+        pending_gradient(ctx.saved_tensors[0], grad_x, tag='norm_output')
+
+
 class RoutedLoRAFFN(torch.autograd.Function):
     """y = LoRARoutedFFN(x) for frozen base weights (reference formula:
     naive_gpt/layers/tuning/lora_ffn.py:87-111), as four fused block GEMMs:
@@ -317,6 +325,7 @@ class RoutedLoRAFFN(torch.autograd.Function):
         del ds, du
         grad_x = ext.rows_combine(dxs, bk.pos)
         del dxs
+        _offer(ctx, grad_x)
         return (grad_x, grad_coeff, grad_l1, grad_r1, grad_l2, grad_r2,
                 None, None, None, None, None, None, None, None)
 
@@ -441,6 +450,7 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
         del dxs_s
         grad_x = ext.rows_combine(dxs_g, bk.pos)
         del dxs_g
+        _offer(ctx, grad_x)
         grad_coeff = grad_coeff + dc_g + dc_s
         grad_ld = _tn_blocks(h, dzt, bk)
         grad_rd = _tn(dy, ext.rows_combine(z, bk.pos))

@@ -17,6 +17,8 @@ No reference counterpart: the reference keeps every activation (plain autograd).
 import torch
 from torch import nn
 
+from naive_gpt.kernels.pq_loss import _PENDING
+
 _RECOMPUTABLE = (nn.LayerNorm,)
 
 
@@ -41,6 +43,8 @@ def tag(output: torch.Tensor, module: nn.Module, input: torch.Tensor) -> torch.T
     # allocator hands the same addresses out step after step -- so it is dropped here; inside
     # one backward the saved input is alive and its address cannot be reused.
     release()
+    if _PENDING:
+        _PENDING.clear()            # (kernels/pq_loss.py) gradients offered by an earlier backward
     if torch.is_grad_enabled() and input.requires_grad and isinstance(module, _RECOMPUTABLE) \
             and input.is_cuda and not input.is_inference():
         output._spt_origin = Origin(module, input)
@@ -87,7 +91,17 @@ class RecomputedLinear(torch.autograd.Function):
         origin_input, weight = ctx.saved_tensors
         x = output(ctx.module, origin_input).reshape(-1, weight.size(1))
         dy2 = dy.reshape(-1, weight.size(0))
-        grad_x = torch.matmul(dy2, weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        grad_x = None
+        if ctx.needs_input_grad[0]:
+            # the norm output's other consumer (the routed FFN, whose backward ran first) may have
+            # left its gradient for the same tensor: add into it (GEMM with beta = 1) instead of
+            # handing autograd a second [tokens, d] tensor to add (kernels/pq_loss.py: _PENDING)
+            from naive_gpt.kernels.pq_loss import take_pending_gradient
+            other = take_pending_gradient(origin_input, tag='norm_output')
+            if other is not None and other.numel() == dy2.size(0) * weight.size(1):
+                other.view(-1, weight.size(1)).addmm_(dy2, weight)
+            else:
+                grad_x = torch.matmul(dy2, weight).view(ctx.x_shape)
         grad_w = None
         if ctx.needs_input_grad[2]:
             # [out, tokens] x [tokens, d]: as one GEMM a handful of workgroups (39 us for 4 x 8192 x

@@ -59,7 +59,16 @@ class SparseTuner:
         # default "foreach" form is ~66 launches and 1.06 ms of the 63 ms BERT-large step; with
         # `capturable=True` it falls to per-parameter divisions, 1,040 launches and 3.8 ms)
         self._fused = bool(self.params) and all(p.is_cuda for p in self.params)
-        self.optimizer = optim.AdamW(self.params, lr=lr, weight_decay=weight_decay,
+        # The trainable parameters (464 small tensors in the 24-layer model) live in ONE flat
+        # buffer -- each `p.data` a view of it -- and so do their gradients once a backward has
+        # produced them: the exchange (all-reduce), the clip and AdamW are then a handful of
+        # launches on one tensor instead of ~40 multi-tensor launches at N = 1 and 928 copies
+        # around the all-reduce at N > 1.  Same arithmetic element by element.
+        self._flat = self._flat_grad = None
+        if self.params and len({(p.device, p.dtype) for p in self.params}) == 1 \
+                and self.params[0].dtype == torch.float32:
+            self._flatten()
+        self.optimizer = optim.AdamW(self._optimised(), lr=lr, weight_decay=weight_decay,
                                      **({'fused': True} if self._fused else {}))
         self.scheduler = optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=gamma)
         self.loss_fn = nn.CrossEntropyLoss()
@@ -154,14 +163,64 @@ class SparseTuner:
             self.apply_gradients()
         return loss.detach()
 
+    def _flatten(self) -> None:
+        sizes = [p.numel() for p in self.params]
+        first = self.params[0]
+        with torch.no_grad():
+            flat = torch.empty([sum(sizes)], dtype=first.dtype, device=first.device)
+            offset = 0
+            for p, n in zip(self.params, sizes):
+                view = flat[offset:offset + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                offset += n
+        self._flat = nn.Parameter(flat)
+        self._flat_grad = torch.zeros_like(flat)
+        self._sizes = sizes
+        self._missing = {}                      # zeros standing in for a parameter without gradient
+
+    def _optimised(self):
+        return [self._flat] if self._flat is not None else self.params
+
+    def _gather_gradients(self) -> None:
+        """p.grad of every trainable parameter, side by side in `_flat_grad` (torch.cat: one
+        launch per 128 tensors); a parameter without gradient contributes zeros."""
+        pieces = []
+        for p, n in zip(self.params, self._sizes):
+            g = p.grad
+            if g is None:
+                g = self._missing.get(n)
+                if g is None:
+                    g = self._missing[n] = torch.zeros([n], dtype=self._flat.dtype, device=self._flat.device)
+            pieces.append(g.reshape(-1))
+        torch.cat(pieces, out=self._flat_grad)
+        self._flat.grad = self._flat_grad
+
     def apply_gradients(self) -> None:
-        if self.world_size > 1:
-            distributed.allreduce_gradients(self.params, group=self.group,
-                                            world_size=self.world_size)
-        if self.clip_norm is not None:
-            self.last_grad_norm = nn.utils.clip_grad_norm_(self.params, self.clip_norm)
+        if self._flat is None:
+            if self.world_size > 1:
+                distributed.allreduce_gradients(self.params, group=self.group,
+                                                world_size=self.world_size)
+            if self.clip_norm is not None:
+                self.last_grad_norm = nn.utils.clip_grad_norm_(self.params, self.clip_norm)
+            self.optimizer.step()
+            self.optimizer.zero_grad(set_to_none=True)
+            return
+        with torch.no_grad():
+            self._gather_gradients()
+            grad = self._flat_grad
+            if self.world_size > 1:             # the whole exchange: one all-reduce, in place
+                torch.distributed.all_reduce(grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
+                grad.div_(self.world_size)
+            if self.clip_norm is not None:
+                # nn.utils.clip_grad_norm_ (script/4-sparse-tuning-0.py: gradient_clip_val): the
+                # 2-norm over all gradients, coefficient max_norm / (norm + 1e-6) capped at 1
+                norm = torch.linalg.vector_norm(grad)
+                grad.mul_(torch.clamp(self.clip_norm / (norm + 1e-6), max=1.0))
+                self.last_grad_norm = norm
         self.optimizer.step()
-        self.optimizer.zero_grad(set_to_none=True)
+        for p in self.params:
+            p.grad = None
 
     def end_epoch(self) -> None:
         self.scheduler.step()
@@ -177,7 +236,7 @@ class SparseTuner:
         lr = self.lr
         self._graph_lr = torch.tensor(lr, dtype=torch.float32, device=device)
         group = self.optimizer.param_groups[0]
-        self.optimizer = optim.AdamW(self.params, lr=self._graph_lr, betas=group['betas'],
+        self.optimizer = optim.AdamW(self._optimised(), lr=self._graph_lr, betas=group['betas'],
                                      eps=group['eps'], weight_decay=group['weight_decay'],
                                      capturable=True, **({'fused': True} if self._fused else {}))
         gamma = self.scheduler.gamma

@@ -677,6 +677,12 @@ def test_norm_outputs_are_recomputed_not_kept(monkeypatch):
     block = build()
     run(block)                             # first use: per-weight caches (row norms) fill up
     block.zero_grad()
+    # (the router's gradient joining the FFN's in place -- another rounding than autograd's sum,
+    # next test -- is switched off for the bit-for-bit comparison)
+    import importlib
+    pq = importlib.import_module('naive_gpt.kernels.pq_loss')
+    offer = pq.pending_gradient
+    monkeypatch.setattr(pq, 'pending_gradient', lambda z, g, tag=None: None if tag else offer(z, g))
     y1, gx1, g1, held1 = run(block)
     monkeypatch.setattr(recompute, 'tag', lambda output, module, input: output)
     block.zero_grad()
@@ -692,6 +698,50 @@ def test_norm_outputs_are_recomputed_not_kept(monkeypatch):
             assert torch.equal(g1[n], g0[n]), n
     act = N * S * d * 4
     assert held0 - held1 >= 1.9 * act, (held0, held1, act)     # both norm outputs are gone
+
+
+def test_router_gradient_joins_the_ffn_gradient_in_place(monkeypatch):
+    """Behind a recomputed norm the routed FFN offers its input gradient and the router's backward
+    adds its own into it (one GEMM with beta = 1) instead of autograd summing two [tokens, d]
+    tensors: the same numbers to fp32 rounding, and the offer is taken."""
+    from naive_gpt import layers, utils
+    import contextlib
+    import importlib
+    import io
+    pq = importlib.import_module('naive_gpt.kernels.pq_loss')
+    d, heads, d_ff, N, S = 1024, 16, 4096, 2, 512
+    torch.manual_seed(0)
+    block = layers.TransformerBlock(
+        d_model=d, n_heads=heads, layernorm_fn=nn.LayerNorm(d),
+        attention_fn=layers.VanillaAttention(d_head=d // heads, p_dropout=0.0),
+        feedforward_fn=layers.Feedforward(d_model=d, d_feedforward=d_ff, activation=nn.ReLU(), p_dropout=0.0),
+        attention_bias=True, pre_norm=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        for stage in ('lora', 'ffn', 'mha_v1', 'mha_v2'):
+            block = utils.ModuleUpgrader(utils.SparseLoRAHandler(d_lora=16, stage=stage)).visit(block)
+    for name, p in block.named_parameters():
+        if name.endswith('lora.right.weight'):
+            p.data.normal_(0, 0.02)
+    block = block.cuda()
+    x0 = torch.randn([N, S, d], device='cuda')
+
+    def run():
+        x = x0.clone().requires_grad_(True)
+        block.zero_grad()
+        block(x).square().sum().backward()
+        return [x.grad.clone()] + [p.grad.clone() for p in block.parameters() if p.grad is not None]
+
+    taken = []
+    take = pq.take_pending_gradient
+    monkeypatch.setattr(pq, 'take_pending_gradient',
+                        lambda z, tag=None: (lambda r: (taken.append(tag) if r is not None else None, r)[1])(take(z, tag)))
+    joined = run()
+    assert taken == ['norm_output'] and not pq._PENDING
+    monkeypatch.setattr(pq, 'pending_gradient', lambda z, g, tag=None: None)
+    plain = run()
+    assert len(joined) == len(plain)
+    for a, b in zip(joined, plain):
+        assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * b.abs().max().item())
 
 
 def test_frozen_lora_linear_with_a_ragged_output_width(monkeypatch):
