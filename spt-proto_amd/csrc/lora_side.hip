@@ -15,8 +15,8 @@
 //
 // Measured alone (rocprofv3, 16384 x 1024): u 13.8 us (the library GEMM: 13.8), u + image + norms
 // 22.8 us against 20.1 (split) + 13.8 + a norm pass.  The transposed table-gradient products
-// (x^T du) were written the same way and were NOT faster than the library's split-K form
-// (13.5 + reduction against 12.0 + 5.2 us): they stay torch matmuls (layers/tuning/lora.py: tall_tn).
+// (x^T du) are spt_tall_tn further down: plain fp32 FMAs, as fast as the library's split-K form
+// (11.8 + 3.9 us against 11.5 + 5.1) at a quarter of its host time.
 //
 // Arithmetic as everywhere else in this library: fp32 operands split in two bf16 parts, three
 // MFMAs per product (v_mfma_f32_16x16x32_bf16: its 16-wide output is the adapter's rank), fp32

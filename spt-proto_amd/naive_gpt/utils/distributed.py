@@ -54,20 +54,25 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None,
         return 0
     device = params[0].device
     sizes = [p.numel() for p in params]
-    flat = torch.zeros([sum(sizes)], dtype=torch.float32, device=device)
-    offset = 0
+    # gather with torch.cat (one launch per 128 tensors, not one copy per parameter), exchange,
+    # scatter back with one multi-tensor copy
+    zeros = {}
+    pieces = []
     for p, n in zip(params, sizes):
         if p.grad is not None:
-            flat[offset:offset + n].copy_(p.grad.reshape(-1))
-        offset += n
+            pieces.append(p.grad.reshape(-1).to(torch.float32))
+        else:
+            if n not in zeros:
+                zeros[n] = torch.zeros([n], dtype=torch.float32, device=device)
+            pieces.append(zeros[n])
+    flat = torch.cat(pieces)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.div_(world_size)
-    offset = 0
-    for p, n in zip(params, sizes):
-        g = flat[offset:offset + n].view_as(p)
+    views = [v.view_as(p) for v, p in zip(flat.split(sizes), params)]
+    have = [(p.grad, v) for p, v in zip(params, views) if p.grad is not None]
+    if have:
+        torch._foreach_copy_([g for g, _ in have], [v for _, v in have])
+    for p, v in zip(params, views):
         if p.grad is None:
-            p.grad = g.clone()
-        else:
-            p.grad.copy_(g)
-        offset += n
+            p.grad = v.clone()
     return int(flat.numel())
