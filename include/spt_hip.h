@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 29
+#define SPT_ABI_VERSION 30
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -484,6 +484,15 @@ int spt_split_bf16(const float *src, void *image, long long rows, int cols, long
  */
 int spt_lora_down(const float *x, long long ldx, long long rows, int k, const float *l, int n,
                   float *u, long long ldu, int u_block_major, void *image, float *norms, void *stream);
+/*
+ * The per-block tables of the routed FFN (lora_ffn.py:87-111: `h_i @ l2[i]`, and `ds_i @ r1[i]` in
+ * its backward): rows offsets[g] .. offsets[g + 1] - 1 (device int32 [n_groups + 1], rows sorted by
+ * block, offsets[n_groups] == rows) use the table l + g * l_group_stride.  u [rows, n] with row
+ * stride ldu (0 = n); `image` / `norms` as above.  n_groups <= 64.
+ */
+int spt_lora_down_grouped(const float *x, long long ldx, long long rows, int k, const float *l,
+                          long long l_group_stride, int n, const int32_t *offsets, int n_groups,
+                          float *u, long long ldu, void *image, float *norms, void *stream);
 
 /*
  * Softmax cross-entropy of the language-model head (script/4-sparse-tuning-0.py:45-59:

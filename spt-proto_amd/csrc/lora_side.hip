@@ -64,17 +64,37 @@ __device__ __forceinline__ ls_f32x4 ls_mma3(const LsFrag &a, const LsFrag &b, ls
 // the first is used; with eight such waves per CU that is 128 KiB in flight per CU.  The table's
 // fragments (lane (c, g): l[k + 8g + i][c]) come from L2 one k-step ahead.
 constexpr int LS_CH = 8;            // k-steps (of 32) per chunk of loads
+// Grouped form (offsets != null): rows offsets[q] .. offsets[q + 1] - 1 use the table l + q *
+// l_gstride (the routed FFN's per-block tables; rows are sorted by block).  A workgroup's 16 rows
+// then lie inside ONE group -- the MFMA's B operand is common to the tile -- so the tiles are
+// counted per group (at most one short tile each: rows / 16 + n_groups workgroups, the surplus
+// ones find no group and leave).
 template <int NB, bool IMAGE, bool NORMS>
 __global__ __launch_bounds__(256) void lora_down_kernel(
     const float *__restrict__ x, long long ldx, long long rows, int K, const float *__restrict__ l,
     int n, float *__restrict__ u, long long u_ld, long long u_block, char *__restrict__ image,
-    float *__restrict__ norms) {
+    float *__restrict__ norms, const int32_t *__restrict__ offsets, int n_groups, long long l_gstride) {
     __shared__ float red[4][NB][256];
     __shared__ float nred[4][16];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const long long row0 = (long long)blockIdx.x * 16;
+    long long row0 = (long long)blockIdx.x * 16;
+    if (offsets) {                                           // tile -> (group, first row, end)
+        int base = 0, grp = -1;
+        long long first = 0, end = 0;
+        for (int q = 0; q < n_groups; q++) {
+            const int lo = offsets[q], hi = offsets[q + 1];
+            const int nt = (hi - lo + 15) >> 4;
+            if (grp < 0 && (int)blockIdx.x < base + nt) {
+                grp = q; first = lo + 16ll * ((int)blockIdx.x - base); end = hi;
+            }
+            base += nt;
+        }
+        if (grp < 0) return;
+        row0 = first; rows = end;                            // (rows: one past the tile's last usable row)
+        l += grp * l_gstride;
+    }
     const long long row = min(row0 + r, rows - 1);          // (clamped rows are never stored)
     const int KQ = K >> 2, kbeg = w * KQ;
     const float *xp = x + row * ldx + kbeg + 8 * g;
@@ -152,14 +172,16 @@ using namespace spt;
 
 static bool ls_aligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-extern "C" int spt_lora_down(const float *x, long long ldx, long long rows, int k, const float *l,
-                             int n, float *u, long long ldu, int u_block_major, void *image,
-                             float *norms, void *stream) {
+static int lora_down_any(const float *x, long long ldx, long long rows, int k, const float *l,
+                         int n, float *u, long long ldu, int u_block_major, void *image,
+                         float *norms, const int32_t *offsets, int n_groups, long long l_gstride,
+                         void *stream) {
     if (!x || !l || !u) return SPT_EINVAL;
     if (rows <= 0 || k <= 0 || n <= 0 || ldx < k) return SPT_EINVAL;
     if (k % (4 * 32 * LS_CH) != 0 || n % 16 != 0 || n > 64) return SPT_EUNSUP;
     if (ldx % 4 != 0 || !ls_aligned(x) || (image && !ls_aligned(image))) return SPT_ESHAPE;
-    const long long nblk = (rows + 15) / 16;
+    if (offsets && (n_groups <= 0 || n_groups > 64)) return SPT_EINVAL;
+    const long long nblk = (rows + 15) / 16 + (offsets ? n_groups : 0);
     if (nblk > 0x7FFFFFFFll) return SPT_EUNSUP;
     hipStream_t s = (hipStream_t)stream;
     char *img = static_cast<char *>(image);
@@ -168,7 +190,7 @@ extern "C" int spt_lora_down(const float *x, long long ldx, long long rows, int 
     const long long u_ld = u_block_major ? 16 : (ldu ? ldu : n), u_block = u_block_major ? rows * 16 : 16;
 #define SPT_LD(NB, IM, NO)                                                                      \
     hipLaunchKernelGGL((lora_down_kernel<NB, IM, NO>), dim3((unsigned)nblk), dim3(256), 0, s, x, \
-                       ldx, rows, k, l, n, u, u_ld, u_block, img, norms)
+                       ldx, rows, k, l, n, u, u_ld, u_block, img, norms, offsets, n_groups, l_gstride)
 #define SPT_LD_NB(NB)                                                   \
     do {                                                                \
         if (image && norms) SPT_LD(NB, true, true);                     \
@@ -186,6 +208,21 @@ extern "C" int spt_lora_down(const float *x, long long ldx, long long rows, int 
 #undef SPT_LD
     SPT_LAUNCH_CHECK();
     return SPT_OK;
+}
+
+extern "C" int spt_lora_down(const float *x, long long ldx, long long rows, int k, const float *l,
+                             int n, float *u, long long ldu, int u_block_major, void *image,
+                             float *norms, void *stream) {
+    return lora_down_any(x, ldx, rows, k, l, n, u, ldu, u_block_major, image, norms, nullptr, 1, 0, stream);
+}
+
+extern "C" int spt_lora_down_grouped(const float *x, long long ldx, long long rows, int k,
+                                     const float *l, long long l_group_stride, int n,
+                                     const int32_t *offsets, int n_groups, float *u, long long ldu,
+                                     void *image, float *norms, void *stream) {
+    if (!offsets) return SPT_EINVAL;
+    return lora_down_any(x, ldx, rows, k, l, n, u, ldu, 0, image, norms, offsets, n_groups,
+                         l_group_stride, stream);
 }
 
 // ---- out = wide^T . narrow (the LoRA table gradients) ----------------------------------------

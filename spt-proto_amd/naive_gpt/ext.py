@@ -81,6 +81,8 @@ _PROTOTYPES = {
                                 _c_ptr, ctypes.c_longlong, _c_ptr], _c_int),
     'spt_lora_down': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_int,
                        _c_ptr, ctypes.c_longlong, _c_int] + [_c_ptr] * 3, _c_int),
+    'spt_lora_down_grouped': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, ctypes.c_longlong,
+                               _c_int, _c_ptr, _c_int, _c_ptr, ctypes.c_longlong] + [_c_ptr] * 3, _c_int),
     'spt_tall_tn_workspace_bytes': ([ctypes.c_longlong, _c_int, _c_int, _c_int], ctypes.c_longlong),
     'spt_tall_tn': ([_c_ptr, ctypes.c_longlong, _c_ptr, ctypes.c_longlong, _c_ptr, _c_ptr, _c_int,
                      ctypes.c_longlong, _c_int, _c_int, _c_ptr, _c_int, _c_ptr, _c_ptr], _c_int),
@@ -92,7 +94,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 _lib = None
 
@@ -1299,6 +1301,39 @@ def lora_down(x: torch.Tensor, table: torch.Tensor, want_image: bool = False,
     if rc != 0:
         _raise(lib, rc, 'lora_down')
     return (u, image, norms) if (want_image or want_norms) else u
+
+
+def lora_down_grouped_supported(x: torch.Tensor, tables: torch.Tensor) -> bool:
+    """x [rows, K] as for `lora_down`; tables [G, K, n] contiguous, n in 16 .. 64, G <= 64."""
+    return (tables.dim() == 3 and tables.is_contiguous() and 0 < tables.size(0) <= 64
+            and lora_down_supported(x, tables[0]))
+
+
+def lora_down_grouped(x: torch.Tensor, tables: torch.Tensor, offsets: torch.Tensor,
+                      want_image: bool = False):
+    """``spt_lora_down_grouped``: u[p] = x[p] @ tables[g(p)] for rows sorted by group (offsets
+    [G + 1] int32 on the device, offsets[G] == rows).  Returns u [rows, n], or (u, image) with
+    ``want_image``."""
+    _require(lora_down_grouped_supported(x, tables), 'lora_down_grouped: see lora_down_grouped_supported')
+    _check_type(offsets, torch.int32, 'offsets')
+    G, k, n = tables.shape
+    _require(offsets.is_contiguous() and offsets.numel() == G + 1, 'offsets: [G + 1] int32')
+    rows = x.size(0)
+    dev = _same_device(x, tables, offsets)
+    lib = load_library()
+    with _on(dev):
+        u = torch.empty([rows, n], dtype=torch.float32, device=dev)
+        image = None
+        if want_image:
+            image = SplitImage(torch.empty([lib.spt_split_bf16_bytes(rows, k)], dtype=torch.uint8,
+                                           device=dev), rows, k)
+        rc = lib.spt_lora_down_grouped(x.data_ptr(), x.stride(0), rows, k, tables.data_ptr(), k * n, n,
+                                       offsets.data_ptr(), G, u.data_ptr(), 0,
+                                       image.buffer.data_ptr() if want_image else None, None,
+                                       _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'lora_down_grouped')
+    return (u, image) if want_image else u
 
 
 def cross_entropy_grad_(logits: torch.Tensor, n_classes: int, target: torch.Tensor,

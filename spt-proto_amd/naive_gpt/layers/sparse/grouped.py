@@ -210,6 +210,20 @@ def _down(a: torch.Tensor, table: torch.Tensor, want_image: bool, want_norms: bo
             ext.row_norms(a) if want_norms else None)
 
 
+def _down_blocks(a: torch.Tensor, table: torch.Tensor, bk: Buckets, want_image: bool):
+    """(a[p] @ table_g(p) [P, r], split image of a | None) for a per-block table [nb * bs, r] and
+    rows sorted by block: one grouped pass (ext.lora_down_grouped) instead of the product with all
+    blocks' tables side by side, a gather of the row's own block and a copy."""
+    nb = bk.n_blocks
+    tables = table.view(nb, table.size(0) // nb, table.size(1))
+    if ext.lora_down_grouped_supported(a, tables):
+        if want_image:
+            return ext.lora_down_grouped(a, tables, bk.offsets, want_image=True)
+        return ext.lora_down_grouped(a, tables, bk.offsets), None
+    wide, image, _ = _down(a, _block_cat(table, nb), want_image, False)
+    return _own_block(wide, bk.block, nb).contiguous(), image
+
+
 def _tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     from naive_gpt.layers.tuning.lora import tall_tn
     return tall_tn(a, b)
@@ -272,8 +286,7 @@ class RoutedLoRAFFN(torch.autograd.Function):
             epilogue=ext.EPI_ACT, activation=act, keep_preact=not relu,
             a_image=x_img, w_image=ext.weight_image(w1) if imgs else None,
             a_norm=x_norm, w_norm=ext.weight_row_norms(w1) if relu else None)
-        zw, h_img, _ = _down(h, _block_cat(l2, nb), imgs, False)
-        z = _own_block(zw, bk.block, nb).contiguous()                        # [P, r]
+        z, h_img = _down_blocks(h, l2, bk, imgs)                             # [P, r]
         ys = ext.grouped_gemm_fused(
             h, w2, bk.offsets, nb, n=d, k=bs, w_group_stride=bs, w_ldn=d_ff, w_ldk=1,
             n_rows=rows, rowscale=coeff, a2=z, b2=r2, b2_group_stride=0,
@@ -304,7 +317,7 @@ class RoutedLoRAFFN(torch.autograd.Function):
             a2=dzt, gather2=bk.token, b2=l2, b2_group_stride=bs * rank,
             epilogue=ext.EPI_DACT, activation=act, h_in=h, s_in=s,
             a_image=dy_img, w_image=ext.weight_image(w2) if imgs else None, raw_dots=True)
-        du = _own_block(torch.matmul(ds, _block_cat(r1, nb)), bk.block, nb).contiguous()  # [P, r]
+        du, _ = _down_blocks(ds, r1, bk, False)                              # [P, r]
         # d/dc = <dy W2_g^T, h> + <ds, x W1_g^T + b1_g>.  The kernel's dot_main = <v, h> with
         # v = c (dy W2_g^T) + dzt L2_g^T (the value before act'), dot_act = <ds, s> with
         # s = c (x W1^T + b1) + u R1^T; the LoRA parts of both are [*, r] dots:
@@ -432,7 +445,7 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
 
         def down(dpre, pre, w, u, l_table, r_table):
             """-> (dx rows [P, d], d coefficient [P], grad of the two LoRA tables)"""
-            du = _own_block(torch.matmul(dpre, _block_cat(r_table, nb)), bk.block, nb).contiguous()
+            du, _ = _down_blocks(dpre, r_table, bk, False)
             u_rows = u.index_select(0, bk.token_long)
             dc = ((dpre * pre).sum(dim=-1) - (du * u_rows).sum(dim=-1)) / _floor(coeff)
             dxs = ext.grouped_gemm_fused(

@@ -47,3 +47,22 @@ def test_unsupported_shapes_are_refused():
     assert not ext.lora_down_supported(torch.randn([64, 1024], device='cuda'), torch.randn([1024, 8], device='cuda'))
     with pytest.raises(RuntimeError):
         ext.lora_down(x, torch.randn([1000, 16], device='cuda'))
+
+
+@pytest.mark.parametrize('sizes', [[4100, 4000, 4200, 4084], [0, 1000, 0, 17], [16, 1, 15, 33, 0, 64]])
+def test_grouped_down_product_per_block_tables(sizes):
+    """spt_lora_down_grouped: rows sorted by block, each block its own [K, 16] table -- against the
+    composition it replaces (all tables side by side, then the row's own block picked out) and an
+    fp64 reference; the operand image is the one spt_split_bf16 writes."""
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(len(sizes))
+    P, G, K, r = sum(sizes), len(sizes), 1024, 16
+    x = torch.randn([P, K], generator=gen).cuda()
+    tables = (torch.randn([G, K, r], generator=gen) * 0.05).cuda()
+    offsets = torch.tensor([0] + sizes).cumsum(0).int().cuda()
+    block = torch.repeat_interleave(torch.arange(G), torch.tensor(sizes)).cuda()
+    u, image = ext.lora_down_grouped(x, tables, offsets, want_image=True)
+    ref = torch.einsum('pk,pkr->pr', x.double(), tables.double()[block]).float()
+    assert float((u - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert torch.equal(image.buffer, ext.split_bf16(x).buffer)
+    assert torch.equal(ext.lora_down_grouped(x, tables, offsets), u)
