@@ -65,7 +65,10 @@ class SparseTuner:
         # buffer -- each `p.data` a view of it -- and so do their gradients once a backward has
         # produced them: the exchange (all-reduce), the clip and AdamW are then a handful of
         # launches on one tensor instead of ~40 multi-tensor launches at N = 1 and 928 copies
-        # around the all-reduce at N > 1.  Same arithmetic element by element.  (Up to
+        # around the all-reduce at N > 1.  Same arithmetic element by element as long as every
+        # parameter receives a gradient in every step (the recipe arms every trigger every step);
+        # the first step in which one does not, the tuner goes back to per-parameter entries for
+        # good (`_unflatten`: torch's AdamW skips such a parameter).  (Up to
         # FLAT_LIMIT elements: the gathered gradient is a second copy of every gradient while the
         # update runs -- nothing for adapter tables, 1.5 GB for a dense 365 M-parameter fine-tune,
         # which keeps the per-tensor path.)
@@ -183,26 +186,44 @@ class SparseTuner:
         self._flat = nn.Parameter(flat)
         self._flat_grad = torch.zeros_like(flat)
         self._sizes = sizes
-        self._missing = {}                      # zeros standing in for a parameter without gradient
 
     def _optimised(self):
         return [self._flat] if self._flat is not None else self.params
 
     def _gather_gradients(self) -> None:
         """p.grad of every trainable parameter, side by side in `_flat_grad` (torch.cat: one
-        launch per 128 tensors); a parameter without gradient contributes zeros."""
-        pieces = []
-        for p, n in zip(self.params, self._sizes):
-            g = p.grad
-            if g is None:
-                g = self._missing.get(n)
-                if g is None:
-                    g = self._missing[n] = torch.zeros([n], dtype=self._flat.dtype, device=self._flat.device)
-            pieces.append(g.reshape(-1))
-        torch.cat(pieces, out=self._flat_grad)
+        launch per 128 tensors)."""
+        torch.cat([p.grad.reshape(-1) for p in self.params], out=self._flat_grad)
         self._flat.grad = self._flat_grad
 
+    def _unflatten(self) -> None:
+        """Back to one optimiser entry per parameter, for good, carrying the state over: torch's
+        AdamW SKIPS a parameter that has no gradient (no decay, no moment update, its own step
+        count), which one flat tensor cannot express.  Until now every parameter took every step,
+        so the flat state's slices and its step count ARE the per-parameter state."""
+        old, group = self.optimizer, self.optimizer.param_groups[0]
+        new = optim.AdamW(self.params, lr=group['lr'], betas=group['betas'], eps=group['eps'],
+                          weight_decay=group['weight_decay'], capturable=group.get('capturable', False),
+                          **({'fused': True} if group.get('fused') else {}))
+        if 'initial_lr' in group:
+            new.param_groups[0]['initial_lr'] = group['initial_lr']
+        state = old.state.get(self._flat)
+        if state:
+            offset = 0
+            for p, n in zip(self.params, self._sizes):
+                new.state[p] = {
+                    'step': state['step'].clone() if torch.is_tensor(state['step']) else state['step'],
+                    'exp_avg': state['exp_avg'][offset:offset + n].view_as(p).clone(),
+                    'exp_avg_sq': state['exp_avg_sq'][offset:offset + n].view_as(p).clone()}
+                offset += n
+        self.optimizer = new
+        if isinstance(self.scheduler.optimizer, optim.AdamW):       # (not the capturable tuner's stand-in)
+            self.scheduler.optimizer = new
+        self._flat = self._flat_grad = None     # (the parameters stay views of the buffer: harmless)
+
     def apply_gradients(self) -> None:
+        if self._flat is not None and any(p.grad is None for p in self.params):
+            self._unflatten()
         if self._flat is None:
             if self.world_size > 1:
                 distributed.allreduce_gradients(self.params, group=self.group,

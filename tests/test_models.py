@@ -219,6 +219,40 @@ def test_training_step_is_the_pieces_and_accumulates(oracle_ext):
     assert abs(a.lr - 0.9 * lr0) < 1e-12
 
 
+def test_flat_parameter_store_takes_the_per_tensor_step(oracle_ext, monkeypatch):
+    """SparseTuner keeps the trainable parameters and their gradients in one flat buffer (one
+    tensor for the exchange, the clip and AdamW); above FLAT_LIMIT elements it keeps the
+    per-tensor path.  Both take the same steps: same loss, same clip norm, same parameters, with
+    a parameter that receives no gradient (its slice of the flat gradient is zero) included."""
+    from naive_gpt import utils
+    g, model_a = upgraded_from_golden('opt', 'cpu')
+    _, model_b = upgraded_from_golden('opt', 'cpu')
+    batch = T(g['batch'])
+    flat = utils.SparseTuner(model_a)
+    assert flat._flat is not None and flat._flat.numel() == sum(p.numel() for p in flat.params)
+    # every trainable parameter is a view of the flat buffer, in order
+    offset = 0
+    for p in flat.params:
+        assert p.data_ptr() == flat._flat.data_ptr() + 4 * offset
+        offset += p.numel()
+    monkeypatch.setattr(utils.SparseTuner, 'FLAT_LIMIT', 0)
+    plain = utils.SparseTuner(model_b)
+    assert plain._flat is None
+    for step in range(3):
+        pq = step != 1                       # step 1: the quantizer tables get no gradient
+        la, lb = flat.training_step(batch, pq_loss=pq), plain.training_step(batch, pq_loss=pq)
+        assert torch.allclose(la, lb, rtol=1e-6, atol=0)
+        assert torch.allclose(flat.last_grad_norm, plain.last_grad_norm, rtol=1e-5, atol=0)
+        for (n, pa), pb in zip(model_a.named_parameters(), model_b.parameters()):
+            assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-7), (step, n)
+    assert all(p.grad is None for p in flat.params)
+    assert flat._flat is None        # step 1 (a parameter without gradient) ended the flat form, exactly
+    # the state dict reads through the views
+    sd = model_a.state_dict()
+    for n, p in model_a.named_parameters():
+        assert torch.equal(sd[n], p)
+
+
 def test_unarmed_step_registers_no_pq_loss(oracle_ext):
     from naive_gpt import utils
     g, model = upgraded_from_golden('opt', 'cpu')
