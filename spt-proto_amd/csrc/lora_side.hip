@@ -285,6 +285,19 @@ __global__ __launch_bounds__(64 * TN_WAVES, 2) void tall_tn_partial_kernel(
     for (int c = 0; c < 2; c++)
 #pragma unroll
         for (int j = 0; j < N; j++) acc[c][j] = 0.0f;
+    const int wr0 = wave * TN_RW;                            // this wave's rows of the chunk
+    const int wrows = min(TN_RW, rows - wr0);                // (<= 0: nothing, g < 0: rows = 0)
+    // the next batch of rows is requested before the current one is used -- and the first one
+    // before the chunk's `narrow` rows are staged: a wave has only two batches, and every
+    // workgroup of the launch is resident at once, so nothing else hides its prologue
+    float2 vn[UNROLL];
+    const float *wp = wide + (row0 + wr0) * ldw + col;
+    auto request = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++)                     // rows past the end: clamped, weight 0
+            vn[u] = *reinterpret_cast<const float2 *>(wp + (long long)min(r0 + u, wrows - 1) * ldw);
+    };
+    if (wrows > 0) request(0);
     // the chunk's rows of `narrow` -> LDS (the memory of `red`, free until the sums are formed):
     // read from there as wave-wide broadcasts.  (As scalar loads every row was a miss of the
     // scalar cache -- a 64-byte line used once -- in the middle of the FMA chain: 12 us for 33 MB.)
@@ -296,20 +309,7 @@ __global__ __launch_bounds__(64 * TN_WAVES, 2) void tall_tn_partial_kernel(
         reinterpret_cast<float4 *>(nar)[i] = *reinterpret_cast<const float4 *>(narrow + src * ldn + 4 * q);
     }
     __syncthreads();
-    const int wr0 = wave * TN_RW;                            // this wave's rows of the chunk
-    const int wrows = min(TN_RW, rows - wr0);                // (<= 0: nothing, g < 0: rows = 0)
     if (wrows > 0) {
-        const long long base = row0 + wr0;
-        const float *wp = wide + base * ldw + col;
-        // the next batch of rows is requested before the current one is used: a wave has only one
-        // to four batches, and without this its loads and its FMAs (0.4 us per batch) alternate
-        float2 vn[UNROLL];
-        auto request = [&](int r0) {
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++)                 // rows past the end: clamped, weight 0
-                vn[u] = *reinterpret_cast<const float2 *>(wp + (long long)min(r0 + u, wrows - 1) * ldw);
-        };
-        request(0);
         for (int r0 = 0; r0 < wrows; r0 += UNROLL) {
             float2 v[UNROLL];
 #pragma unroll
