@@ -16,7 +16,8 @@ def project_heads(module, q, k, v, attn_mask):
         from ..tuning import lora
         linears = (module.linear_q, module.linear_k, module.linear_v)
         if lora.qkv_usable(q, linears):
-            q, k, v = lora.qkv(q, linears)
+            # (a rotary attention replaces q and k by rotated copies: v gets a buffer of its own)
+            q, k, v = lora.qkv(q, linears, v_apart=hasattr(module.attn_fn, '_rotate'))
             fused = True
         else:
             lora.prepare_shared(q, linears)      # (at least one pass for the three down products)

@@ -275,6 +275,7 @@ class _FrozenLoRAQKV(torch.autograd.Function):
         from naive_gpt import ext
         weights, biases = params[0:3], params[3:6]
         lefts, rights = params[6:9], params[9:12]
+        v_apart = bool(params[12])
         x2 = x.reshape(-1, x.size(-1))
         n, k = weights[0].shape
         rows = x2.size(0)
@@ -286,13 +287,25 @@ class _FrozenLoRAQKV(torch.autograd.Function):
         w3 = _home3(weights)
         b3 = None if biases[0] is None else _home3(biases)
         gather, offsets = _qkv_index(rows, x2.device)
+        # (`v_apart`: q and k in one buffer, v in its own -- a rotary attention replaces q and k by
+        # rotated copies at once, and a shared buffer would keep their memory alive with v)
+        joint = 2 if v_apart else 3
+        r = rights[0].size(1)
+        w_img = ext.weight_image(w3.view(3 * n, k))
         out = ext.grouped_gemm_fused(
-            x2, w3, offsets, 3, n, k, n * k, k, 1, 3 * rows, gather=gather, bias=b3,
-            a2=u3.view(3 * rows, u3.size(-1)), b2=torch.stack([r.detach() for r in rights]),
-            b2_group_stride=n * rights[0].size(1), a_image=image,
-            w_image=ext.weight_image(w3.view(3 * n, k)))
-        out = out.view(3, *x.shape[:-1], n)
-        outs = [out[0], out[1], out[2]]
+            x2, w3, offsets[:joint + 1], joint, n, k, n * k, k, 1, joint * rows, gather=gather[:joint * rows],
+            bias=None if b3 is None else b3[:joint],
+            a2=u3[:joint].view(joint * rows, r), b2=torch.stack([t.detach() for t in rights[:joint]]),
+            b2_group_stride=n * r, a_image=image, w_image=w_img)
+        out = out.view(joint, *x.shape[:-1], n)
+        outs = [out[g] for g in range(joint)]
+        if v_apart:
+            v_img = ext.SplitImage(w_img.buffer[2 * n * k * 4:], n, k)       # the third weight's rows
+            y = ext.grouped_gemm_fused(
+                x2, weights[2], _one_group(rows, x2.device), 1, n, k, 0, k, 1, rows,
+                bias=None if biases[2] is None else biases[2].view(1, n),
+                a2=u3[2], b2=rights[2].detach().contiguous(), a_image=image, w_image=v_img)
+            outs.append(y.view(*x.shape[:-1], n))
         origin = recompute.origin_of(x)
         ctx.origin_module = origin.module if origin is not None else None
         ctx.save_for_backward(origin.input if origin is not None else x2, u3, *weights, *lefts, *rights)
@@ -338,7 +351,7 @@ class _FrozenLoRAQKV(torch.autograd.Function):
             for i, g in enumerate(live):
                 grad_lefts[g] = gl[i]
                 grad_rights[g] = tall_tn(dy2[g], u3[g])
-        return (grad_x, None, None, None, None, None, None, *grad_lefts, *grad_rights)
+        return (grad_x, None, None, None, None, None, None, *grad_lefts, *grad_rights, None)
 
 
 def qkv_usable(x: torch.Tensor, linears) -> bool:
@@ -358,11 +371,12 @@ def qkv_usable(x: torch.Tensor, linears) -> bool:
             and all(m.lora.left.weight.requires_grad and m.lora.right.weight.requires_grad for m in linears))
 
 
-def qkv(x: torch.Tensor, linears):
-    """(linear_q(x), linear_k(x), linear_v(x)) as one autograd function (see _FrozenLoRAQKV)."""
+def qkv(x: torch.Tensor, linears, v_apart: bool = False):
+    """(linear_q(x), linear_k(x), linear_v(x)) as one autograd function (see _FrozenLoRAQKV).
+    `v_apart`: v in a buffer of its own (for callers that drop q and k at once)."""
     args = ([m.weight for m in linears] + [m.bias for m in linears]
             + [m.lora.left.weight for m in linears] + [m.lora.right.weight for m in linears])
-    return _FrozenLoRAQKV.apply(x, *args)
+    return _FrozenLoRAQKV.apply(x, *args, v_apart)
 
 
 class LoRALinear(nn.Linear):
