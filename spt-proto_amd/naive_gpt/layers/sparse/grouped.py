@@ -262,7 +262,8 @@ class RoutedLoRAFFN(torch.autograd.Function):
 
     Saved for backward: h (and the pre-activation only when act is not ReLU), the two
     [*, r] LoRA intermediates -- against ~8 [P, d] tensors of the op-by-op composition.
-    The small [*, r] products and the LoRA table gradients stay torch matmuls.
+    The small [*, r] products and the LoRA table gradients are single calls of libspt_hip too
+    (spt_lora_down[_grouped], spt_tall_tn).
     """
 
     @staticmethod
