@@ -239,7 +239,7 @@ def _home3(tensors):
     hit = _HOMES.get(key)
     if hit is not None and hit[1] == ptrs and all(r() is t for r, t in zip(hit[0], tensors)):
         return hit[2]
-    with torch.no_grad():
+    with torch.inference_mode(False), torch.no_grad():      # (never an inference tensor: it outlives the call)
         home = torch.empty([3, *tensors[0].shape], dtype=tensors[0].dtype, device=tensors[0].device)
         for g, t in enumerate(tensors):
             home[g].copy_(t)
