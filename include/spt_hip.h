@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 30
+#define SPT_ABI_VERSION 31
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -478,7 +478,7 @@ int spt_split_bf16(const float *src, void *image, long long rows, int cols, long
  *                  several adapters' tables side by side in l, each adapter's u contiguous);
  *                  optional by-products of the same read: `image` (spt_split_bf16's layout,
  *                  spt_split_bf16_bytes(rows, k) bytes) and `norms` [rows] (row 2-norms) -- NULL
- *                  to skip.  k % 1024 == 0, n in {16, 32, 48, 64}: SPT_EUNSUP otherwise (callers
+ *                  to skip.  k % 32 == 0, n in {16, 32, 48, 64}: SPT_EUNSUP otherwise (callers
  *                  then use a library GEMM).
  * Split-bf16 matrix-core products as in spt_grouped_gemm: <= 2^-16 relative per product.
  */
@@ -568,6 +568,9 @@ int spt_route_topk(const float *prob, int32_t *token, int32_t *block, int32_t *o
  * spt_route_coeff_backward: the adjoint of `coeff`,
  *   dprob[t, g] = scale * dcoeff[p] if row p is token t's selection of block g, else 0
  * (dprob [n_tokens, n_blocks] is written whole).
+ * spt_route_logit_backward: the same chained through the router's sigmoid (feedforward.py:22-25:
+ * nn.Sequential(nn.Linear, nn.Sigmoid)): dlogit[t, g] = dprob[t, g] * (1 - prob[t, g]) * prob[t, g]
+ * with prob [n_tokens, n_blocks] the sigmoid's outputs (torch's sigmoid backward).
  */
 int spt_route_topk_coeff(const float *prob, int32_t *token, int32_t *block, int32_t *offsets,
                          int32_t *pos, long long *token64, long long *block64, float *coeff,
@@ -575,6 +578,9 @@ int spt_route_topk_coeff(const float *prob, int32_t *token, int32_t *block, int3
 int spt_route_coeff_backward(const float *dcoeff, const int32_t *pos, const int32_t *block,
                              float scale, float *dprob, int n_tokens, int n_blocks, int k,
                              void *stream);
+int spt_route_logit_backward(const float *dcoeff, const int32_t *pos, const int32_t *block,
+                             float scale, const float *prob, float *dlogit, int n_tokens,
+                             int n_blocks, int k, void *stream);
 
 /*
  * Router-coefficient gradient of the routed LoRA FFN's backward (layers/sparse/grouped.py; the

@@ -22,6 +22,7 @@
 // MFMAs per product (v_mfma_f32_16x16x32_bf16: its 16-wide output is the adapter's rank), fp32
 // accumulation; <= 2^-16 relative error per product.
 #include "spt_common.h"
+#include <type_traits>
 
 namespace spt {
 
@@ -57,7 +58,7 @@ __device__ __forceinline__ ls_f32x4 ls_mma3(const LsFrag &a, const LsFrag &b, ls
 }
 
 // ---- u = x . l -------------------------------------------------------------------------------
-// A workgroup = 16 rows, its four waves = the four quarters of K; lane (r, g) = row r, elements
+// A workgroup = 16 rows, its four waves = four contiguous shares of K (K % 32 == 0); lane (r, g) = row r, elements
 // 8g .. 8g + 7 of every 32-wide k-step: the A operand of the 16x16x32 MFMA as it lies in memory
 // (32 bytes per lane, 128 contiguous bytes per row and k-step), and one 128-byte block of the
 // split image.  All of a wave's loads of x for 256 k (16 x 16 bytes per lane) are issued before
@@ -96,10 +97,13 @@ __global__ __launch_bounds__(256) void lora_down_kernel(
         l += grp * l_gstride;
     }
     const long long row = min(row0 + r, rows - 1);          // (clamped rows are never stored)
-    const int KQ = K >> 2, kbeg = w * KQ;
-    const float *xp = x + row * ldx + kbeg + 8 * g;
-    const float *lp = l + (size_t)(kbeg + 8 * g) * n + r;
-    char *ip = IMAGE ? image + ((size_t)row * (K >> 5) + (kbeg >> 5)) * 128 + 16 * g : nullptr;
+    // the K / 32 k-steps dealt to the four waves as evenly as they go (K = 2752, the LLaMA-7B FFN
+    // block: 22, 22, 21, 21); a wave walks its share in chunks of LS_CH steps, the last one ragged
+    const int nsteps = K >> 5, per = nsteps >> 2, extra = nsteps & 3;
+    const int sbeg = w * per + min(w, extra), cnt = per + (w < extra ? 1 : 0);
+    const float *xp = x + row * ldx + 32 * sbeg + 8 * g;
+    const float *lp = l + (size_t)(32 * sbeg + 8 * g) * n + r;
+    char *ip = IMAGE ? image + ((size_t)row * nsteps + sbeg) * 128 + 16 * g : nullptr;
     ls_f32x4 acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; b++) acc[b] = {0.f, 0.f, 0.f, 0.f};
@@ -111,23 +115,27 @@ __global__ __launch_bounds__(256) void lora_down_kernel(
 #pragma unroll
             for (int i = 0; i < 8; i++) bv[b][i] = p[(size_t)i * n + 16 * b];
     };
-    for (int s0 = 0; s0 < (KQ >> 5); s0 += LS_CH) {
+    // one chunk; RAGGED: steps s0 + c >= cnt load a clamped (valid) address and are skipped
+    auto chunk = [&](int s0, auto ragged) {
+        constexpr bool RAGGED = decltype(ragged)::value;
         float4 a[LS_CH][2];
 #pragma unroll
         for (int c = 0; c < LS_CH; c++) {
-            a[c][0] = *reinterpret_cast<const float4 *>(xp + (s0 + c) * 32);
-            a[c][1] = *reinterpret_cast<const float4 *>(xp + (s0 + c) * 32 + 4);
+            const int st = RAGGED ? min(s0 + c, cnt - 1) : s0 + c;
+            a[c][0] = *reinterpret_cast<const float4 *>(xp + st * 32);
+            a[c][1] = *reinterpret_cast<const float4 *>(xp + st * 32 + 4);
         }
         float bnext[NB][8];
         load_l(s0, bnext);
 #pragma unroll
         for (int c = 0; c < LS_CH; c++) {
+            if (RAGGED && s0 + c >= cnt) break;              // (wave-uniform)
             float bv[NB][8];
 #pragma unroll
             for (int b = 0; b < NB; b++)
 #pragma unroll
                 for (int i = 0; i < 8; i++) bv[b][i] = bnext[b][i];
-            if (c + 1 < LS_CH) load_l(s0 + c + 1, bnext);
+            if (c + 1 < LS_CH) load_l(RAGGED ? min(s0 + c + 1, cnt - 1) : s0 + c + 1, bnext);
             const float av[8] = {a[c][0].x, a[c][0].y, a[c][0].z, a[c][0].w,
                                  a[c][1].x, a[c][1].y, a[c][1].z, a[c][1].w};
             const LsFrag af = ls_split8(av);
@@ -143,7 +151,10 @@ __global__ __launch_bounds__(256) void lora_down_kernel(
                 for (int i = 0; i < 8; i++) ss = fmaf(av[i], av[i], ss);
             }
         }
-    }
+    };
+    int s0 = 0;
+    for (; s0 + LS_CH <= cnt; s0 += LS_CH) chunk(s0, std::false_type{});
+    if (s0 < cnt) chunk(s0, std::true_type{});
     // the four k-quarters of the 16 x (16 NB) result through LDS; lane (c, g) holds rows 4g + j
 #pragma unroll
     for (int b = 0; b < NB; b++)
@@ -178,7 +189,7 @@ static int lora_down_any(const float *x, long long ldx, long long rows, int k, c
                          void *stream) {
     if (!x || !l || !u) return SPT_EINVAL;
     if (rows <= 0 || k <= 0 || n <= 0 || ldx < k) return SPT_EINVAL;
-    if (k % (4 * 32 * LS_CH) != 0 || n % 16 != 0 || n > 64) return SPT_EUNSUP;
+    if (k % 32 != 0 || n % 16 != 0 || n > 64) return SPT_EUNSUP;
     if (ldx % 4 != 0 || !ls_aligned(x) || (image && !ls_aligned(image))) return SPT_ESHAPE;
     if (offsets && (n_groups <= 0 || n_groups > 64)) return SPT_EINVAL;
     const long long nblk = (rows + 15) / 16 + (offsets ? n_groups : 0);

@@ -172,9 +172,11 @@ __global__ __launch_bounds__(RT_CHUNK) void route_topk_kernel(
 // elementwise kernels on 16384-element vectors -- ~40 us of launches for 2 MB of data.
 // Adjoint of the `coeff` by-product of route_topk_kernel: d prob[t, g] = scale * d coeff[p] where row
 // p is token t's selection of block g, zero for the blocks t did not select.  A thread per token.
+// With `prob` (the router's sigmoid outputs [T, G]) the sigmoid's derivative is applied too:
+// out = d logit[t, g] = d prob[t, g] * prob (1 - prob)   (torch's sigmoid backward: grad * (1 - y) * y).
 __global__ __launch_bounds__(256) void route_coeff_backward_kernel(
     const float *__restrict__ dcoeff, const int32_t *__restrict__ pos, const int32_t *__restrict__ block,
-    float scale, float *__restrict__ dprob, int T, int G, int k) {
+    float scale, const float *__restrict__ prob, float *__restrict__ dprob, int T, int G, int k) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
     float out[RT_MAXG];
@@ -190,7 +192,11 @@ __global__ __launch_bounds__(256) void route_coeff_backward_kernel(
     }
 #pragma unroll
     for (int g = 0; g < RT_MAXG; g++)
-        if (g < G) dprob[(size_t)t * G + g] = out[g];
+        if (g < G) {
+            float v = out[g];
+            if (prob) { const float y = prob[(size_t)t * G + g]; v = (v * (1.0f - y)) * y; }
+            dprob[(size_t)t * G + g] = v;
+        }
 }
 
 __global__ __launch_bounds__(256) void ffn_coeff_grad_kernel(
@@ -261,7 +267,19 @@ extern "C" int spt_route_coeff_backward(const float *dcoeff, const int32_t *pos,
     if (n_tokens <= 0 || n_blocks <= 0 || k <= 0 || k > n_blocks) return SPT_EINVAL;
     if (n_blocks > RT_MAXG) return SPT_EUNSUP;
     hipLaunchKernelGGL(route_coeff_backward_kernel, dim3((n_tokens + 255) / 256), dim3(256), 0,
-                       (hipStream_t)stream, dcoeff, pos, block, scale, dprob, n_tokens, n_blocks, k);
+                       (hipStream_t)stream, dcoeff, pos, block, scale, nullptr, dprob, n_tokens, n_blocks, k);
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
+extern "C" int spt_route_logit_backward(const float *dcoeff, const int32_t *pos, const int32_t *block,
+                                        float scale, const float *prob, float *dlogit, int n_tokens,
+                                        int n_blocks, int k, void *stream) {
+    if (!dcoeff || !pos || !block || !prob || !dlogit) return SPT_EINVAL;
+    if (n_tokens <= 0 || n_blocks <= 0 || k <= 0 || k > n_blocks) return SPT_EINVAL;
+    if (n_blocks > RT_MAXG) return SPT_EUNSUP;
+    hipLaunchKernelGGL(route_coeff_backward_kernel, dim3((n_tokens + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, dcoeff, pos, block, scale, prob, dlogit, n_tokens, n_blocks, k);
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }

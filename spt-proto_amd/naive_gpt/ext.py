@@ -12,6 +12,7 @@ tensors, every call raises ``RuntimeError``.
 """
 import collections
 import ctypes
+import logging
 import os
 import weakref
 
@@ -89,14 +90,46 @@ _PROTOTYPES = {
     'spt_route_topk': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_route_topk_coeff': ([_c_ptr] * 8 + [_c_f32] + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_route_coeff_backward': ([_c_ptr] * 3 + [_c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_route_logit_backward': ([_c_ptr] * 3 + [_c_f32, _c_ptr, _c_ptr] + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_forward': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_backward': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 _lib = None
+
+# ---- which engine ran ---------------------------------------------------------------------------
+# Every layer-level choice between a kernel of this library and something else (a library GEMM, a
+# torch composition, another kernel of ours) is noted here: `PATH_COUNTS[(site, path)]` counts the
+# calls (tests assert on it: a parity test must know WHICH engine it compared), and the first time a
+# CUDA call leaves its primary path the reason is logged once (logger 'naive_gpt', WARNING).
+PATH_COUNTS = collections.Counter()
+_PATH_LOGGED = set()
+_log = logging.getLogger('naive_gpt')
+
+
+def note_path(site: str, path: str, fallback: bool = False, why='') -> None:
+    """`why`: a string, or a callable that makes one (hot call sites: formatted only when logged)."""
+    PATH_COUNTS[(site, path)] += 1
+    if not fallback:
+        return
+    if callable(why):
+        why = why()
+    if (site, path, why) not in _PATH_LOGGED \
+            and sum(1 for k in _PATH_LOGGED if k[:2] == (site, path)) < 4:     # (a few shapes per site)
+        _PATH_LOGGED.add((site, path, why))
+        _log.warning('naive_gpt: %s takes the %s path%s', site, path, ' (' + why + ')' if why else '')
+
+
+def paths_taken(site: str = None) -> dict:
+    """{(site, path): calls} so far (of one site when given)."""
+    return {k: v for k, v in PATH_COUNTS.items() if site is None or k[0] == site}
+
+
+def reset_paths() -> None:
+    PATH_COUNTS.clear()
 
 
 def load_library() -> ctypes.CDLL:
@@ -1109,6 +1142,7 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                 accumulate=int(bool(accumulate)))
             global LAST_GEMM_USED_IMAGES
             LAST_GEMM_USED_IMAGES = bool(lib.spt_grouped_gemm_image_path(ctypes.byref(desc)))
+            PATH_COUNTS[('grouped_gemm', 'image' if LAST_GEMM_USED_IMAGES else 'register')] += 1
             rc = lib.spt_grouped_gemm_fused(ctypes.byref(desc), _stream(dev))
             if rc != 0:
                 _raise(lib, rc, 'grouped_gemm_fused')
@@ -1216,8 +1250,9 @@ def route_topk_coeff(prob: torch.Tensor, k: int, scale: float):
 
 
 def route_coeff_backward(dcoeff: torch.Tensor, pos: torch.Tensor, block: torch.Tensor,
-                         scale: float, n_blocks: int) -> torch.Tensor:
-    """``spt_route_coeff_backward``: d prob [T, n_blocks] from d coeff [T * k]."""
+                         scale: float, n_blocks: int, prob: torch.Tensor = None) -> torch.Tensor:
+    """``spt_route_coeff_backward``: d prob [T, n_blocks] from d coeff [T * k]; with ``prob`` (the
+    router's sigmoid outputs [T, n_blocks]) ``spt_route_logit_backward``: d logit instead."""
     _check_type(dcoeff, torch.float32, 'dcoeff')
     _check_type(pos, torch.int32, 'pos')
     _check_type(block, torch.int32, 'block')
@@ -1229,8 +1264,16 @@ def route_coeff_backward(dcoeff: torch.Tensor, pos: torch.Tensor, block: torch.T
     lib = load_library()
     with _on(dev):
         dprob = torch.empty([T, n_blocks], dtype=torch.float32, device=dev)
-        rc = lib.spt_route_coeff_backward(dcoeff.data_ptr(), pos.data_ptr(), block.data_ptr(),
-                                          float(scale), dprob.data_ptr(), T, n_blocks, k, _stream(dev))
+        if prob is not None:
+            _check_type(prob, torch.float32, 'prob')
+            _require(prob.is_contiguous() and prob.shape == (T, n_blocks) and prob.device == dev,
+                     'prob: contiguous [T, n_blocks]')
+            rc = lib.spt_route_logit_backward(dcoeff.data_ptr(), pos.data_ptr(), block.data_ptr(),
+                                              float(scale), prob.data_ptr(), dprob.data_ptr(), T,
+                                              n_blocks, k, _stream(dev))
+        else:
+            rc = lib.spt_route_coeff_backward(dcoeff.data_ptr(), pos.data_ptr(), block.data_ptr(),
+                                              float(scale), dprob.data_ptr(), T, n_blocks, k, _stream(dev))
     if rc != 0:
         _raise(lib, rc, 'route_coeff_backward')
     return dprob
@@ -1258,11 +1301,11 @@ def rows_combine(rows: torch.Tensor, pos: torch.Tensor, bias: torch.Tensor = Non
 
 def lora_down_supported(x: torch.Tensor, table: torch.Tensor) -> bool:
     """Shapes ``spt_lora_down`` takes: a CUDA fp32 matrix with unit inner stride and 16-byte
-    aligned rows, K a multiple of 1024, 16 / 32 / 48 / 64 table columns."""
+    aligned rows, K a multiple of 32, 16 / 32 / 48 / 64 table columns."""
     return (x.is_cuda and x.dtype == torch.float32 and table.dtype == torch.float32
             and x.dim() == 2 and table.dim() == 2 and x.size(0) > 0
             and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
-            and x.size(1) == table.size(0) and x.size(1) % 1024 == 0
+            and x.size(1) == table.size(0) and x.size(1) % 32 == 0
             and table.size(1) % 16 == 0 and 0 < table.size(1) <= 64)
 
 

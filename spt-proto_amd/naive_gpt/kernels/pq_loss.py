@@ -27,41 +27,8 @@ class PQLoss(torch.autograd.Function):
         if grad_loss is None:
             return None, None, None
         z, table = ctx.saved_tensors
-        # z usually has a second consumer, the attention core, whose gradient for it may exist
-        # already (`pending_gradient`): the loss's gradient is then added INTO that tensor by the
-        # kernel and nothing is returned for z -- autograd would otherwise add the two with an
-        # elementwise pass (2 x 33 MB read, 33 MB written per q and k and layer).
-        other = take_pending_gradient(z)
-        if other is not None:
-            _, grad_table = ext.pq_loss_backward(z, table, grad_loss.contiguous(), accumulate_into=other)
-            return None, grad_table, None
         grad_z, grad_table = ext.pq_loss_backward(z, table, grad_loss.contiguous())
         return grad_z, grad_table, None
-
-
-# ---- gradients of z that another backward has produced already ---------------------------------
-# Filled by the attention core's backward (layers/sparse/attention.py: _MfmaAttention) for its q
-# and k, emptied by PQLoss.backward above or, at the latest, by the next forward.  Autograd runs
-# the node created last first, and the attention is created after the loss of the same q / k, so
-# in a training step the entry is there; if it is not (another order, another graph), nothing
-# happens and autograd sums as usual.  The consumer of q's total gradient (the projection's
-# backward) depends on BOTH nodes, so it cannot run before the tensor has been completed.
-_PENDING = {}
-
-
-def pending_gradient(z: torch.Tensor, grad: torch.Tensor, tag=None) -> None:
-    """`grad` is the gradient some backward has just produced for a consumer of `z` (`tag`: which
-    tensor derived from z, when it is not z itself); a later backward may add its own into it."""
-    if grad.dtype == torch.float32 and grad.is_contiguous() and (tag is not None or grad.shape == z.shape):
-        _PENDING[(z.data_ptr(), tuple(z.shape), tag)] = grad
-
-
-def take_pending_gradient(z: torch.Tensor, tag=None):
-    return _PENDING.pop((z.data_ptr(), tuple(z.shape), tag), None)
-
-
-def drop_pending_gradients() -> None:
-    _PENDING.clear()
 
 
 def pq_loss(z: torch.Tensor, table: torch.Tensor) -> torch.Tensor:

@@ -78,10 +78,14 @@ def usable(norm: nn.Module, x: torch.Tensor) -> bool:
 
 def add_norm(norm: nn.Module, x: torch.Tensor, r):
     """(x + r, norm(x + r)); r None: (x, norm(x))."""
+    from naive_gpt import ext
     if usable(norm, x):
+        ext.note_path('norm', 'kernel')
         gamma, beta, eps, rms = _kind(norm)
         if r is None:
             return x, _LayerNorm.apply(x, gamma, beta, eps, rms)
         return _AddLayerNorm.apply(x, r, gamma, beta, eps, rms)
+    ext.note_path('norm', 'library', fallback=x.is_cuda and not x.is_inference(),
+                  why=lambda: '{} on x {} {}'.format(type(norm).__name__, tuple(x.shape), x.dtype))
     s = x if r is None else x + r
     return s, norm(s)

@@ -15,7 +15,14 @@ def project_heads(module, q, k, v, attn_mask):
         # self-attention: frozen projections with adapters run as one function of the shared input
         from ..tuning import lora
         linears = (module.linear_q, module.linear_k, module.linear_v)
-        if lora.qkv_usable(q, linears):
+        from naive_gpt import ext
+        joint = lora.qkv_usable(q, linears)
+        if all(isinstance(m, lora.LoRALinear) for m in linears):
+            ext.note_path('qkv_projection', 'joint' if joint else 'separate', fallback=not joint and q.is_cuda,
+                          why=lambda: 'x {} {}, W {}: one grouped launch needs frozen rank-16 adapters, fp32, '
+                              '>= 2048 rows, k % 32 == 0'.format(tuple(q.shape), q.dtype,
+                                                                 tuple(linears[0].weight.shape)))
+        if joint:
             # (a rotary attention replaces q and k by rotated copies: v gets a buffer of its own)
             q, k, v = lora.qkv(q, linears, v_apart=hasattr(module.attn_fn, '_rotate'))
             fused = True

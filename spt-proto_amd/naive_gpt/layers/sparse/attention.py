@@ -25,6 +25,9 @@ from naive_gpt import ext, kernels, layers
 
 SPARSE_COEFF = 8     # Z = S / 8 keys per query (reference: attention.py:109-117)
 CLAMP = 10.0         # reference: attention.py:125-127
+# the armed step's PQ loss as a second output of the attention's autograd node (_MfmaAttention);
+# False: two separate autograd functions whose q / k gradients autograd sums (tests compare both)
+FOLD_PQ_LOSS = True
 
 
 class _ScaledClampedSDDMM(torch.autograd.Function):
@@ -151,31 +154,53 @@ class _MfmaAttention(torch.autograd.Function):
     """The same function as _FusedAttention on the matrix cores (mfma_attention.hip): dense
     32 x 32 score tiles from split-bf16 MFMAs, the CSR only selecting the live cells.  Saves
     q, k, v, y and the [N*H, S] row sums -- nothing of size nnz; the backward recomputes the
-    tiles in two launches (grad_q; grad_k and grad_v)."""
+    tiles in two launches (grad_q; grad_k and grad_v).
+
+    Armed form (`table`, `loss_q`, `loss_k` given: the step's PQ codebook loss,
+    attention.py:98-104): the loss of the same q and k is a second OUTPUT of this node -- its
+    values were formed with the PQ codes in front of the lookup (ext.pq_loss_forward(want_codes)) --
+    so that q and k have ONE consumer and the loss's input gradient is added into the attention's
+    grad_q / grad_k by the loss's own backward kernel, inside this node (autograd would add the two
+    with an elementwise pass per tensor: 2 x 33 MB read, 33 MB written per q and k and layer).
+    Whatever else reads q or k is summed by autograd as usual."""
 
     @staticmethod
-    def forward(ctx, indices, q, k, v, scale: float, armed: bool = False):
-        ctx.armed = armed
+    def forward(ctx, indices, q, k, v, scale: float, table=None, loss_q=None, loss_k=None):
+        ctx.armed = table is not None
         # `indices` come straight from kernels.lookup: only its padding column 0 repeats in a
         # row, which is what the compact tile layout needs (70 -> 17 MB per BERT-large layer)
         tiles = ext.attention_mfma_prepare(indices, q.size(1), lookup_pattern=True)
         y, row_sum = ext.attention_mfma_forward(tiles, q, k, v, scale, CLAMP, y_transposed=True)
         ctx.scale, ctx.tiles = scale, tiles
+        if ctx.armed:
+            ctx.save_for_backward(q, k, v, y, row_sum, table)
+            return y.view(q.shape), loss_q + loss_k
         ctx.save_for_backward(q, k, v, y, row_sum)
         return y.view(q.shape)
 
     @staticmethod
-    def backward(ctx, grad_out: torch.Tensor):
-        q, k, v, y, row_sum = ctx.saved_tensors
+    def backward(ctx, grad_out: torch.Tensor, grad_loss: torch.Tensor = None):
+        q, k, v, y, row_sum = ctx.saved_tensors[:5]
         grad_q, grad_k, grad_v = ext.attention_mfma_backward(
             ctx.tiles, q, k, v, y, grad_out.contiguous(), row_sum, ctx.scale, CLAMP,
             transposed=True)
-        if ctx.armed:
-            # the PQ loss of the same q / k adds its gradient into these (kernels/pq_loss.py)
-            from naive_gpt.kernels.pq_loss import pending_gradient
-            pending_gradient(q, grad_q)
-            pending_gradient(k, grad_k)
-        return None, grad_q, grad_k, grad_v, None, None
+        if not ctx.armed:
+            return None, grad_q, grad_k, grad_v, None
+        table = ctx.saved_tensors[5]
+        grad_table = None
+        if grad_loss is not None:
+            grad_loss = grad_loss.contiguous()
+            if q.dtype == torch.float32:
+                _, gt_q = ext.pq_loss_backward(q, table, grad_loss, accumulate_into=grad_q)
+                _, gt_k = ext.pq_loss_backward(k, table, grad_loss, accumulate_into=grad_k)
+            else:
+                # bf16 storage: the loss was formed in fp32 from the widened values
+                gz_q, gt_q = ext.pq_loss_backward(q.float(), table, grad_loss)
+                gz_k, gt_k = ext.pq_loss_backward(k.float(), table, grad_loss)
+                grad_q = (grad_q.float() + gz_q).to(q.dtype)
+                grad_k = (grad_k.float() + gz_k).to(k.dtype)
+            grad_table = gt_q + gt_k
+        return None, grad_q, grad_k, grad_v, None, grad_table, None, None
 
 
 class _SparseCore:
@@ -263,16 +288,27 @@ class _SparseCore:
         q, k = q.contiguous(), k.contiguous()
         q_c = k_c = None
         armed = self._take_trigger()
-        self.__dict__['_armed_now'] = armed          # (read by _sparse_apply of the same forward)
+        self.__dict__.pop('_armed_losses', None)
+        mfma = seq_length % 4 == 0 and ext.attention_mfma_supported(
+            seq_length, q.size(-1), seq_length * (seq_length // SPARSE_COEFF))
         if armed:
-            from naive_gpt.kernels.pq_loss import drop_pending_gradients
-            drop_pending_gradients()                 # nothing of an earlier backward survives
             # the PQ loss is a mean over all sub-vectors: the head layout holds the same set
             # (bf16 storage: the loss is formed in fp32 from the widened values); its argmin is
             # the PQ code, so an armed step needs no encode pass
-            loss_q, q_c = self.quantizer.train_loss_and_codes(q.float())
-            loss_k, k_c = self.quantizer.train_loss_and_codes(k.float())
-            self.register_buffer('loss', loss_q + loss_k, persistent=False)
+            qf, kf = q.float(), k.float()
+            if FOLD_PQ_LOSS and mfma and torch.is_grad_enabled() \
+                    and ext.pq_loss_supported(qf, self.quantizer.weight):
+                # values and codes now; the loss becomes a differentiable output of the attention's
+                # own autograd node in _sparse_apply (_MfmaAttention, armed form)
+                with torch.no_grad():
+                    loss_q, q_c = ext.pq_loss_forward(qf.contiguous(), self.quantizer.weight, want_codes=True)
+                    loss_k, k_c = ext.pq_loss_forward(kf.contiguous(), self.quantizer.weight, want_codes=True)
+                    self.register_buffer('loss', loss_q + loss_k, persistent=False)     # (until then)
+                self.__dict__['_armed_losses'] = (loss_q, loss_k)
+            else:
+                loss_q, q_c = self.quantizer.train_loss_and_codes(qf)
+                loss_k, k_c = self.quantizer.train_loss_and_codes(kf)
+                self.register_buffer('loss', loss_q + loss_k, persistent=False)
         table = self.quantizer.weight.detach()
         if q_c is None:
             q_c = ext.pq_encode_heads(q.detach(), table)
@@ -281,13 +317,17 @@ class _SparseCore:
         topk_indices = kernels.lookup(q_c, k_c, sparse_coeff=SPARSE_COEFF)
         csr_indices = topk_indices.flatten(start_dim=1)
         indptr = self._uniform_indptr(seq_length, q.device)
-        if seq_length % 4 == 0 and ext.attention_mfma_supported(seq_length, q.size(-1),
-                                                                csr_indices.size(-1)):
+        if mfma:
+            ext.note_path('attention', 'mfma')
             return 'mfma', indptr, csr_indices, q, k
         if ext.fused_attention_supported(seq_length, q.size(-1), q.size(0) * heads,
                                          csr_indices.size(-1)):
             # scores, softmax and the product with v run as one launch in _sparse_apply
+            ext.note_path('attention', 'fused_gather', fallback=True,
+                          why=lambda: 'q {}: the matrix-core kernels take d_head 64 / 128, S % 32 == 0, S <= 2048'.format(
+                              tuple(q.shape)))
             return 'fused', indptr, csr_indices, q, k
+        ext.note_path('attention', 'operators_head_layout', fallback=True, why=lambda: 'q {}'.format(tuple(q.shape)))
         values = _HeadScores.apply(indptr, csr_indices, q, k, self.scaling, heads)
         return indptr, csr_indices, values, heads
 
@@ -300,6 +340,9 @@ class _SparseCore:
             raise RuntimeError('sparse attention: {} tensors only on the matrix-core path (cuda, '
                                'PQ v2, d_head 64 / 128, S <= 2048, S % 32 == 0)'.format(q.dtype))
         seq_length = q.size(1)
+        ext.note_path('attention', 'operators', fallback=q.is_cuda,
+                      why=lambda: 'q {} {}, PQ {}: the fast paths take n * h >= 32, d_head 64 / 128, PQ v2'.format(
+                          tuple(q.shape), q.dtype, self.quantizer.method))
         q = q.transpose(1, 2).contiguous()
         k = k.transpose(1, 2).contiguous()
         q = q.view([-1, q.size(-2), q.size(-1)])
@@ -322,8 +365,13 @@ class _SparseCore:
         if len(attn) == 5:
             kind, indptr, indices, q, k = attn
             if kind == 'mfma':
-                return _MfmaAttention.apply(indices, q, k, v.contiguous(), self.scaling,
-                                            bool(self.__dict__.pop('_armed_now', False)))
+                losses = self.__dict__.pop('_armed_losses', None)
+                if losses is None:
+                    return _MfmaAttention.apply(indices, q, k, v.contiguous(), self.scaling)
+                y, loss = _MfmaAttention.apply(indices, q, k, v.contiguous(), self.scaling,
+                                               self.quantizer.weight, losses[0], losses[1])
+                self.register_buffer('loss', loss, persistent=False)
+                return y
             return _FusedAttention.apply(indptr, indices, q, k, v.contiguous(), self.scaling)
         if len(attn) == 4:
             indptr, indices, values, heads = attn

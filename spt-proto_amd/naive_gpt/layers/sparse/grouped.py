@@ -63,8 +63,12 @@ def make_buckets(prob: torch.Tensor, k: int, scale: float = 1.0) -> Buckets:
             and ext.route_topk_supported(n_tokens, n_blocks):
         # one launch (routing.hip) instead of topk + argsort + bincount + cumsum + gathers
         token, _, offsets, pos, token_long, block_long, coeff = _RouteTopK.apply(prob, k, float(scale))
+        ext.note_path('route_topk', 'kernel')
         return Buckets(token=token, token_long=token_long, block=block_long, offsets=offsets,
                        coeff=coeff, n_blocks=n_blocks, pos=pos)
+    ext.note_path('route_topk', 'torch', fallback=prob.is_cuda,
+                  why=lambda: 'prob {} {}: spt_route_topk takes fp32, <= 8 blocks, <= 65536 tokens'.format(
+                      tuple(prob.shape), prob.dtype))
     indices = torch.topk(prob, k=k, dim=-1, sorted=False).indices       # [T, k]
     block = indices.reshape(-1)
     order = torch.argsort(block, stable=True)
@@ -203,9 +207,13 @@ def _down(a: torch.Tensor, table: torch.Tensor, want_image: bool, want_norms: bo
     """(a @ table, split image of a | None, row norms of a | None): one pass over `a`
     (ext.lora_down) where its shapes allow, else the separate operators."""
     if ext.lora_down_supported(a, table):
+        ext.note_path('lora_down', 'kernel')
         if want_image or want_norms:
             return ext.lora_down(a, table, want_image=want_image, want_norms=want_norms)
         return ext.lora_down(a, table), None, None
+    ext.note_path('lora_down', 'library', fallback=a.is_cuda,
+                  why=lambda: 'a {} x table {}: spt_lora_down takes K % 32 == 0, 16-64 columns'.format(
+                      tuple(a.shape), tuple(table.shape)))
     return (torch.matmul(a, table), ext.split_bf16(a) if want_image else None,
             ext.row_norms(a) if want_norms else None)
 
@@ -217,9 +225,12 @@ def _down_blocks(a: torch.Tensor, table: torch.Tensor, bk: Buckets, want_image: 
     nb = bk.n_blocks
     tables = table.view(nb, table.size(0) // nb, table.size(1))
     if ext.lora_down_grouped_supported(a, tables):
+        ext.note_path('lora_down_grouped', 'kernel')
         if want_image:
             return ext.lora_down_grouped(a, tables, bk.offsets, want_image=True)
         return ext.lora_down_grouped(a, tables, bk.offsets), None
+    ext.note_path('lora_down_grouped', 'side_by_side', fallback=a.is_cuda,
+                  why=lambda: 'a {} x tables {}'.format(tuple(a.shape), tuple(tables.shape)))
     wide, image, _ = _down(a, _block_cat(table, nb), want_image, False)
     return _own_block(wide, bk.block, nb).contiguous(), image
 
@@ -236,17 +247,45 @@ def _tn_blocks(wide: torch.Tensor, per_token: torch.Tensor, bk: Buckets) -> torc
     [P, nb * r] matrix of mostly zeros times wide."""
     nb = bk.n_blocks
     if ext.tall_tn_supported(wide, per_token):
+        ext.note_path('tall_tn_blocks', 'kernel')
         return ext.tall_tn(wide, per_token, gather=bk.token, offsets=bk.offsets).view(nb * wide.size(1), -1)
+    ext.note_path('tall_tn_blocks', 'library', fallback=wide.is_cuda,
+                  why=lambda: 'wide {} x per_token {}'.format(tuple(wide.shape), tuple(per_token.shape)))
     rows = per_token.index_select(0, bk.token_long)
     return _block_major(_tn(wide, _in_own_block(rows, bk.block, nb)), nb)
 
 
-def _offer(ctx, grad_x: torch.Tensor) -> None:
-    """The FFN's input gradient, offered to the router's backward (the same norm output's other
-    consumer, which runs next: tuning/recompute.py RecomputedLinear) to add its own into."""
-    if ctx.origin_module is not None:
-        from naive_gpt.kernels.pq_loss import pending_gradient
-        pending_gradient(ctx.saved_tensors[0], grad_x, tag='norm_output')
+def _route(x: torch.Tensor, rw: torch.Tensor, rb, n_blocks: int, k: int):
+    """The router (sparse/feedforward.py:22-25: Linear + Sigmoid) and the bucketing of its top-k, inside
+    the routed FFN's own autograd node: -> (prob [T, nb], Buckets with coeff = 2 prob
+    (lora_ffn.py:96), block ids as int32 [P])."""
+    prob = torch.sigmoid(torch.nn.functional.linear(x, rw, rb))
+    if ext.route_topk_supported(prob.size(0), n_blocks):
+        ext.note_path('route_topk', 'kernel')
+        token, block, offsets, pos, token_long, block_long, coeff = ext.route_topk_coeff(prob, k, 2.0)
+        return prob, Buckets(token=token, token_long=token_long, block=block_long, offsets=offsets,
+                             coeff=coeff, n_blocks=n_blocks, pos=pos), block
+    bk = make_buckets(prob, k, scale=2.0)
+    return prob, bk, bk.block.int()
+
+
+def _route_backward(ctx, grad_coeff, prob, bk: Buckets, block, x, rw, grad_x):
+    """The router's share of the backward: d coeff [P] -> d logit [T, nb] (one launch: the adjoint of
+    the bucketing chained through the sigmoid), its input gradient ADDED into `grad_x` (the FFN's
+    own, same tensor: one sum inside one autograd node), and the gradients of its weight and bias.
+    -> (grad_rw, grad_rb)."""
+    from naive_gpt.layers.tuning.lora import tall_tn
+    nb = bk.n_blocks
+    if grad_coeff.is_cuda and nb <= 8:
+        dlogit = ext.route_coeff_backward(grad_coeff.contiguous(), bk.pos, block, 2.0, nb, prob=prob)
+    else:
+        dprob = torch.zeros_like(prob)
+        dprob.view(-1).index_put_((bk.token_long * nb + bk.block,), 2.0 * grad_coeff)
+        dlogit = dprob * (1.0 - prob) * prob
+    grad_x.addmm_(dlogit, rw)
+    grad_rw = tall_tn(dlogit, x) if ctx.needs_input_grad[1] else None       # [nb, d]
+    grad_rb = dlogit.sum(dim=0) if ctx.needs_input_grad[2] else None
+    return grad_rw, grad_rb
 
 
 class RoutedLoRAFFN(torch.autograd.Function):
@@ -267,12 +306,13 @@ class RoutedLoRAFFN(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk: Buckets, act: int,
+    def forward(ctx, x, rw, rb, l1, r1, l2, r2, w1, b1, w2, b2, nb: int, top_k: int, act: int,
                 origin_input=None, origin_module=None):
-        nb = bk.n_blocks
         d_ff, d = w1.shape
+        x = x.contiguous()
+        prob, bk, block = _route(x, rw, rb, nb, top_k)
+        coeff = bk.coeff
         bs, rank, rows = d_ff // nb, l1.size(1), bk.token.numel()
-        x, coeff = x.contiguous(), coeff.contiguous()
         # Both block GEMMs run from pre-split images: the weights' are made from the frozen
         # parameters, x's and h's cost one pass each -- the pass that also forms the LoRA down
         # product and, in front of a ReLU, the row norms the kernel wants (include/spt_hip.h:
@@ -297,12 +337,12 @@ class RoutedLoRAFFN(torch.autograd.Function):
         # x is a norm output the block can recompute: keep its origin instead (tuning/recompute.py)
         ctx.origin_module = origin_module
         ctx.save_for_backward(x if origin_module is None else origin_input, coeff, u, h, s, z,
-                              l1, r1, l2, r2, w1, w2)
+                              l1, r1, l2, r2, w1, w2, prob, block, rw)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, coeff, u, h, s, z, l1, r1, l2, r2, w1, w2 = ctx.saved_tensors
+        x, coeff, u, h, s, z, l1, r1, l2, r2, w1, w2, prob, block, rw = ctx.saved_tensors
         if ctx.origin_module is not None:
             x = recompute.output(ctx.origin_module, x).view(-1, w1.size(1))
         bk, act = ctx.bk, ctx.act
@@ -339,15 +379,17 @@ class RoutedLoRAFFN(torch.autograd.Function):
         del ds, du
         grad_x = ext.rows_combine(dxs, bk.pos)
         del dxs
-        _offer(ctx, grad_x)
-        return (grad_x, grad_coeff, grad_l1, grad_r1, grad_l2, grad_r2,
-                None, None, None, None, None, None, None, None)
+        grad_rw, grad_rb = _route_backward(ctx, grad_coeff, prob, bk, block, x, rw, grad_x)
+        return (grad_x, grad_rw, grad_rb, grad_l1, grad_r1, grad_l2, grad_r2,
+                None, None, None, None, None, None, None, None, None)
 
 
-def routed_lora_ffn(x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk: Buckets, act: int, origin=None):
+def routed_lora_ffn(x, rw, rb, l1, r1, l2, r2, w1, b1, w2, b2, n_blocks: int, top_k: int, act: int,
+                    origin=None):
+    """`rw`, `rb`: the router's Linear (its Sigmoid, the top-k and the bucketing run inside)."""
     if origin is None:
-        return RoutedLoRAFFN.apply(x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk, act)
-    return RoutedLoRAFFN.apply(x, coeff, l1, r1, l2, r2, w1, b1, w2, b2, bk, act,
+        return RoutedLoRAFFN.apply(x, rw, rb, l1, r1, l2, r2, w1, b1, w2, b2, n_blocks, top_k, act)
+    return RoutedLoRAFFN.apply(x, rw, rb, l1, r1, l2, r2, w1, b1, w2, b2, n_blocks, top_k, act,
                                origin.input, origin.module)
 
 
@@ -376,20 +418,24 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
     identity for the two up projections."""
 
     @staticmethod
-    def forward(ctx, x, coeff, lg, rg, ls, rs, ld, rd, wg, ws, wd, bk: Buckets, activation,
+    def forward(ctx, x, rw, rb, lg, rg, ls, rs, ld, rd, wg, ws, wd, nb: int, top_k: int, activation,
                 origin_input=None, origin_module=None):
-        nb = bk.n_blocks
         d_ff, d = wg.shape
+        x = x.contiguous()
+        prob, bk, block = _route(x, rw, rb, nb, top_k)
+        coeff = bk.coeff
         bs, rank, rows = d_ff // nb, lg.size(1), bk.token.numel()
-        x, coeff = x.contiguous(), coeff.contiguous()
         imgs = _images_usable(x, wg, wd, d, bs)
         # one pass over x: both adapters' down products and the image both up projections read
         table = torch.cat([lg, ls], dim=1)
         if rank == 16 and ext.lora_down_supported(x, table):
+            ext.note_path('lora_down', 'kernel')
             ugs, x_image, _ = ext.lora_down(x, table, want_image=True, block_major=True) if imgs \
                 else (ext.lora_down(x, table, block_major=True), None, None)
             ug, us = ugs[0], ugs[1]                                               # [T, r]
         else:
+            ext.note_path('lora_down', 'library', fallback=True,
+                          why=lambda: 'gated FFN: x {} x [lg | ls] {}'.format(tuple(x.shape), tuple(table.shape)))
             ug, us = torch.matmul(x, lg), torch.matmul(x, ls)
             x_image = ext.split_bf16(x) if imgs else None
 
@@ -413,12 +459,13 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
         ctx.bk, ctx.activation = bk, activation
         ctx.origin_module = origin_module
         ctx.save_for_backward(x if origin_module is None else origin_input, coeff, ug, us, g, sd,
-                              h, z, lg, rg, ls, rs, ld, rd, wg, ws, wd)
+                              h, z, lg, rg, ls, rs, ld, rd, wg, ws, wd, prob, block, rw)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, coeff, ug, us, g, sd, h, z, lg, rg, ls, rs, ld, rd, wg, ws, wd = ctx.saved_tensors
+        (x, coeff, ug, us, g, sd, h, z, lg, rg, ls, rs, ld, rd, wg, ws, wd, prob, block,
+         rw) = ctx.saved_tensors
         if ctx.origin_module is not None:
             x = recompute.output(ctx.origin_module, x).view(-1, wg.size(1))
         bk, activation = ctx.bk, ctx.activation
@@ -464,17 +511,18 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
         del dxs_s
         grad_x = ext.rows_combine(dxs_g, bk.pos)
         del dxs_g
-        _offer(ctx, grad_x)
         grad_coeff = grad_coeff + dc_g + dc_s
+        grad_rw, grad_rb = _route_backward(ctx, grad_coeff, prob, bk, block, x, rw, grad_x)
         grad_ld = _tn_blocks(h, dzt, bk)
         grad_rd = _tn(dy, ext.rows_combine(z, bk.pos))
-        return (grad_x, grad_coeff, grad_lg, grad_rg, grad_ls, grad_rs, grad_ld, grad_rd,
-                None, None, None, None, None, None, None)
+        return (grad_x, grad_rw, grad_rb, grad_lg, grad_rg, grad_ls, grad_rs, grad_ld, grad_rd,
+                None, None, None, None, None, None, None, None)
 
 
-def routed_lora_llama_ffn(x, coeff, lg, rg, ls, rs, ld, rd, wg, ws, wd, bk: Buckets, activation,
-                          origin=None):
+def routed_lora_llama_ffn(x, rw, rb, lg, rg, ls, rs, ld, rd, wg, ws, wd, n_blocks: int, top_k: int,
+                          activation, origin=None):
     if origin is None:
-        return RoutedLoRALLaMAFFN.apply(x, coeff, lg, rg, ls, rs, ld, rd, wg, ws, wd, bk, activation)
-    return RoutedLoRALLaMAFFN.apply(x, coeff, lg, rg, ls, rs, ld, rd, wg, ws, wd, bk, activation,
-                                    origin.input, origin.module)
+        return RoutedLoRALLaMAFFN.apply(x, rw, rb, lg, rg, ls, rs, ld, rd, wg, ws, wd, n_blocks, top_k,
+                                        activation)
+    return RoutedLoRALLaMAFFN.apply(x, rw, rb, lg, rg, ls, rs, ld, rd, wg, ws, wd, n_blocks, top_k,
+                                    activation, origin.input, origin.module)

@@ -55,9 +55,14 @@ def tall_tn(a: torch.Tensor, b: torch.Tensor, chunk: int = 256) -> torch.Tensor:
         # of these products and is within 10 % of being host-bound)
         from naive_gpt import ext
         if a.size(1) >= b.size(1) and ext.tall_tn_supported(a, b):
+            ext.note_path('tall_tn', 'kernel')
             return ext.tall_tn(a, b)[0]
         if a.size(1) < b.size(1) and ext.tall_tn_supported(b, a):
+            ext.note_path('tall_tn', 'kernel')
             return ext.tall_tn(b, a, transposed=True)[0]
+        ext.note_path('tall_tn', 'library', fallback=True,
+                      why=lambda: 'a {} b {}: spt_tall_tn takes a narrow side of 4, 16 or 48 columns'.format(
+                          tuple(a.shape), tuple(b.shape)))
     if not a.is_cuda or rows % chunk != 0 or rows < 8 * chunk:
         return torch.matmul(a.t(), b)
     parts = rows // chunk
@@ -156,9 +161,16 @@ def _down(x: torch.Tensor, x2: torch.Tensor, left: torch.Tensor, images: bool):
         return u
     if images and ext.lora_down_supported(x2, left) and x2.size(1) % 32 == 0:
         if ext.cached_image(x2, x) is None and not x.is_inference():
+            ext.note_path('lora_down', 'kernel')
             u, image, _ = ext.lora_down(x2, left, want_image=True)
             ext.put_image(x2, x, image)
             return u
+    if images and ext.lora_down_supported(x2, left):
+        # (the image exists already -- another consumer made it: the library's product is as fast alone)
+        ext.note_path('lora_down', 'library_beside_cached_image')
+    else:
+        ext.note_path('lora_down', 'library', fallback=x2.is_cuda and x2.size(0) >= 2048,
+                      why=lambda: 'x {} x left {}'.format(tuple(x2.shape), tuple(left.shape)))
     return torch.matmul(x2, left)
 
 
@@ -168,7 +180,10 @@ def _down_grad(dy2: torch.Tensor, right: torch.Tensor, out: torch.Tensor = None)
     into a column slice `out` of a wider matrix."""
     from naive_gpt import ext
     if ext.lora_down_supported(dy2, right):
+        ext.note_path('lora_down', 'kernel')
         return ext.lora_down(dy2, right, out=out)
+    ext.note_path('lora_down', 'library', fallback=dy2.is_cuda,
+                  why=lambda: 'dy {} x right {}'.format(tuple(dy2.shape), tuple(right.shape)))
     du = torch.matmul(dy2, right)
     if out is None:
         return du
@@ -184,9 +199,14 @@ class _FrozenLoRALinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, left, right):
+        from naive_gpt import ext
         x2 = x.reshape(-1, x.size(-1))
         n, k = weight.shape
         ctx.mfma = _mfma_linear_usable(x2, weight, left.size(1))
+        ext.note_path('lora_linear', 'mfma' if ctx.mfma else 'library', fallback=not ctx.mfma,
+                      why=lambda: 'x {} {} contiguous={} W {}: the split-bf16 GEMM takes fp32, >= 2048 rows, '
+                          'k % 4 == 0, rank <= 32'.format(tuple(x2.shape), x2.dtype, x2.is_contiguous(),
+                                                          tuple(weight.shape)))
         u = _down(x, x2, left, ctx.mfma and x2.is_contiguous())      # [T, r]
         if ctx.mfma:
             # one launch: base product, bias and the side product (the K extension) together
@@ -212,7 +232,12 @@ class _FrozenLoRALinear(torch.autograd.Function):
         grad_x = None
         if ctx.needs_input_grad[0]:
             n, k = weight.shape
-            if ctx.mfma and dy2.is_contiguous() and _mfma_linear_usable(dy2, weight, left.size(1), False):
+            from naive_gpt import ext
+            mfma = ctx.mfma and dy2.is_contiguous() and _mfma_linear_usable(dy2, weight, left.size(1), False)
+            ext.note_path('lora_linear_backward', 'mfma' if mfma else 'library', fallback=not mfma,
+                          why=lambda: 'dy {} contiguous={} W {}'.format(tuple(dy2.shape), dy2.is_contiguous(),
+                                                                tuple(weight.shape)))
+            if mfma:
                 # dX = dY W + dU L^T: the weight read with n contiguous... W'(k', n) = W[n, k']
                 grad_x = _mfma_gemm(dy2, weight, k, n, 1, k, a2=du.contiguous(),
                                     b2=left.contiguous())
@@ -367,7 +392,7 @@ def qkv_usable(x: torch.Tensor, linears) -> bool:
     x2 = x.reshape(-1, x.size(-1))
     n, k = w.shape
     return (x2.is_contiguous() and _mfma_linear_usable(x2, w, 16) and _mfma_linear_usable(x2, w, 16, False)
-            and k % 1024 == 0 and n % 32 == 0
+            and k % 32 == 0 and n % 32 == 0
             and all(m.lora.left.weight.requires_grad and m.lora.right.weight.requires_grad for m in linears))
 
 

@@ -16,9 +16,17 @@ Both use top-k = n_blocks // 2 (also the LLaMA one, unlike its plain base class)
 import torch
 from torch import nn
 
-from naive_gpt import layers
+from naive_gpt import ext, layers
 from naive_gpt.layers.sparse import grouped, routing
 from . import recompute
+
+
+def _plain_router(router) -> bool:
+    """The router as `sparse/feedforward.py:_make_router` builds it (Linear + Sigmoid): what the
+    fused function restates inside its own autograd node."""
+    return (isinstance(router, nn.Sequential) and len(router) == 2
+            and type(router[0]) is nn.Linear and type(router[1]) is nn.Sigmoid
+            and router[0].bias is not None)
 
 
 def _load_routed(model: nn.Module, source: nn.Module):
@@ -62,18 +70,24 @@ class LoRARoutedFFN(layers.RoutedFFN):
         weights (layers/sparse/grouped.py); LoRA side paths as dense K = n_blocks * r
         matmuls on the same row space.  No host synchronisation."""
         nb, bs, d, r = self.n_blocks, self.block_size, self.d_model, self.fc1.lora.left.weight.size(1)
+        act = grouped.activation_code(self.activation)
+        if act is not None and grouped.fused_usable(r) and self.fc2.bias is not None \
+                and not self.fc2.bias.requires_grad and _plain_router(self.router):
+            # four fused block GEMMs, the router and the bucketing of its top-k as ONE autograd
+            # node (layers/sparse/grouped.py: RoutedLoRAFFN); coeff = 2 prob (lora_ffn.py:96)
+            ext.note_path('routed_ffn', 'fused')
+            return grouped.routed_lora_ffn(
+                x, self.router[0].weight, self.router[0].bias,
+                self.fc1.lora.left.weight, self.fc1.lora.right.weight,
+                self.fc2.lora.left.weight, self.fc2.lora.right.weight,
+                self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, nb, nb // 2, act,
+                origin=origin)
         prob = self._router(x, origin)
         bk = grouped.make_buckets(prob, k=nb // 2, scale=2.0)       # coeff = 2 prob (lora_ffn.py:96)
         coeff = bk.coeff
-        act = grouped.activation_code(self.activation)
-        if act is not None and grouped.fused_usable(r) and self.fc2.bias is not None \
-                and not self.fc2.bias.requires_grad:
-            # four fused block GEMMs (layers/sparse/grouped.py: RoutedLoRAFFN)
-            return grouped.routed_lora_ffn(
-                x, coeff, self.fc1.lora.left.weight, self.fc1.lora.right.weight,
-                self.fc2.lora.left.weight, self.fc2.lora.right.weight,
-                self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, bk, act,
-                origin=origin)
+        ext.note_path('routed_ffn', 'grouped_linear', fallback=True,
+                      why=lambda: 'activation {} rank {}: the fused epilogues take ReLU / GELU / SiLU, '
+                          'rank % 4 == 0, rank <= 32, a frozen fc2.bias'.format(type(self.activation).__name__, r))
         rows = torch.arange(bk.block.numel(), device=x.device)
 
         g1 = grouped.grouped_linear(
@@ -101,6 +115,9 @@ class LoRARoutedFFN(layers.RoutedFFN):
         if grouped.usable(x, self.fc1.weight, self.fc1.bias, self.fc2.weight) \
                 and self.d_model % 4 == 0 and self.block_size % 4 == 0:
             return self._forward_grouped(x.contiguous(), origin).view(x_size)
+        ext.note_path('routed_ffn', 'torch_loop', fallback=x.is_cuda,
+                      why=lambda: 'x {} {}: the grouped GEMMs take fp32 CUDA activations and frozen base weights'.format(
+                          tuple(x.shape), x.dtype))
         prob = self.router(x)
         route = routing.route_topk(prob, k=self.n_blocks // 2)
 
@@ -151,17 +168,21 @@ class LoRARoutedLLaMaFFN(layers.RoutedLLaMaFFN):
     def _forward_grouped(self, x: torch.Tensor, origin=None):
         """MI355X path, see LoRARoutedFFN._forward_grouped."""
         nb, bs, d, r = self.n_blocks, self.block_size, self.d_model, self.gate.lora.left.weight.size(1)
+        if grouped.fused_usable(r) and _plain_router(self.router):
+            # three fused block GEMMs forward, router and bucketing inside
+            # (layers/sparse/grouped.py: RoutedLoRALLaMAFFN)
+            ext.note_path('routed_ffn', 'fused')
+            return grouped.routed_lora_llama_ffn(
+                x, self.router[0].weight, self.router[0].bias,
+                self.gate.lora.left.weight, self.gate.lora.right.weight,
+                self.side.lora.left.weight, self.side.lora.right.weight,
+                self.down.lora.left.weight, self.down.lora.right.weight,
+                self.gate.weight, self.side.weight, self.down.weight, nb, nb // 2, self.activation,
+                origin=origin)
         prob = self._router(x, origin)
         bk = grouped.make_buckets(prob, k=nb // 2, scale=2.0)       # coeff = 2 prob (lora_ffn.py:96)
         coeff = bk.coeff
-        if grouped.fused_usable(r):
-            # three fused block GEMMs forward (layers/sparse/grouped.py: RoutedLoRALLaMAFFN)
-            return grouped.routed_lora_llama_ffn(
-                x, coeff, self.gate.lora.left.weight, self.gate.lora.right.weight,
-                self.side.lora.left.weight, self.side.lora.right.weight,
-                self.down.lora.left.weight, self.down.lora.right.weight,
-                self.gate.weight, self.side.weight, self.down.weight, bk, self.activation,
-                origin=origin)
+        ext.note_path('routed_ffn', 'grouped_linear', fallback=True, why=lambda: 'rank {}'.format(r))
         rows = torch.arange(bk.block.numel(), device=x.device)
 
         def up(linear):
@@ -189,6 +210,9 @@ class LoRARoutedLLaMaFFN(layers.RoutedLLaMaFFN):
         if grouped.usable(x, self.gate.weight, self.side.weight, self.down.weight) \
                 and self.d_model % 4 == 0 and self.block_size % 4 == 0:
             return self._forward_grouped(x.contiguous(), origin).view(x_size)
+        ext.note_path('routed_ffn', 'torch_loop', fallback=x.is_cuda,
+                      why=lambda: 'x {} {}: the grouped GEMMs take fp32 CUDA activations and frozen base weights'.format(
+                          tuple(x.shape), x.dtype))
         prob = self.router(x)
         route = routing.route_topk(prob, k=self.n_blocks // 2)
 

@@ -17,8 +17,6 @@ No reference counterpart: the reference keeps every activation (plain autograd).
 import torch
 from torch import nn
 
-from naive_gpt.kernels.pq_loss import _PENDING
-
 _RECOMPUTABLE = (nn.LayerNorm,)
 
 
@@ -43,8 +41,6 @@ def tag(output: torch.Tensor, module: nn.Module, input: torch.Tensor) -> torch.T
     # allocator hands the same addresses out step after step -- so it is dropped here; inside
     # one backward the saved input is alive and its address cannot be reused.
     release()
-    if _PENDING:
-        _PENDING.clear()            # (kernels/pq_loss.py) gradients offered by an earlier backward
     if torch.is_grad_enabled() and input.requires_grad and isinstance(module, _RECOMPUTABLE) \
             and input.is_cuda and not input.is_inference():
         output._spt_origin = Origin(module, input)
@@ -76,7 +72,8 @@ def release():
 
 class RecomputedLinear(torch.autograd.Function):
     """y = x W^T + b for a SMALL trainable linear (the FFN router, d -> 4) whose input is a
-    tagged norm output: saves the norm's input instead of x."""
+    tagged norm output: saves the norm's input instead of x.  (Used by the routed FFN's composed
+    path; the fused function holds its router inside its own node: sparse/grouped.py.)"""
 
     @staticmethod
     def forward(ctx, x, origin_input, weight, bias, module):
@@ -93,15 +90,7 @@ class RecomputedLinear(torch.autograd.Function):
         dy2 = dy.reshape(-1, weight.size(0))
         grad_x = None
         if ctx.needs_input_grad[0]:
-            # the norm output's other consumer (the routed FFN, whose backward ran first) may have
-            # left its gradient for the same tensor: add into it (GEMM with beta = 1) instead of
-            # handing autograd a second [tokens, d] tensor to add (kernels/pq_loss.py: _PENDING)
-            from naive_gpt.kernels.pq_loss import take_pending_gradient
-            other = take_pending_gradient(origin_input, tag='norm_output')
-            if other is not None and other.numel() == dy2.size(0) * weight.size(1):
-                other.view(-1, weight.size(1)).addmm_(dy2, weight)
-            else:
-                grad_x = torch.matmul(dy2, weight).view(ctx.x_shape)
+            grad_x = torch.matmul(dy2, weight).view(ctx.x_shape)
         grad_w = None
         if ctx.needs_input_grad[2]:
             # [out, tokens] x [tokens, d]: as one GEMM a handful of workgroups (39 us for 4 x 8192 x

@@ -140,9 +140,14 @@ class SparseTuner:
         plain = (type(fn) is nn.CrossEntropyLoss and fn.weight is None and fn.reduction == 'mean'
                  and fn.label_smoothing == 0.0)
         if plain and hasattr(model, 'hidden') and hasattr(model, 'lm_output') and torch.is_grad_enabled():
+            from naive_gpt import ext
             h = model.hidden(src)
             if head_loss.fused_usable(model.lm_output, h):
+                ext.note_path('head_loss', 'fused')
                 return head_loss.lm_head_loss(model.lm_output, h, target, fn.ignore_index)
+            ext.note_path('head_loss', 'library', fallback=h.is_cuda,
+                          why=lambda: 'head {} on h {}: the fused loss takes a frozen bias-free LoRALinear, '
+                              'fp32, >= 2048 tokens'.format(type(model.lm_output).__name__, tuple(h.shape)))
             return fn(model.lm_output(h).flatten(end_dim=-2), target=target.flatten())
         return self.shared_step(src, target)[-1]
 

@@ -677,12 +677,6 @@ def test_norm_outputs_are_recomputed_not_kept(monkeypatch):
     block = build()
     run(block)                             # first use: per-weight caches (row norms) fill up
     block.zero_grad()
-    # (the router's gradient joining the FFN's in place -- another rounding than autograd's sum,
-    # next test -- is switched off for the bit-for-bit comparison)
-    import importlib
-    pq = importlib.import_module('naive_gpt.kernels.pq_loss')
-    offer = pq.pending_gradient
-    monkeypatch.setattr(pq, 'pending_gradient', lambda z, g, tag=None: None if tag else offer(z, g))
     y1, gx1, g1, held1 = run(block)
     monkeypatch.setattr(recompute, 'tag', lambda output, module, input: output)
     block.zero_grad()
@@ -700,15 +694,16 @@ def test_norm_outputs_are_recomputed_not_kept(monkeypatch):
     assert held0 - held1 >= 1.9 * act, (held0, held1, act)     # both norm outputs are gone
 
 
-def test_router_gradient_joins_the_ffn_gradient_in_place(monkeypatch):
-    """Behind a recomputed norm the routed FFN offers its input gradient and the router's backward
-    adds its own into it (one GEMM with beta = 1) instead of autograd summing two [tokens, d]
-    tensors: the same numbers to fp32 rounding, and the offer is taken."""
-    from naive_gpt import layers, utils
+def test_third_consumers_of_q_and_of_the_norm_output_keep_their_gradients(monkeypatch):
+    """The fused functions keep every in-place gradient sum inside ONE autograd node (the router
+    inside the routed FFN's, the PQ loss inside the attention's).  A third consumer of q and of the
+    norm output in front of the FFN -- tapped with forward pre-hooks -- must see its gradient
+    arrive whatever the order: against the op-by-op path (per-block torch loop, separate PQ loss
+    function, gather attention), whose sums are all autograd's."""
+    from naive_gpt import ext, layers, utils
+    from naive_gpt.layers.sparse import attention as A, grouped
     import contextlib
-    import importlib
     import io
-    pq = importlib.import_module('naive_gpt.kernels.pq_loss')
     d, heads, d_ff, N, S = 1024, 16, 4096, 2, 512
     torch.manual_seed(0)
     block = layers.TransformerBlock(
@@ -724,24 +719,35 @@ def test_router_gradient_joins_the_ffn_gradient_in_place(monkeypatch):
             p.data.normal_(0, 0.02)
     block = block.cuda()
     x0 = torch.randn([N, S, d], device='cuda')
+    wh = torch.randn([N, S, d], device='cuda')
+    taps = {}
+    block.mha.attn_fn.register_forward_pre_hook(lambda m, args: taps.__setitem__('q', args[0]))
+    block.ffd.register_forward_pre_hook(lambda m, args: taps.__setitem__('h', args[0]))
 
     def run():
         x = x0.clone().requires_grad_(True)
         block.zero_grad()
-        block(x).square().sum().backward()
+        block.mha.attn_fn.arm()
+        y = block(x)
+        loss = y.square().sum() + 2.0 * block.mha.attn_fn.loss \
+            + 0.5 * taps['q'].square().sum() + (taps['h'] * wh).sum()
+        loss.backward()
         return [x.grad.clone()] + [p.grad.clone() for p in block.parameters() if p.grad is not None]
 
-    taken = []
-    take = pq.take_pending_gradient
-    monkeypatch.setattr(pq, 'take_pending_gradient',
-                        lambda z, tag=None: (lambda r: (taken.append(tag) if r is not None else None, r)[1])(take(z, tag)))
-    joined = run()
-    assert taken == ['norm_output'] and not pq._PENDING
-    monkeypatch.setattr(pq, 'pending_gradient', lambda z, g, tag=None: None)
+    ext.reset_paths()
+    fused = run()
+    assert ext.paths_taken('routed_ffn') == {('routed_ffn', 'fused'): 1}
+    assert ext.paths_taken('attention') == {('attention', 'mfma'): 1}
+    monkeypatch.setattr(grouped, 'usable', lambda *a, **k: False)
+    monkeypatch.setattr(A, 'FOLD_PQ_LOSS', False)
+    monkeypatch.setattr(ext, 'attention_mfma_supported', lambda *a: False)
+    ext.reset_paths()
     plain = run()
-    assert len(joined) == len(plain)
-    for a, b in zip(joined, plain):
-        assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * b.abs().max().item())
+    assert ext.paths_taken('routed_ffn') == {('routed_ffn', 'torch_loop'): 1}
+    assert ext.paths_taken('attention') == {('attention', 'fused_gather'): 1}
+    assert len(fused) == len(plain)
+    for a, b in zip(fused, plain):
+        assert _scaled_close(a, b, rtol=2e-3), float((a - b).abs().max() / b.abs().max())
 
 
 def test_frozen_lora_linear_with_a_ragged_output_width(monkeypatch):

@@ -14,7 +14,11 @@ def _close(got, want, name):
 
 
 @pytest.mark.parametrize('rows,K,n', [(8192, 1024, 16), (1000, 1024, 16), (16384, 1024, 64),
-                                      (4096, 2048, 32), (520, 4096, 48), (16, 1024, 16), (5, 1024, 16)])
+                                      (4096, 2048, 32), (520, 4096, 48), (16, 1024, 16), (5, 1024, 16),
+                                      # K % 1024 != 0: the LLaMA-7B FFN block (2752 = 86 k-steps: 22, 22,
+                                      # 21, 21 per wave), fewer steps than waves, one ragged chunk only
+                                      (4096, 2752, 16), (1000, 2752, 32), (77, 32, 16), (300, 96, 16),
+                                      (640, 160, 64), (2048, 11008, 16), (130, 1056, 48)])
 def test_lora_down_is_x_times_table(rows, K, n):
     from naive_gpt import ext
     gen = torch.Generator().manual_seed(rows + n)
@@ -42,21 +46,23 @@ def test_lora_down_reads_a_strided_matrix():
 
 def test_unsupported_shapes_are_refused():
     from naive_gpt import ext
-    x = torch.randn([64, 1000], device='cuda')
+    x = torch.randn([64, 1000], device='cuda')                  # K % 32 != 0
     assert not ext.lora_down_supported(x, torch.randn([1000, 16], device='cuda'))
+    assert ext.lora_down_supported(torch.randn([64, 2752], device='cuda'), torch.randn([2752, 16], device='cuda'))
     assert not ext.lora_down_supported(torch.randn([64, 1024], device='cuda'), torch.randn([1024, 8], device='cuda'))
     with pytest.raises(RuntimeError):
         ext.lora_down(x, torch.randn([1000, 16], device='cuda'))
 
 
+@pytest.mark.parametrize('K', [1024, 2752])
 @pytest.mark.parametrize('sizes', [[4100, 4000, 4200, 4084], [0, 1000, 0, 17], [16, 1, 15, 33, 0, 64]])
-def test_grouped_down_product_per_block_tables(sizes):
+def test_grouped_down_product_per_block_tables(sizes, K):
     """spt_lora_down_grouped: rows sorted by block, each block its own [K, 16] table -- against the
     composition it replaces (all tables side by side, then the row's own block picked out) and an
     fp64 reference; the operand image is the one spt_split_bf16 writes."""
     from naive_gpt import ext
     gen = torch.Generator().manual_seed(len(sizes))
-    P, G, K, r = sum(sizes), len(sizes), 1024, 16
+    P, G, r = sum(sizes), len(sizes), 16
     x = torch.randn([P, K], generator=gen).cuda()
     tables = (torch.randn([G, K, r], generator=gen) * 0.05).cuda()
     offsets = torch.tensor([0] + sizes).cumsum(0).int().cuda()

@@ -360,34 +360,49 @@ def test_bf16_storage_outside_the_matrix_core_path_is_refused():
         attn(q, q, q, attn_mask=None)
 
 
-def test_pq_loss_gradient_joins_the_attention_gradient_in_place(monkeypatch):
-    """An armed layer: the PQ loss's gradient of q / k is added into the attention's gradient
-    tensors by the loss's backward kernel (kernels/pq_loss.py: pending_gradient) instead of by
-    autograd's elementwise sum -- same numbers."""
+def test_pq_loss_is_an_output_of_the_attention_node(monkeypatch):
+    """An armed layer: the PQ loss of q / k is a second output of the attention's autograd node and
+    its input gradient is added into the attention's grad_q / grad_k by the loss's backward kernel,
+    inside that node -- against two separate autograd functions summed by autograd.  q also has a
+    THIRD consumer here (a regulariser): whatever order autograd visits the consumers in, no
+    contribution may be lost (round-2 ADVICE: the earlier process-global hand-over could drop one)."""
     from naive_gpt import layers
-    import importlib
-    pq = importlib.import_module('naive_gpt.kernels.pq_loss')
+    from naive_gpt.layers.sparse import attention as A
     torch.manual_seed(0)
     attn = layers.SparseVanillaAttentionV2(d_head=64, d_codeword=8, n_codewords=16, p_dropout=0.0).cuda()
     q, k, v, w = [torch.randn([2, 256, 16, 64], device='cuda') for _ in range(4)]
 
-    def run():
+    def run(third_first):
         qi, ki, vi = [t.clone().requires_grad_(True) for t in (q, k, v)]
         attn.zero_grad()
         attn.arm()
+        extra = 0.25 * (qi * qi).sum() + (ki * w).sum() if third_first else None
         y = attn(qi, ki, vi, attn_mask=None)
-        ((y * w).sum() + 3.0 * attn.loss).backward()
+        if extra is None:
+            extra = 0.25 * (qi * qi).sum() + (ki * w).sum()
+        ((y * w).sum() + 3.0 * attn.loss + extra).backward()
         return qi.grad, ki.grad, vi.grad, attn.quantizer.weight.grad.clone()
 
-    used = []
-    orig = pq.take_pending_gradient
-    monkeypatch.setattr(pq, 'take_pending_gradient', lambda z: used.append(1) or orig(z))
-    joined = run()
-    assert len(used) == 2 and not pq._PENDING                  # q and k: both taken
-    monkeypatch.setattr(pq, 'pending_gradient', lambda z, g: None)
-    plain = run()
-    for a, b in zip(joined, plain):
-        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * b.abs().max().item())
+    assert A.FOLD_PQ_LOSS
+    folded = [run(False), run(True)]
+    assert attn.loss.grad_fn is not None and 'MfmaAttention' in type(attn.loss.grad_fn).__name__
+    monkeypatch.setattr(A, 'FOLD_PQ_LOSS', False)
+    plain = run(False)
+    assert 'PQLoss' in str(type(attn.loss.grad_fn.next_functions[0][0]))
+    for got in folded:
+        for a, b in zip(got, plain):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * b.abs().max().item())
+    # only the loss is used: the attention's share of the gradients is zero, the loss's is there
+    qi = q.clone().requires_grad_(True)
+    monkeypatch.setattr(A, 'FOLD_PQ_LOSS', True)
+    attn.zero_grad()
+    attn.arm()
+    attn(qi, k, v, attn_mask=None)
+    attn.loss.backward()
+    assert qi.grad is not None and float(qi.grad.abs().max()) > 0
+    qj = q.clone().requires_grad_(True)
+    attn.quantizer.train_loss(qj).backward()
+    assert torch.allclose(qi.grad, qj.grad, rtol=1e-5, atol=1e-7)
 
 
 def test_host_side_arming_equals_the_reference_protocol():
