@@ -11,8 +11,15 @@
 //     z[i, :] <- (softmax(z[i, :]) - onehot(target_i)) * scale          (scale = 1 / #targets)
 // over the logits.  Rows may be padded (ld >= n_classes, ld % 4 == 0): the pad columns are
 // written as zeros, so that the buffer is directly the A operand of the head's backward GEMM
-// (contraction over the vocabulary, 16-byte aligned rows).  fp32 throughout, expf / logf as the
-// library uses; the row reductions are fixed-order trees (reproducible).
+// (contraction over the vocabulary, 16-byte aligned rows).  fp32 throughout; exp and log are the
+// fast intrinsics (__expf / __logf: v_exp_f32 / v_log_f32 with a pre-scale, ~2 ulp -- the library's
+// log_softmax uses the precise expf / logf; tests bound the difference at 1e-5 of the loss, 1e-4 of a
+// gradient element); the row reductions are fixed-order trees (reproducible).
+// Two deliberate differences from nn.CrossEntropyLoss: a target outside [0, n_classes) that is not
+// `ignore_index` counts as ignored here (torch: a device-side assert), and a row that is not
+// counted gets a zero gradient even when NO row is counted (torch's mean then divides 0 by 0: the
+// host side, layers/tuning/head_loss.py, returns torch's NaN loss in that case; the gradients stay
+// zero instead of NaN).
 #include "spt_common.h"
 
 namespace spt {

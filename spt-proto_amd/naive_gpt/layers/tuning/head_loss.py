@@ -93,10 +93,13 @@ class _FrozenLoRAHeadLoss(torch.autograd.Function):
                                a_image=ext.image_of(x2, x) if images else None,
                                w_image=ext.weight_image(weight) if images else None, out=buf)
         target = target.reshape(-1).contiguous()
-        counted = ((target != ignore_index) & (target >= 0) & (target < V)).sum()
-        scale = (1.0 / counted.clamp_min(1).to(torch.float32)).reshape(1)
+        # (a target outside [0, V) that is not `ignore_index` counts as ignored -- torch raises a
+        # device-side assert there; documented in csrc/head_loss.hip)
+        counted = ((target != ignore_index) & (target >= 0) & (target < V)).sum().to(torch.float32)
+        scale = (1.0 / counted.clamp_min(1.0)).reshape(1)
         rows_loss = ext.cross_entropy_grad_(buf, V, target, scale, ignore_index)
-        loss = rows_loss.sum() * scale[0]
+        # the mean over the counted targets; no counted target at all: 0 / 0 = NaN, as torch's mean
+        loss = rows_loss.sum() / counted
         # buf now holds d loss / d logits (pad columns zero).  Everything that needs it, now:
         dl = buf[:, :V]
         du = torch.matmul(dl, right)                                   # [T, r]

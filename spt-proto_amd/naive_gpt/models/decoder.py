@@ -14,6 +14,17 @@ import torch
 from torch import nn
 
 
+def _has_hooks(module: nn.Module) -> bool:
+    """Forward (pre-)hooks or backward hooks on `module`, or registered for every module: the pair
+    form below calls `block.forward_pair` directly, which `nn.Module.__call__`'s hooks never see --
+    a hooked block (profilers, activation checkpoint wrappers that hook) takes the plain loop."""
+    from torch.nn.modules import module as M
+    return bool(module._forward_hooks or module._forward_pre_hooks or module._backward_hooks
+                or module._backward_pre_hooks or M._global_forward_hooks
+                or M._global_forward_pre_hooks or M._global_backward_hooks
+                or M._global_backward_pre_hooks)
+
+
 class DecoderLM(nn.Module):
     #: OPT stores positions shifted by two (a fairseq padding convention); 0 = no
     #: learned positions at all (LLaMA: rotary, inside the attention)
@@ -49,7 +60,7 @@ class DecoderLM(nn.Module):
         mask = self.attn_mask[:seq_length, :seq_length]
         h = self.embed(x)
         if all(getattr(block, 'pre_norm', False) and hasattr(block, 'forward_pair')
-               for block in self.decoders):
+               and not _has_hooks(block) for block in self.decoders):
             # pre-norm stack as (stream, pending addend) pairs: each residual addition is fused
             # with the norm behind it, the last one with the final norm (layers/basic/fused_norm.py)
             from naive_gpt.layers.basic import fused_norm

@@ -21,6 +21,7 @@ would deliver.
 import contextlib
 import io
 import math
+import weakref
 from typing import Iterable, Optional
 
 import torch
@@ -117,8 +118,16 @@ class SparseTuner:
         # (every sub-module's `loss` buffer, as `named_buffers()` names ending in '.loss' -- from a
         # module list made once: the walk over a 24-layer model's ~930 modules is ~1 ms of host
         # time per step, and the step is within 10 % of being host-bound)
-        if self._submodules is None:
-            self._submodules = [m for m in self.model.modules() if m is not self.model]
+        # (the list is re-made when any module's set of children has changed -- an upgrade or a
+        # replaced layer after the first step: ~0.1 ms for the fingerprint against ~1 ms for the walk)
+        mark = None
+        if self._submodules is not None:
+            mark = hash(tuple(id(c) for m in self._submodules_all for c in m._modules.values()))
+        if self._submodules is None or mark != self._submodules_mark:
+            self._submodules_all = list(self.model.modules())
+            self._submodules = [m for m in self._submodules_all if m is not self.model]
+            self._submodules_mark = hash(tuple(id(c) for m in self._submodules_all
+                                               for c in m._modules.values()))
         losses = [m._buffers['loss'] for m in self._submodules if m._buffers.get('loss') is not None]
         if not losses:
             return 0.0
@@ -139,7 +148,12 @@ class SparseTuner:
         model, fn = self.model, self.loss_fn
         plain = (type(fn) is nn.CrossEntropyLoss and fn.weight is None and fn.reduction == 'mean'
                  and fn.label_smoothing == 0.0)
-        if plain and hasattr(model, 'hidden') and hasattr(model, 'lm_output') and torch.is_grad_enabled():
+        # (`model.hidden` / `model.lm_output` are called directly: a model with hooks of its own
+        # goes through `model(...)` so that they fire)
+        hooked = bool(model._forward_hooks or model._forward_pre_hooks
+                      or getattr(getattr(model, 'lm_output', None), '_forward_hooks', None))
+        if plain and not hooked and hasattr(model, 'hidden') and hasattr(model, 'lm_output') \
+                and torch.is_grad_enabled():
             from naive_gpt import ext
             h = model.hidden(src)
             if head_loss.fused_usable(model.lm_output, h):
@@ -154,12 +168,15 @@ class SparseTuner:
     def training_step(self, batch: torch.Tensor, pq_loss: bool = True) -> torch.Tensor:
         """One micro-batch: forward, backward; every ``n_accumulate``-th call also
         exchanges, clips and applies the gradients.  Returns the (detached) loss.
-        After `capture()` a batch of the captured shape replays the HIP graph."""
+        After `capture()` a batch of the captured shape replays the HIP graph (the returned loss is
+        a copy of the graph's static output: callers may keep it across steps)."""
         if self._graph is not None and batch.shape == self._graph_batch.shape \
                 and pq_loss == self._graph_pq:
+            if not self.model.training:
+                self.model.train()
             self._graph_batch.copy_(batch)
             self._graph.replay()
-            return self._graph_loss
+            return self._graph_loss.clone()
         return self._eager_step(batch, pq_loss)
 
     def _eager_step(self, batch: torch.Tensor, pq_loss: bool = True) -> torch.Tensor:
@@ -177,20 +194,69 @@ class SparseTuner:
             self.apply_gradients()
         return loss.detach()
 
+    FLAT_ALIGN = 4          # elements: every slice starts on a 16-byte boundary (float4 kernels read
+                            # gamma / beta, LoRA tables and biases straight out of these views)
+
     def _flatten(self) -> None:
+        for p in self.params:
+            owner = getattr(p, '_spt_flat_owner', None)
+            owner = owner() if owner is not None else None
+            if owner is not None and owner is not self and owner._flat is not None:
+                raise RuntimeError(
+                    'SparseTuner: these parameters already live in the flat buffer of another live '
+                    'SparseTuner (its optimiser would go on updating memory the model no longer '
+                    'reads): call `release()` on that tuner first')
         sizes = [p.numel() for p in self.params]
+        align = self.FLAT_ALIGN
+        offsets, total = [], 0
+        for n in sizes:
+            offsets.append(total)
+            total += (n + align - 1) // align * align
         first = self.params[0]
         with torch.no_grad():
-            flat = torch.empty([sum(sizes)], dtype=first.dtype, device=first.device)
-            offset = 0
-            for p, n in zip(self.params, sizes):
+            flat = torch.zeros([total], dtype=first.dtype, device=first.device)
+            for p, n, offset in zip(self.params, sizes, offsets):
                 view = flat[offset:offset + n].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
-                offset += n
+                p._spt_flat_owner = weakref.ref(self)
         self._flat = nn.Parameter(flat)
         self._flat_grad = torch.zeros_like(flat)
-        self._sizes = sizes
+        self._sizes, self._offsets = sizes, offsets
+        # the gaps behind slices whose length is not a multiple of FLAT_ALIGN: zero gradient there
+        # (zero parameter, zero moments: AdamW leaves them at zero)
+        self._pads = {}
+        for i, (n, offset) in enumerate(zip(sizes, offsets)):
+            end = offsets[i + 1] if i + 1 < len(offsets) else total
+            if end - offset != n:
+                self._pads[i] = torch.zeros([end - offset - n], dtype=first.dtype, device=first.device)
+
+    def _check_flat_views(self) -> None:
+        """Every trainable `p.data` must still be ITS slice of the flat buffer (the optimiser only
+        owns the buffer).  `model.to()`, `.float()`, `p.data = ...` or a checkpoint loaded with
+        `assign=True` re-point a parameter silently: its current values are then copied back into
+        the slice and the view restored; another dtype or device cannot be expressed and raises."""
+        base, item = self._flat.data_ptr(), self._flat.element_size()
+        for p, n, offset in zip(self.params, self._sizes, self._offsets):
+            if p.data_ptr() == base + offset * item:
+                continue
+            if p.dtype != self._flat.dtype or p.device != self._flat.device or p.numel() != n:
+                raise RuntimeError(
+                    'SparseTuner: a trainable parameter was moved to {} / {} after the tuner was '
+                    'built; build the tuner after `model.to(...)`'.format(p.device, p.dtype))
+            with torch.no_grad():
+                view = self._flat.data[offset:offset + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+
+    def release(self) -> None:
+        """Give the parameters back: one optimiser entry per parameter from now on (state carried
+        over), no flat buffer; another tuner may then be built on the same model."""
+        if self._flat is not None:
+            self._unflatten()
+        for p in self.params:
+            if getattr(p, '_spt_flat_owner', None) is not None and p._spt_flat_owner() is self:
+                p._spt_flat_owner = None
 
     def _optimised(self):
         return [self._flat] if self._flat is not None else self.params
@@ -198,7 +264,15 @@ class SparseTuner:
     def _gather_gradients(self) -> None:
         """p.grad of every trainable parameter, side by side in `_flat_grad` (torch.cat: one
         launch per 128 tensors)."""
-        torch.cat([p.grad.reshape(-1) for p in self.params], out=self._flat_grad)
+        if not self._pads:
+            parts = [p.grad.reshape(-1) for p in self.params]
+        else:
+            parts = []
+            for i, p in enumerate(self.params):
+                parts.append(p.grad.reshape(-1))
+                if i in self._pads:
+                    parts.append(self._pads[i])
+        torch.cat(parts, out=self._flat_grad)
         self._flat.grad = self._flat_grad
 
     def _unflatten(self) -> None:
@@ -214,19 +288,19 @@ class SparseTuner:
             new.param_groups[0]['initial_lr'] = group['initial_lr']
         state = old.state.get(self._flat)
         if state:
-            offset = 0
-            for p, n in zip(self.params, self._sizes):
+            for p, n, offset in zip(self.params, self._sizes, self._offsets):
                 new.state[p] = {
                     'step': state['step'].clone() if torch.is_tensor(state['step']) else state['step'],
                     'exp_avg': state['exp_avg'][offset:offset + n].view_as(p).clone(),
                     'exp_avg_sq': state['exp_avg_sq'][offset:offset + n].view_as(p).clone()}
-                offset += n
         self.optimizer = new
         if isinstance(self.scheduler.optimizer, optim.AdamW):       # (not the capturable tuner's stand-in)
             self.scheduler.optimizer = new
         self._flat = self._flat_grad = None     # (the parameters stay views of the buffer: harmless)
 
     def apply_gradients(self) -> None:
+        if self._flat is not None:
+            self._check_flat_views()
         if self._flat is not None and any(p.grad is None for p in self.params):
             self._unflatten()
         if self._flat is None:

@@ -73,6 +73,52 @@ def test_fused_head_loss_equals_cross_entropy_of_the_lora_head(d, V):
     assert head.weight.is_contiguous() and not head.weight.requires_grad
 
 
+def test_fused_head_loss_with_ignored_and_uncounted_targets():
+    """ignore_index rows, an all-ignored batch and out-of-range targets (round-2 ADVICE).  Against
+    nn.CrossEntropyLoss where it defines a value: ignored rows drop out of the mean; no counted
+    target at all gives torch's NaN loss (gradients: zeros here).  A target outside [0, V) that is
+    not ignore_index is treated as ignored -- torch raises a device-side assert there, so that
+    case has no reference value: parity unpinned, behaviour documented in csrc/head_loss.hip."""
+    from naive_gpt.layers.tuning import head_loss
+    d, V = 256, 1000
+    head = _head(d, V)
+    x = torch.randn([2, 1024, d], device='cuda')
+    target = torch.randint(0, V, [2, 1024], device='cuda')
+    target[:, ::3] = -100
+
+    def fused(tgt):
+        head.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        loss = head_loss.lm_head_loss(head, xi, tgt)
+        loss.backward()
+        return loss.detach(), xi.grad, head.lora.left.weight.grad.clone(), head.lora.right.weight.grad.clone()
+
+    def composed(tgt):
+        head.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        loss = nn.CrossEntropyLoss()(head(xi).flatten(end_dim=-2), tgt.flatten())
+        loss.backward()
+        return loss.detach(), xi.grad, head.lora.left.weight.grad.clone(), head.lora.right.weight.grad.clone()
+
+    got, want = fused(target), composed(target)
+    assert torch.allclose(got[0], want[0], rtol=1e-5)
+    for a, b in zip(got[1:], want[1:]):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * b.abs().max().item())
+    assert float(got[1].view(-1, d)[::3].abs().max()) == 0.0        # ignored rows: no input gradient
+    # nothing counted: torch's mean is 0 / 0
+    nothing = torch.full_like(target, -100)
+    got = fused(nothing)
+    assert torch.isnan(got[0]) and torch.isnan(composed(nothing)[0])
+    assert all(float(g.abs().max()) == 0.0 for g in got[1:])
+    # out-of-range targets count as ignored (no reference value: torch asserts on the device)
+    wild = target.clone()
+    wild[:, 1::3] = V + 5
+    ignored = target.clone()
+    ignored[:, 1::3] = -100
+    a, b = fused(wild), fused(ignored)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
 def test_fused_head_loss_is_what_the_tuner_steps_on():
     """SparseTuner.step_loss takes the fused path for an upgraded model and gives the loss (and,
     through backward, the gradients) of the plain composition."""

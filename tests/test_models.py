@@ -229,12 +229,13 @@ def test_flat_parameter_store_takes_the_per_tensor_step(oracle_ext, monkeypatch)
     _, model_b = upgraded_from_golden('opt', 'cpu')
     batch = T(g['batch'])
     flat = utils.SparseTuner(model_a)
-    assert flat._flat is not None and flat._flat.numel() == sum(p.numel() for p in flat.params)
-    # every trainable parameter is a view of the flat buffer, in order
+    assert flat._flat is not None and flat._flat.numel() >= sum(p.numel() for p in flat.params)
+    # every trainable parameter is a view of the flat buffer, in order, on a 16-byte boundary
     offset = 0
     for p in flat.params:
-        assert p.data_ptr() == flat._flat.data_ptr() + 4 * offset
-        offset += p.numel()
+        assert p.data_ptr() == flat._flat.data_ptr() + 4 * offset and (4 * offset) % 16 == 0
+        offset += (p.numel() + 3) // 4 * 4
+    assert offset == flat._flat.numel()
     monkeypatch.setattr(utils.SparseTuner, 'FLAT_LIMIT', 0)
     plain = utils.SparseTuner(model_b)
     assert plain._flat is None
@@ -251,6 +252,123 @@ def test_flat_parameter_store_takes_the_per_tensor_step(oracle_ext, monkeypatch)
     sd = model_a.state_dict()
     for n, p in model_a.named_parameters():
         assert torch.equal(sd[n], p)
+
+
+def test_flat_store_survives_repointed_parameters_and_refuses_a_second_owner(oracle_ext):
+    """Round-2 ADVICE: the optimiser only owns the flat buffer, so a parameter whose `.data` was
+    re-pointed (`model.float()`, `p.data = ...`) would silently stop being trained, and a second
+    tuner on the same model would leave the first one updating dead memory.  The tuner now checks
+    the views before every update (re-homes a moved parameter with its current values), pads every
+    slice to 16 bytes (float4 kernels read the views) and refuses a second live owner."""
+    from naive_gpt import utils
+    g, model_a = upgraded_from_golden('opt', 'cpu')
+    _, model_b = upgraded_from_golden('opt', 'cpu')
+    batch = T(g['batch'])
+    # a trainable parameter whose length is not a multiple of four elements: padded slice
+    odd_a, odd_b = [torch.nn.Parameter(torch.full([7], 0.5)) for _ in range(2)]
+    model_a.register_parameter('odd', odd_a)
+    model_b.register_parameter('odd', odd_b)
+    a, b = utils.SparseTuner(model_a), utils.SparseTuner(model_b)
+    assert a._pads and all(off % 4 == 0 for off in a._offsets)
+    for tuner, odd in ((a, odd_a), (b, odd_b)):
+        hook = tuner.model.embedding.register_forward_hook(lambda m, i, o, odd=odd: o + odd.sum() * 1e-3)
+        tuner._hook = hook
+    a.training_step(batch)
+    b.training_step(batch)
+    # re-point two parameters of model_b the way `model.float()` / a manual assignment would
+    moved = [p for p in b.params if p.dim() == 2][:2]
+    for p in moved:
+        p.data = p.data.clone() * 1.0
+    assert any(p.data_ptr() != b._flat.data_ptr() + 4 * off for p, off in zip(b.params, b._offsets))
+    a.training_step(batch)
+    b.training_step(batch)                                  # heals the views, then updates
+    for p, off in zip(b.params, b._offsets):
+        assert p.data_ptr() == b._flat.data_ptr() + 4 * off
+    for (n, pa), pb in zip(model_a.named_parameters(), model_b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-8), n
+    assert not torch.equal(odd_a.detach(), torch.full([7], 0.5))         # the padded slice is trained
+    # a second owner is refused while the first is alive; `release()` hands the parameters back
+    with pytest.raises(RuntimeError):
+        utils.SparseTuner(model_a)
+    a.release()
+    c = utils.SparseTuner(model_a)
+    assert c._flat is not None
+    a.training_step(batch)                                   # the released tuner still steps (per tensor)
+    # another dtype cannot be expressed by the flat buffer: loud, not silent
+    c.params[0].data = c.params[0].data.double()
+    with pytest.raises(RuntimeError):
+        c.apply_gradients()
+
+
+def test_aux_loss_sees_modules_replaced_after_the_first_step(oracle_ext):
+    """`aux_loss` caches the module list; a layer replaced later (same parent, same name) must
+    still be found (round-2 ADVICE)."""
+    import copy
+    from naive_gpt import utils
+    g, model = upgraded_from_golden('opt', 'cpu')
+    tuner = utils.SparseTuner(model)
+    batch = T(g['batch'])
+    tuner.training_step(batch)
+    block = model.decoders[0]
+    old = block.mha.attn_fn
+    old._buffers.pop('loss', None)                           # (a graph output: not deep-copyable)
+    block.mha.add_module('attn_fn', copy.deepcopy(old))
+    assert block.mha.attn_fn is not old
+    tuner._armable = [m for m in model.modules() if hasattr(m, 'arm')]
+    tuner.arm_triggers()
+    model(batch[:, 1:-1])
+    found = tuner.aux_loss()
+    want = sum(m._buffers['loss'] for m in model.modules() if m._buffers.get('loss') is not None)
+    assert torch.allclose(found, want)
+    assert block.mha.attn_fn._buffers.get('loss') is not None
+
+
+def test_hooked_blocks_and_checkpointed_blocks_take_the_same_step(oracle_ext):
+    """`DecoderLM.hidden` runs the pre-norm stack as (stream, addend) pairs through
+    `block.forward_pair`, past `nn.Module.__call__`: a block with hooks must still see them fire
+    (it takes the plain loop), and a block whose forward is re-run inside the backward (activation
+    checkpointing: `recompute.tag` drops its one-entry cache on every forward) must produce the same
+    gradients (round-2 ADVICE)."""
+    from torch.utils import checkpoint as ckpt
+    from naive_gpt import utils
+    g, model = upgraded_from_golden('opt', 'cpu')
+    batch = T(g['batch'])
+    src, target = batch[:, 1:-1], batch[:, 2:]
+
+    def grads():
+        model.zero_grad()
+        out = model(src)
+        torch.nn.functional.cross_entropy(out.flatten(end_dim=-2), target.flatten()).backward()
+        return out.detach(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    out0, g0 = grads()
+    seen = []
+    handle = model.decoders[0].register_forward_hook(lambda m, i, o: seen.append(tuple(o.shape)))
+    out1, g1 = grads()
+    handle.remove()
+    assert seen == [tuple(out0.shape[:2]) + (model.embedding.embedding_dim,)]
+    assert torch.allclose(out1, out0, rtol=1e-5, atol=1e-6)
+    for n in g0:
+        assert torch.allclose(g1[n], g0[n], rtol=1e-4, atol=1e-7), n
+    # every block under torch.utils.checkpoint (its forward runs again in the backward)
+    block = model.decoders[0]
+    original = type(block).forward_pair
+
+    def checkpointed(self, x, pending, attn_mask=None):
+        if pending is None:
+            pending = torch.zeros_like(x)
+        return ckpt.checkpoint(lambda a, b: original(self, a, b, attn_mask=attn_mask), x, pending,
+                               use_reentrant=False)
+
+    type(block).forward_pair = checkpointed
+    try:
+        out2, g2 = grads()
+    finally:
+        type(block).forward_pair = original
+    assert torch.allclose(out2, out0, rtol=1e-5, atol=1e-6)
+    assert set(g2) == set(g0)
+    for n in g0:
+        assert torch.allclose(g2[n], g0[n], rtol=1e-4, atol=1e-7), n
 
 
 def test_unarmed_step_registers_no_pq_loss(oracle_ext):
