@@ -152,9 +152,27 @@ class GemmTimer:
 
 
 # ------------------------------------------------------------------------------- builders
+class SDPAAttention(nn.Module):
+    """Dense causal attention through the library's fused kernel
+    (F.scaled_dot_product_attention, is_causal): the `full_sdpa` / `lora_sdpa` legs -- the dense
+    baselines with an attention that, like the sparse path, never materialises the [S, S] scores.
+    Same function as layers.VanillaAttention with the causal mask (attention.py:21-31)."""
+
+    def __init__(self, d_head: int):
+        super().__init__()
+        self.scaling = float(d_head) ** -0.5
+
+    def forward(self, q, k, v, attn_mask=None):
+        y = nn.functional.scaled_dot_product_attention(
+            q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), is_causal=True, scale=self.scaling)
+        return y.transpose(1, 2).contiguous()
+
+
 def build_model(tuning, dev, layers=LAYERS):
     from naive_gpt import models, utils
     torch.manual_seed(0)
+    sdpa = tuning.endswith('_sdpa')
+    tuning = tuning.replace('_sdpa', '')
     with torch.device(dev):
         model = models.OPTModel(d_model=D_MODEL, n_heads=H, n_layers=layers, max_length=S,
                                 vocab_size=VOCAB, d_feedforward=D_FF, p_dropout=0.0)
@@ -162,6 +180,9 @@ def build_model(tuning, dev, layers=LAYERS):
             model = utils.upgrade_sparse(model, d_lora=16, stages=('lora',))
         elif tuning == 'sparse':
             model = utils.upgrade_sparse(model, d_lora=16)
+        if sdpa:
+            for block in model.decoders:
+                block.mha.attn_fn = SDPAAttention(E)
     return model.to(dev)
 
 
@@ -201,21 +222,47 @@ def model_record(tuning, args, world, rank, dev, gemm_timer=None):
         batch = torch.randint(3, VOCAB, [N, S + 2], device=dev, generator=gen)
         tuner.training_step(batch, pq_loss=(tuning == 'sparse'))
 
+    rec = {}
+    if world > 1:
+        # step 0 of the run, outside the timed region: every rank must clip by the SAME norm (the
+        # norm is taken after the exchange) -- what proves that the all-reduce averaged the ranks'
+        # different micro-batches and that the replicas started identical
+        step()
+        norms = [torch.zeros([], device=dev) for _ in range(world)]
+        dist.all_gather(norms, tuner.last_grad_norm.detach().float().reshape([]))
+        norms = [float(t) for t in norms]
+        assert all(abs(n - norms[0]) <= 1e-6 * abs(norms[0]) for n in norms), \
+            'clip norms differ over the ranks: {}'.format(norms)
+        rec['clip_norm_step0'] = norms[0]
+        rec['clip_norm_equal_on_all_ranks'] = True
     timed_loop(step, 0, args.warmup, world)
     if gemm_timer is not None:
         gemm_timer.reserve(2 * args.layers * args.steps + 8)
         gemm_timer.enabled = True
+    if world > 1:
+        tuner.allreduce_every = 2                  # HIP events around every 2nd exchange, timed region
+        tuner.allreduce_events.clear()
     dt = timed_loop(step, args.steps, 0, world)
     if gemm_timer is not None:
         gemm_timer.enabled = False
     tokens = N * S * world * args.steps
     trainable = sum(p.numel() for p in tuner.params)
-    rec = {'value': tokens / dt, 'unit': 'tokens/s', 'ms_per_step': 1e3 * dt / args.steps,
-           'peak_hbm_gb': torch.cuda.max_memory_allocated() / 1e9,
-           'trainable_params': trainable,
-           'total_params': sum(p.numel() for p in model.parameters())}
+    rec.update({'value': tokens / dt, 'unit': 'tokens/s', 'ms_per_step': 1e3 * dt / args.steps,
+                'peak_hbm_gb': torch.cuda.max_memory_allocated() / 1e9,
+                'trainable_params': trainable,
+                'total_params': sum(p.numel() for p in model.parameters())})
     if world > 1:
-        rec['allreduce_bytes_per_step'] = 4 * trainable
+        nbytes = 4 * (tuner._flat.numel() if tuner._flat is not None else trainable)
+        rec['allreduce_bytes_per_step'] = nbytes
+        if tuner.allreduce_events:
+            ms = float(np.mean([a.elapsed_time(b) for a, b in tuner.allreduce_events]))
+            t = torch.tensor([ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t.item())
+            rec['allreduce_ms'] = ms
+            # ring / tree-independent "bus bandwidth" of an all-reduce: 2 (N - 1) / N of the bytes
+            rec['allreduce_bus_gbs'] = 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9
+            rec['allreduce_sampled'] = len(tuner.allreduce_events)
     del model, tuner
     _release()
     return rec
@@ -455,7 +502,41 @@ def cpu_baseline(args):
         rec['oracle_1core'] = cpu_oracle(args.cpu_seqs)
     except Exception as exc:                    # the baseline line must not die with the extra
         rec['oracle_1core'] = {'error': repr(exc)}
+    try:
+        rec['c1_dense_block_forward'] = cpu_c1()
+    except Exception as exc:
+        rec['c1_dense_block_forward'] = {'error': repr(exc)}
     return rec
+
+
+def cpu_c1():
+    """BASELINE.json configs[0] / BASELINE.md 3 "C1": the dense TransformerBlock at BERT-base
+    dimensions (d 768, 12 heads, d_ff 3072), `randn[8, 128, 768]`, forward only, PyTorch CPU -- the
+    reference's own CPU-runnable case (plumbing; BASELINE.md 4 quotes 36.6 ms for the imported
+    reference on the 8-core survey container).  3 warm-up + 10 timed calls, median."""
+    from naive_gpt import layers
+    torch.manual_seed(0)
+    d, heads, d_ff, n, s = 768, 12, 3072, 8, 128
+    block = layers.TransformerBlock(
+        d_model=d, n_heads=heads, layernorm_fn=nn.LayerNorm(d),
+        attention_fn=layers.VanillaAttention(d_head=d // heads, p_dropout=0.0),
+        feedforward_fn=layers.Feedforward(d_model=d, d_feedforward=d_ff, activation=nn.ReLU(),
+                                          p_dropout=0.0),
+        attention_bias=True, pre_norm=True)
+    x = torch.randn([n, s, d])
+    mask = torch.full([s, s], float('-inf')).triu(1)
+    times = []
+    with torch.no_grad():
+        for i in range(13):
+            t0 = time.perf_counter()
+            block(x, attn_mask=mask)
+            if i >= 3:
+                times.append(time.perf_counter() - t0)
+    ms = 1e3 * float(np.median(times))
+    return {'value': n * s / (ms * 1e-3), 'unit': 'tokens/s', 'ms_per_call': ms,
+            'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'dense TransformerBlock d 768 / 12 heads / d_ff 3072, randn[8, 128, 768], '
+                      'forward, PyTorch CPU fp32, median of 10 calls'}
 
 
 def measured_traffic(kernel_prefix):
@@ -543,12 +624,19 @@ def main():
             'arithmetic': 'fp32 tensors; dense and attention products = 3 bf16 MFMAs on hi/lo-'
                           'split fp32 operands, fp32 accumulation (ReLU pre-activations within '
                           'the split error of zero recomputed in fp32); PQ codes / top-k '
-                          'indices exact'},
+                          'indices exact.  The dense full fine-tune leg (`full`) runs its linears '
+                          'on the library fp32 GEMM; the LoRA leg runs its frozen linears on the '
+                          'same split-bf16 engine as the sparse step'},
         'peak_hbm_gb': sparse['peak_hbm_gb'],
         'trainable_params': sparse['trainable_params'], 'total_params': sparse['total_params'],
     }
     if world > 1:
-        result['allreduce_bytes_per_step'] = sparse['allreduce_bytes_per_step']
+        result['ranks'] = dist.get_world_size()
+        result['backend'] = dist.get_backend()
+        for key in ('allreduce_bytes_per_step', 'allreduce_ms', 'allreduce_bus_gbs', 'allreduce_sampled',
+                    'clip_norm_step0', 'clip_norm_equal_on_all_ranks'):
+            if key in sparse:
+                result[key] = sparse[key]
 
     if rank == 0 and gemm is not None:
         per_step = gemm['calls'] / args.steps
@@ -575,6 +663,23 @@ def main():
         result['peak_hbm_vs_dense'] = result['peak_hbm_gb'] / result['full']['peak_hbm_gb']
         result['speedup_vs_lora'] = result['value'] / result['lora']['value']
         result['peak_hbm_vs_lora'] = result['peak_hbm_gb'] / result['lora']['peak_hbm_gb']
+        # the same two baselines with a fused dense attention (F.scaled_dot_product_attention):
+        # no [S, S] score tensors, so the memory ratio is quoted against that too
+        for tuning in ('full_sdpa', 'lora_sdpa'):
+            try:
+                result[tuning] = model_record(tuning, args, world, rank, dev)
+                base = tuning.split('_')[0]
+                result['speedup_vs_{}_sdpa'.format(base)] = result['value'] / result[tuning]['value']
+                result['peak_hbm_vs_{}_sdpa'.format(base)] = result['peak_hbm_gb'] / result[tuning]['peak_hbm_gb']
+            except Exception as exc:
+                result[tuning] = {'error': repr(exc)}
+        result['baselines'] = (
+            'full = dense full fine-tune: every nn.Linear on the LIBRARY fp32 GEMM, naive '
+            'softmax(QK^T + mask)V attention, weight gradients + AdamW on all 365 M parameters; '
+            'lora = frozen base + rank-16 adapters: frozen linears on the SAME split-bf16 GEMM engine '
+            'as the sparse step, naive dense attention -- speedup_vs_lora is the same-engine, '
+            'same-trainable-set comparison (what sparsity itself buys); *_sdpa = the same two with '
+            "torch's fused scaled_dot_product_attention")
     if single and not args.no_block:
         blk = {t: block_record(t, args, dev) for t in ('sparse', 'full', 'lora')}
         blk['what'] = ('one TransformerBlock, protocol of script/0-profile.py:203-226: fwd + bwd '

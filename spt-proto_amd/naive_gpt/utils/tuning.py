@@ -94,6 +94,11 @@ class SparseTuner:
         self.last_grad_norm = None
         self._graph = None
         self._graph_lr = None
+        # measurement hook (bench.py at N > 1): HIP events around the gradient exchange of every
+        # `allreduce_every`-th update; `allreduce_events` = [(start, end), ...]
+        self.allreduce_every = 0
+        self.allreduce_events = []
+        self._updates = 0
 
     @classmethod
     def from_checkpoint(cls, path: str, d_lora: int = 16, device=None, **kwargs):
@@ -298,6 +303,22 @@ class SparseTuner:
             self.scheduler.optimizer = new
         self._flat = self._flat_grad = None     # (the parameters stay views of the buffer: harmless)
 
+    @contextlib.contextmanager
+    def _exchange_timer(self):
+        """Events on the CURRENT stream around the exchange: the collective runs on the backend's
+        own stream, which waits for the current one and which the current one then waits for
+        (synchronous all_reduce), so the pair brackets it."""
+        self._updates += 1
+        timed = (self.allreduce_every > 0 and self._updates % self.allreduce_every == 0
+                 and self.params[0].is_cuda)
+        if timed:
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+        yield
+        if timed:
+            end.record()
+            self.allreduce_events.append((start, end))
+
     def apply_gradients(self) -> None:
         if self._flat is not None:
             self._check_flat_views()
@@ -305,8 +326,9 @@ class SparseTuner:
             self._unflatten()
         if self._flat is None:
             if self.world_size > 1:
-                distributed.allreduce_gradients(self.params, group=self.group,
-                                                world_size=self.world_size)
+                with self._exchange_timer():
+                    distributed.allreduce_gradients(self.params, group=self.group,
+                                                    world_size=self.world_size)
             if self.clip_norm is not None:
                 self.last_grad_norm = nn.utils.clip_grad_norm_(self.params, self.clip_norm)
             self.optimizer.step()
@@ -316,7 +338,8 @@ class SparseTuner:
             self._gather_gradients()
             grad = self._flat_grad
             if self.world_size > 1:             # the whole exchange: one all-reduce, in place
-                torch.distributed.all_reduce(grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
+                with self._exchange_timer():
+                    torch.distributed.all_reduce(grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
                 grad.div_(self.world_size)
             if self.clip_norm is not None:
                 # nn.utils.clip_grad_norm_ (script/4-sparse-tuning-0.py: gradient_clip_val): the

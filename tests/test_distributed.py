@@ -114,10 +114,15 @@ def _tuner_worker(rank, world, port, out):
             p.data.mul_(1.5)               # the tuner's broadcast must undo this
     tuner = utils.SparseTuner(model, clip_norm=0.05)      # small enough to clip for real
     assert tuner.world_size == world
+    tuner.allreduce_every = 1          # bench.py's measurement hook: HIP events on CUDA, inert on CPU
+    norms = []
     for _ in range(2):
         tuner.training_step(_tokens(rank), pq_loss=False)
-    torch.save({k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad},
-               out.format(rank))
+        norms.append(tuner.last_grad_norm.detach().clone())
+    assert tuner._updates == 2 and tuner.allreduce_events == []
+    saved = {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+    saved['__clip_norms'] = torch.stack(norms)
+    torch.save(saved, out.format(rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -134,6 +139,10 @@ def test_tuner_replicas_stay_identical_and_match_the_global_batch(tmp_path):
     assert set(r0) == set(r1) and len(r0) > 5
     for k in r0:
         assert torch.equal(r0[k], r1[k]), k
+    # (bench.py asserts this at N > 1: the ranks clip by the same norm, taken after the exchange)
+    norms = r0.pop('__clip_norms')
+    r1.pop('__clip_norms')
+    assert bool((norms > 0.05).all())
 
     from naive_gpt import utils
     model = _tiny_lm()

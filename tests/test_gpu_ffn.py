@@ -709,7 +709,8 @@ def test_third_consumers_of_q_and_of_the_norm_output_keep_their_gradients(monkey
     block = layers.TransformerBlock(
         d_model=d, n_heads=heads, layernorm_fn=nn.LayerNorm(d),
         attention_fn=layers.VanillaAttention(d_head=d // heads, p_dropout=0.0),
-        feedforward_fn=layers.Feedforward(d_model=d, d_feedforward=d_ff, activation=nn.ReLU(), p_dropout=0.0),
+        # (GELU: a ReLU pre-activation within rounding of zero takes either sign in the loop's library GEMM)
+        feedforward_fn=layers.Feedforward(d_model=d, d_feedforward=d_ff, activation=nn.GELU(), p_dropout=0.0),
         attention_bias=True, pre_norm=True)
     with contextlib.redirect_stdout(io.StringIO()):
         for stage in ('lora', 'ffn', 'mha_v1', 'mha_v2'):
@@ -720,6 +721,7 @@ def test_third_consumers_of_q_and_of_the_norm_output_keep_their_gradients(monkey
     block = block.cuda()
     x0 = torch.randn([N, S, d], device='cuda')
     wh = torch.randn([N, S, d], device='cuda')
+    wy = torch.randn([N, S, d], device='cuda')
     taps = {}
     block.mha.attn_fn.register_forward_pre_hook(lambda m, args: taps.__setitem__('q', args[0]))
     block.ffd.register_forward_pre_hook(lambda m, args: taps.__setitem__('h', args[0]))
@@ -729,7 +731,8 @@ def test_third_consumers_of_q_and_of_the_norm_output_keep_their_gradients(monkey
         block.zero_grad()
         block.mha.attn_fn.arm()
         y = block(x)
-        loss = y.square().sum() + 2.0 * block.mha.attn_fn.loss \
+        # four terms of comparable gradient size: a lost contribution would show
+        loss = (y * wy).sum() + 50.0 * block.mha.attn_fn.loss \
             + 0.5 * taps['q'].square().sum() + (taps['h'] * wh).sum()
         loss.backward()
         return [x.grad.clone()] + [p.grad.clone() for p in block.parameters() if p.grad is not None]

@@ -37,7 +37,18 @@ def _scaled_close(got, want, rtol=1e-3, frac=3e-4):
 
 
 def _worst(got, want):
-    return float((got.double() - want.double()).abs().max()) / max(float(want.abs().max()), 1e-30)
+    return float((got.detach().double() - want.detach().double()).abs().max()) \
+        / max(float(want.detach().abs().max()), 1e-30)
+
+
+def _rows_close(got, want, rtol=1e-3, frac=3e-4, bad_rows=0.0):
+    """_scaled_close per row (token), tolerating a fraction `bad_rows` of rows: a ReLU
+    pre-activation within rounding of zero takes either sign in ANY fp32 evaluation (the library
+    GEMM's included), and one flipped sign moves that token's input gradient by O(1)."""
+    got, want = got.reshape(-1, got.size(-1)), want.reshape(-1, want.size(-1))
+    tol = frac * float(want.abs().max()) + rtol * want.abs()
+    bad = ((got - want).abs() > tol).any(dim=-1).float().mean()
+    return float(bad) <= bad_rows
 
 
 @pytest.fixture(autouse=True)
@@ -150,14 +161,19 @@ def _make_ffn(c, gen):
     return ffn
 
 
-def _ffn_fp64(ffn, x, family):
+def _ffn_fp64(ffn, x, family, w=None):
     """The reference formula (lora_ffn.py:87-111 / :196-222) in fp64 for a few tokens: every block
-    evaluated, the token's top-k (taken from the layer's own fp32 router: the same decisions) kept."""
+    evaluated, the token's top-k (taken from the layer's own fp32 router: the same decisions) kept.
+    With `w` (the upstream gradient of these tokens) also d <w, y> / d x by fp64 autograd -- tokens
+    are independent given the parameters."""
     nb, bs = ffn.n_blocks, ffn.block_size
-    prob = ffn.router(x)                                                      # fp32, as the layer
-    chosen = torch.zeros_like(prob, dtype=torch.bool)
-    chosen.scatter_(1, torch.topk(prob, k=nb // 2, dim=-1, sorted=False).indices, True)
-    x64, coeff = x.double(), 2.0 * prob.double()
+    with torch.no_grad():
+        prob32 = ffn.router(x)                                                # fp32, as the layer
+    chosen = torch.zeros_like(prob32, dtype=torch.bool)
+    chosen.scatter_(1, torch.topk(prob32, k=nb // 2, dim=-1, sorted=False).indices, True)
+    x64 = x.double().requires_grad_(w is not None)
+    lin = ffn.router[0]
+    coeff = 2.0 * torch.sigmoid(x64 @ lin.weight.double().t() + lin.bias.double())
     y = torch.zeros_like(x64)
 
     def lora_of(linear):
@@ -183,7 +199,10 @@ def _ffn_fp64(ffn, x, family):
         y = y + out * chosen[:, i:i + 1]
     if family == 'opt':
         y = y + ffn.fc2.bias.double()
-    return y
+    if w is None:
+        return y.detach()
+    grad_x, = torch.autograd.grad(y, x64, w.double())
+    return y.detach(), grad_x
 
 
 @pytest.mark.parametrize('name', list(CONFIGS))
@@ -229,16 +248,21 @@ def test_routed_ffn_at_block_dims(name):
     y0, gx0, g0 = run(False)
     assert _paths('routed_ffn') == {'torch_loop': 1}
     assert _scaled_close(y1, y0), _worst(y1, y0)
-    assert _scaled_close(gx1, gx0), _worst(gx1, gx0)
-    assert set(g0) == set(g1) and len(g0) >= (6 if c['family'] == 'opt' else 8)
+    # input gradient: per token; with ReLU a few tokens per thousand own a pre-activation within
+    # fp32 rounding of zero whose sign the LIBRARY GEMM of the torch loop decides by its summation
+    # order (the fused path recomputes those in exact fp32: DESIGN.md 5.2) -- fp64 arbitrates below
+    relu = c['family'] == 'opt'
+    assert _rows_close(gx1, gx0, bad_rows=0.01 if relu else 0.0), _worst(gx1, gx0)
+    assert set(g0) == set(g1) and len(g0) >= 6
     for n in g0:
-        assert _scaled_close(g1[n], g0[n], rtol=2e-3), (n, _worst(g1[n], g0[n]))
-    # fp64 slice of the forward
+        assert _scaled_close(g1[n], g0[n], rtol=2e-3, frac=1e-3 if relu else 3e-4), (n, _worst(g1[n], g0[n]))
+    # fp64 slice: forward and input gradient of the fused path (and the loop's forward)
     T = c['N'] * c['S']
     rows = torch.arange(5, T, T // 96, device='cuda')
-    want = _ffn_fp64(ffn, x.view(T, d)[rows], c['family'])
-    assert _worst(y1.view(T, d)[rows], want) <= 1e-3
-    assert _worst(y0.view(T, d)[rows], want) <= 1e-3
+    want_y, want_gx = _ffn_fp64(ffn, x.view(T, d)[rows], c['family'], w.view(T, d)[rows])
+    assert _worst(y1.view(T, d)[rows], want_y) <= 1e-3
+    assert _worst(y0.view(T, d)[rows], want_y) <= 1e-3
+    assert _worst(gx1.view(T, d)[rows], want_gx) <= 1e-3
 
 
 # ------------------------------------------------------------------------------ the block
@@ -299,7 +323,7 @@ def test_upgraded_block_step_at_block_dims(name):
     y1, gx1, g1 = run(True)
     assert _paths('qkv_projection') == {'joint': 1}
     assert _paths('attention') == {'mfma': 1}
-    assert _paths('norm') == {'kernel': 2}
+    assert set(_paths('norm')) == {'kernel'}        # (forward twice, recomputed twice in the backward)
     assert _paths('lora_linear') == {'mfma': 1} and _paths('lora_linear_backward') == {'mfma': 1}   # linear_o
     assert _paths('routed_ffn') == {'fused': 1} and _paths('route_topk') == {'kernel': 1}
     assert 'library' not in _paths('lora_down'), _paths('lora_down')
