@@ -247,21 +247,35 @@ def test_routed_ffn_at_block_dims(name):
     ext.reset_paths()
     y0, gx0, g0 = run(False)
     assert _paths('routed_ffn') == {'torch_loop': 1}
-    assert _scaled_close(y1, y0), _worst(y1, y0)
-    # input gradient: per token; with ReLU a few tokens per thousand own a pre-activation within
-    # fp32 rounding of zero whose sign the LIBRARY GEMM of the torch loop decides by its summation
-    # order (the fused path recomputes those in exact fp32: DESIGN.md 5.2) -- fp64 arbitrates below
-    relu = c['family'] == 'opt'
-    assert _rows_close(gx1, gx0, bad_rows=0.01 if relu else 0.0), _worst(gx1, gx0)
     assert set(g0) == set(g1) and len(g0) >= 6
+    # The arbiter: the same layer in fp64 (its dtype sends it through the per-block torch loop) on
+    # the whole batch.  The FUSED path must agree with it everywhere to the north-star bar; the
+    # fp32 loop agrees per token except where a ReLU pre-activation lies within fp32 rounding of
+    # zero -- there the library GEMM's summation order decides its sign (the fused path recomputes
+    # those in exact fp32), which moves that token's input gradient by O(1).
+    import copy
+    ffn64 = copy.deepcopy(ffn).double()
+    ffn64.zero_grad()
+    x64 = x.double().requires_grad_(True)
+    y64 = ffn64(x64)
+    (y64 * w.double()).sum().backward()
+    g64 = {n: p.grad for n, p in ffn64.named_parameters() if p.grad is not None}
+    relu = c['family'] == 'opt'
+    assert _scaled_close(y1.double(), y64.detach()), _worst(y1, y64)
+    assert _scaled_close(gx1.double(), x64.grad), _worst(gx1, x64.grad)
+    assert set(g64) == set(g1)
+    for n in g1:
+        assert _scaled_close(g1[n].double(), g64[n]), (n, _worst(g1[n], g64[n]))
+    assert _scaled_close(y0.double(), y64.detach()), _worst(y0, y64)
+    assert _rows_close(gx0.double(), x64.grad, bad_rows=0.01 if relu else 0.0), _worst(gx0, x64.grad)
     for n in g0:
-        assert _scaled_close(g1[n], g0[n], rtol=2e-3, frac=1e-3 if relu else 3e-4), (n, _worst(g1[n], g0[n]))
-    # fp64 slice: forward and input gradient of the fused path (and the loop's forward)
+        assert _scaled_close(g0[n].double(), g64[n], rtol=2e-3, frac=5e-3 if relu else 3e-4), \
+            (n, _worst(g0[n], g64[n]))
+    # and an independent restatement of the formula (not the layer's own code) on a slice
     T = c['N'] * c['S']
     rows = torch.arange(5, T, T // 96, device='cuda')
     want_y, want_gx = _ffn_fp64(ffn, x.view(T, d)[rows], c['family'], w.view(T, d)[rows])
     assert _worst(y1.view(T, d)[rows], want_y) <= 1e-3
-    assert _worst(y0.view(T, d)[rows], want_y) <= 1e-3
     assert _worst(gx1.view(T, d)[rows], want_gx) <= 1e-3
 
 
