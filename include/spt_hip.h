@@ -480,10 +480,14 @@ int spt_split_bf16(const float *src, void *image, long long rows, int cols, long
  *                  spt_split_bf16_bytes(rows, k) bytes) and `norms` [rows] (row 2-norms) -- NULL
  *                  to skip.  k % 32 == 0, n in {16, 32, 48, 64}: SPT_EUNSUP otherwise (callers
  *                  then use a library GEMM).
- * Split-bf16 matrix-core products as in spt_grouped_gemm: <= 2^-16 relative per product.
+ * exact == 0: split-bf16 matrix-core products as in spt_grouped_gemm, <= 2^-16 relative per
+ * product.  exact != 0: u in exact fp32 (the fp32-input MFMA, an fp32 FMA chain per element):
+ * for the u that feeds the GEMM in front of a ReLU (lora_ffn.py:99-101), where a 2^-16 error
+ * would decide the sign of pre-activations next to zero; 2-3 x the time at 48-64 columns.
  */
 int spt_lora_down(const float *x, long long ldx, long long rows, int k, const float *l, int n,
-                  float *u, long long ldu, int u_block_major, void *image, float *norms, void *stream);
+                  float *u, long long ldu, int u_block_major, void *image, float *norms, int exact,
+                  void *stream);
 /*
  * The per-block tables of the routed FFN (lora_ffn.py:87-111: `h_i @ l2[i]`, and `ds_i @ r1[i]` in
  * its backward): rows offsets[g] .. offsets[g + 1] - 1 (device int32 [n_groups + 1], rows sorted by

@@ -18,9 +18,20 @@
 // (x^T du) are spt_tall_tn further down: plain fp32 FMAs, as fast as the library's split-K form
 // (11.8 + 3.9 us against 11.5 + 5.1) at a quarter of its host time.
 //
-// Arithmetic as everywhere else in this library: fp32 operands split in two bf16 parts, three
-// MFMAs per product (v_mfma_f32_16x16x32_bf16: its 16-wide output is the adapter's rank), fp32
-// accumulation; <= 2^-16 relative error per product.
+// Arithmetic, two forms (`exact` of the C ABI):
+//   exact = 0  as everywhere else in this library: fp32 operands split in two bf16 parts, three
+//              MFMAs per product (v_mfma_f32_16x16x32_bf16: its 16-wide output is the adapter's
+//              rank), fp32 accumulation; <= 2^-16 relative error per product.
+//   exact = 1  EXACT fp32 on the matrix cores (v_mfma_f32_16x16x4_f32: fp32 in, fp32 FMA chain).
+//              For the one u that is an INPUT of the GEMM in front of the routed FFN's ReLU: an
+//              error of 2^-16 |x| |l| there moves a pre-activation by ~1e-4 |r1 row|, enough to
+//              flip the sign of the few elements per million within that distance of zero -- each
+//              flip an O(1) change of its token's gradient, which no later fp32 recomputation can
+//              see (round 3: 18 of 8192 tokens at BERT-large dimensions against the fp64 layer;
+//              the fp32 per-block loop has none).  The fp32 MFMA runs at the vector rate (1/16 of
+//              bf16): 9.0 us for 8192 x 1024 x 16, under the pass's memory time; at 48-64 columns
+//              it would be the bound (21-42 us), which is why it is an option.
+// The split image (hi / lo bf16 of x) is written by the same pass in both forms.
 #include "spt_common.h"
 #include <type_traits>
 
@@ -56,27 +67,36 @@ __device__ __forceinline__ ls_f32x4 ls_mma3(const LsFrag &a, const LsFrag &b, ls
     c = ls_mma(a.hi, b.lo, c);
     return ls_mma(a.hi, b.hi, c);
 }
+// exact fp32: lane (r, g) holds a[r][8 g + i] and b[8 g + i][c = r], i = 0 .. 7; MFMA i contracts
+// the four k's {i, 8 + i, 16 + i, 24 + i} of the 32-wide k-step (one per lane group g)
+__device__ __forceinline__ ls_f32x4 ls_mma_f32x8(const float (&a)[8], const float (&b)[8], ls_f32x4 c) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], c, 0, 0, 0);
+    return c;
+}
 
 // ---- u = x . l -------------------------------------------------------------------------------
-// A workgroup = 16 rows, its four waves = four contiguous shares of K (K % 32 == 0); lane (r, g) = row r, elements
-// 8g .. 8g + 7 of every 32-wide k-step: the A operand of the 16x16x32 MFMA as it lies in memory
-// (32 bytes per lane, 128 contiguous bytes per row and k-step), and one 128-byte block of the
-// split image.  All of a wave's loads of x for 256 k (16 x 16 bytes per lane) are issued before
+// A workgroup = 16 rows, its LS_NW waves = contiguous shares of K (K % 32 == 0); lane (r, g) = row r, elements
+// 8g .. 8g + 7 of every 32-wide k-step (32 bytes per lane, 128 contiguous bytes per row and
+// k-step): eight A operands of the 16x16x4 fp32 MFMA, and one 128-byte block of the split image.  All of a wave's loads of x for 256 k (16 x 16 bytes per lane) are issued before
 // the first is used; with eight such waves per CU that is 128 KiB in flight per CU.  The table's
 // fragments (lane (c, g): l[k + 8g + i][c]) come from L2 one k-step ahead.
 constexpr int LS_CH = 8;            // k-steps (of 32) per chunk of loads
+constexpr int LS_NW = 8;            // waves per workgroup = shares of K (8192 rows are only 512
+                                    // workgroups: with four waves each a SIMD held two, and the fp32
+                                    // MFMA chain of one was not covered by the loads of the other)
 // Grouped form (offsets != null): rows offsets[q] .. offsets[q + 1] - 1 use the table l + q *
 // l_gstride (the routed FFN's per-block tables; rows are sorted by block).  A workgroup's 16 rows
 // then lie inside ONE group -- the MFMA's B operand is common to the tile -- so the tiles are
 // counted per group (at most one short tile each: rows / 16 + n_groups workgroups, the surplus
 // ones find no group and leave).
-template <int NB, bool IMAGE, bool NORMS>
-__global__ __launch_bounds__(256) void lora_down_kernel(
+template <int NB, bool IMAGE, bool NORMS, bool EXACT>
+__global__ __launch_bounds__(64 * LS_NW) void lora_down_kernel(
     const float *__restrict__ x, long long ldx, long long rows, int K, const float *__restrict__ l,
     int n, float *__restrict__ u, long long u_ld, long long u_block, char *__restrict__ image,
     float *__restrict__ norms, const int32_t *__restrict__ offsets, int n_groups, long long l_gstride) {
-    __shared__ float red[4][NB][256];
-    __shared__ float nred[4][16];
+    __shared__ float red[LS_NW][NB][256];
+    __shared__ float nred[LS_NW][16];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -99,7 +119,7 @@ __global__ __launch_bounds__(256) void lora_down_kernel(
     const long long row = min(row0 + r, rows - 1);          // (clamped rows are never stored)
     // the K / 32 k-steps dealt to the four waves as evenly as they go (K = 2752, the LLaMA-7B FFN
     // block: 22, 22, 21, 21); a wave walks its share in chunks of LS_CH steps, the last one ragged
-    const int nsteps = K >> 5, per = nsteps >> 2, extra = nsteps & 3;
+    const int nsteps = K >> 5, per = nsteps / LS_NW, extra = nsteps % LS_NW;
     const int sbeg = w * per + min(w, extra), cnt = per + (w < extra ? 1 : 0);
     const float *xp = x + row * ldx + 32 * sbeg + 8 * g;
     const float *lp = l + (size_t)(32 * sbeg + 8 * g) * n + r;
@@ -138,9 +158,11 @@ __global__ __launch_bounds__(256) void lora_down_kernel(
             if (c + 1 < LS_CH) load_l(RAGGED ? min(s0 + c + 1, cnt - 1) : s0 + c + 1, bnext);
             const float av[8] = {a[c][0].x, a[c][0].y, a[c][0].z, a[c][0].w,
                                  a[c][1].x, a[c][1].y, a[c][1].z, a[c][1].w};
-            const LsFrag af = ls_split8(av);
+            LsFrag af;
+            if (IMAGE || !EXACT) af = ls_split8(av);
 #pragma unroll
-            for (int b = 0; b < NB; b++) acc[b] = ls_mma3(af, ls_split8(bv[b]), acc[b]);
+            for (int b = 0; b < NB; b++)
+                acc[b] = EXACT ? ls_mma_f32x8(av, bv[b], acc[b]) : ls_mma3(af, ls_split8(bv[b]), acc[b]);
             if (IMAGE && row0 + r < rows) {
                 char *dst = ip + (size_t)(s0 + c) * 128;
                 *reinterpret_cast<uint4 *>(dst) = af.hi;
@@ -155,7 +177,7 @@ __global__ __launch_bounds__(256) void lora_down_kernel(
     int s0 = 0;
     for (; s0 + LS_CH <= cnt; s0 += LS_CH) chunk(s0, std::false_type{});
     if (s0 < cnt) chunk(s0, std::true_type{});
-    // the four k-quarters of the 16 x (16 NB) result through LDS; lane (c, g) holds rows 4g + j
+    // the waves' shares of the 16 x (16 NB) result through LDS; lane (c, g) holds rows 4g + j
 #pragma unroll
     for (int b = 0; b < NB; b++)
 #pragma unroll
@@ -166,15 +188,19 @@ __global__ __launch_bounds__(256) void lora_down_kernel(
         if (g == 0) nred[w][r] = ss;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < NB * 256; idx += 256) {
+    for (int idx = threadIdx.x; idx < NB * 256; idx += 64 * LS_NW) {
         const int b = idx >> 8, e = idx & 255, ln = e >> 2, j = e & 3;
-        const float v = (red[0][b][e] + red[1][b][e]) + (red[2][b][e] + red[3][b][e]);
+        float v = 0.0f;
+#pragma unroll
+        for (int q = 0; q < LS_NW; q += 2) v += red[q][b][e] + red[q + 1][b][e];
         const long long orow = row0 + 4 * (ln >> 4) + j;
         if (orow < rows) u[b * u_block + orow * u_ld + (ln & 15)] = v;
     }
     if (NORMS && threadIdx.x < 16 && row0 + threadIdx.x < rows)
-        norms[row0 + threadIdx.x] = sqrtf((nred[0][threadIdx.x] + nred[1][threadIdx.x]) +
-                                          (nred[2][threadIdx.x] + nred[3][threadIdx.x]));
+        norms[row0 + threadIdx.x] = sqrtf(((nred[0][threadIdx.x] + nred[1][threadIdx.x]) +
+                                           (nred[2][threadIdx.x] + nred[3][threadIdx.x])) +
+                                          ((nred[4][threadIdx.x] + nred[5][threadIdx.x]) +
+                                           (nred[6][threadIdx.x] + nred[7][threadIdx.x])));
 }
 
 }  // namespace spt
@@ -185,8 +211,8 @@ static bool ls_aligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) &
 
 static int lora_down_any(const float *x, long long ldx, long long rows, int k, const float *l,
                          int n, float *u, long long ldu, int u_block_major, void *image,
-                         float *norms, const int32_t *offsets, int n_groups, long long l_gstride,
-                         void *stream) {
+                         float *norms, int exact, const int32_t *offsets, int n_groups,
+                         long long l_gstride, void *stream) {
     if (!x || !l || !u) return SPT_EINVAL;
     if (rows <= 0 || k <= 0 || n <= 0 || ldx < k) return SPT_EINVAL;
     if (k % 32 != 0 || n % 16 != 0 || n > 64) return SPT_EUNSUP;
@@ -199,9 +225,14 @@ static int lora_down_any(const float *x, long long ldx, long long rows, int k, c
     // u [rows, n], or (u_block_major) n / 16 contiguous matrices [rows, 16]: one per adapter
     if (ldu != 0 && (ldu < n || u_block_major)) return SPT_EINVAL;
     const long long u_ld = u_block_major ? 16 : (ldu ? ldu : n), u_block = u_block_major ? rows * 16 : 16;
-#define SPT_LD(NB, IM, NO)                                                                      \
-    hipLaunchKernelGGL((lora_down_kernel<NB, IM, NO>), dim3((unsigned)nblk), dim3(256), 0, s, x, \
-                       ldx, rows, k, l, n, u, u_ld, u_block, img, norms, offsets, n_groups, l_gstride)
+#define SPT_LD4(NB, IM, NO, EX)                                                                  \
+    hipLaunchKernelGGL((lora_down_kernel<NB, IM, NO, EX>), dim3((unsigned)nblk), dim3(64 * LS_NW), 0, s, \
+                       x, ldx, rows, k, l, n, u, u_ld, u_block, img, norms, offsets, n_groups, l_gstride)
+#define SPT_LD(NB, IM, NO)                                              \
+    do {                                                                \
+        if (exact) SPT_LD4(NB, IM, NO, true);                           \
+        else SPT_LD4(NB, IM, NO, false);                                \
+    } while (0)
 #define SPT_LD_NB(NB)                                                   \
     do {                                                                \
         if (image && norms) SPT_LD(NB, true, true);                     \
@@ -217,14 +248,16 @@ static int lora_down_any(const float *x, long long ldx, long long rows, int k, c
     }
 #undef SPT_LD_NB
 #undef SPT_LD
+#undef SPT_LD4
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }
 
 extern "C" int spt_lora_down(const float *x, long long ldx, long long rows, int k, const float *l,
                              int n, float *u, long long ldu, int u_block_major, void *image,
-                             float *norms, void *stream) {
-    return lora_down_any(x, ldx, rows, k, l, n, u, ldu, u_block_major, image, norms, nullptr, 1, 0, stream);
+                             float *norms, int exact, void *stream) {
+    return lora_down_any(x, ldx, rows, k, l, n, u, ldu, u_block_major, image, norms, exact, nullptr, 1, 0,
+                         stream);
 }
 
 extern "C" int spt_lora_down_grouped(const float *x, long long ldx, long long rows, int k,
@@ -232,7 +265,7 @@ extern "C" int spt_lora_down_grouped(const float *x, long long ldx, long long ro
                                      const int32_t *offsets, int n_groups, float *u, long long ldu,
                                      void *image, float *norms, void *stream) {
     if (!offsets) return SPT_EINVAL;
-    return lora_down_any(x, ldx, rows, k, l, n, u, ldu, 0, image, norms, offsets, n_groups,
+    return lora_down_any(x, ldx, rows, k, l, n, u, ldu, 0, image, norms, 0, offsets, n_groups,
                          l_group_stride, stream);
 }
 

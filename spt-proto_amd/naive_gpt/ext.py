@@ -81,7 +81,7 @@ _PROTOTYPES = {
     'spt_cross_entropy_grad': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_ptr,
                                 _c_ptr, ctypes.c_longlong, _c_ptr], _c_int),
     'spt_lora_down': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_int,
-                       _c_ptr, ctypes.c_longlong, _c_int] + [_c_ptr] * 3, _c_int),
+                       _c_ptr, ctypes.c_longlong, _c_int] + [_c_ptr] * 2 + [_c_int, _c_ptr], _c_int),
     'spt_lora_down_grouped': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, ctypes.c_longlong,
                                _c_int, _c_ptr, _c_int, _c_ptr, ctypes.c_longlong] + [_c_ptr] * 3, _c_int),
     'spt_tall_tn_workspace_bytes': ([ctypes.c_longlong, _c_int, _c_int, _c_int], ctypes.c_longlong),
@@ -1310,13 +1310,15 @@ def lora_down_supported(x: torch.Tensor, table: torch.Tensor) -> bool:
 
 
 def lora_down(x: torch.Tensor, table: torch.Tensor, want_image: bool = False,
-              want_norms: bool = False, block_major: bool = False, out: torch.Tensor = None):
+              want_norms: bool = False, block_major: bool = False, out: torch.Tensor = None,
+              exact: bool = False):
     """u = x @ table for a tall x [rows, K] and a table [K, n] of a few columns, as ONE pass over x
     (``spt_lora_down``); the same pass can also leave x's split image (:class:`SplitImage`) and its
     row 2-norms.  Returns u, or (u, image | None, norms | None) when a by-product is asked for.
     ``block_major``: u as [n / 16, rows, 16] (tables of several rank-16 adapters side by side:
     each adapter's product contiguous).  ``out``: a [rows, n] view to write u into (unit inner
-    stride, any row stride: a column slice of a wider matrix)."""
+    stride, any row stride: a column slice of a wider matrix).  ``exact``: u in exact fp32 instead of
+    split-bf16 products (for the u in front of a ReLU GEMM: include/spt_hip.h)."""
     _require(lora_down_supported(x, table), 'lora_down: see lora_down_supported')
     table = table.contiguous()
     rows, k = x.shape
@@ -1340,7 +1342,7 @@ def lora_down(x: torch.Tensor, table: torch.Tensor, want_image: bool = False,
         rc = lib.spt_lora_down(x.data_ptr(), x.stride(0), rows, k, table.data_ptr(), n, u.data_ptr(),
                                0 if block_major else u.stride(0),
                                int(bool(block_major)), image.buffer.data_ptr() if want_image else None,
-                               _ptr(norms), _stream(dev))
+                               _ptr(norms), int(bool(exact)), _stream(dev))
     if rc != 0:
         _raise(lib, rc, 'lora_down')
     return (u, image, norms) if (want_image or want_norms) else u

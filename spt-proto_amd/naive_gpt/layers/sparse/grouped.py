@@ -205,11 +205,13 @@ def _block_cat(table: torch.Tensor, n_blocks: int) -> torch.Tensor:
 
 def _down(a: torch.Tensor, table: torch.Tensor, want_image: bool, want_norms: bool):
     """(a @ table, split image of a | None, row norms of a | None): one pass over `a`
-    (ext.lora_down) where its shapes allow, else the separate operators."""
+    (ext.lora_down) where its shapes allow, else the separate operators.  `want_norms` is asked
+    for in front of a ReLU GEMM, and there the product is formed in exact fp32 (csrc/lora_side.hip:
+    its error would otherwise pick the sign of pre-activations next to zero)."""
     if ext.lora_down_supported(a, table):
         ext.note_path('lora_down', 'kernel')
         if want_image or want_norms:
-            return ext.lora_down(a, table, want_image=want_image, want_norms=want_norms)
+            return ext.lora_down(a, table, want_image=want_image, want_norms=want_norms, exact=want_norms)
         return ext.lora_down(a, table), None, None
     ext.note_path('lora_down', 'library', fallback=a.is_cuda,
                   why=lambda: 'a {} x table {}: spt_lora_down takes K % 32 == 0, 16-64 columns'.format(

@@ -262,10 +262,12 @@ def test_routed_ffn_at_block_dims(name):
     g64 = {n: p.grad for n, p in ffn64.named_parameters() if p.grad is not None}
     relu = c['family'] == 'opt'
     assert _scaled_close(y1.double(), y64.detach()), _worst(y1, y64)
-    assert _scaled_close(gx1.double(), x64.grad), _worst(gx1, x64.grad)
+    # (one token in a few thousand may own a pre-activation within fp32 rounding of zero, whose sign
+    # no fp32 evaluation can promise: 1 of 4096 at the OPT dims, |pre| = 9e-7)
+    assert _rows_close(gx1.double(), x64.grad, bad_rows=0.001 if relu else 0.0), _worst(gx1, x64.grad)
     assert set(g64) == set(g1)
     for n in g1:
-        assert _scaled_close(g1[n].double(), g64[n]), (n, _worst(g1[n], g64[n]))
+        assert _scaled_close(g1[n].double(), g64[n], frac=1e-3 if relu else 3e-4), (n, _worst(g1[n], g64[n]))
     assert _scaled_close(y0.double(), y64.detach()), _worst(y0, y64)
     assert _rows_close(gx0.double(), x64.grad, bad_rows=0.01 if relu else 0.0), _worst(gx0, x64.grad)
     for n in g0:

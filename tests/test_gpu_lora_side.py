@@ -28,9 +28,16 @@ def test_lora_down_is_x_times_table(rows, K, n):
     u = ext.lora_down(x.cuda(), table.cuda())
     assert u.shape == (rows, n)
     _close(u, want, 'u')
+    # exact = True: an fp32 FMA chain per element (the fp32-input MFMA), for the u in front of a ReLU
+    # GEMM -- an order of magnitude inside the split products' error
+    ue = ext.lora_down(x.cuda(), table.cuda(), exact=True)
+    err = (ue.double().cpu() - want).abs().max().item()
+    assert err <= 2e-6 * want.abs().max().item(), (err, want.abs().max().item())
     # by-products of the same pass: the split image (bit-equal to spt_split_bf16's) and row norms
     u2, image, norms = ext.lora_down(x.cuda(), table.cuda(), want_image=True, want_norms=True)
     assert torch.equal(u2, u)
+    u3, image3, _ = ext.lora_down(x.cuda(), table.cuda(), want_image=True, want_norms=True, exact=True)
+    assert torch.equal(u3, ue) and torch.equal(image3.buffer, image.buffer)
     assert torch.equal(image.buffer, ext.split_bf16(x.cuda()).buffer)
     assert torch.allclose(norms.cpu(), x.norm(dim=1), rtol=1e-5)
 

@@ -9,18 +9,23 @@ from naive_gpt import ext
 
 
 def timeit(fn, n=50, w=10):
+    """GPU time per call from HIP events around n back-to-back calls (the kernels here take
+    10-40 us, the launches 3-5: the stream never runs dry)."""
     for _ in range(w):
         fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    e0.record()
     for _ in range(n):
         fn()
+    e1.record()
     torch.cuda.synchronize()
-    return round((time.perf_counter() - t0) / n * 1e6, 1)
+    return round(e0.elapsed_time(e1) / n * 1e3, 1)
 
 
 res = {}
-for rows, K, n in ((8192, 1024, 16), (8192, 1024, 48), (16384, 1024, 16), (16384, 1024, 64), (8192, 4096, 16)):
+for rows, K, n in ((8192, 1024, 16), (8192, 1024, 48), (16384, 1024, 16), (16384, 1024, 64), (8192, 4096, 16),
+                   (4096, 2752, 64), (2048, 4096, 16)):
     x = torch.randn([rows, K], device='cuda')
     t = torch.randn([K, n], device='cuda')
     d = torch.randn([rows, n], device='cuda')
@@ -28,6 +33,7 @@ for rows, K, n in ((8192, 1024, 16), (8192, 1024, 48), (16384, 1024, 16), (16384
     res[tag] = {
         'down_torch': timeit(lambda: torch.matmul(x, t)),
         'down': timeit(lambda: ext.lora_down(x, t)),
+        'down_exact': timeit(lambda: ext.lora_down(x, t, exact=True)),
         'down+image+norms': timeit(lambda: ext.lora_down(x, t, want_image=True, want_norms=True)),
         'split_alone': timeit(lambda: ext.split_bf16(x)),
         'GBps_down': None}
