@@ -434,6 +434,45 @@ class LoRALinear(nn.Linear):
         return y
 
 
+class _LookupRows(torch.autograd.Function):
+    """table[ids] (the adapter's `left(x)`, lora.py:118-126) with a backward that a HIP graph can
+    replay.  torch's `embedding_dense_backward` sorts the ids and, above 3072 of them, takes the
+    number of DISTINCT ids to the host to size its next launches (thrust::unique_by_key_copy on
+    ROCm): captured, that count is the capture batch's for ever -- a replay on other tokens reads
+    its segment table past the end (round 3: `Memory access fault` / MEMORY_APERTURE_VIOLATION in
+    rocprim's partition_kernel on the bench's captured step; round 2's captured step ran on the
+    same stale count without faulting).  Here every launch has a shape fixed by T alone, and the
+    result does not depend on timing: stable sort by id, one fp64 running sum down the sorted
+    rows, every run's total = difference of two of its values, added to a zeroed table at the
+    run's LAST position only (the other positions add an exact 0.0, in any order)."""
+
+    @staticmethod
+    def forward(ctx, ids, table):
+        ctx.save_for_backward(ids)
+        ctx.rows = table.size(0)
+        return nn.functional.embedding(ids, table)
+
+    @staticmethod
+    def backward(ctx, grad):
+        ids, = ctx.saved_tensors
+        flat = ids.reshape(-1)
+        g = grad.reshape(flat.numel(), -1)
+        sid, order = torch.sort(flat, stable=True)
+        total = torch.cumsum(g.index_select(0, order).double(), dim=0)          # [T, r] fp64
+        pos = torch.arange(flat.numel(), device=flat.device)
+        first = torch.ones_like(sid, dtype=torch.bool)
+        first[1:] = sid[1:] != sid[:-1]
+        start = torch.cummax(torch.where(first, pos, torch.zeros_like(pos)), dim=0).values
+        before = torch.where((start > 0).unsqueeze(1), total.index_select(0, (start - 1).clamp_min(0)),
+                             torch.zeros_like(total))
+        last = torch.ones_like(first)
+        last[:-1] = first[1:]
+        runs = ((total - before) * last.unsqueeze(1)).to(g.dtype)
+        out = torch.zeros([ctx.rows, g.size(1)], dtype=g.dtype, device=g.device)
+        out.index_add_(0, sid, runs)
+        return None, out
+
+
 class LoRAEmbedding(nn.Embedding):
     def __init__(self, d_lora: int, num_embeddings: int, embedding_dim: int,
                  *args, **kwargs):
@@ -450,5 +489,11 @@ class LoRAEmbedding(nn.Embedding):
         return _load_base(model, source)
 
     def forward(self, x: torch.Tensor):
-        side = torch.matmul(self.lora.left(x), self.lora.right.weight.T)
+        left = self.lora.left
+        if x.is_cuda and left.weight.requires_grad and left.padding_idx is None \
+                and left.max_norm is None and not left.scale_grad_by_freq and not left.sparse:
+            u = _LookupRows.apply(x, left.weight)          # (graph-safe backward, see above)
+        else:
+            u = left(x)
+        side = torch.matmul(u, self.lora.right.weight.T)
         return nn.functional.embedding(x, weight=self.weight) + side

@@ -133,7 +133,8 @@ class SparseTuner:
             self._submodules = [m for m in self._submodules_all if m is not self.model]
             self._submodules_mark = hash(tuple(id(c) for m in self._submodules_all
                                                for c in m._modules.values()))
-        losses = [m._buffers['loss'] for m in self._submodules if m._buffers.get('loss') is not None]
+        self._loss_modules = [m for m in self._submodules if m._buffers.get('loss') is not None]
+        losses = [m._buffers['loss'] for m in self._loss_modules]
         if not losses:
             return 0.0
         if len(losses) == 1 or any(l.dim() != 0 for l in losses):
@@ -194,6 +195,16 @@ class SparseTuner:
         if pq_loss:
             loss = loss + self.aux_weight * self.aux_loss()
         (loss / self.n_accumulate).backward()
+        if pq_loss:
+            # The `loss` buffers are graph outputs: left as they are (the reference does) each keeps
+            # its step's autograd graph alive until the layer's next forward -- the attention nodes
+            # with their cell tiles (17 MB a layer), and every AccumulateGrad node, whose stream is
+            # then the PREVIOUS step's: under `capture()` that pulls the warm-up stream into the
+            # capture (torch warns: "may break CUDA graph capture"; it did, round 3).  Keep the values.
+            for m in getattr(self, '_loss_modules', ()):
+                held = m._buffers.get('loss')
+                if held is not None and held.grad_fn is not None:
+                    m._buffers['loss'] = held.detach()
         self._micro += 1
         if self._micro % self.n_accumulate == 0:
             self.apply_gradients()

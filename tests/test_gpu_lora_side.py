@@ -79,3 +79,24 @@ def test_grouped_down_product_per_block_tables(sizes, K):
     assert float((u - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
     assert torch.equal(image.buffer, ext.split_bf16(x).buffer)
     assert torch.equal(ext.lora_down_grouped(x, tables, offsets), u)
+
+
+def test_embedding_rows_backward_is_the_embedding_gradient_and_bit_reproducible():
+    """lora._LookupRows (the adapter's left(x) of LoRAEmbedding, lora.py:118-126): same gradient as
+    torch's embedding backward, identical bits over repeated runs (no atomics on distinct
+    addends), with many repeated ids."""
+    from naive_gpt.layers.tuning.lora import _LookupRows
+    gen = torch.Generator().manual_seed(4)
+    ids = torch.randint(0, 3000, [16, 512], generator=gen).cuda()
+    ids[0, :64] = 7                                              # a long run
+    table = torch.randn([30522, 16], generator=gen).cuda().requires_grad_(True)
+    w = torch.randn([16, 512, 16], generator=gen).cuda()
+    (torch.nn.functional.embedding(ids, table) * w).sum().backward()
+    want, table.grad = table.grad.clone(), None
+    runs = []
+    for _ in range(3):
+        (_LookupRows.apply(ids, table) * w).sum().backward()
+        runs.append(table.grad.clone())
+        table.grad = None
+    assert torch.allclose(runs[0], want, rtol=1e-5, atol=1e-5)
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])

@@ -398,12 +398,16 @@ def test_validation_step_metrics(oracle_ext):
 
 
 @pytest.mark.gpu
-def test_captured_step_replays_the_eager_step():
+@pytest.mark.parametrize('n_seq', [4, 16])
+def test_captured_step_replays_the_eager_step(n_seq):
     """SparseTuner.capture(): the whole training step (forward through the HIP kernels, backward,
     clip, AdamW) as one HIP graph.  Three replays on fresh batches leave the parameters where
     three eager steps of an identical tuner with the same (capturable) optimiser leave them.
     (Against the default AdamW the comparison is ill-posed after the first step: its 2e-7
-    rounding difference flips PQ codes / top-k choices, and the gradient norm moves by 4e-4.)"""
+    rounding difference flips PQ codes / top-k choices, and the gradient norm moves by 4e-4.)
+    n_seq = 16: 4096 tokens -- the matrix-core linears, the fused head loss, and more than the 3072
+    ids above which torch's own embedding backward sizes its launches from a host-side count of
+    the capture batch's distinct tokens (layers/tuning/lora.py: _LookupRows replaces it)."""
     from naive_gpt import models, utils
     config = dict(d_model=1024, n_heads=16, n_layers=2, max_length=256, vocab_size=512,
                   d_feedforward=4096, p_dropout=0.0)
@@ -418,12 +422,12 @@ def test_captured_step_replays_the_eager_step():
         return utils.SparseTuner(model.cuda())
 
     gen = torch.Generator().manual_seed(9)
-    batches = [torch.randint(3, 512, [4, 258], generator=gen).cuda() for _ in range(3)]
+    batches = [torch.randint(3, 512, [n_seq, 258], generator=gen).cuda() for _ in range(3)]
     eager, graphed = build(), build()
     # capture() warms up with three eager steps (library initialisations must not fall into the
     # capture): the eager twin takes the same three.  (Not on the default all-zero batch: with
     # every token equal most gradients are rounding noise, whose sign Adam turns into +-lr.)
-    warm = torch.randint(3, 512, [4, 258], generator=gen).cuda()
+    warm = torch.randint(3, 512, [n_seq, 258], generator=gen).cuda()
     eager.use_capturable_optimizer()
     graphed.capture(batches[0].shape, pq_loss=True, warmup=3, example=warm)
     for _ in range(3):
@@ -435,6 +439,12 @@ def test_captured_step_replays_the_eager_step():
         losses.append((float(le), float(lg)))
     for le, lg in losses:
         assert abs(le - lg) <= 1e-6 * abs(le), losses
+    # back-to-back replays without a host synchronisation in between (bench.py's timed loop)
+    if n_seq == 16:
+        for b in batches + batches:
+            eager.training_step(b, pq_loss=True)
+            graphed.training_step(b, pq_loss=True)
+        torch.cuda.synchronize()
     for (n, pe), pg in zip(eager.model.named_parameters(), graphed.model.parameters()):
         if pe.requires_grad:
             assert torch.allclose(pe, pg, rtol=1e-6, atol=1e-7), n
