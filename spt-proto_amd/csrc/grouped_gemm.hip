@@ -1125,9 +1125,10 @@ static int launch_grouped(GroupedArgs g, int epilogue, void *stream) {
     const bool k_tail = (g.K % GG_BK) != 0;
     const bool relu_queue = epilogue == EPI_ACT && g.act == ACT_RELU && g.fix_list && g.G < 256 &&
                             g.N < (1 << 24);
-    if (relu_queue)
-        SPT_HIP_TRY(hipMemsetAsync(g.fix_count, 0, GG_FIX_SEGS * 64, s));
-    else
+    if (relu_queue) {
+        SPT_ZERO_WORDS(g.fix_count, GG_FIX_SEGS * 16, s);
+        SPT_LAUNCH_CHECK();
+    } else
         g.fix_list = nullptr;
     if (g.ldk == 1) {
         if (ext) SPT_GG_EPI(false, true); else SPT_GG_EPI(false, false);

@@ -1351,7 +1351,8 @@ extern "C" int spt_attention_mfma_prepare(const int32_t *indices, void *tiles, i
     const size_t lds = (size_t)MB_WAVES * prepare_lds_per_wave();
     const dim3 grid((total + MB_WAVES - 1) / MB_WAVES), block(MB_WAVES * SPT_WAVE);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    SPT_HIP_TRY(hipMemsetAsync(tiles, 0, MA_HEADER, s));
+    SPT_ZERO_WORDS(tiles, MA_HEADER / 4, s);
+    SPT_LAUNCH_CHECK();
     if (Z > 255) {
         SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_cell_tiles_kernel<true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -29,6 +29,18 @@ enum { SPT_F32 = 0, SPT_BF16 = 1 };
 
 namespace spt {
 
+// Zero `n_words` 32-bit words, as a KERNEL.  Not hipMemsetAsync: in a captured HIP graph a memset
+// node did not keep its place between the kernel nodes around it when the replay started on an idle
+// GPU (round 3: the near-the-kink queue's counters held the bytes of whatever had owned the block
+// before, relu_fix_kernel walked a queue of garbage entries -> `Memory access fault`); a kernel node
+// does.  One launch of a few waves instead of a blit: the same cost.
+static __global__ __launch_bounds__(256) void zero_words_kernel(unsigned *p, int n_words) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_words; i += gridDim.x * 256) p[i] = 0u;
+}
+#define SPT_ZERO_WORDS(ptr, n_words, stream)                                                    \
+    hipLaunchKernelGGL(spt::zero_words_kernel, dim3(((n_words) + 255) / 256 > 64 ? 64 : ((n_words) + 255) / 256), \
+                       dim3(256), 0, (stream), reinterpret_cast<unsigned *>(ptr), (int)(n_words))
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (SPT_WAVE - 1); }
 
 // ---- DPP helpers: lane movement inside a row of 16 lanes, no LDS traffic ----
