@@ -453,7 +453,11 @@ typedef struct SptGroupedGemm {
 } SptGroupedGemm;
 int spt_grouped_gemm_fused(const SptGroupedGemm *desc, void *stream);
 int spt_grouped_gemm_pdot_width(int n);
-/* 1 when spt_grouped_gemm_fused would run `desc` from its images, 0 when from the fp32 operands */
+/* How spt_grouped_gemm_fused would run `desc`: 1 = both operands from their images (a_image and
+ * w_image given, k % 32 == 0); 2 = "A32": the weight from w_image, the activation from its fp32
+ * rows `a` (a_image NULL; a 16-byte aligned, lda % 4 == 0), moved global -> LDS by LDS-DMA and split
+ * into its bf16 parts inside the kernel -- no image of the activation is needed at all;
+ * 0 = from the fp32 operands through registers (k % 32 != 0, or no w_image). */
 int spt_grouped_gemm_image_path(const SptGroupedGemm *desc);
 
 /*

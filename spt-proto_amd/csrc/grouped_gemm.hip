@@ -442,17 +442,39 @@ __device__ __forceinline__ uint4 gi_frag_nc(const char *tile, int ncol0, int q2,
     const uint2 lo = gg_tr_b64(ptr), hi = gg_tr_b64(ptr + 4 * 512);
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
+// The same fragment of an fp32 tile [row][32 k floats] (the A32 form: the activation goes
+// global -> LDS by LDS-DMA as it is, 128 bytes per row and k-step like an image row, and is split
+// HERE, on its way into the matrix cores): the lane's 8 floats are chunks 4 q2 + 2 fh and + 1 of
+// its row, same swizzle, two conflict-free ds_read_b128; 24 VALU per fragment (96 per k-step and
+// wave at NI = 2, under 24 MFMAs).  What it buys: no pre-split image of the activation -- no
+// split pass, no second copy of the activation in memory, and every GEMM (the backward's dX
+// products too, whose operand nobody else reads) takes the LDS-DMA k-loop.
+__device__ __forceinline__ GgFrag gi_frag_a32(const char *tile, int row, int q2, int fh) {
+    const int c0 = 4 * q2 + 2 * fh, sw = (row >> 1) & 7;
+    const float4 x = *reinterpret_cast<const float4 *>(tile + row * 128 + ((c0 ^ sw) << 4));
+    const float4 y = *reinterpret_cast<const float4 *>(tile + row * 128 + (((c0 | 1) ^ sw) << 4));
+    GgFrag f;
+    gg_split2(x.x, x.y, f.hi.x, f.lo.x);
+    gg_split2(x.z, x.w, f.hi.y, f.lo.y);
+    gg_split2(y.x, y.y, f.hi.z, f.lo.z);
+    gg_split2(y.z, y.w, f.hi.w, f.lo.w);
+    return f;
+}
 template <int NI>
 struct GiFrags {
     GgFrag a[NI], b[2];
 };
-template <int NI, int NA, bool KC_B>
+template <int NI, int NA, bool KC_B, bool A32 = false>
 __device__ __forceinline__ void gi_read(const GiLane<NI, NA> &c, const char *As, const char *Bs,
                                         int q2, GiFrags<NI> &f) {
 #pragma unroll
     for (int i = 0; i < NI; i++) {
-        f.a[i].hi = gi_frag_kc(As, c.wm + 32 * i + c.frow, q2, 0, c.fh);
-        f.a[i].lo = gi_frag_kc(As, c.wm + 32 * i + c.frow, q2, 1, c.fh);
+        if constexpr (A32) {
+            f.a[i] = gi_frag_a32(As, c.wm + 32 * i + c.frow, q2, c.fh);
+        } else {
+            f.a[i].hi = gi_frag_kc(As, c.wm + 32 * i + c.frow, q2, 0, c.fh);
+            f.a[i].lo = gi_frag_kc(As, c.wm + 32 * i + c.frow, q2, 1, c.fh);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 2; j++) {
@@ -499,7 +521,7 @@ __device__ __forceinline__ void gi_stage(const GiLane<NI, NA> &c, char *dma, int
 // ds_reads alias scopes, and only with those does hipcc (ROCm 7.2) leave out the
 // `s_waitcnt vmcnt(0)` it otherwise puts in front of the first ds_read behind an LDS-DMA in
 // flight -- which would wait for the next tile before the current one is contracted.
-template <int NI, int NA, bool BN_LAYOUT>
+template <int NI, int NA, bool BN_LAYOUT, bool A32>
 __device__ __forceinline__ void gi_step(const GiLane<NI, NA> &c, char *__restrict__ dma,
                                         const char *__restrict__ cur, bool prefetch, int k_next,
                                         f32x16 (&acc)[NI][2]) {
@@ -511,10 +533,10 @@ __device__ __forceinline__ void gi_step(const GiLane<NI, NA> &c, char *__restric
     // barrier that follows (with its vmcnt(0), the wait for the NEXT tile) above half the MFMAs.
     GiFrags<NI> f0, f1;
     if (prefetch) gi_stage<NI, NA, BN_LAYOUT>(c, dma, k_next);
-    gi_read<NI, NA, !BN_LAYOUT>(c, cur, cur + GI_TILE, 0, f0);
+    gi_read<NI, NA, !BN_LAYOUT, A32>(c, cur, cur + GI_TILE, 0, f0);
     __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0) only
     __builtin_amdgcn_sched_barrier(0);
-    gi_read<NI, NA, !BN_LAYOUT>(c, cur, cur + GI_TILE, 1, f1);
+    gi_read<NI, NA, !BN_LAYOUT, A32>(c, cur, cur + GI_TILE, 1, f1);
     __builtin_amdgcn_sched_barrier(0);
     gi_mma<NI>(f0, acc);
     __builtin_amdgcn_sched_barrier(0);
@@ -522,7 +544,7 @@ __device__ __forceinline__ void gi_step(const GiLane<NI, NA> &c, char *__restric
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int BM, bool BN_LAYOUT, int EPI, bool EXT>
+template <int BM, bool BN_LAYOUT, int EPI, bool EXT, bool A32>
 __device__ __forceinline__ void gemm_tile_img(const GroupedArgs &g, float *smem, int bucket,
                                               int row_lo, int row_hi, int col_tile) {
     constexpr int NI = BM / 64;                 // 32-row sub-blocks per wave
@@ -554,7 +576,9 @@ __device__ __forceinline__ void gemm_tile_img(const GroupedArgs &g, float *smem,
         const int r = 8 * (wave + 4 * j) + (lane >> 3);
         const int p = min(row_lo + r, row_hi - 1);
         const long long src = g.gather ? g.gather[p] : p;
-        c.a_src[j] = g.a_img + src * g.a_rowb + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+        // (A32: the fp32 rows themselves, a_rowb = 4 lda; 32 k = 128 bytes per k-step either way)
+        c.a_src[j] = (A32 ? reinterpret_cast<const char *>(g.a) : g.a_img) + src * g.a_rowb +
+                     (((lane & 7) ^ ((r >> 1) & 7)) << 4);
     }
     const char *wg = g.w_img + (long long)bucket * g.w_grow * g.w_rowb + (size_t)bucket * g.w_gblk * 128;
     if constexpr (!BN_LAYOUT) {
@@ -594,11 +618,11 @@ __device__ __forceinline__ void gemm_tile_img(const GroupedArgs &g, float *smem,
     gi_stage<NI, NA, BN_LAYOUT>(c, lds0, 0);
     __syncthreads();
     for (int k0 = 0; k0 < g.K; k0 += 2 * GG_BK) {
-        gi_step<NI, NA, BN_LAYOUT>(c, lds0 + GI_STAGE, lds0, k0 + GG_BK < g.K, k0 + GG_BK, acc);
+        gi_step<NI, NA, BN_LAYOUT, A32>(c, lds0 + GI_STAGE, lds0, k0 + GG_BK < g.K, k0 + GG_BK, acc);
         __syncthreads();
         if (k0 + GG_BK < g.K) {
-            gi_step<NI, NA, BN_LAYOUT>(c, lds0, lds0 + GI_STAGE, k0 + 2 * GG_BK < g.K,
-                                       k0 + 2 * GG_BK, acc);
+            gi_step<NI, NA, BN_LAYOUT, A32>(c, lds0, lds0 + GI_STAGE, k0 + 2 * GG_BK < g.K,
+                                            k0 + 2 * GG_BK, acc);
             __syncthreads();
         }
     }
@@ -952,7 +976,7 @@ __global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_kernel(GroupedArgs
                                                              w.col_tile);
 }
 
-template <bool BN_LAYOUT, int EPI, bool EXT>
+template <bool BN_LAYOUT, int EPI, bool EXT, bool A32>
 __global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_img_kernel(GroupedArgs g) {
     // ALL of the kernel's LDS in one array (a second __shared__ object beside an LDS-DMA
     // target can make hipcc drain vmcnt before every ds_read: cdna guide, section 5)
@@ -960,9 +984,10 @@ __global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_img_kernel(Grouped
     const GgWork w = gg_find_work(g);
     if (w.bucket < 0) return;
     if (w.half < 0)
-        gemm_tile_img<GG_BM, BN_LAYOUT, EPI, EXT>(g, smem, w.bucket, w.row_lo, w.row_hi, w.col_tile);
+        gemm_tile_img<GG_BM, BN_LAYOUT, EPI, EXT, A32>(g, smem, w.bucket, w.row_lo, w.row_hi, w.col_tile);
     else
-        gemm_tile_img<GG_BM / 2, BN_LAYOUT, EPI, EXT>(g, smem, w.bucket, w.row_lo, w.row_hi, w.col_tile);
+        gemm_tile_img<GG_BM / 2, BN_LAYOUT, EPI, EXT, A32>(g, smem, w.bucket, w.row_lo, w.row_hi,
+                                                           w.col_tile);
 }
 
 // fp32 [rows, cols] (leading dimension ld) -> the bf16 image [row][cols / 32][hi | lo][32]:
@@ -1054,16 +1079,23 @@ static int resident_slots() {
 
 // The image path takes a GEMM when both images are given, K is a whole number of k-steps and
 // the group offsets of the weight fall on image rows / 128-byte blocks.
-static bool image_path(GroupedArgs &g, int epilogue) {
-    if (!g.a_img || !g.w_img) return false;
-    if (g.K % GG_BK != 0) return false;
+// -> 0: register path; 1: both operands as images; 2 ("A32"): the weight as an image, the
+// activation as its fp32 rows (16-byte aligned, lda % 4 == 0: one LDS-DMA lane moves 16 bytes)
+static int image_path(GroupedArgs &g, int epilogue) {
+    if (!g.w_img || (!g.a_img && !g.a)) return 0;
+    if (g.K % GG_BK != 0) return 0;
     const long long row_len = g.ldk == 1 ? g.ldn : g.ldk;       // elements of one weight row
-    if (row_len <= 0 || g.gstride % 32 != 0 || row_len % 32 != 0) return false;
+    if (row_len <= 0 || g.gstride % 32 != 0 || row_len % 32 != 0) return 0;
     g.w_grow = g.gstride / row_len;
     g.w_gblk = (int)((g.gstride % row_len) / 32);
-    g.a_rowb = (long long)(g.K / 32) * 128;
     g.w_rowb = (row_len / 32) * 128;
-    return true;
+    if (g.a_img) {
+        g.a_rowb = (long long)(g.K / 32) * 128;
+        return 1;
+    }
+    if ((reinterpret_cast<uintptr_t>(g.a) & 15) != 0 || g.lda % 4 != 0) return 0;
+    g.a_rowb = (long long)g.lda * 4;
+    return 2;
 }
 
 static int launch_grouped(GroupedArgs g, int epilogue, void *stream) {
@@ -1102,12 +1134,15 @@ static int launch_grouped(GroupedArgs g, int epilogue, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     g.slots = resident_slots();
     if (g.slots <= 0) return SPT_EINVAL;
-    const bool img = image_path(g, epilogue);
+    const int img = image_path(g, epilogue);
     if (!img && (!g.a || !g.w)) return SPT_EUNSUP;              // images only, but not usable
 #define SPT_GG(BN, EPI, EXT)                                                                  \
     do {                                                                                      \
-        if (img)                                                                              \
-            hipLaunchKernelGGL((grouped_gemm_img_kernel<BN, EPI, EXT>), grid,                 \
+        if (img == 1)                                                                         \
+            hipLaunchKernelGGL((grouped_gemm_img_kernel<BN, EPI, EXT, false>), grid,          \
+                               dim3(GG_THREADS), 0, s, g);                                    \
+        else if (img == 2)                                                                    \
+            hipLaunchKernelGGL((grouped_gemm_img_kernel<BN, EPI, EXT, true>), grid,           \
                                dim3(GG_THREADS), 0, s, g);                                    \
         else if (k_tail)                                                                      \
             hipLaunchKernelGGL((grouped_gemm_kernel<BN, EPI, EXT, true>), grid,               \
@@ -1191,9 +1226,10 @@ extern "C" int spt_grouped_gemm_image_path(const SptGroupedGemm *d) {
     GroupedArgs g = {};
     g.K = d->k; g.gstride = d->w_group_stride; g.ldn = d->w_ldn; g.ldk = d->w_ldk;
     g.act = d->activation;
+    g.a = d->a; g.lda = d->lda;
     g.a_img = reinterpret_cast<const char *>(d->a_image);
     g.w_img = reinterpret_cast<const char *>(d->w_image);
-    return image_path(g, d->epilogue) ? 1 : 0;
+    return image_path(g, d->epilogue);
 }
 
 extern "C" size_t spt_split_bf16_bytes(long long rows, int cols) {

@@ -891,6 +891,7 @@ class _GroupedDesc(ctypes.Structure):
 
 EPI_PLAIN, EPI_ACT, EPI_DACT = 0, 1, 2
 LAST_GEMM_USED_IMAGES = False      # which operand path the last grouped_gemm_fused call took
+LAST_GEMM_PATH = 'register'        # ... by name: 'image' | 'a32' | 'register'
 LAST_RELU_QUEUE = None              # (tests) the near-the-kink queue of the last ReLU GEMM
 ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2
 
@@ -1092,10 +1093,14 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                      name + ': one fp32 norm per row')
     else:
         a_norm = w_norm = None
-    images = a_image is not None and w_image is not None
-    if images:
+    # operand forms of the k-loop (include/spt_hip.h): both images; or (`w_image` alone) the weight's
+    # image and the activation's own fp32 rows, split inside the kernel ("A32"); or neither
+    images = w_image is not None
+    if a_image is not None:
+        _require(w_image is not None, 'a_image: only together with w_image')
         _require(a_image.rows == a.size(0) and a_image.cols == a.size(1) == k
                  and a.stride(0) == a.size(1), 'a_image: the image of the contiguous [*, k] matrix a')
+    if images:
         _require(w_image.rows * w_image.cols == weight.numel()
                  and w_image.cols == (w_ldn if w_ldk == 1 else w_ldk),
                  'w_image: the image of the weight with rows of w_ldn (w_ldk) elements')
@@ -1135,14 +1140,15 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                 epilogue=epilogue, activation=activation, out2=_ptr(preact),
                 h_in=_ptr(h_in), s_in=_ptr(s_in), pdot_main=_ptr(dot_main),
                 pdot_act=_ptr(dot_act), pdot_ld=width,
-                a_image=a_image.buffer.data_ptr() if images else None,
+                a_image=a_image.buffer.data_ptr() if a_image is not None else None,
                 w_image=w_image.buffer.data_ptr() if images else None,
                 a_norm=_ptr(a_norm), w_norm=_ptr(w_norm), relu_queue=_ptr(queue),
                 relu_queue_bytes=queue.numel() if queue is not None else 0, ldo=out.stride(0),
                 accumulate=int(bool(accumulate)))
-            global LAST_GEMM_USED_IMAGES
-            LAST_GEMM_USED_IMAGES = bool(lib.spt_grouped_gemm_image_path(ctypes.byref(desc)))
-            PATH_COUNTS[('grouped_gemm', 'image' if LAST_GEMM_USED_IMAGES else 'register')] += 1
+            global LAST_GEMM_USED_IMAGES, LAST_GEMM_PATH
+            LAST_GEMM_PATH = ('register', 'image', 'a32')[lib.spt_grouped_gemm_image_path(ctypes.byref(desc))]
+            LAST_GEMM_USED_IMAGES = LAST_GEMM_PATH != 'register'
+            PATH_COUNTS[('grouped_gemm', LAST_GEMM_PATH)] += 1
             rc = lib.spt_grouped_gemm_fused(ctypes.byref(desc), _stream(dev))
             if rc != 0:
                 _raise(lib, rc, 'grouped_gemm_fused')

@@ -90,7 +90,7 @@ class _FrozenLoRAHeadLoss(torch.autograd.Function):
         buf = torch.empty([T, Vp], dtype=torch.float32, device=x2.device)
         ext.grouped_gemm_fused(x2, weight, one, 1, V, d, 0, d, 1, T, a2=u.contiguous(),
                                b2=right.contiguous(),
-                               a_image=ext.image_of(x2, x) if images else None,
+                               a_image=ext.cached_image(x2, x) if images else None,   # (else: A32)
                                w_image=ext.weight_image(weight) if images else None, out=buf)
         target = target.reshape(-1).contiguous()
         # (a target outside [0, V) that is not `ignore_index` counts as ignored -- torch raises a

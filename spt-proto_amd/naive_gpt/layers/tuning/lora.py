@@ -109,7 +109,11 @@ def _mfma_gemm(a, weight, n, k, ldn, ldk, bias=None, a2=None, b2=None, images=Fa
     rows = a.size(0)
     a_image = w_image = None
     if images and k % 32 == 0 and a.is_contiguous():
-        a_image, w_image = ext.image_of(a, owner), ext.weight_image(weight)
+        # the activation's image only when one exists already (another consumer of the same input
+        # made it: lora_down's by-product, q / k / v); a lone consumer reads the fp32 rows
+        # themselves -- the kernel's A32 form, ~10 % slower than from an image, whose making costs
+        # a pass of its own (include/spt_hip.h: spt_grouped_gemm_image_path)
+        a_image, w_image = ext.cached_image(a, owner), ext.weight_image(weight)
     return ext.grouped_gemm_fused(a, weight, _one_group(rows, a.device), 1, n, k, 0, ldn, ldk,
                                   rows, bias=bias, a2=a2, b2=b2, a_image=a_image, w_image=w_image)
 
@@ -159,18 +163,12 @@ def _down(x: torch.Tensor, x2: torch.Tensor, left: torch.Tensor, images: bool):
     u = _shared_u(x, left)
     if u is not None:
         return u
-    if images and ext.lora_down_supported(x2, left) and x2.size(1) % 32 == 0:
-        if ext.cached_image(x2, x) is None and not x.is_inference():
-            ext.note_path('lora_down', 'kernel')
-            u, image, _ = ext.lora_down(x2, left, want_image=True)
-            ext.put_image(x2, x, image)
-            return u
-    if images and ext.lora_down_supported(x2, left):
-        # (the image exists already -- another consumer made it: the library's product is as fast alone)
-        ext.note_path('lora_down', 'library_beside_cached_image')
-    else:
-        ext.note_path('lora_down', 'library', fallback=x2.is_cuda and x2.size(0) >= 2048,
-                      why=lambda: 'x {} x left {}'.format(tuple(x2.shape), tuple(left.shape)))
+    if ext.lora_down_supported(x2, left):
+        # (no image by-product: the GEMM behind a lone layer reads the fp32 rows, _mfma_gemm)
+        ext.note_path('lora_down', 'kernel')
+        return ext.lora_down(x2, left)
+    ext.note_path('lora_down', 'library', fallback=x2.is_cuda and x2.size(0) >= 2048,
+                  why=lambda: 'x {} x left {}'.format(tuple(x2.shape), tuple(left.shape)))
     return torch.matmul(x2, left)
 
 

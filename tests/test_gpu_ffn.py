@@ -187,7 +187,8 @@ def _call_fused(c, images=False, **kw):
     G = len(c['offsets']) - 1
     dev = 'cuda'
     if images:
-        kw['a_image'] = ext.split_bf16(c['a'].to(dev))
+        if images != 'a32':                   # 'a32': the weight's image only, fp32 activation rows
+            kw['a_image'] = ext.split_bf16(c['a'].to(dev))
         kw['w_image'] = ext.split_bf16(c['w'].to(dev))
     return ext.grouped_gemm_fused(
         c['a'].to(dev), c['w'].to(dev), torch.tensor(c['offsets'], dtype=torch.int32, device=dev),
@@ -296,6 +297,11 @@ def test_image_path_matches_per_bucket_product(P, K, N, G, R, layout):
     assert not ext.LAST_GEMM_USED_IMAGES
     # same split, same products, a different summation order only
     assert (out - regs).abs().max() <= 1e-5 * regs.abs().max()
+    # A32: the activation's fp32 rows through LDS-DMA, split at the fragment read -- the image
+    # path's arithmetic exactly (same parts, same products, same order)
+    a32 = _call_fused(c, images='a32', epilogue=ext.EPI_PLAIN)
+    assert ext.LAST_GEMM_PATH == 'a32'
+    assert torch.equal(a32, out)
 
 
 @pytest.mark.parametrize('act', ['relu', 'gelu', 'silu'])
@@ -322,10 +328,16 @@ def test_image_path_activation_derivative_epilogue(act, layout):
                             keep_preact=True)
     assert ext.LAST_GEMM_USED_IMAGES
     _close64(pre, c['base'] + c['side'], 'preact')
+    # the same two epilogues on the A32 path: bit-equal to the image path's
+    o3, dm3, da3 = _call_fused(c, images='a32', epilogue=ext.EPI_DACT, activation=_act_code(act), **kw)
+    assert ext.LAST_GEMM_PATH == 'a32'
+    assert torch.equal(o3, out) and torch.equal(dm3, dot_main) and torch.equal(da3, dot_act)
+    o4, p4 = _call_fused(c, images='a32', epilogue=ext.EPI_ACT, activation=_act_code(act), keep_preact=True)
+    assert torch.equal(p4, pre)
 
 
 @pytest.mark.parametrize('queue', [None, 0, 512])      # default queue / none / one that overflows (2 per segment)
-@pytest.mark.parametrize('images', [False, True])
+@pytest.mark.parametrize('images', [False, True, 'a32'])
 def test_relu_preactivations_near_the_kink_are_fp32_exact(images, queue):
     """A product of split operands is off by up to 2^-16 |a| |w|: too much where it decides a
     ReLU derivative.  The epilogue recomputes every pre-activation inside that bound in fp32.
@@ -356,6 +368,8 @@ def test_relu_preactivations_near_the_kink_are_fp32_exact(images, queue):
             + a2[lo:hi].double() @ b2[g * N:(g + 1) * N].double().T
     dev = 'cuda'
     kw = dict(a_image=ext.split_bf16(a.to(dev)), w_image=ext.split_bf16(w.to(dev))) if images else {}
+    if images == 'a32':
+        del kw['a_image']
 
     def run(act):
         return ext.grouped_gemm_fused(
@@ -365,7 +379,7 @@ def test_relu_preactivations_near_the_kink_are_fp32_exact(images, queue):
             relu_queue_entries=queue, **kw)
 
     h, pre = run(ext.ACT_RELU)
-    assert ext.LAST_GEMM_USED_IMAGES == images
+    assert ext.LAST_GEMM_PATH == {False: 'register', True: 'image', 'a32': 'a32'}[images]
     _, pre_split = run(ext.ACT_SILU)                       # the same products, no recomputation
     scale = (a.double().norm(dim=1)[:, None] * torch.cat(
         [w[g * N:(g + 1) * N].double().norm(dim=1)[None, :].expand(offsets[g + 1] - offsets[g], N)
@@ -392,6 +406,9 @@ def test_image_path_is_refused_where_it_does_not_apply():
     c = _fused_case(300, 36, 128, 2, 4, 'bt', seed=5)          # K % 32 != 0
     out = _call_fused(c, images=True, epilogue=ext.EPI_PLAIN)
     assert not ext.LAST_GEMM_USED_IMAGES
+    _close64(out, c['base'] + c['side'], 'out')
+    out = _call_fused(c, images='a32', epilogue=ext.EPI_PLAIN)
+    assert ext.LAST_GEMM_PATH == 'register'
     _close64(out, c['base'] + c['side'], 'out')
 
 

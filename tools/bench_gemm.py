@@ -40,8 +40,11 @@ def both(tag, flops, call):
     res[tag + '.regs'] = {'us': round(us, 1), 'TFLOPs': round(flops / us / 1e6, 1)}
     imgs = call.images()
     us = timeit(lambda: call(*imgs))
-    assert ext.LAST_GEMM_USED_IMAGES
+    assert ext.LAST_GEMM_PATH == 'image'
     res[tag + '.image'] = {'us': round(us, 1), 'TFLOPs': round(flops / us / 1e6, 1)}
+    us = timeit(lambda: call(None, imgs[1]))
+    assert ext.LAST_GEMM_PATH == 'a32'
+    res[tag + '.a32'] = {'us': round(us, 1), 'TFLOPs': round(flops / us / 1e6, 1)}
 
 
 class FfnUp:                      # x[gather] . W1_g^T : bt, gathered rows
