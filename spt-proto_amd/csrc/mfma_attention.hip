@@ -27,6 +27,7 @@
 // cell counts already permuted into the accumulator layout: a consumer lane loads its 16
 // bytes with one global_load_dwordx4 a tile ahead and touches no LDS for them.
 #include "spt_common.h"
+#include <stdlib.h>
 
 // The file is compiled twice: for d_head 64 (this is the unit that also holds the cell-tile
 // pass and the C entry points) and, with -DMA_E_VALUE=128, for d_head 128 into namespace
@@ -1163,6 +1164,302 @@ void attention_mfma_backward_keys_kernel(
     }
 }
 
+// ===================================== fused backward ======================================
+// One launch for grad_q, grad_k and grad_v of a slice (round 3; d_head 64, fp32, S <= 512).
+// The two kernels above each recompute the score tile D and dP = dY V^T: 84 MFMAs per (row tile,
+// key tile) pair, 7 products.  Here the key-owned kernel keeps what it has computed: a wave owns a
+// key tile (K, V fragments and the grad_k, grad_v accumulators in registers, as above), the
+// workgroup of eight waves streams the slice's row tiles through LDS, and the pair's dS tile --
+// needed once more, for grad_q = dS K -- goes to a wave-private LDS tile as a [key][row] image
+// (8-byte stores of the accumulator's 4-row runs).  After the barrier the EIGHT waves share the
+// row tile's grad_q: wave (rb, cb) forms its 16 x 16 block sum over the pass's key tiles of
+// dS(rt, kt) K_kt with v_mfma_f32_16x16x32_bf16 -- A fragments of dS and B fragments of the K
+// rows images (one per wave, written in the pass prologue) both through the transposing LDS read
+// -- so no partial sums cross waves.  5 products per pair: 48 + 12 (32-cycle equivalents) = 60.
+// A slice has more key tiles than the workgroup has waves: pass p takes key tiles 8 p .. 8 p + 7
+// and the row tiles at or below them, grad_q of those rows is carried from pass to pass through
+// its own memory (read-add-write by the same lanes: no atomics, fixed order).  One workgroup
+// per slice: at B >= 256 slices (the benchmark shapes) every CU has one; the register budget is
+// what forbids more -- K, V fragments and both accumulators of 8 key tiles are 256 KiB, half
+// the CU's register file.  delta = max(1e-9, dY . Y) per row (softmax.cu:69) comes from a small
+// kernel of its own in front (the row-owned kernel produced it as a by-product).
+#if MA_E_VALUE == 64
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+constexpr int MF_STREAM = MK_IMG;                       // one stage of the row-tile stream
+constexpr int MF_DSPART = MA_KT * MA_VLD;               // one part of a dS tile [key][row]: 2304 B
+constexpr int MF_DS = 2 * MF_DSPART;                    // hi | lo: 4608 B (= a 32 x MA_TLD float tile)
+constexpr int MF_KIMG = 2 * MA_RIMG;                    // a K rows image, hi | lo: 9216 B
+constexpr int MF_OFF_DS = 2 * MF_STREAM, MF_OFF_K = MF_OFF_DS + MA_WAVES * MF_DS;
+constexpr int MF_LDS = MF_OFF_K + MA_WAVES * MF_KIMG;   // 147,712 B
+constexpr int MF_MAX_RT = 16;                           // S <= 512
+static_assert(MF_DS >= 32 * MA_TLD * 4, "the epilogue's transposing tile fits a dS tile");
+
+__device__ __forceinline__ f32x4 mma16(const uint4 &a, const uint4 &b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// operand fragments of the 16x16x32 product: lane (i = lane & 15, kg = lane >> 4) holds the 8 k's
+// 8 kg .. 8 kg + 7 of row / column `col0 + i`, read from an image whose ROWS are the k index
+// (row stride `ld` bytes, 16-bit elements) through the transposing read
+__device__ __forceinline__ uint4 frag16_tr(const char *img, int ld, int col0, int lane) {
+    const int kg = lane >> 4, gl = lane & 15, qq = gl >> 2, pp = gl & 3;
+    const char *ptr = img + (8 * kg + qq) * ld + (col0 + 4 * pp) * 2;
+    const uint2 a = lds_tr_b64(ptr), b = lds_tr_b64(ptr + 4 * ld);
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+
+// delta[b, row] = max(1e-9, sum_e gy[b, row, e] y[b, row, e])   (softmax.cu:60-69: sum of P dP over
+// a row = dY . (P V) = dY . Y).  GT: both operands stored [B, E, S].
+template <bool GT>
+__global__ __launch_bounds__(256) void attention_delta_kernel(
+    const float *__restrict__ gy, const float *__restrict__ y, float *__restrict__ delta, int S,
+    long long total_rows) {
+    if (GT) {                                           // a thread: four consecutive rows, all e
+        const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+        const long long r4 = 4 * t;
+        if (r4 >= total_rows) return;
+        const long long b = r4 / S, i4 = r4 - b * S;    // (S % 4 == 0)
+        const float *gp = gy + b * S * MA_E + i4, *yp = y + b * S * MA_E + i4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int e = 0; e < MA_E; e++) {
+            const float4 a = *reinterpret_cast<const float4 *>(gp + (size_t)e * S);
+            const float4 c = *reinterpret_cast<const float4 *>(yp + (size_t)e * S);
+            acc.x = fmaf(a.x, c.x, acc.x); acc.y = fmaf(a.y, c.y, acc.y);
+            acc.z = fmaf(a.z, c.z, acc.z); acc.w = fmaf(a.w, c.w, acc.w);
+        }
+        *reinterpret_cast<float4 *>(delta + r4) = make_float4(
+            fmaxf(1e-9f, acc.x), fmaxf(1e-9f, acc.y), fmaxf(1e-9f, acc.z), fmaxf(1e-9f, acc.w));
+    } else {                                            // 16 lanes per row, a float4 each
+        const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
+        const int e4 = (threadIdx.x & 15) * 4;
+        const long long rc = row < total_rows ? row : total_rows - 1;
+        const float4 a = *reinterpret_cast<const float4 *>(gy + rc * MA_E + e4);
+        const float4 c = *reinterpret_cast<const float4 *>(y + rc * MA_E + e4);
+        const float d = group_sum<16>((a.x * c.x + a.y * c.y) + (a.z * c.z + a.w * c.w));
+        if ((threadIdx.x & 15) == 0 && row < total_rows) delta[row] = fmaxf(1e-9f, d);
+    }
+}
+
+template <bool GT>
+__global__ __launch_bounds__(MA_THREADS)
+__attribute__((amdgpu_waves_per_eu(2, 2)))
+void attention_mfma_backward_fused_kernel(
+    const unsigned long long *__restrict__ masks, const unsigned char *__restrict__ cells_t,
+    const unsigned char *__restrict__ pool_t,
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    const float *__restrict__ gy, const float *__restrict__ row_sum,
+    const float *__restrict__ delta, float *__restrict__ grad_q, float *__restrict__ grad_k,
+    float *__restrict__ grad_v, int S, float scale, float clampv, int heads) {
+    typedef float T;
+    constexpr int PI = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, c32 = lane & 31;
+    const int b = blockIdx.x;
+    const DenseView dv = dense_view(b, S, MA_E, heads);
+    const int RT = (S + MA_WROWS - 1) / MA_WROWS;
+    const ScoreMap sm(scale, clampv);
+    char *const stream = smem;
+    char *const dsbuf = smem + MF_OFF_DS + wave * MF_DS;            // this wave's dS tile
+    char *const kimg = smem + MF_OFF_K + wave * MF_KIMG;            // this wave's K rows image
+
+    const unsigned long long mask_reg = lane < RT ? masks[2 * ((size_t)b * RT + lane)] : 0ull;
+    const unsigned long long multi_reg = lane < RT ? masks[2 * ((size_t)b * RT + lane) + 1] : 0ull;
+    auto lane_u64 = [&](unsigned long long reg, int rt) -> unsigned long long {
+        if (rt >= RT) return 0ull;
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)reg, rt);
+        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(reg >> 32), rt);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    const int cstride = cell_slot_bytes(pool_t) / 16;
+    const uint4 *cell_b = reinterpret_cast<const uint4 *>(
+        cells_t + (size_t)b * tri(RT) * cell_slot_bytes(pool_t));
+    const uint4 *pool_b = pool_t ? reinterpret_cast<const uint4 *>(pool_t + (size_t)b * RT * MA_CELLS)
+                                 : nullptr;
+    const KeysStager<T, GT> stager{q + dv.base, gy + (size_t)b * S * MA_E, row_sum + (size_t)b * S,
+                                   delta + (size_t)b * S, dv.ld, S, tid};
+    const int rb = wave >> 2, cb = wave & 3;            // this wave's 16 x 16 block of a grad_q tile
+
+    for (int ps = 0; 8 * ps < RT; ps++) {
+        const int kt = 8 * ps + wave, j0 = kt * MA_KT;
+        const bool have = kt < RT;
+        auto multi_of = [&](int rt) {
+            const int rc = min(rt, RT - 1);
+            return (bool)((lane_u64(multi_reg, rc) >> min(kt, rc)) & 1ull);
+        };
+        auto live = [&](unsigned long long m, int rt) {
+            return have && rt >= kt && rt < RT && ((m >> kt) & 1ull);
+        };
+        auto cell_load = [&](int rt) {
+            const int rc = min(rt, RT - 1), kc = min(kt, rc);
+            if (multi_of(rt)) return pool_b ? pool_b[rc * 64 + lane] : cell_b[(tri(rc) + kc) * 64 + lane];
+            return cell_b[(tri(rc) + kc) * cstride + (c32 >> 2)];
+        };
+        // ---- the pass's key tile: K, V fragments; the K rows image for grad_q ----
+        Frag kf[MA_KS], vf[MA_KS];
+        {
+            float xk[MA_E / 2];
+            load_own_rows_raw(xk, k + dv.base, dv.ld, S, min(j0, max(S - 1, 0)), lane);
+            __syncthreads();                 // (the previous pass has read every K image and dS tile)
+#pragma unroll
+            for (int ks = 0; ks < MA_KS; ks++) {
+                const Frag f = split8(xk[8 * ks], xk[8 * ks + 1], xk[8 * ks + 2], xk[8 * ks + 3],
+                                      xk[8 * ks + 4], xk[8 * ks + 5], xk[8 * ks + 6], xk[8 * ks + 7]);
+                char *dst = kimg + c32 * MA_KLD + 16 * h + 32 * ks;
+                *reinterpret_cast<uint4 *>(dst) = f.hi;
+                *reinterpret_cast<uint4 *>(dst + MA_RIMG) = f.lo;
+            }
+            split_own_rows(kf, xk, sm.sl2);
+            float xv[MA_E / 2];
+            load_own_rows_raw(xv, v + dv.base, dv.ld, S, min(j0, max(S - 1, 0)), lane);
+            split_own_rows(vf, xv);
+        }
+        const int rt0 = 8 * ps;
+        stager.store(stream, stager.load(min(rt0, RT - 1)), rt0);
+        unsigned long long mcur_mask = lane_u64(mask_reg, rt0);
+        uint4 mcur = cell_load(rt0);
+        __syncthreads();
+
+        f32x16 kacc[MA_ET], vacc[MA_ET];
+#pragma unroll
+        for (int e = 0; e < MA_ET; e++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) kacc[e][r] = vacc[e][r] = 0.f;
+
+        for (int rt = rt0; rt < RT; rt++) {
+            const char *buf = stream + ((rt - rt0) & 1) * MF_STREAM;
+            const typename KeysStager<T, GT>::Regs nxt = stager.load(min(rt + 1, RT - 1));
+            const unsigned long long mnxt_mask = lane_u64(mask_reg, rt + 1);
+            const uint4 mnxt = cell_load(rt + 1);
+            // this wave's 16 x 16 block of grad_q[row tile rt] as the earlier passes left it: requested
+            // now, needed behind the pair's arithmetic and the barrier
+            float *const gq_dst = grad_q + dv.base +
+                                  (size_t)min(MA_WROWS * rt + 16 * rb + 4 * (lane >> 4), S - 1) * dv.ld +
+                                  16 * cb + (lane & 15);
+            float carried[4] = {0.f, 0.f, 0.f, 0.f};
+            if (ps > 0) {                                        // (wave-uniform)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int row = MA_WROWS * rt + 16 * rb + 4 * (lane >> 4) + j;
+                    carried[j] = grad_q[dv.base + (size_t)min(row, S - 1) * dv.ld + 16 * cb + (lane & 15)];
+                }
+            }
+            if (live(mcur_mask, rt)) {
+                f32x16 d, dp;
+#pragma unroll
+                for (int r = 0; r < 16; r++) d[r] = dp[r] = 0.f;
+#ifndef MF_NO_DDP
+#pragma unroll
+                for (int ks = 0; ks < MA_KS; ks++) {
+                    d = mm<PI, 2>(read_rows<PI>(buf + MK_QR, buf + MK_QR + MA_RIMG, lane, ks), kf[ks], d);
+                    dp = mm<2, PI>(GT ? read_rows_tr(buf + MK_G, buf + MK_G + MA_CIMG, lane, ks)
+                                      : read_rows<2>(buf + MK_G, buf + MK_G + MA_RIMG, lane, ks),
+                                   vf[ks], dp);
+                }
+#endif
+                // this lane: key j0 + c32, rows 8g + 4h + u of the tile in register 4g + u
+                const float *st = reinterpret_cast<const float *>(buf + MK_ST);
+                const uint4 mm4 = cell_words(mcur, multi_of(rt), lane);
+                const unsigned mw[4] = {mm4.x, mm4.y, mm4.z, mm4.w};
+                float p[16], ds[16];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const float4 del4 = *reinterpret_cast<const float4 *>(st + 8 * g4 + 4 * h);
+                    const float del[4] = {del4.x, del4.y, del4.z, del4.w};
+                    const float m4[4] = {cell_count<0>(mw[g4]), cell_count<1>(mw[g4]),
+                                         cell_count<2>(mw[g4]), cell_count<3>(mw[g4])};
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int r = 4 * g4 + u;
+#ifndef MF_NO_CELLS
+                        p[r] = m4[u] * sm.exp_of(d[r]);          // x 1 / row_sum: in the dY images
+                        ds[r] = sm.inside(d[r]) ? p[r] * (dp[r] - del[u]) : 0.0f;   // x scale: at the stores
+#else
+                        p[r] = m4[u] + d[r]; ds[r] = dp[r] - del[u];
+#endif
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    const Frag pf = split8(p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3],
+                                           p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]);
+                    const Frag sf = split8(ds[8 * s2], ds[8 * s2 + 1], ds[8 * s2 + 2], ds[8 * s2 + 3],
+                                           ds[8 * s2 + 4], ds[8 * s2 + 5], ds[8 * s2 + 6], ds[8 * s2 + 7]);
+                    // dS -> the wave's [key][row] image: registers 8 s2 .. + 3 are rows 16 s2 + 4 h ..
+                    // + 3 of key c32, registers 8 s2 + 4 .. + 7 the rows 8 further down
+#ifndef MF_NO_DSWRITE
+                    char *drow = dsbuf + c32 * MA_VLD + (16 * s2 + 4 * h) * 2;
+                    *reinterpret_cast<uint2 *>(drow) = make_uint2(sf.hi.x, sf.hi.y);
+                    *reinterpret_cast<uint2 *>(drow + 16) = make_uint2(sf.hi.z, sf.hi.w);
+                    *reinterpret_cast<uint2 *>(drow + MF_DSPART) = make_uint2(sf.lo.x, sf.lo.y);
+                    *reinterpret_cast<uint2 *>(drow + MF_DSPART + 16) = make_uint2(sf.lo.z, sf.lo.w);
+#endif
+#ifndef MF_NO_KV
+#pragma unroll
+                    for (int eh = 0; eh < MA_ET; eh++) {
+                        vacc[eh] = mm<2, 2>(pf, GT ? read_cols(buf + MK_G, buf + MK_G + MA_CIMG,
+                                                               c32 + 32 * eh, h, s2)
+                                                   : read_cols_tr<2>(buf + MK_G, buf + MK_G + MA_RIMG,
+                                                                     32 * eh, lane, s2), vacc[eh]);
+                        kacc[eh] = mm<2, PI>(sf, read_cols_tr<PI>(buf + MK_QR, buf + MK_QR + MA_RIMG,
+                                                                  32 * eh, lane, s2), kacc[eh]);
+                    }
+#else
+                    kacc[0][s2] += __builtin_bit_cast(float, pf.hi.x ^ sf.lo.y);
+#endif
+                }
+            }
+            if (rt + 1 < RT) stager.store(stream + ((rt + 1 - rt0) & 1) * MF_STREAM, nxt, rt + 1);
+            __syncthreads();
+            // ---- grad_q of row tile rt: this wave's 16 x 16 block over the pass's live key tiles ----
+            {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const unsigned long long mrow = mcur_mask;
+#ifndef MF_NO_DQ
+#pragma unroll 2
+                for (int kw = 0; kw < MA_WAVES; kw++) {
+                    const int ktw = 8 * ps + kw;
+                    if (ktw <= rt && ktw < RT && ((mrow >> ktw) & 1ull)) {          // (wave-uniform)
+                        const char *dsw = smem + MF_OFF_DS + kw * MF_DS;
+                        const char *kw_img = smem + MF_OFF_K + kw * MF_KIMG;
+                        const uint4 ah = frag16_tr(dsw, MA_VLD, 16 * rb, lane);
+                        const uint4 al = frag16_tr(dsw + MF_DSPART, MA_VLD, 16 * rb, lane);
+                        const uint4 bh = frag16_tr(kw_img, MA_KLD, 16 * cb, lane);
+                        const uint4 bl = frag16_tr(kw_img + MA_RIMG, MA_KLD, 16 * cb, lane);
+                        acc = mma16(al, bh, acc);
+                        acc = mma16(ah, bl, acc);
+                        acc = mma16(ah, bh, acc);
+                    }
+                }
+#endif
+                // C layout: register j of lane (i, g) = row 4 g + j, column i of the block
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int row = MA_WROWS * rt + 16 * rb + 4 * (lane >> 4) + j;
+                    if (row < S) gq_dst[(size_t)j * dv.ld] = fmaf(acc[j], scale, carried[j]);
+                }
+            }
+            mcur = mnxt;
+            mcur_mask = mnxt_mask;
+            __syncthreads();                 // the dS tiles are free for the next row tile
+        }
+        if (have && j0 < S) {
+            float *tile = reinterpret_cast<float *>(dsbuf);
+            float *gk_b = grad_k + dv.base + (size_t)j0 * dv.ld;
+            float *gv_b = grad_v + dv.base + (size_t)j0 * dv.ld;
+#pragma unroll
+            for (int eh = 0; eh < MA_ET; eh++)
+                store_acc_half(kacc[eh], scale, tile, gk_b + 32 * eh, dv.ld, S - j0, lane);
+#pragma unroll
+            for (int eh = 0; eh < MA_ET; eh++)
+                store_acc_half(vacc[eh], 1.0f, tile, gv_b + 32 * eh, dv.ld, S - j0, lane);
+        }
+    }
+}
+#endif  // MA_E_VALUE == 64
+
 static size_t mfma_forward_lds() {
     return 2 * MA_IMG + (size_t)MA_WAVES * MA_WROWS * sizeof(float);
 }
@@ -1200,6 +1497,48 @@ static int launch_backward_t(const unsigned long long *masks, const unsigned cha
     const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
     const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
     const size_t lds_r = 2 * MA_IMG, lds_k = 2 * MK_IMG;
+#if MA_E_VALUE == 64
+    if constexpr (sizeof(T) == 4) {
+        // The fused form (one workgroup per slice): fp32, S <= 512.  OPT-IN (SPT_ATTENTION_BACKWARD=
+        // fused): measured inside bench.py at the configs[1] shape it takes 164.6 us against the two
+        // kernels' 165.0 -- 60 instead of 84 MFMA-equivalents per tile pair bought nothing, because
+        // neither form is bound by the matrix pipe (ablation of the fused kernel)
+        // (read at every call: tests switch it inside one process)
+        const char *e = getenv("SPT_ATTENTION_BACKWARD");
+        const bool fused = e && e[0] == 'f';
+        const int RT = (S + MA_WROWS - 1) / MA_WROWS;
+        const bool fits = RT <= MF_MAX_RT && (!transposed || (S & 3) == 0);
+        if (fits && fused) {
+            const long long rows = (long long)batch_size * S;
+            if (transposed)
+                hipLaunchKernelGGL(attention_delta_kernel<true>, dim3((unsigned)((rows / 4 + 255) / 256)),
+                                   dim3(256), 0, s, (const float *)grad_y, (const float *)y, delta, S, rows);
+            else
+                hipLaunchKernelGGL(attention_delta_kernel<false>, dim3((unsigned)((rows * 16 + 255) / 256)),
+                                   dim3(256), 0, s, (const float *)grad_y, (const float *)y, delta, S, rows);
+            SPT_LAUNCH_CHECK();
+            if (transposed) {
+                SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_mfma_backward_fused_kernel<true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
+                hipLaunchKernelGGL(attention_mfma_backward_fused_kernel<true>, dim3((unsigned)batch_size),
+                                   block, MF_LDS, s, masks, cells_t, pool_t, (const float *)q,
+                                   (const float *)k, (const float *)v, (const float *)grad_y, row_sum,
+                                   delta, (float *)grad_q, (float *)grad_k, (float *)grad_v, S, scale,
+                                   clamp, heads);
+            } else {
+                SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_mfma_backward_fused_kernel<false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
+                hipLaunchKernelGGL(attention_mfma_backward_fused_kernel<false>, dim3((unsigned)batch_size),
+                                   block, MF_LDS, s, masks, cells_t, pool_t, (const float *)q,
+                                   (const float *)k, (const float *)v, (const float *)grad_y, row_sum,
+                                   delta, (float *)grad_q, (float *)grad_k, (float *)grad_v, S, scale,
+                                   clamp, heads);
+            }
+            SPT_LAUNCH_CHECK();
+            return SPT_OK;
+        }
+    }
+#endif
     // 64 gradient columns per launch (the accumulators of 128 would not fit the registers
     // beside the operands' fragments): d_head 128 runs each kernel twice
 #define SPT_MB(GT)                                                                              \

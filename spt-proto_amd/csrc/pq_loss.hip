@@ -34,6 +34,7 @@
 // exp(-log d_c - max) is up to rounding; sums run in a different order than torch's.
 // Parity is therefore "fp32 within 1e-3 rel" (tests/test_gpu_pq_loss.py), not bit-exact.
 #include "spt_common.h"
+#include <stdlib.h>
 
 namespace spt {
 
@@ -174,23 +175,47 @@ __global__ void pq_loss_finish_kernel(const float *__restrict__ partial, float *
 
 // grad_z and one [M][C][D] slab of grad_weight per block.
 //
-// Two lanes per sub-vector: lane `half` owns codewords {8*half .. 8*half+7}, i.e. 8*D
-// accumulators of grad_weight instead of 16*D (which, with the loop temporaries, does not
-// fit a 256-VGPR budget: 340 registers + scratch, one wave per SIMD, measured 153 us at
-// the BASELINE size).  The pair exchanges through DPP quad_perm [1,0,3,2]: the argmin, the
-// softmax denominator, the partial zw and <soft, gs>, and the grad_z halves.
-constexpr int PQL_HC = PQL_C / 2;
-
-__device__ __forceinline__ float pair_other(float v) { return dpp_mov<0xB1>(v); }
-__device__ __forceinline__ int pair_other(int v) {
+// NL lanes per sub-vector (a DPP quad holds one or two sub-vectors): lane `part` owns the
+// codewords {CL * part .. CL * part + CL - 1}, CL = 16 / NL, i.e. CL * D accumulators of
+// grad_weight instead of 16 * D (which, with the loop temporaries, does not fit a 256-VGPR
+// budget: 340 registers + scratch, one wave per SIMD, measured 153 us at the BASELINE size).
+// The lanes of a sub-vector exchange through DPP quad permutations: the argmin, the softmax
+// denominator, the partial zw and <soft, gs>, and the pieces of grad_z.
+//   NL = 2 (rounds 1-2): 64 accumulators, ~190 VGPRs, two waves per SIMD: 65 us -- a quarter of
+//   the VALU rate its ~1,250 instructions per sub-vector need: one wave's dependent chains and LDS
+//   latencies with one other wave to cover them.
+//   NL = 4 (round 3): 32 accumulators, four waves per SIMD; the per-lane duplicates (z, gzw, the
+//   quad sums) cost ~15 % more instructions.
+__device__ __forceinline__ float quad_x1(float v) { return dpp_mov<0xB1>(v); }      // lane ^ 1
+__device__ __forceinline__ float quad_x2(float v) { return dpp_mov<0x4E>(v); }      // lane ^ 2
+__device__ __forceinline__ int quad_x1(int v) {
     return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
 }
+__device__ __forceinline__ int quad_x2(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+}
+template <int NL>
+__device__ __forceinline__ float sub_sum(float v) {          // sum over the NL lanes of a sub-vector
+    v += quad_x1(v);
+    if (NL == 4) v += quad_x2(v);
+    return v;
+}
 
-template <int D>
-__global__ __launch_bounds__(PQL_THREADS, 2) void pq_loss_backward_kernel(
+// WREG: the lane's CL codewords live in REGISTERS for the whole kernel (its subspace never changes):
+// with them in LDS every sub-vector cost each lane 4 passes of ds_read_b128 over its codewords --
+// 66 reads per lane and sub-vector, two-way bank-conflicted (the two halves of a subspace lie 256
+// bytes apart): ~28 us of LDS time per launch at the bench shape, serialised with the arithmetic
+// by the two-waves-per-SIMD occupancy.  Only the best codeword (a data-dependent row) is still
+// read from LDS.
+template <int D, int NL, bool WREG>
+__global__ __launch_bounds__(PQL_THREADS, NL == 4 ? 3 : 2) void pq_loss_backward_kernel(
     const float *__restrict__ z, const float *__restrict__ table,
     const float *__restrict__ grad_loss, float *__restrict__ grad_z,
     float *__restrict__ partial, int total, int M, float inv_count, int accumulate) {
+    constexpr int CL = PQL_C / NL;                  // codewords per lane
+    constexpr int DL = D / NL;                      // elements of grad_z a lane stores
+    static_assert(NL == 2 || NL == 4, "two or four lanes per sub-vector");
+    static_assert(DL == 1 || DL == 2 || DL == 4, "grad_z pieces of 4, 8 or 16 bytes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *tab = reinterpret_cast<float *>(smem);
     constexpr int CD = PQL_C * D;
@@ -199,20 +224,32 @@ __global__ __launch_bounds__(PQL_THREADS, 2) void pq_loss_backward_kernel(
     float *red = tab + M * tstride;  // [waves][M][CD]
 
     const int gtid = blockIdx.x * PQL_THREADS + threadIdx.x;
-    const int half = gtid & 1;
-    const int first = gtid >> 1;
+    const int part = gtid & (NL - 1);
+    const int first = gtid / NL;
     const int m = first % M;
     const float *tsub = tab + m * tstride;          // the whole subspace (for zq)
-    const float *tm = tsub + half * PQL_HC * D;     // this lane's codewords
+    const float *tm = tsub + part * CL * D;         // this lane's codewords
     const float g = grad_loss[0] * inv_count;
 
-    float gt[PQL_HC][D];
+    float gt[CL][D];
 #pragma unroll
-    for (int c = 0; c < PQL_HC; c++)
+    for (int c = 0; c < CL; c++)
 #pragma unroll
         for (int i = 0; i < D; i++) gt[c][i] = 0.0f;
 
-    const int stride = gridDim.x * (PQL_THREADS / 2);
+    float4 wr[WREG ? CL : 1][D / 4];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int c = 0; c < CL; c++)
+#pragma unroll
+            for (int i = 0; i < D / 4; i++) wr[c][i] = reinterpret_cast<const float4 *>(tm + c * D)[i];
+    }
+    // codeword c of this lane, float4 i: from the registers or from LDS
+    auto cw = [&](int c, int i) -> float4 {
+        if constexpr (WREG) return wr[c][i];
+        else return reinterpret_cast<const float4 *>(tm + c * D)[i];
+    };
+    const int stride = gridDim.x * (PQL_THREADS / NL);
     float4 znext[D / 4];
     if (first < total) {
 #pragma unroll
@@ -231,18 +268,17 @@ __global__ __launch_bounds__(PQL_THREADS, 2) void pq_loss_backward_kernel(
             for (int i = 0; i < D / 4; i++)
                 znext[i] = reinterpret_cast<const float4 *>(z + (size_t)(j + stride) * D)[i];
         }
-        asm volatile("" ::: "memory");   // keep the codebook in LDS, not in registers
+        if constexpr (!WREG) asm volatile("" ::: "memory");   // keep the codebook in LDS, not in registers
         // ---- forward, recomputed: distances, argmin, soft assignment, zw, zq ----------
-        float d[PQL_HC], soft[PQL_HC];
+        float d[CL], soft[CL];
         int best_i = 0;
         float best_d = 1e13f;
 #pragma unroll
-        for (int c = 0; c < PQL_HC; c++) {
-            const float4 *tp = reinterpret_cast<const float4 *>(tm + c * D);
+        for (int c = 0; c < CL; c++) {
             float r = 0.0f;
 #pragma unroll
             for (int i = 0; i < D / 4; i++) {
-                const float4 tv = tp[i];
+                const float4 tv = cw(c, i);
                 r += fabsf(zv[4 * i + 0] - tv.x);
                 r += fabsf(zv[4 * i + 1] - tv.y);
                 r += fabsf(zv[4 * i + 2] - tv.z);
@@ -250,40 +286,41 @@ __global__ __launch_bounds__(PQL_THREADS, 2) void pq_loss_backward_kernel(
             }
             d[c] = r;
             const bool cond = r < best_d;
-            best_i = cond ? (half * PQL_HC + c) : best_i;
+            best_i = cond ? (part * CL + c) : best_i;
             best_d = cond ? r : best_d;
         }
         {   // smaller distance, then smaller index: the sequential strict-'<' scan's pick
-            const float od = pair_other(best_d);
-            const int oi = pair_other(best_i);
-            const bool take = (od < best_d) || (od == best_d && oi < best_i);
-            best_d = take ? od : best_d;
-            best_i = take ? oi : best_i;
+            auto merge = [&](float od, int oi) {
+                const bool take = (od < best_d) || (od == best_d && oi < best_i);
+                best_d = take ? od : best_d;
+                best_i = take ? oi : best_i;
+            };
+            merge(quad_x1(best_d), quad_x1(best_i));
+            if (NL == 4) merge(quad_x2(best_d), quad_x2(best_i));
         }
         // 1 / max(d, 1e-5) by v_rcp_f32 (1 ulp): used for the soft assignment and again
         // for d(-log d)/dd; sixteen IEEE divisions were a third of the kernel
         const float dmin = fmaxf(best_d, 1e-5f);
-        float rd[PQL_HC];
+        float rd[CL];
         float wsum = 0.0f;
 #pragma unroll
-        for (int c = 0; c < PQL_HC; c++) {
+        for (int c = 0; c < CL; c++) {
             rd[c] = __builtin_amdgcn_rcpf(fmaxf(d[c], 1e-5f));
             soft[c] = dmin * rd[c];
             wsum += soft[c];
         }
-        wsum += pair_other(wsum);
+        wsum = sub_sum<NL>(wsum);
         const float inv = __builtin_amdgcn_rcpf(wsum);
         float zw[D];
 #pragma unroll
         for (int i = 0; i < D; i++) zw[i] = 0.0f;
-        asm volatile("" ::: "memory");
+        if constexpr (!WREG) asm volatile("" ::: "memory");
 #pragma unroll
-        for (int c = 0; c < PQL_HC; c++) {
+        for (int c = 0; c < CL; c++) {
             soft[c] *= inv;
-            const float4 *tp = reinterpret_cast<const float4 *>(tm + c * D);
 #pragma unroll
             for (int i = 0; i < D / 4; i++) {
-                const float4 tv = tp[i];
+                const float4 tv = cw(c, i);
                 zw[4 * i + 0] = fmaf(soft[c], tv.x, zw[4 * i + 0]);
                 zw[4 * i + 1] = fmaf(soft[c], tv.y, zw[4 * i + 1]);
                 zw[4 * i + 2] = fmaf(soft[c], tv.z, zw[4 * i + 2]);
@@ -300,25 +337,24 @@ __global__ __launch_bounds__(PQL_THREADS, 2) void pq_loss_backward_kernel(
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int ii = 4 * i + u;
-                    const float zwi = zw[ii] + pair_other(zw[ii]);
+                    const float zwi = sub_sum<NL>(zw[ii]);
                     gzw[ii] = 2.0f * g * (zwi - zq[u]);
                     const float e2 = 2.0f * g * (zv[ii] - zq[u]);   // d/dz of the second term
                     hard[ii] = -gzw[ii] - e2;            // d/dzq of both terms -> W[best]
-                    gz[ii] = half == 0 ? e2 : 0.0f;      // counted once per pair
+                    gz[ii] = part == 0 ? e2 : 0.0f;      // counted once per sub-vector
                 }
             }
         }
         // ---- softmax backward: ga_c = soft_c (gs_c - <soft, gs>), gs_c = <gzw, W_c> ----
-        asm volatile("" ::: "memory");
-        float gs[PQL_HC];
+        if constexpr (!WREG) asm volatile("" ::: "memory");
+        float gs[CL];
         float dot = 0.0f;
 #pragma unroll
-        for (int c = 0; c < PQL_HC; c++) {
-            const float4 *tp = reinterpret_cast<const float4 *>(tm + c * D);
+        for (int c = 0; c < CL; c++) {
             float r = 0.0f;
 #pragma unroll
             for (int i = 0; i < D / 4; i++) {
-                const float4 tv = tp[i];
+                const float4 tv = cw(c, i);
                 r = fmaf(gzw[4 * i + 0], tv.x, r);
                 r = fmaf(gzw[4 * i + 1], tv.y, r);
                 r = fmaf(gzw[4 * i + 2], tv.z, r);
@@ -327,19 +363,19 @@ __global__ __launch_bounds__(PQL_THREADS, 2) void pq_loss_backward_kernel(
             gs[c] = r;
             dot = fmaf(soft[c], r, dot);
         }
-        dot += pair_other(dot);
-        asm volatile("" ::: "memory");
+        dot = sub_sum<NL>(dot);
+        if constexpr (!WREG) asm volatile("" ::: "memory");
 #pragma unroll
-        for (int c = 0; c < PQL_HC; c++) {
+        for (int c = 0; c < CL; c++) {
             // a = -log(max(d, 1e-5)): da/dd = -1/d where d >= 1e-5 (torch.clamp passes the
             // gradient at the boundary), 0 below
             const float ga = soft[c] * (gs[c] - dot);
             const float gd = (d[c] >= 1e-5f) ? -ga * rd[c] : 0.0f;
-            const bool is_best = (half * PQL_HC + c == best_i);
-            const float4 *tp = reinterpret_cast<const float4 *>(tm + c * D);
+            // (one fma per element with a 0 / 1 factor instead of a select and an add)
+            const float is_best = (part * CL + c == best_i) ? 1.0f : 0.0f;
 #pragma unroll
             for (int i = 0; i < D / 4; i++) {
-                const float4 tv = tp[i];
+                const float4 tv = cw(c, i);
                 const float w[4] = {tv.x, tv.y, tv.z, tv.w};
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -347,49 +383,57 @@ __global__ __launch_bounds__(PQL_THREADS, 2) void pq_loss_backward_kernel(
                     // cdist backward, extension/cdist.cu:113-119,167-174
                     const float sg = (zv[ii] - w[u]) > 0.0f ? gd : -gd;
                     gz[ii] += sg;
-                    float t = fmaf(soft[c], gzw[ii], -sg);
-                    t += is_best ? hard[ii] : 0.0f;
-                    gt[c][ii] += t;
+                    gt[c][ii] = fmaf(is_best, hard[ii], fmaf(soft[c], gzw[ii], gt[c][ii])) - sg;
                 }
             }
         }
-        // grad_z: each lane of the pair stores one half of the sub-vector
+        // grad_z: lane `part` of the sub-vector stores elements DL part .. DL part + DL - 1
 #pragma unroll
-        for (int i = 0; i < D; i++) gz[i] += pair_other(gz[i]);
-        float *gp = grad_z + (size_t)j * D + half * (D / 2);
+        for (int i = 0; i < D; i++) gz[i] = sub_sum<NL>(gz[i]);
+        float *gp = grad_z + (size_t)j * D + part * DL;
+        float o[DL];
+#pragma unroll
+        for (int e = 0; e < DL; e++) {
+            // (a select chain over the lane's part: no dynamically indexed register array)
+            float v = gz[e];
+#pragma unroll
+            for (int q = 1; q < NL; q++) v = part == q ? gz[q * DL + e] : v;
+            o[e] = v;
+        }
         // accumulate: grad_z already holds the gradient that reached z over another path (the
         // attention's grad_q / grad_k): added here instead of by an elementwise pass of its own
-        if constexpr (D == 8) {
-            float4 o = half == 0 ? make_float4(gz[0], gz[1], gz[2], gz[3])
-                                 : make_float4(gz[4], gz[5], gz[6], gz[7]);
+        if constexpr (DL == 4) {
+            float4 v = make_float4(o[0], o[1], o[2], o[3]);
             if (accumulate) {
                 const float4 b = *reinterpret_cast<const float4 *>(gp);
-                o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
             }
-            *reinterpret_cast<float4 *>(gp) = o;
-        } else {
-            float2 o = half == 0 ? make_float2(gz[0], gz[1]) : make_float2(gz[2], gz[3]);
+            *reinterpret_cast<float4 *>(gp) = v;
+        } else if constexpr (DL == 2) {
+            float2 v = make_float2(o[0], o[1]);
             if (accumulate) {
                 const float2 b = *reinterpret_cast<const float2 *>(gp);
-                o.x += b.x; o.y += b.y;
+                v.x += b.x; v.y += b.y;
             }
-            *reinterpret_cast<float2 *>(gp) = o;
+            *reinterpret_cast<float2 *>(gp) = v;
+        } else {
+            *gp = accumulate ? o[0] + *gp : o[0];
         }
     }
 
-    // lanes l, l+2M, l+4M .. of a wave hold the same (subspace, half): butterfly over
+    // lanes l, l + NL M, l + 2 NL M .. of a wave hold the same (subspace, part): butterfly over
     // those, then the waves of the block through LDS
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int step = 2 * M; step < 64; step <<= 1) {
+    for (int step = NL * M; step < 64; step <<= 1) {
 #pragma unroll
-        for (int c = 0; c < PQL_HC; c++)
+        for (int c = 0; c < CL; c++)
 #pragma unroll
             for (int i = 0; i < D; i++) gt[c][i] += __shfl_xor(gt[c][i], step, 64);
     }
-    if (lane < 2 * M) {
-        float *dst = red + ((size_t)wave * M + m) * CD + half * PQL_HC * D;
+    if (lane < NL * M) {
+        float *dst = red + ((size_t)wave * M + m) * CD + part * CL * D;
 #pragma unroll
-        for (int c = 0; c < PQL_HC; c++)
+        for (int c = 0; c < CL; c++)
 #pragma unroll
             for (int i = 0; i < D; i++) dst[c * D + i] = gt[c][i];
     }
@@ -439,10 +483,26 @@ static bool pq_loss_shape_ok(long long n_vectors, int M, int C, int D) {
     return n_vectors * M < 0x7FFFFFFFLL - 4 * 1024 * 1024;
 }
 
-static int pq_loss_blocks(long long total) {
+static int pq_loss_blocks(long long total, int cap = 512) {
     long long nblk = (total + PQL_THREADS - 1) / PQL_THREADS;
-    if (nblk > 512) nblk = 512;  // two blocks per CU; grid stride 512*256 is a multiple of M
+    if (nblk > cap) nblk = cap;  // `cap / 256` blocks per CU; the grid stride cap * 256 / NL is a multiple of M
     return (int)nblk;
+}
+// lanes per sub-vector of the backward (pq_loss_backward_kernel): 2; SPT_PQ_LANES=4 runs the
+// four-lane form with the codewords in registers (round 3: measured 80-87 us against 74 -- the
+// kernel is bound by the instructions it issues, not by occupancy or LDS, and four lanes issue
+// 15 % more); the workspace is sized for either
+static int pq_backward_lanes() {
+    static int lanes = 0;
+    if (lanes == 0) {
+        const char *e = getenv("SPT_PQ_LANES");
+        lanes = (e && e[0] == '4') ? 4 : 2;
+    }
+    return lanes;
+}
+static int pq_backward_blocks(long long total) {
+    const int nl = pq_backward_lanes();
+    return pq_loss_blocks((long long)nl * total, nl == 4 ? 768 : 512);
 }
 
 }  // namespace spt
@@ -452,7 +512,7 @@ using namespace spt;
 extern "C" int64_t spt_pq_loss_workspace_bytes(int64_t n_vectors, int n_subspaces,
                                                int n_codewords, int d_code) {
     if (n_vectors <= 0 || !pq_loss_shape_ok(n_vectors, n_subspaces, n_codewords, d_code)) return 0;
-    const int nblk = pq_loss_blocks(2 * n_vectors * n_subspaces);   // backward: 2 lanes each
+    const int nblk = pq_loss_blocks(4 * n_vectors * n_subspaces, 1024);   // backward: upper bound
     return (int64_t)nblk * n_subspaces * n_codewords * d_code * (int64_t)sizeof(float);
 }
 
@@ -507,7 +567,8 @@ extern "C" int spt_pq_loss_backward(const float *z, const float *table, const fl
     if (n_vectors <= 0 || n_subspaces <= 0 || n_codewords <= 0 || d_code <= 0) return SPT_EINVAL;
     if (!pq_loss_shape_ok(n_vectors, n_subspaces, n_codewords, d_code)) return SPT_EUNSUP;
     const int total = (int)(n_vectors * n_subspaces);
-    const int nblk = pq_loss_blocks(2LL * total);
+    const int nblk = pq_backward_blocks(total);
+    const bool four = pq_backward_lanes() == 4;
     const int CD = n_codewords * d_code;
     const size_t lds = ((size_t)n_subspaces * (CD + 4) +
                         (size_t)(PQL_THREADS / 64) * n_subspaces * CD) * sizeof(float);
@@ -516,10 +577,17 @@ extern "C" int spt_pq_loss_backward(const float *z, const float *table, const fl
     float *partial = reinterpret_cast<float *>(workspace);
     hipStream_t s = (hipStream_t)stream;
     if (d_code == 4)
-        hipLaunchKernelGGL((pq_loss_backward_kernel<4>), dim3(nblk), dim3(PQL_THREADS), lds, s, z,
+        if (four)
+            hipLaunchKernelGGL((pq_loss_backward_kernel<4, 4, true>), dim3(nblk), dim3(PQL_THREADS), lds, s, z,
+                               table, grad_loss, grad_z, partial, total, n_subspaces, inv_count, accumulate);
+        else
+            hipLaunchKernelGGL((pq_loss_backward_kernel<4, 2, false>), dim3(nblk), dim3(PQL_THREADS), lds, s, z,
+                               table, grad_loss, grad_z, partial, total, n_subspaces, inv_count, accumulate);
+    else if (four)
+        hipLaunchKernelGGL((pq_loss_backward_kernel<8, 4, true>), dim3(nblk), dim3(PQL_THREADS), lds, s, z,
                            table, grad_loss, grad_z, partial, total, n_subspaces, inv_count, accumulate);
     else
-        hipLaunchKernelGGL((pq_loss_backward_kernel<8>), dim3(nblk), dim3(PQL_THREADS), lds, s, z,
+        hipLaunchKernelGGL((pq_loss_backward_kernel<8, 2, false>), dim3(nblk), dim3(PQL_THREADS), lds, s, z,
                            table, grad_loss, grad_z, partial, total, n_subspaces, inv_count, accumulate);
     SPT_LAUNCH_CHECK();
     const int elems = n_subspaces * CD;

@@ -53,13 +53,19 @@ def test_mfma_forward_matches_oracle_chain(N, H, S, Z, E, yt):
     assert (y.cpu() - want_y).abs().max() < 2e-4 * want_y.abs().max()
 
 
+@pytest.mark.parametrize('form', ['split', 'fused'])
 @pytest.mark.parametrize('gt', [False, True])
 @pytest.mark.parametrize('N,H,S,Z,E', SHAPES)
-def test_mfma_backward_matches_oracle_chain(N, H, S, Z, E, gt):
+def test_mfma_backward_matches_oracle_chain(N, H, S, Z, E, gt, form, monkeypatch):
     """grad_q, grad_k, grad_v against the oracle operators chained as the reference's autograd
     does: dP = sddmm(dY, V); dS = clamp-mask(scale * softmax_backward(P, dP));
-    dQ = spmm(dS, K); dK = spmm(dS^T, Q); dV = spmm(P^T, dY)."""
+    dQ = spmm(dS, K); dK = spmm(dS^T, Q); dV = spmm(P^T, dY).
+    form: the two kernels (row-owned + key-owned, the default) or the fused single kernel
+    (SPT_ATTENTION_BACKWARD=fused: d_head 64, S <= 512; other shapes take the two kernels anyway)."""
     import numpy as np
+    if form == 'fused' and (E != 64 or S > 512):
+        pytest.skip('the fused backward covers d_head 64, S <= 512')
+    monkeypatch.setenv('SPT_ATTENTION_BACKWARD', form)
     from oracle import ext_stub
     from naive_gpt import ext
     gen = torch.Generator().manual_seed(7 * N + S + Z)
