@@ -456,16 +456,18 @@ class _LookupRows(torch.autograd.Function):
         flat = ids.reshape(-1)
         g = grad.reshape(flat.numel(), -1)
         sid, order = torch.sort(flat, stable=True)
-        total = torch.cumsum(g.index_select(0, order).double(), dim=0)          # [T, r] fp64
+        # (the running sum along the LAST dimension of the transposed rows: torch's scan over an
+        # outer dimension took 1.06 ms for [8192, 16] doubles, over the inner one it is ~10 us)
+        total = torch.cumsum(g.index_select(0, order).double().t().contiguous(), dim=1)   # [r, T] fp64
         pos = torch.arange(flat.numel(), device=flat.device)
         first = torch.ones_like(sid, dtype=torch.bool)
         first[1:] = sid[1:] != sid[:-1]
         start = torch.cummax(torch.where(first, pos, torch.zeros_like(pos)), dim=0).values
-        before = torch.where((start > 0).unsqueeze(1), total.index_select(0, (start - 1).clamp_min(0)),
+        before = torch.where((start > 0).unsqueeze(0), total.index_select(1, (start - 1).clamp_min(0)),
                              torch.zeros_like(total))
         last = torch.ones_like(first)
         last[:-1] = first[1:]
-        runs = ((total - before) * last.unsqueeze(1)).to(g.dtype)
+        runs = ((total - before) * last.unsqueeze(0)).to(g.dtype).t()         # [T, r]
         out = torch.zeros([ctx.rows, g.size(1)], dtype=g.dtype, device=g.device)
         out.index_add_(0, sid, runs)
         return None, out

@@ -140,6 +140,41 @@ def test_routed_ffn_grouped_path_equals_torch_path(kind):
         assert _scaled_close(g1[n], g2[n], rtol=2e-3), n
 
 
+@pytest.mark.parametrize('kind', ['opt', 'llama'])
+def test_plain_routed_ffn_with_frozen_weights_runs_grouped_and_equals_the_loop(kind):
+    """RoutedFFN / RoutedLLaMaFFN (no adapters; reference layers/sparse/feedforward.py:37-98,
+    133-187): with frozen base weights the blocks are grouped launches with device-side bucket
+    boundaries; trainable weights keep the per-block loop.  Same weights, both ways."""
+    from naive_gpt import ext, layers
+    torch.manual_seed(5)
+    d, dff, bs = 64, 1024, 128
+    if kind == 'opt':
+        m = layers.RoutedFFN(block_size=bs, d_model=d, d_feedforward=dff, activation=nn.ReLU())
+    else:
+        m = layers.RoutedLLaMaFFN(block_size=bs, d_model=d, d_feedforward=dff, activation=nn.SiLU())
+    m = m.cuda()
+    x = torch.randn([3, 211, d], device='cuda', requires_grad=True)
+    w = torch.randn([3, 211, d], device='cuda')
+
+    ext.reset_paths()
+    y_loop = m(x)
+    (y_loop * w).sum().backward()
+    gx_loop = x.grad.clone()
+    assert ext.paths_taken('routed_ffn_plain') == {('routed_ffn_plain', 'torch_loop'): 1}
+    x.grad = None
+    for p in m.parameters():
+        p.requires_grad_(False)
+    ext.reset_paths()
+    y = m(x)
+    (y * w).sum().backward()
+    assert ext.paths_taken('routed_ffn_plain') == {('routed_ffn_plain', 'grouped'): 1}
+    assert ext.paths_taken('route_topk') == {('route_topk', 'kernel'): 1}
+    assert _scaled_close(y, y_loop)
+    assert _scaled_close(x.grad, gx_loop)
+    with torch.no_grad():
+        assert _scaled_close(m(x), y_loop)      # (the fixed-order row combine of the no-grad path)
+
+
 # ------------------------------------------------------------------ fused epilogues
 
 def _act(name):
