@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 31
+#define SPT_ABI_VERSION 32
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -385,7 +385,8 @@ int spt_grouped_gemm(const float *a, const int32_t *gather, const float *w,
  *   The kernel multiplies its accumulators by rowscale after the k-loop and runs the second
  *   term as one more k-step on top: nothing is ever divided by rowscale (0 is a legal router
  *   coefficient: 2 sigmoid(logit) underflows below logit -104).
- * The second term is the LoRA side path (lora_ffn.py:97-100,108-110): r <= 32, r % 4 == 0.
+ * The second term is the LoRA side path (lora_ffn.py:97-100,108-110): r <= 32 (SPT_EPI_PLAIN
+ * through the fp32 operands: r <= 64), r % 4 == 0.
  * The pdot rows are the two inner products the gradient of the router coefficient needs,
  * <v, h> and <dS, s>: with c = rowscale, v = c (dY W2_g^T) + E and s = c (x W1_g^T + b1_g) + F,
  * d c = <dY W2_g^T, h> + <dS, x W1_g^T + b1_g> = (<v, h> - <E, h> + <dS, s> - <dS, F>) / c, and
@@ -450,6 +451,14 @@ typedef struct SptGroupedGemm {
                                   16-byte aligned for the kernels that read them next */
     int32_t accumulate;        /* != 0 (SPT_EPI_PLAIN only): out += the product instead of out = --
                                   the sum of several products (dX of q / k / v) without a pass of its own */
+    /* K in segments (0: none; SPT_EPI_PLAIN, fp32 operands only): the contraction walks k / a_seg_k
+     * matrices [*, a_seg_k] that lie a_seg_stride floats apart,
+     *   A(row, kk) = a[(kk / a_seg_k) * a_seg_stride + src(row) * lda + kk % a_seg_k],
+     * so dX = dQ Wq + dK Wk + dV Wv is ONE product with k = 3 n against the three weights stacked
+     * (a_seg_k % 32 == 0, k % a_seg_k == 0, a_seg_stride % 4 == 0, lda >= a_seg_k).  With it (and
+     * SPT_EPI_PLAIN) the second term may be r <= 64 wide: the three rank-16 products side by side. */
+    int32_t a_seg_k;
+    int64_t a_seg_stride;
 } SptGroupedGemm;
 int spt_grouped_gemm_fused(const SptGroupedGemm *desc, void *stream);
 int spt_grouped_gemm_pdot_width(int n);
@@ -554,6 +563,15 @@ long long spt_tall_tn_workspace_bytes(long long rows, int n_groups, int width, i
 int spt_tall_tn(const float *wide, long long ldw, const float *narrow, long long ldn,
                 const int32_t *gather, const int32_t *offsets, int n_groups, long long rows,
                 int width, int n, float *out, int transposed, void *workspace, void *stream);
+/* `count` (1 .. 4) products of ONE shape, ONE pair of leading dimensions and ONE (gather, offsets)
+ * in a single pair of launches: outs[i] = the spt_tall_tn result of (wides[i], narrows[i]) (host
+ * arrays of `count` device pointers; the two table gradients of a LoRA linear, the three `right`
+ * gradients of q / k / v, the two per-block tables of a routed FFN).  workspace:
+ * count * spt_tall_tn_workspace_bytes(rows, n_groups, width, n) bytes. */
+int spt_tall_tn_batch(int count, const float *const *wides, long long ldw, const float *const *narrows,
+                      long long ldn, const int32_t *gather, const int32_t *offsets, int n_groups,
+                      long long rows, int width, int n, float *const *outs, int transposed,
+                      void *workspace, void *stream);
 
 /*
  * Bucketing for the routed FFN: the k largest of the n_blocks router probabilities of every

@@ -103,6 +103,11 @@ struct GroupedArgs {
     float *out;             // [P, N] row-major
     int P, K, N, G;
     int lda;
+    // K in segments (register path): A(row, kk) = a[(kk / a_seg_k) * a_seg_stride + row * lda + kk % a_seg_k]
+    // -- the k-loop walks several matrices [*, a_seg_k] that lie a_seg_stride floats apart (the sum
+    // of the q / k / v products of a backward as ONE contraction); 0: one matrix [*, K]
+    int a_seg_k;
+    long long a_seg_stride;
     long long ldo;          // row stride of out / out2 / h_in / s_in (>= N; launch_grouped: 0 -> N)
     int accumulate;         // EPI_PLAIN: out += result (the sum of several products in one buffer)
     long long gstride;
@@ -800,6 +805,10 @@ __device__ __forceinline__ void gemm_tile_regs(const GroupedArgs &g, float *smem
     // ---- software pipeline: the global loads of k-step t+1 are in flight while the MFMAs
     // of step t run; registers -> LDS happens at the top of the next step ----
     float4 av[NUA], bv[GG_NU];
+    // segments of K (a_seg_k > 0; the calls below visit k0 = 0, 32, 64 .. in order): the offset of
+    // the current segment's matrix, less the k's that lie before it
+    long long a_adj = 0;
+    int seg_left = g.a_seg_k > 0 ? g.a_seg_k : 0x7FFFFFFF;
     // KTAIL == false (K % GG_BK == 0): no predicate anywhere in the loads.  The predicated
     // form compiles into branches around the loads, 8 per k-step.
     auto load_tile = [&](int k0) {
@@ -808,10 +817,12 @@ __device__ __forceinline__ void gemm_tile_regs(const GroupedArgs &g, float *smem
 #pragma unroll
         for (int u = 0; u < NUA; u++) {
             if constexpr (KTAIL)
-                av[u] = k < g.K ? *reinterpret_cast<const float4 *>(a_src[u] + k) : zero;
+                av[u] = k < g.K ? *reinterpret_cast<const float4 *>(a_src[u] + a_adj + k) : zero;
             else
-                av[u] = *reinterpret_cast<const float4 *>(a_src[u] + k);
+                av[u] = *reinterpret_cast<const float4 *>(a_src[u] + a_adj + k);
         }
+        seg_left -= GG_BK;
+        if (seg_left <= 0) { a_adj += g.a_seg_stride - g.a_seg_k; seg_left = g.a_seg_k; }
         if constexpr (!BN_LAYOUT) {
 #pragma unroll
             for (int u = 0; u < GG_NU; u++) {
@@ -866,37 +877,41 @@ __device__ __forceinline__ void gemm_tile_regs(const GroupedArgs &g, float *smem
 
     gg_scale_rows<NI>(g, acc, row_lo, row_hi, wm);
 
-    // ---- K extension on top: acc += A2 . B2_g^T (R <= 32: one k-step, zero beyond R) ----
+    // ---- K extension on top: acc += A2 . B2_g^T, 32 columns of the two operands per k-step (zero
+    // beyond R; R > 32 -- several rank-16 side products side by side -- only without the ReLU
+    // epilogue, whose `extras` hold the norms of ONE step's rows) ----
     if (EXT) {
-        __syncthreads();                  // the last k-step's tiles are consumed
-        const int k = 4 * s_kq;
+        for (int r0 = 0; r0 < g.R; r0 += GG_BK) {
+            __syncthreads();              // the last k-step's tiles are consumed
+            const int k = r0 + 4 * s_kq;
 #pragma unroll
-        for (int u = 0; u < NUA; u++) {
-            const int r = s_row + GG_RPP * u;
-            const int p = row_lo + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < row_hi && k < g.R) {
-                const int src = g.gather2 ? g.gather2[p] : p;
-                v = *reinterpret_cast<const float4 *>(g.a2 + (size_t)src * g.lda2 + k);
+            for (int u = 0; u < NUA; u++) {
+                const int r = s_row + GG_RPP * u;
+                const int p = row_lo + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < row_hi && k < g.R) {
+                    const int src = g.gather2 ? g.gather2[p] : p;
+                    v = *reinterpret_cast<const float4 *>(g.a2 + (size_t)src * g.lda2 + k);
+                }
+                put4(As, GG_AIMG, r * GG_ROWB + 8 * s_kq, v);
+                const float ss = group_sum<8>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+                if (s_kq == 0) extras[r] = ss;              // |a2 row|^2, for the epilogue
             }
-            put4(As, GG_AIMG, r * GG_ROWB + 8 * s_kq, v);
-            const float ss = group_sum<8>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
-            if (s_kq == 0) extras[r] = ss;                  // |a2 row|^2, for the epilogue
-        }
 #pragma unroll
-        for (int u = 0; u < GG_NU; u++) {
-            const int r = s_row + GG_RPP * u;
-            const int n = n0 + r;
-            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < g.N && k < g.R)
-                b = *reinterpret_cast<const float4 *>(g.b2 + (size_t)bucket * g.b2_gstride +
-                                                      (size_t)n * g.b2_ldn + k);
-            put4(Bs, GG_BIMG, r * GG_ROWB + 8 * s_kq, b);
-            const float ss = group_sum<8>(b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w);
-            if (s_kq == 0) extras[128 + r] = ss;            // |b2 row|^2
+            for (int u = 0; u < GG_NU; u++) {
+                const int r = s_row + GG_RPP * u;
+                const int n = n0 + r;
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < g.N && k < g.R)
+                    b = *reinterpret_cast<const float4 *>(g.b2 + (size_t)bucket * g.b2_gstride +
+                                                          (size_t)n * g.b2_ldn + k);
+                put4(Bs, GG_BIMG, r * GG_ROWB + 8 * s_kq, b);
+                const float ss = group_sum<8>(b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w);
+                if (s_kq == 0) extras[128 + r] = ss;        // |b2 row|^2
+            }
+            __syncthreads();
+            contract(min(GG_BK, g.R - r0), true);
         }
-        __syncthreads();
-        contract(g.R, true);
     }
     __syncthreads();   // all waves are done with the operand tiles
     gg_epilogue<NI, EPI>(g, smem, acc, bucket, row_lo, row_hi, col_tile, wm, wn, extras, EXT);
@@ -1083,7 +1098,7 @@ static int resident_slots() {
 // activation as its fp32 rows (16-byte aligned, lda % 4 == 0: one LDS-DMA lane moves 16 bytes)
 static int image_path(GroupedArgs &g, int epilogue) {
     if (!g.w_img || (!g.a_img && !g.a)) return 0;
-    if (g.K % GG_BK != 0) return 0;
+    if (g.K % GG_BK != 0 || g.a_seg_k > 0 || (g.a2 && g.R > GG_BK)) return 0;
     const long long row_len = g.ldk == 1 ? g.ldn : g.ldk;       // elements of one weight row
     if (row_len <= 0 || g.gstride % 32 != 0 || row_len % 32 != 0) return 0;
     g.w_grow = g.gstride / row_len;
@@ -1100,7 +1115,12 @@ static int image_path(GroupedArgs &g, int epilogue) {
 
 static int launch_grouped(GroupedArgs g, int epilogue, void *stream) {
     if ((!g.a && !g.a_img) || (!g.w && !g.w_img) || !g.offsets || !g.out) return SPT_EINVAL;
-    if (g.P <= 0 || g.K <= 0 || g.N <= 0 || g.G <= 0 || g.lda < g.K) return SPT_EINVAL;
+    if (g.P <= 0 || g.K <= 0 || g.N <= 0 || g.G <= 0) return SPT_EINVAL;
+    if (g.a_seg_k < 0 || g.lda < (g.a_seg_k > 0 ? g.a_seg_k : g.K)) return SPT_EINVAL;
+    if (g.a_seg_k > 0) {
+        if (g.a_seg_k % GG_BK != 0 || g.K % g.a_seg_k != 0 || g.a_seg_stride % 4 != 0) return SPT_ESHAPE;
+        if (epilogue != EPI_PLAIN || !g.a) return SPT_EUNSUP;
+    }
     if (g.ldo == 0) g.ldo = g.N;
     if (g.ldo < g.N) return SPT_EINVAL;
     if (g.accumulate && epilogue != EPI_PLAIN) return SPT_EUNSUP;
@@ -1110,7 +1130,8 @@ static int launch_grouped(GroupedArgs g, int epilogue, void *stream) {
     if (g.ldk != 1 && (g.ldk % 4 != 0 || g.N % 4 != 0 || g.gstride % 4 != 0)) return SPT_ESHAPE;
     const bool ext = g.a2 != nullptr;
     if (ext) {
-        if (!g.b2 || g.R <= 0 || g.R > GG_BK) return SPT_EINVAL;
+        if (!g.b2 || g.R <= 0 || g.R > 2 * GG_BK) return SPT_EINVAL;
+        if (g.R > GG_BK && epilogue != EPI_PLAIN) return SPT_EUNSUP;
         if (g.R % 4 != 0 || g.lda2 % 4 != 0 || g.lda2 < g.R || g.b2_ldn % 4 != 0 ||
             g.b2_gstride % 4 != 0)
             return SPT_ESHAPE;
@@ -1211,6 +1232,7 @@ extern "C" int spt_grouped_gemm_fused(const SptGroupedGemm *d, void *stream) {
     g.a_norm = d->a_norm; g.w_norm = d->w_norm;
     g.ldo = d->ldo;
     g.accumulate = d->accumulate;
+    g.a_seg_k = d->a_seg_k; g.a_seg_stride = d->a_seg_stride;
     const long long header = GG_FIX_SEGS * 64;
     if (d->relu_queue && d->relu_queue_bytes >= header + GG_FIX_SEGS * 8) {
         g.fix_count = reinterpret_cast<unsigned *>(d->relu_queue);
@@ -1227,6 +1249,7 @@ extern "C" int spt_grouped_gemm_image_path(const SptGroupedGemm *d) {
     g.K = d->k; g.gstride = d->w_group_stride; g.ldn = d->w_ldn; g.ldk = d->w_ldk;
     g.act = d->activation;
     g.a = d->a; g.lda = d->lda;
+    g.a2 = d->a2; g.R = d->r; g.a_seg_k = d->a_seg_k;
     g.a_img = reinterpret_cast<const char *>(d->a_image);
     g.w_img = reinterpret_cast<const char *>(d->w_image);
     return image_path(g, d->epilogue);

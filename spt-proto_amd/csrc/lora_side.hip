@@ -311,13 +311,26 @@ __device__ __forceinline__ void tn_chunk(const int32_t *offsets, int G, long lon
     }
 }
 
+// Up to TN_BATCH products of one shape in one launch (blockIdx.z picks the problem): the two table
+// gradients of a LoRA linear, the three `right` gradients of q / k / v -- each alone is 512
+// workgroups for ~6 us of HBM time, half of what the launch takes.
+constexpr int TN_BATCH = 4;
+struct TnBatch {
+    const float *wide[TN_BATCH];
+    const float *narrow[TN_BATCH];
+    float *out[TN_BATCH];
+};
+
 template <int N, int UNROLL, bool GATHER>
 __global__ __launch_bounds__(64 * TN_WAVES, 2) void tall_tn_partial_kernel(
-    const float *__restrict__ wide, long long ldw, const float *__restrict__ narrow, long long ldn,
+    TnBatch batch, long long ldw, long long ldn,
     const int32_t *__restrict__ gather, const int32_t *__restrict__ offsets, int G, long long R, int W,
     float *__restrict__ partial) {
     constexpr int JB = N < 16 ? N : 16;                      // table columns per reduction pass
     __shared__ float2 red[TN_WAVES][JB][64];
+    const float *__restrict__ wide = batch.wide[blockIdx.z];
+    const float *__restrict__ narrow = batch.narrow[blockIdx.z];
+    partial += (size_t)blockIdx.z * gridDim.x * N * W;
     int g, rows; long long row0;
     tn_chunk(offsets, G, R, blockIdx.x, g, row0, rows);
     const int lane = threadIdx.x & 63;
@@ -403,8 +416,10 @@ __global__ __launch_bounds__(64 * TN_WAVES, 2) void tall_tn_partial_kernel(
 // summation tree.  (One thread per element: 16 K threads on 64 CUs, 8 us for 4 MB.)
 __global__ __launch_bounds__(256) void tall_tn_reduce_kernel(
     const float *__restrict__ partial, const int32_t *__restrict__ offsets, int G, int W, int n,
-    int nchunks, float *__restrict__ out, int transposed) {
+    int nchunks, TnBatch batch, int transposed) {
     __shared__ float slice_sum[4][64];
+    float *__restrict__ out = batch.out[blockIdx.z];
+    partial += (size_t)blockIdx.z * nchunks * n * W;
     const int g = blockIdx.y;
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;                    // element (j, w) of the group's table
@@ -452,40 +467,62 @@ extern "C" long long spt_tall_tn_workspace_bytes(long long rows, int n_groups, i
     return nchunks * width * n * (long long)sizeof(float);
 }
 
-extern "C" int spt_tall_tn(const float *wide, long long ldw, const float *narrow, long long ldn,
-                           const int32_t *gather, const int32_t *offsets, int n_groups,
-                           long long rows, int width, int n, float *out, int transposed,
-                           void *workspace, void *stream) {
-    if (!wide || !narrow || !out || !workspace) return SPT_EINVAL;
+static int tall_tn_any(int count, const float *const *wides, long long ldw, const float *const *narrows,
+                       long long ldn, const int32_t *gather, const int32_t *offsets, int n_groups,
+                       long long rows, int width, int n, float *const *outs, int transposed,
+                       void *workspace, void *stream) {
+    if (count <= 0 || count > TN_BATCH || !wides || !narrows || !outs || !workspace) return SPT_EINVAL;
     if (rows <= 0 || width <= 0 || n <= 0 || n_groups <= 0 || ldw < width || ldn < n) return SPT_EINVAL;
     if (!offsets && n_groups != 1) return SPT_EINVAL;
     if (n != 4 && n != 16 && n != 48) return SPT_EUNSUP;
     if (transposed < 0 || transposed > 2 || (transposed == 2 && n % 16 != 0)) return SPT_EINVAL;
     if (n_groups > 64 || rows > 0x7FFFFFFFll) return SPT_EUNSUP;
-    if (width % 2 != 0 || ldw % 2 != 0 || (reinterpret_cast<uintptr_t>(wide) & 7) != 0) return SPT_ESHAPE;
-    if (ldn % 4 != 0 || !ls_aligned(narrow)) return SPT_ESHAPE;
+    if (width % 2 != 0 || ldw % 2 != 0 || ldn % 4 != 0) return SPT_ESHAPE;
+    TnBatch batch = {};
+    for (int i = 0; i < count; i++) {
+        if (!wides[i] || !narrows[i] || !outs[i]) return SPT_EINVAL;
+        if ((reinterpret_cast<uintptr_t>(wides[i]) & 7) != 0 || !ls_aligned(narrows[i])) return SPT_ESHAPE;
+        batch.wide[i] = wides[i]; batch.narrow[i] = narrows[i]; batch.out[i] = outs[i];
+    }
     // (upper bound of the chunk count: each group ends with at most one short chunk; chunks past a
     // group's rows find no group and write zeros that the reduction never reads)
     const int nchunks = (int)((rows + TN_RC - 1) / TN_RC) + (offsets ? n_groups : 0);
     hipStream_t s = (hipStream_t)stream;
     float *partial = static_cast<float *>(workspace);
-    const dim3 grid(nchunks, (width + TN_COLS - 1) / TN_COLS);
+    const dim3 grid(nchunks, (width + TN_COLS - 1) / TN_COLS, count);
 #define SPT_TN(N, U)                                                                              \
     do {                                                                                          \
         if (gather)                                                                               \
             hipLaunchKernelGGL((tall_tn_partial_kernel<N, U, true>), grid, dim3(64 * TN_WAVES), 0, s, \
-                               wide, ldw, narrow, ldn, gather, offsets, n_groups, rows, width, partial); \
+                               batch, ldw, ldn, gather, offsets, n_groups, rows, width, partial); \
         else                                                                                      \
             hipLaunchKernelGGL((tall_tn_partial_kernel<N, U, false>), grid, dim3(64 * TN_WAVES), 0, s, \
-                               wide, ldw, narrow, ldn, gather, offsets, n_groups, rows, width, partial); \
+                               batch, ldw, ldn, gather, offsets, n_groups, rows, width, partial); \
     } while (0)
     if (n == 4) SPT_TN(4, 8);
     else if (n == 16) SPT_TN(16, 8);
     else SPT_TN(48, 4);
 #undef SPT_TN
     SPT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(tall_tn_reduce_kernel, dim3((width * n + 63) / 64, n_groups), dim3(256), 0, s,
-                       partial, offsets, n_groups, width, n, nchunks, out, transposed);
+    hipLaunchKernelGGL(tall_tn_reduce_kernel, dim3((width * n + 63) / 64, n_groups, count), dim3(256), 0, s,
+                       partial, offsets, n_groups, width, n, nchunks, batch, transposed);
     SPT_LAUNCH_CHECK();
     return SPT_OK;
+}
+
+extern "C" int spt_tall_tn(const float *wide, long long ldw, const float *narrow, long long ldn,
+                           const int32_t *gather, const int32_t *offsets, int n_groups,
+                           long long rows, int width, int n, float *out, int transposed,
+                           void *workspace, void *stream) {
+    return tall_tn_any(1, &wide, ldw, &narrow, ldn, gather, offsets, n_groups, rows, width, n, &out,
+                       transposed, workspace, stream);
+}
+
+extern "C" int spt_tall_tn_batch(int count, const float *const *wides, long long ldw,
+                                 const float *const *narrows, long long ldn, const int32_t *gather,
+                                 const int32_t *offsets, int n_groups, long long rows, int width,
+                                 int n, float *const *outs, int transposed, void *workspace,
+                                 void *stream) {
+    return tall_tn_any(count, wides, ldw, narrows, ldn, gather, offsets, n_groups, rows, width, n, outs,
+                       transposed, workspace, stream);
 }

@@ -85,6 +85,8 @@ _PROTOTYPES = {
     'spt_lora_down_grouped': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, ctypes.c_longlong,
                                _c_int, _c_ptr, _c_int, _c_ptr, ctypes.c_longlong] + [_c_ptr] * 3, _c_int),
     'spt_tall_tn_workspace_bytes': ([ctypes.c_longlong, _c_int, _c_int, _c_int], ctypes.c_longlong),
+    'spt_tall_tn_batch': ([_c_int, _c_ptr, ctypes.c_longlong, _c_ptr, ctypes.c_longlong, _c_ptr, _c_ptr, _c_int,
+                           ctypes.c_longlong, _c_int, _c_int, _c_ptr, _c_int, _c_ptr, _c_ptr], _c_int),
     'spt_tall_tn': ([_c_ptr, ctypes.c_longlong, _c_ptr, ctypes.c_longlong, _c_ptr, _c_ptr, _c_int,
                      ctypes.c_longlong, _c_int, _c_int, _c_ptr, _c_int, _c_ptr, _c_ptr], _c_int),
     'spt_route_topk': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
@@ -96,7 +98,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 _lib = None
 
@@ -642,7 +644,9 @@ def attention_mfma_backward(tiles: MfmaTiles, q: torch.Tensor, k: torch.Tensor, 
     dev = _same_device(tiles.buffer, q, k, v, y, grad_y, row_sum)
     lib = load_library()
     with _on(dev):
-        grad_q, grad_k, grad_v = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        # (one buffer: the projections' backward contracts the three as ONE matrix product when
+        # they are equally spaced in memory -- layers/tuning/lora.py, `qkv_dx`)
+        grad_q, grad_k, grad_v = torch.empty([3, *q.shape], dtype=q.dtype, device=dev).unbind(0)
         delta = torch.empty([B, S], dtype=torch.float32, device=dev)
         fn = (lib.spt_attention_mfma_backward if q.dtype == torch.float32
               else lib.spt_attention_mfma_backward_bf16)
@@ -885,7 +889,7 @@ class _GroupedDesc(ctypes.Structure):
         ('pdot_main', _c_ptr), ('pdot_act', _c_ptr), ('pdot_ld', ctypes.c_int32),
         ('a_image', _c_ptr), ('w_image', _c_ptr), ('a_norm', _c_ptr), ('w_norm', _c_ptr),
         ('relu_queue', _c_ptr), ('relu_queue_bytes', ctypes.c_int64), ('ldo', ctypes.c_int64),
-        ('accumulate', ctypes.c_int32),
+        ('accumulate', ctypes.c_int32), ('a_seg_k', ctypes.c_int32), ('a_seg_stride', ctypes.c_int64),
     ]
 
 
@@ -1055,7 +1059,8 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                        a_image: SplitImage = None, w_image: SplitImage = None,
                        a_norm: torch.Tensor = None, w_norm: torch.Tensor = None,
                        relu_queue_entries: int = None, out: torch.Tensor = None,
-                       accumulate: bool = False, raw_dots: bool = False):
+                       accumulate: bool = False, raw_dots: bool = False,
+                       a_segments: tuple = None):
     """``spt_grouped_gemm_fused``: the block GEMM of a routed FFN with its LoRA side
     product, rowscale / bias, and the activation (EPI_ACT) or its derivative plus the two
     row dots of the coefficient gradient (EPI_DACT) folded in (include/spt_hip.h).
@@ -1063,7 +1068,9 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
     Returns ``out`` (EPI_PLAIN), ``(out, preact | None)`` (EPI_ACT) or
     ``(out, dot_main [P], dot_act [P])`` (EPI_DACT).  ``out``: a buffer [n_rows, >= n] to write
     into (EPI_PLAIN; its row stride may exceed n: ``ldo`` of include/spt_hip.h); with
-    ``accumulate`` the product is ADDED to what `out` holds."""
+    ``accumulate`` the product is ADDED to what `out` holds.  ``a_segments`` = (seg_k, seg_stride):
+    `a` is the first of k / seg_k matrices [rows, seg_k] that lie seg_stride floats apart (the
+    caller vouches for the others' memory), contracted one after the other."""
     for t, name in ((a, 'a'), (weight, 'weight')):
         _check_type(t, torch.float32, name)
     _check_type(offsets, torch.int32, 'offsets')
@@ -1144,7 +1151,9 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                 w_image=w_image.buffer.data_ptr() if images else None,
                 a_norm=_ptr(a_norm), w_norm=_ptr(w_norm), relu_queue=_ptr(queue),
                 relu_queue_bytes=queue.numel() if queue is not None else 0, ldo=out.stride(0),
-                accumulate=int(bool(accumulate)))
+                accumulate=int(bool(accumulate)),
+                a_seg_k=a_segments[0] if a_segments else 0,
+                a_seg_stride=a_segments[1] if a_segments else 0)
             global LAST_GEMM_USED_IMAGES, LAST_GEMM_PATH
             LAST_GEMM_PATH = ('register', 'image', 'a32')[lib.spt_grouped_gemm_image_path(ctypes.byref(desc))]
             LAST_GEMM_USED_IMAGES = LAST_GEMM_PATH != 'register'
@@ -1227,6 +1236,51 @@ def tall_tn(wide: torch.Tensor, narrow: torch.Tensor, gather: torch.Tensor = Non
     if rc != 0:
         _raise(lib, rc, 'tall_tn')
     return out
+
+
+def tall_tn_batchable(wides, narrows) -> bool:
+    """1 .. 4 (wide, narrow) pairs of one shape and one pair of row strides, each `tall_tn_supported`"""
+    if not (1 <= len(wides) <= 4 and len(narrows) == len(wides)):
+        return False
+    w0, n0 = wides[0], narrows[0]
+    return all(tall_tn_supported(w, nr) and w.shape == w0.shape and nr.shape == n0.shape
+               and w.stride(0) == w0.stride(0) and nr.stride(0) == n0.stride(0) and w.device == w0.device
+               for w, nr in zip(wides, narrows))
+
+
+def tall_tn_batch(wides, narrows, gather: torch.Tensor = None, offsets: torch.Tensor = None):
+    """``spt_tall_tn_batch``: the `tall_tn` results [G, width, n] of 1 .. 4 (wide, narrow) pairs of one
+    shape and one pair of row strides (`tall_tn_batchable`), sharing `gather` and `offsets`: one
+    pair of launches for all of them."""
+    count = len(wides)
+    _require(tall_tn_batchable(wides, narrows), 'tall_tn_batch: 1 .. 4 supported pairs of one shape')
+    w0, n0 = wides[0], narrows[0]
+    rows, width = w0.shape
+    n = n0.size(1)
+    G = 1 if offsets is None else offsets.numel() - 1
+    if gather is not None:
+        _check_type(gather, torch.int32, 'gather')
+        _require(gather.is_contiguous() and gather.numel() == rows, 'gather: one int32 per row of wide')
+    else:
+        _require(n0.size(0) == rows, 'narrow: one row per row of wide')
+    if offsets is not None:
+        _check_type(offsets, torch.int32, 'offsets')
+        _require(offsets.is_contiguous() and G >= 1, 'offsets: [G + 1] int32')
+    dev = w0.device
+    lib = load_library()
+    array = ctypes.c_void_p * count
+    with _on(dev):
+        out = torch.empty([count, G, width, n], dtype=torch.float32, device=dev)
+        work = torch.empty([count * lib.spt_tall_tn_workspace_bytes(rows, G, width, n)], dtype=torch.uint8,
+                           device=dev)
+        rc = lib.spt_tall_tn_batch(count, array(*[w.data_ptr() for w in wides]), w0.stride(0),
+                                   array(*[t.data_ptr() for t in narrows]), n0.stride(0),
+                                   _ptr(gather), _ptr(offsets), G, rows, width, n,
+                                   array(*[out[i].data_ptr() for i in range(count)]), 0,
+                                   work.data_ptr(), _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'tall_tn_batch')
+    return list(out.unbind(0))
 
 
 def route_topk_coeff(prob: torch.Tensor, k: int, scale: float):

@@ -257,6 +257,16 @@ def _tn_blocks(wide: torch.Tensor, per_token: torch.Tensor, bk: Buckets) -> torc
     return _block_major(_tn(wide, _in_own_block(rows, bk.block, nb)), nb)
 
 
+def _tn_blocks_many(pairs, bk: Buckets):
+    """[_tn_blocks(wide, per_token, bk) for the pairs]: one pair of launches when they have one shape"""
+    wides, narrows = [p[0] for p in pairs], [p[1] for p in pairs]
+    if ext.tall_tn_batchable(wides, narrows):
+        ext.note_path('tall_tn_blocks', 'kernel_batch')
+        outs = ext.tall_tn_batch(wides, narrows, gather=bk.token, offsets=bk.offsets)
+        return [t.view(bk.n_blocks * wides[0].size(1), -1) for t in outs]
+    return [_tn_blocks(w, t, bk) for w, t in pairs]
+
+
 def _route(x: torch.Tensor, rw: torch.Tensor, rb, n_blocks: int, k: int):
     """The router (sparse/feedforward.py:22-25: Linear + Sigmoid) and the bucketing of its top-k, inside
     the routed FFN's own autograd node: -> (prob [T, nb], Buckets with coeff = 2 prob
@@ -370,10 +380,10 @@ class RoutedLoRAFFN(torch.autograd.Function):
         # LoRA tables (before the last GEMM: ds [P, bs] is released as soon as that has read it --
         # the step's peak memory is here, with h, ds, dxs and grad_x alive)
         du_tok = ext.rows_combine(du, bk.pos)                                # [T, r]: du[pos].sum(1)
-        grad_l1 = _tn(x, du_tok)
-        grad_r1 = _tn_blocks(ds, u, bk)
-        grad_l2 = _tn_blocks(h, dzt, bk)
-        grad_r2 = _tn(dy, ext.rows_combine(z, bk.pos))
+        # (two pairs of equal shape: one pair of launches each)
+        from naive_gpt.layers.tuning.lora import tall_tn_many
+        grad_l1, grad_r2 = tall_tn_many([(x, du_tok), (dy, ext.rows_combine(z, bk.pos))])
+        grad_r1, grad_l2 = _tn_blocks_many([(ds, u), (h, dzt)], bk)
         del dot_main, dot_act, du_tok, dzt
         dxs = ext.grouped_gemm_fused(
             ds, w1, bk.offsets, nb, n=d, k=bs, w_group_stride=bs * d, w_ldn=1, w_ldk=d,

@@ -71,6 +71,26 @@ def tall_tn(a: torch.Tensor, b: torch.Tensor, chunk: int = 256) -> torch.Tensor:
     return out.sum(dim=0)
 
 
+def tall_tn_many(pairs):
+    """[tall_tn(a, b) for a, b in pairs] (None entries pass through) -- as ONE pair of launches
+    (spt_tall_tn_batch) when the pairs have one shape and `a` is the wide side: a step makes these
+    products in twos and threes (the two tables of a LoRA linear, the `right` tables of q / k / v),
+    each alone half launch overhead."""
+    live = [i for i, p in enumerate(pairs) if p is not None]
+    out = [None] * len(pairs)
+    if len(live) >= 2 and pairs[live[0]][0].is_cuda and pairs[live[0]][0].size(0) >= 512:
+        from naive_gpt import ext
+        wides, narrows = [pairs[i][0] for i in live], [pairs[i][1] for i in live]
+        if len(live) <= 4 and ext.tall_tn_batchable(wides, narrows):
+            ext.note_path('tall_tn', 'kernel_batch')
+            for i, t in zip(live, ext.tall_tn_batch(wides, narrows)):
+                out[i] = t[0]
+            return out
+    for i in live:
+        out[i] = tall_tn(*pairs[i])
+    return out
+
+
 _OFFSETS = {}
 
 
@@ -243,8 +263,8 @@ class _FrozenLoRALinear(torch.autograd.Function):
                 grad_x = torch.matmul(dy2, weight)
                 grad_x.addmm_(du, left.t())
             grad_x = grad_x.view(ctx.x_shape)
-        grad_left = tall_tn(x2, du) if ctx.needs_input_grad[3] else None
-        grad_right = tall_tn(dy2, u) if ctx.needs_input_grad[4] else None
+        grad_left, grad_right = tall_tn_many([(x2, du) if ctx.needs_input_grad[3] else None,
+                                              (dy2, u) if ctx.needs_input_grad[4] else None])
         return grad_x, None, None, grad_left, grad_right
 
 
@@ -271,6 +291,20 @@ def _home3(tensors):
     refs += [weakref.ref(t) for t in tensors[1:]]
     _HOMES[key] = (refs, tuple(t.data_ptr() for t in tensors), home)
     return home
+
+
+def _equal_spacing(mats) -> int:
+    """floats from each matrix to the next when the three [rows, n] fp32 matrices are contiguous,
+    disjoint and equally spaced in memory (views of one buffer), else 0"""
+    a, b, c = mats
+    if not all(m.is_contiguous() and m.dtype == torch.float32 and m.shape == a.shape for m in mats):
+        return 0
+    step = b.data_ptr() - a.data_ptr()
+    if step < a.numel() * 4 or c.data_ptr() - b.data_ptr() != step or step % 16 != 0:
+        return 0
+    if not (a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() == c.untyped_storage().data_ptr()):
+        return 0
+    return step // 4
 
 
 def _qkv_index(rows: int, device):
@@ -356,13 +390,28 @@ class _FrozenLoRAQKV(torch.autograd.Function):
             dus[g] = _down_grad(dy2[g], rights[g], out=du_cat[:, i * r:(i + 1) * r])
         grad_x = None
         if ctx.needs_input_grad[0]:
-            for g in range(3):
-                if dy2[g] is None:
-                    continue
-                # dX (+)= dY_g W_g + dU_g L_g^T
+            step = _equal_spacing(dy2) if len(live) == 3 and r == 16 else 0
+            if step and _equal_spacing(weights) == n * k:
+                # dX = [dQ | dK | dV] [Wq; Wk; Wv] + [dU_q | dU_k | dU_v] [L_q | L_k | L_v]^T: ONE
+                # contraction over k = 3 n -- the three gradients lie `step` floats apart (the
+                # attention's backward writes them into one buffer) and the three weights are one
+                # [3 n, k] matrix (_home3): a third of the launches, each three times as long, and
+                # no read-add-write of dX between them
+                ext.note_path('qkv_dx', 'joint')
                 grad_x = ext.grouped_gemm_fused(
-                    dy2[g], weights[g], one, 1, k, n, 0, 1, k, rows, a2=dus[g],
-                    b2=lefts[g].contiguous(), out=grad_x, accumulate=grad_x is not None)
+                    dy2[0], weights[0].as_strided((3 * n, k), (k, 1)), one, 1, k, 3 * n, 0, 1, k, rows, a2=du_cat,
+                    b2=torch.cat([t.detach() for t in lefts], dim=1), a_segments=(n, step))
+            else:
+                ext.note_path('qkv_dx', 'three_launches', fallback=len(live) == 3,
+                              why=lambda: 'the gradients of q, k, v are not three equally spaced matrices '
+                                          '(another op between the projection and the attention)')
+                for g in range(3):
+                    if dy2[g] is None:
+                        continue
+                    # dX (+)= dY_g W_g + dU_g L_g^T
+                    grad_x = ext.grouped_gemm_fused(
+                        dy2[g], weights[g], one, 1, k, n, 0, 1, k, rows, a2=dus[g],
+                        b2=lefts[g].contiguous(), out=grad_x, accumulate=grad_x is not None)
             if grad_x is not None:
                 grad_x = grad_x.view(ctx.x_shape)
         grad_lefts, grad_rights = [None] * 3, [None] * 3
@@ -371,9 +420,10 @@ class _FrozenLoRAQKV(torch.autograd.Function):
                 gl = ext.tall_tn(x2, du_cat, split16=True)[0]                  # [len(live), k, 16]
             else:
                 gl = tall_tn(x2, du_cat).view(x2.size(1), len(live), r).permute(1, 0, 2)
+            rights = tall_tn_many([(dy2[g], u3[g]) for g in live])
             for i, g in enumerate(live):
                 grad_lefts[g] = gl[i]
-                grad_rights[g] = tall_tn(dy2[g], u3[g])
+                grad_rights[g] = rights[i]
         return (grad_x, None, None, None, None, None, None, *grad_lefts, *grad_rights, None)
 
 

@@ -927,3 +927,70 @@ def test_joint_qkv_projection_equals_three_lora_linears():
     ((linears[0](xr) * ws[0]).sum() + (linears[2](xr) * ws[2]).sum()).backward()
     assert torch.allclose(x.grad, xr.grad, rtol=1e-3, atol=2e-5 * xr.grad.abs().max().item())
     assert linears[1].lora.left.weight.grad is None or not linears[1].lora.left.weight.grad.any()
+
+
+def test_segmented_contraction_and_a_48_wide_second_term():
+    """SptGroupedGemm.a_seg_k / a_seg_stride: three [rows, n] matrices that lie apart in one buffer
+    contracted as ONE k = 3 n product, with a second term of three rank-16 products side by side
+    (include/spt_hip.h) -- against the fp64 sum of the three products."""
+    from naive_gpt import ext
+    torch.manual_seed(1)
+    rows, n, k, r = 700, 256, 384, 16
+    buf = torch.randn([3, rows + 5, n], device='cuda')          # (5 rows of padding between the matrices)
+    dys = [buf[g, :rows] for g in range(3)]
+    w3 = torch.randn([3 * n, k], device='cuda')
+    du = torch.randn([rows, 3 * r], device='cuda')
+    lcat = torch.randn([k, 3 * r], device='cuda')
+    one = torch.tensor([0, rows], dtype=torch.int32, device='cuda')
+    got = ext.grouped_gemm_fused(dys[0], w3, one, 1, k, 3 * n, 0, 1, k, rows, a2=du, b2=lcat,
+                                 a_segments=(n, (rows + 5) * n))
+    assert ext.LAST_GEMM_PATH == 'register'
+    want = sum(dys[g].double() @ w3[g * n:(g + 1) * n].double() for g in range(3)) + du.double() @ lcat.double().T
+    _close64(got, want.cpu(), 'segmented', rtol=1e-4)
+    # the image of the weight does not change the path: segments read the fp32 operands
+    got2 = ext.grouped_gemm_fused(dys[0], w3, one, 1, k, 3 * n, 0, 1, k, rows, a2=du, b2=lcat,
+                                  a_segments=(n, (rows + 5) * n), w_image=ext.split_bf16(w3))
+    assert ext.LAST_GEMM_PATH == 'register' and torch.equal(got, got2)
+    with pytest.raises(Exception):          # a segment is a whole number of 32-wide k-steps
+        ext.grouped_gemm_fused(dys[0], w3, one, 1, k, 3 * n, 0, 1, k, rows, a_segments=(n + 16, rows * n))
+
+
+def test_joint_qkv_backward_is_one_contraction_when_the_gradients_share_a_buffer(monkeypatch):
+    """The attention's backward hands dQ, dK, dV over as three slices of one buffer
+    (ext.attention_mfma_backward): `_FrozenLoRAQKV.backward` then forms dX with ONE launch.  Same
+    gradients as the three accumulating launches."""
+    from naive_gpt import ext, layers
+    from naive_gpt.layers.tuning import lora
+    torch.manual_seed(0)
+    d = 512
+    linears = [layers.LoRALinear.from_pretrained(16, nn.Linear(d, d)).cuda() for _ in range(3)]
+    for m in linears:
+        m.lora.right.weight.data.normal_(0, 0.02)
+    x0 = torch.randn([4, 512, d], device='cuda')
+    feed = torch.randn([3, 4, 512, d], device='cuda')
+
+    class Feed(torch.autograd.Function):        # d loss / d (q, k, v) = the three slices of `feed`
+        @staticmethod
+        def forward(ctx, q, k, v):
+            return q.new_zeros([])
+
+        @staticmethod
+        def backward(ctx, g):
+            return feed[0], feed[1], feed[2]
+
+    def run():
+        x = x0.clone().requires_grad_(True)
+        for m in linears:
+            m.zero_grad()
+        ext.reset_paths()
+        Feed.apply(*lora.qkv(x, linears)).backward()
+        return [x.grad] + [m.lora.left.weight.grad.clone() for m in linears] \
+            + [m.lora.right.weight.grad.clone() for m in linears]
+
+    joint = run()
+    assert ext.paths_taken('qkv_dx') == {('qkv_dx', 'joint'): 1}
+    monkeypatch.setattr(lora, '_equal_spacing', lambda mats: 0)
+    apart = run()
+    assert ext.paths_taken('qkv_dx') == {('qkv_dx', 'three_launches'): 1}
+    for a, b in zip(joint, apart):
+        assert torch.allclose(a, b, rtol=1e-3, atol=2e-5 * b.abs().max().item())

@@ -81,3 +81,42 @@ def test_bad_arguments_are_refused():
         ext.tall_tn(wide, torch.randn([1000, 16]).cuda())             # rows disagree
     with pytest.raises(Exception):
         ext.tall_tn(wide[:, :63], torch.randn([1024, 16]).cuda())      # odd width
+
+
+@pytest.mark.parametrize('count', [2, 3, 4])
+def test_batch_of_products_is_bit_equal_to_the_single_launches(count):
+    """spt_tall_tn_batch: the same kernels with the problem in blockIdx.z -- every product bit-equal
+    to its own spt_tall_tn call (plain and grouped with a shared gather)."""
+    from naive_gpt import ext
+    torch.manual_seed(count)
+    rows, width, n = 4000, 384, 16
+    wides = [torch.randn([rows, width], device='cuda') for _ in range(count)]
+    block = torch.randn([count, rows, n], device='cuda')           # narrow sides: slices of one buffer
+    narrows = [block[i] for i in range(count)]
+    assert ext.tall_tn_batchable(wides, narrows)
+    for got, w, nr in zip(ext.tall_tn_batch(wides, narrows), wides, narrows):
+        assert torch.equal(got, ext.tall_tn(w, nr))
+    # grouped: rows sorted by block, per-token narrow sides picked by a shared gather
+    T = 1000
+    token = torch.randint(0, T, [rows], device='cuda', dtype=torch.int32)
+    offsets = torch.tensor([0, 900, 2100, 2100, rows], dtype=torch.int32, device='cuda')
+    per_token = [torch.randn([T, n], device='cuda') for _ in range(count)]
+    for got, w, nr in zip(ext.tall_tn_batch(wides, per_token, gather=token, offsets=offsets), wides, per_token):
+        assert torch.equal(got, ext.tall_tn(w, nr, gather=token, offsets=offsets))
+    assert not ext.tall_tn_batchable(wides, narrows[:-1] + [torch.randn([rows, 4], device='cuda')])
+    assert not ext.tall_tn_batchable(wides * 3, narrows * 3)          # at most four
+
+
+def test_lora_table_gradients_in_pairs():
+    from naive_gpt import ext
+    from naive_gpt.layers.tuning import lora
+    torch.manual_seed(0)
+    x, dy = torch.randn([2048, 256], device='cuda'), torch.randn([2048, 256], device='cuda')
+    du, u = torch.randn([2048, 16], device='cuda'), torch.randn([2048, 16], device='cuda')
+    ext.reset_paths()
+    gl, none, gr = lora.tall_tn_many([(x, du), None, (dy, u)])
+    assert none is None and ext.paths_taken('tall_tn') == {('tall_tn', 'kernel_batch'): 1}
+    assert torch.equal(gl, lora.tall_tn(x, du)) and torch.equal(gr, lora.tall_tn(dy, u))
+    # different shapes: one by one
+    a, b = lora.tall_tn_many([(x, du), (dy[:, :128].contiguous(), u)])
+    assert torch.equal(a, gl) and torch.equal(b, lora.tall_tn(dy[:, :128].contiguous(), u))

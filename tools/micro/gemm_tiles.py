@@ -9,17 +9,19 @@ from naive_gpt import ext
 d = 1024
 dev = 'cuda'
 torch.manual_seed(0)
-w = torch.randn([d, d], device=dev)
-wi = ext.split_bf16(w)
 out = {}
-for mt in [16, 32, 64, 96, 112, 128, 130, 160, 192, 256, 288, 384]:
+ks = [d] if len(sys.argv) < 2 else [int(v) for v in sys.argv[1:]]
+for mt in [32, 64, 128, 130, 192, 256]:
     rows = 128 * mt
-    a = torch.randn([rows, d], device=dev)
-    ai = ext.split_bf16(a)
     one = torch.tensor([0, rows], dtype=torch.int32, device=dev)
-    for kk in ([d] if len(sys.argv) < 2 else [int(v) for v in sys.argv[1:]]):
+    for kk in ks:
+        # (K = 1056: image rows of 33 blocks = 4224 bytes, not a power of two)
+        w = torch.randn([d, kk], device=dev)
+        wi = ext.split_bf16(w)
+        a = torch.randn([rows, kk], device=dev)
+        ai = ext.split_bf16(a)
         def call():
-            return ext.grouped_gemm_fused(a, w, one, 1, d, kk, 0, d, 1, rows, a_image=ai, w_image=wi)
+            return ext.grouped_gemm_fused(a, w, one, 1, d, kk, 0, kk, 1, rows, a_image=ai, w_image=wi)
         for _ in range(5):
             call()
         torch.cuda.synchronize()
@@ -33,4 +35,5 @@ for mt in [16, 32, 64, 96, 112, 128, 130, 160, 192, 256, 288, 384]:
         tiles = mt * 8
         out['tiles%d_k%d' % (tiles, kk)] = {'us': round(us, 1), 'rounds': round(tiles / 768, 2),
                                             'TF': round(6.0 * rows * d * kk / us / 1e6)}
-print(json.dumps(out, indent=0))
+for k, v in out.items():
+    print(k, v)
