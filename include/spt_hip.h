@@ -107,6 +107,19 @@ int spt_pq_loss_backward(const float *z, const float *table, const float *grad_l
                          float *grad_z, float *grad_table, void *workspace,
                          int64_t n_vectors, int n_subspaces, int n_codewords, int d_code,
                          int accumulate, void *stream);
+/* `parts` (1 .. 4) tensors back to back in z -- q and k of one attention, which the joint projection
+ * writes into one buffer -- against the SAME table in ONE pass: loss = the SUM of the parts' losses
+ * (each a mean over its own n_vectors = batch * seq * heads rows), codes [parts * batch * heads, seq, M],
+ * grad_z / the accumulation target laid out like z, grad_table the sum over the parts (what the
+ * reference's `loss_q + loss_k` of attention.py:98-104 differentiates to).  workspace:
+ * spt_pq_loss_workspace_bytes(parts * n_vectors, ...) bytes. */
+int spt_pq_loss_forward_codes_parts(const float *z, const float *table, float *loss, void *workspace,
+                                    int32_t *codes, int parts, int batch, int seq_length, int n_heads,
+                                    int n_subspaces, int n_codewords, int d_code, void *stream);
+int spt_pq_loss_backward_parts(const float *z, const float *table, const float *grad_loss,
+                               float *grad_z, float *grad_table, void *workspace,
+                               int64_t n_vectors, int parts, int n_subspaces, int n_codewords,
+                               int d_code, int accumulate, void *stream);
 
 /*
  * cdist_backward_cuda(query, table, grad_output) -> [grad_query, grad_table]

@@ -194,6 +194,15 @@ __device__ __forceinline__ int quad_x1(int v) {
 __device__ __forceinline__ int quad_x2(int v) {
     return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
 }
+// floats from one lane's codewords to the next lane's in the backward kernel's LDS table
+__host__ __device__ constexpr int pq_part_stride(int D, int NL) {
+    return (PQL_C / NL) * D + ((NL == 2 && D == 8) ? 32 : 0);
+}
+typedef float pq_v2f __attribute__((ext_vector_type(2)));
+// +1 or -1 with the sign bit of e (one v_bfi_b32)
+__device__ __forceinline__ float pq_copysign1(float e) {
+    return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, e) & 0x80000000u) | 0x3f800000u);
+}
 template <int NL>
 __device__ __forceinline__ float sub_sum(float v) {          // sum over the NL lanes of a sub-vector
     v += quad_x1(v);
@@ -219,8 +228,20 @@ __global__ __launch_bounds__(PQL_THREADS, NL == 4 ? 3 : 2) void pq_loss_backward
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *tab = reinterpret_cast<float *>(smem);
     constexpr int CD = PQL_C * D;
-    const int tstride = CD + 4;
-    pq_stage_table(table, tab, M, CD, tstride);
+    // the table in LDS: subspace m at m * tstride, the CL codewords of lane `part` at part * PSTRIDE.
+    // The 16 lanes of one ds_read_b128 group are 16 / NL sub-vectors of consecutive subspaces; with
+    // the parts 256 bytes apart (D = 8, two lanes) both lanes of a sub-vector read the same banks:
+    // every codeword read two-way conflicted, 66 reads per lane and sub-vector.  96 floats apart
+    // (32 banks) and subspaces 4 banks apart, the 16 addresses of a group fall on 16 different
+    // four-bank windows.
+    constexpr int PSTRIDE = pq_part_stride(D, NL);
+    constexpr int tstride = NL * PSTRIDE + 4;
+    for (int i = threadIdx.x; i < M * CD; i += PQL_THREADS) {
+        const int mm = i / CD, e = i - mm * CD;
+        const int c = e / D;
+        tab[mm * tstride + (c / CL) * PSTRIDE + (c % CL) * D + (e - c * D)] = table[i];
+    }
+    __syncthreads();
     float *red = tab + M * tstride;  // [waves][M][CD]
 
     const int gtid = blockIdx.x * PQL_THREADS + threadIdx.x;
@@ -228,14 +249,14 @@ __global__ __launch_bounds__(PQL_THREADS, NL == 4 ? 3 : 2) void pq_loss_backward
     const int first = gtid / NL;
     const int m = first % M;
     const float *tsub = tab + m * tstride;          // the whole subspace (for zq)
-    const float *tm = tsub + part * CL * D;         // this lane's codewords
+    const float *tm = tsub + part * PSTRIDE;        // this lane's codewords
     const float g = grad_loss[0] * inv_count;
 
-    float gt[CL][D];
+    pq_v2f gt[CL][D / 2];
 #pragma unroll
     for (int c = 0; c < CL; c++)
 #pragma unroll
-        for (int i = 0; i < D; i++) gt[c][i] = 0.0f;
+        for (int p = 0; p < D / 2; p++) gt[c][p] = pq_v2f{0.0f, 0.0f};
 
     float4 wr[WREG ? CL : 1][D / 4];
     if constexpr (WREG) {
@@ -256,12 +277,17 @@ __global__ __launch_bounds__(PQL_THREADS, NL == 4 ? 3 : 2) void pq_loss_backward
         for (int i = 0; i < D / 4; i++)
             znext[i] = reinterpret_cast<const float4 *>(z + (size_t)first * D)[i];
     }
+#ifdef PQ_ABL_ONE_ITERATION
+    total = min(total, stride);
+#endif
     for (int j = first; j < total; j += stride) {
-        float zv[D];
+        // element pairs (2 p, 2 p + 1) as one 64-bit operand: the products and sums below are
+        // v_pk_fma_f32 / v_pk_add_f32, two lanes of arithmetic per issued instruction
+        pq_v2f zp[D / 2];
 #pragma unroll
         for (int i = 0; i < D / 4; i++) {
-            zv[4 * i + 0] = znext[i].x; zv[4 * i + 1] = znext[i].y;
-            zv[4 * i + 2] = znext[i].z; zv[4 * i + 3] = znext[i].w;
+            zp[2 * i + 0] = pq_v2f{znext[i].x, znext[i].y};
+            zp[2 * i + 1] = pq_v2f{znext[i].z, znext[i].w};
         }
         if (j + stride < total) {   // next sub-vector: in flight during this one's arithmetic
 #pragma unroll
@@ -269,20 +295,23 @@ __global__ __launch_bounds__(PQL_THREADS, NL == 4 ? 3 : 2) void pq_loss_backward
                 znext[i] = reinterpret_cast<const float4 *>(z + (size_t)(j + stride) * D)[i];
         }
         if constexpr (!WREG) asm volatile("" ::: "memory");   // keep the codebook in LDS, not in registers
+        // codeword c of this lane as D / 2 pairs
+        auto cwp = [&](int c, int p) -> pq_v2f {
+            const float4 tv = cw(c, p >> 1);
+            return (p & 1) ? pq_v2f{tv.z, tv.w} : pq_v2f{tv.x, tv.y};
+        };
         // ---- forward, recomputed: distances, argmin, soft assignment, zw, zq ----------
         float d[CL], soft[CL];
         int best_i = 0;
         float best_d = 1e13f;
 #pragma unroll
         for (int c = 0; c < CL; c++) {
-            float r = 0.0f;
+            float r = 0.0f;                 // (the forward kernel's order of additions: same argmin)
 #pragma unroll
-            for (int i = 0; i < D / 4; i++) {
-                const float4 tv = cw(c, i);
-                r += fabsf(zv[4 * i + 0] - tv.x);
-                r += fabsf(zv[4 * i + 1] - tv.y);
-                r += fabsf(zv[4 * i + 2] - tv.z);
-                r += fabsf(zv[4 * i + 3] - tv.w);
+            for (int p = 0; p < D / 2; p++) {
+                const pq_v2f e = zp[p] - cwp(c, p);
+                r += fabsf(e.x);
+                r += fabsf(e.y);
             }
             d[c] = r;
             const bool cond = r < best_d;
@@ -311,38 +340,30 @@ __global__ __launch_bounds__(PQL_THREADS, NL == 4 ? 3 : 2) void pq_loss_backward
         }
         wsum = sub_sum<NL>(wsum);
         const float inv = __builtin_amdgcn_rcpf(wsum);
-        float zw[D];
+        pq_v2f zw[D / 2];
 #pragma unroll
-        for (int i = 0; i < D; i++) zw[i] = 0.0f;
+        for (int p = 0; p < D / 2; p++) zw[p] = pq_v2f{0.0f, 0.0f};
         if constexpr (!WREG) asm volatile("" ::: "memory");
 #pragma unroll
         for (int c = 0; c < CL; c++) {
             soft[c] *= inv;
+            const pq_v2f sc = pq_v2f{soft[c], soft[c]};
 #pragma unroll
-            for (int i = 0; i < D / 4; i++) {
-                const float4 tv = cw(c, i);
-                zw[4 * i + 0] = fmaf(soft[c], tv.x, zw[4 * i + 0]);
-                zw[4 * i + 1] = fmaf(soft[c], tv.y, zw[4 * i + 1]);
-                zw[4 * i + 2] = fmaf(soft[c], tv.z, zw[4 * i + 2]);
-                zw[4 * i + 3] = fmaf(soft[c], tv.w, zw[4 * i + 3]);
-            }
+            for (int p = 0; p < D / 2; p++) zw[p] = __builtin_elementwise_fma(sc, cwp(c, p), zw[p]);
         }
-        float gzw[D], hard[D], gz[D];
+        pq_v2f gzw[D / 2], hard[D / 2], gz[D / 2];
         {
-            const float4 *bp = reinterpret_cast<const float4 *>(tsub + best_i * D);
+            const float4 *bp = reinterpret_cast<const float4 *>(tsub + (best_i / CL) * PSTRIDE + (best_i % CL) * D);
+            const float g2 = 2.0f * g;
 #pragma unroll
-            for (int i = 0; i < D / 4; i++) {
-                const float4 tv = bp[i];
-                const float zq[4] = {tv.x, tv.y, tv.z, tv.w};
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int ii = 4 * i + u;
-                    const float zwi = sub_sum<NL>(zw[ii]);
-                    gzw[ii] = 2.0f * g * (zwi - zq[u]);
-                    const float e2 = 2.0f * g * (zv[ii] - zq[u]);   // d/dz of the second term
-                    hard[ii] = -gzw[ii] - e2;            // d/dzq of both terms -> W[best]
-                    gz[ii] = part == 0 ? e2 : 0.0f;      // counted once per sub-vector
-                }
+            for (int p = 0; p < D / 2; p++) {
+                const float4 tv = bp[p >> 1];
+                const pq_v2f zq = (p & 1) ? pq_v2f{tv.z, tv.w} : pq_v2f{tv.x, tv.y};
+                const pq_v2f zws = pq_v2f{sub_sum<NL>(zw[p].x), sub_sum<NL>(zw[p].y)};
+                gzw[p] = g2 * (zws - zq);
+                const pq_v2f e2 = g2 * (zp[p] - zq);         // d/dz of the second term
+                hard[p] = -gzw[p] - e2;                      // d/dzq of both terms -> W[best]
+                gz[p] = part == 0 ? e2 : pq_v2f{0.0f, 0.0f}; // counted once per sub-vector
             }
         }
         // ---- softmax backward: ga_c = soft_c (gs_c - <soft, gs>), gs_c = <gzw, W_c> ----
@@ -351,53 +372,58 @@ __global__ __launch_bounds__(PQL_THREADS, NL == 4 ? 3 : 2) void pq_loss_backward
         float dot = 0.0f;
 #pragma unroll
         for (int c = 0; c < CL; c++) {
-            float r = 0.0f;
+            pq_v2f r2 = gzw[0] * cwp(c, 0);
 #pragma unroll
-            for (int i = 0; i < D / 4; i++) {
-                const float4 tv = cw(c, i);
-                r = fmaf(gzw[4 * i + 0], tv.x, r);
-                r = fmaf(gzw[4 * i + 1], tv.y, r);
-                r = fmaf(gzw[4 * i + 2], tv.z, r);
-                r = fmaf(gzw[4 * i + 3], tv.w, r);
-            }
-            gs[c] = r;
-            dot = fmaf(soft[c], r, dot);
+            for (int p = 1; p < D / 2; p++) r2 = __builtin_elementwise_fma(gzw[p], cwp(c, p), r2);
+            gs[c] = r2.x + r2.y;
+            dot = fmaf(soft[c], gs[c], dot);
         }
         dot = sub_sum<NL>(dot);
         if constexpr (!WREG) asm volatile("" ::: "memory");
+#ifndef PQ_ABL_NO_PASS4
 #pragma unroll
         for (int c = 0; c < CL; c++) {
             // a = -log(max(d, 1e-5)): da/dd = -1/d where d >= 1e-5 (torch.clamp passes the
             // gradient at the boundary), 0 below
             const float ga = soft[c] * (gs[c] - dot);
             const float gd = (d[c] >= 1e-5f) ? -ga * rd[c] : 0.0f;
+            const pq_v2f gd2 = pq_v2f{gd, gd}, ngd2 = pq_v2f{-gd, -gd};
+            const pq_v2f sc = pq_v2f{soft[c], soft[c]};
             // (one fma per element with a 0 / 1 factor instead of a select and an add)
             const float is_best = (part * CL + c == best_i) ? 1.0f : 0.0f;
+            const pq_v2f ib = pq_v2f{is_best, is_best};
 #pragma unroll
-            for (int i = 0; i < D / 4; i++) {
-                const float4 tv = cw(c, i);
-                const float w[4] = {tv.x, tv.y, tv.z, tv.w};
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int ii = 4 * i + u;
-                    // cdist backward, extension/cdist.cu:113-119,167-174
-                    const float sg = (zv[ii] - w[u]) > 0.0f ? gd : -gd;
-                    gz[ii] += sg;
-                    gt[c][ii] = fmaf(is_best, hard[ii], fmaf(soft[c], gzw[ii], gt[c][ii])) - sg;
-                }
+            for (int p = 0; p < D / 2; p++) {
+                // cdist backward, extension/cdist.cu:113-119,167-174: sg = (z - w > 0) ? gd : -gd.
+                // With e = w - z and s = copysign(1, e) (one v_bfi_b32; w == z gives e = +0: s = +1,
+                // the "not greater" side) sg = -s gd exactly, so both accumulations are ONE fma each:
+                //   gz += sg = fma(s, -gd, gz),   gt -= sg = fma(s, gd, gt)
+                const pq_v2f e = cwp(c, p) - zp[p];
+                const pq_v2f sgn = pq_v2f{pq_copysign1(e.x), pq_copysign1(e.y)};
+                gz[p] = __builtin_elementwise_fma(sgn, ngd2, gz[p]);
+                pq_v2f t = __builtin_elementwise_fma(sc, gzw[p], gt[c][p]);
+                t = __builtin_elementwise_fma(ib, hard[p], t);
+                gt[c][p] = __builtin_elementwise_fma(sgn, gd2, t);
             }
         }
+#else
+        gz[0].x += dot + gs[0];
+#endif
         // grad_z: lane `part` of the sub-vector stores elements DL part .. DL part + DL - 1
+        float gzs[D];
 #pragma unroll
-        for (int i = 0; i < D; i++) gz[i] = sub_sum<NL>(gz[i]);
+        for (int p = 0; p < D / 2; p++) {
+            gzs[2 * p] = sub_sum<NL>(gz[p].x);
+            gzs[2 * p + 1] = sub_sum<NL>(gz[p].y);
+        }
         float *gp = grad_z + (size_t)j * D + part * DL;
         float o[DL];
 #pragma unroll
         for (int e = 0; e < DL; e++) {
             // (a select chain over the lane's part: no dynamically indexed register array)
-            float v = gz[e];
+            float v = gzs[e];
 #pragma unroll
-            for (int q = 1; q < NL; q++) v = part == q ? gz[q * DL + e] : v;
+            for (int q = 1; q < NL; q++) v = part == q ? gzs[q * DL + e] : v;
             o[e] = v;
         }
         // accumulate: grad_z already holds the gradient that reached z over another path (the
@@ -428,14 +454,20 @@ __global__ __launch_bounds__(PQL_THREADS, NL == 4 ? 3 : 2) void pq_loss_backward
 #pragma unroll
         for (int c = 0; c < CL; c++)
 #pragma unroll
-            for (int i = 0; i < D; i++) gt[c][i] += __shfl_xor(gt[c][i], step, 64);
+            for (int p = 0; p < D / 2; p++) {
+                gt[c][p].x += __shfl_xor(gt[c][p].x, step, 64);
+                gt[c][p].y += __shfl_xor(gt[c][p].y, step, 64);
+            }
     }
     if (lane < NL * M) {
         float *dst = red + ((size_t)wave * M + m) * CD + part * CL * D;
 #pragma unroll
         for (int c = 0; c < CL; c++)
 #pragma unroll
-            for (int i = 0; i < D; i++) dst[c * D + i] = gt[c][i];
+            for (int p = 0; p < D / 2; p++) {
+                dst[c * D + 2 * p] = gt[c][p].x;
+                dst[c * D + 2 * p + 1] = gt[c][p].y;
+            }
     }
     __syncthreads();
     float *out = partial + (size_t)blockIdx.x * M * CD;
@@ -516,18 +548,21 @@ extern "C" int64_t spt_pq_loss_workspace_bytes(int64_t n_vectors, int n_subspace
     return (int64_t)nblk * n_subspaces * n_codewords * d_code * (int64_t)sizeof(float);
 }
 
+// `parts` tensors of n_vectors rows each, back to back in z (q and k of one attention): one pass
+// over all of them; every part's loss is a mean over ITS sub-vectors and `loss` their sum
 static int pq_loss_forward_any(const float *z, const float *table, float *loss, void *workspace,
-                               int64_t n_vectors, int n_subspaces, int n_codewords, int d_code,
+                               int64_t n_vectors, int parts, int n_subspaces, int n_codewords, int d_code,
                                int32_t *codes, int seq_length, int n_heads, void *stream) {
     if (!z || !table || !loss || !workspace) return SPT_EINVAL;
-    if (n_vectors <= 0 || n_subspaces <= 0 || n_codewords <= 0 || d_code <= 0) return SPT_EINVAL;
-    if (!pq_loss_shape_ok(n_vectors, n_subspaces, n_codewords, d_code)) return SPT_EUNSUP;
+    if (n_vectors <= 0 || parts <= 0 || parts > 4 || n_subspaces <= 0 || n_codewords <= 0 || d_code <= 0)
+        return SPT_EINVAL;
+    if (!pq_loss_shape_ok(n_vectors * parts, n_subspaces, n_codewords, d_code)) return SPT_EUNSUP;
     if (codes && (seq_length <= 0 || n_heads <= 0 || n_vectors % ((int64_t)seq_length * n_heads) != 0))
         return SPT_ESHAPE;
-    const int total = (int)(n_vectors * n_subspaces);
+    const int total = (int)(n_vectors * parts * n_subspaces);
     const int nblk = pq_loss_blocks(total);
     const size_t lds = (size_t)n_subspaces * (n_codewords * d_code + 4) * sizeof(float);
-    const float inv_count = 1.0f / ((float)total * (float)d_code);
+    const float inv_count = 1.0f / ((float)(n_vectors * n_subspaces) * (float)d_code);
     float *partial = reinterpret_cast<float *>(workspace);
     hipStream_t s = (hipStream_t)stream;
     if (d_code == 4)
@@ -546,7 +581,7 @@ static int pq_loss_forward_any(const float *z, const float *table, float *loss, 
 extern "C" int spt_pq_loss_forward(const float *z, const float *table, float *loss,
                                    void *workspace, int64_t n_vectors, int n_subspaces,
                                    int n_codewords, int d_code, void *stream) {
-    return pq_loss_forward_any(z, table, loss, workspace, n_vectors, n_subspaces, n_codewords,
+    return pq_loss_forward_any(z, table, loss, workspace, n_vectors, 1, n_subspaces, n_codewords,
                                d_code, nullptr, 0, 0, stream);
 }
 
@@ -555,25 +590,56 @@ extern "C" int spt_pq_loss_forward_codes(const float *z, const float *table, flo
                                          int seq_length, int n_heads, int n_subspaces,
                                          int n_codewords, int d_code, void *stream) {
     if (!codes || batch <= 0 || seq_length <= 0 || n_heads <= 0) return SPT_EINVAL;
-    return pq_loss_forward_any(z, table, loss, workspace, (int64_t)batch * seq_length * n_heads,
+    return pq_loss_forward_any(z, table, loss, workspace, (int64_t)batch * seq_length * n_heads, 1,
                                n_subspaces, n_codewords, d_code, codes, seq_length, n_heads, stream);
 }
+
+extern "C" int spt_pq_loss_forward_codes_parts(const float *z, const float *table, float *loss,
+                                               void *workspace, int32_t *codes, int parts, int batch,
+                                               int seq_length, int n_heads, int n_subspaces,
+                                               int n_codewords, int d_code, void *stream) {
+    if (!codes || batch <= 0 || seq_length <= 0 || n_heads <= 0) return SPT_EINVAL;
+    return pq_loss_forward_any(z, table, loss, workspace, (int64_t)batch * seq_length * n_heads, parts,
+                               n_subspaces, n_codewords, d_code, codes, seq_length, n_heads, stream);
+}
+
+static int pq_loss_backward_any(const float *z, const float *table, const float *grad_loss,
+                                float *grad_z, float *grad_table, void *workspace,
+                                int64_t n_vectors, int parts, int n_subspaces, int n_codewords,
+                                int d_code, int accumulate, void *stream);
 
 extern "C" int spt_pq_loss_backward(const float *z, const float *table, const float *grad_loss,
                                     float *grad_z, float *grad_table, void *workspace,
                                     int64_t n_vectors, int n_subspaces, int n_codewords,
                                     int d_code, int accumulate, void *stream) {
+    return pq_loss_backward_any(z, table, grad_loss, grad_z, grad_table, workspace, n_vectors, 1,
+                                n_subspaces, n_codewords, d_code, accumulate, stream);
+}
+
+extern "C" int spt_pq_loss_backward_parts(const float *z, const float *table, const float *grad_loss,
+                                          float *grad_z, float *grad_table, void *workspace,
+                                          int64_t n_vectors, int parts, int n_subspaces,
+                                          int n_codewords, int d_code, int accumulate, void *stream) {
+    return pq_loss_backward_any(z, table, grad_loss, grad_z, grad_table, workspace, n_vectors, parts,
+                                n_subspaces, n_codewords, d_code, accumulate, stream);
+}
+
+static int pq_loss_backward_any(const float *z, const float *table, const float *grad_loss,
+                                float *grad_z, float *grad_table, void *workspace,
+                                int64_t n_vectors, int parts, int n_subspaces, int n_codewords,
+                                int d_code, int accumulate, void *stream) {
     if (!z || !table || !grad_loss || !grad_z || !grad_table || !workspace) return SPT_EINVAL;
-    if (n_vectors <= 0 || n_subspaces <= 0 || n_codewords <= 0 || d_code <= 0) return SPT_EINVAL;
-    if (!pq_loss_shape_ok(n_vectors, n_subspaces, n_codewords, d_code)) return SPT_EUNSUP;
-    const int total = (int)(n_vectors * n_subspaces);
+    if (n_vectors <= 0 || parts <= 0 || parts > 4 || n_subspaces <= 0 || n_codewords <= 0 || d_code <= 0)
+        return SPT_EINVAL;
+    if (!pq_loss_shape_ok(n_vectors * parts, n_subspaces, n_codewords, d_code)) return SPT_EUNSUP;
+    const int total = (int)(n_vectors * parts * n_subspaces);
     const int nblk = pq_backward_blocks(total);
     const bool four = pq_backward_lanes() == 4;
     const int CD = n_codewords * d_code;
-    const size_t lds = ((size_t)n_subspaces * (CD + 4) +
+    const size_t lds = ((size_t)n_subspaces * ((four ? 4 : 2) * pq_part_stride(d_code, four ? 4 : 2) + 4) +
                         (size_t)(PQL_THREADS / 64) * n_subspaces * CD) * sizeof(float);
     if (lds > 64 * 1024) return SPT_EUNSUP;
-    const float inv_count = 1.0f / ((float)total * (float)d_code);
+    const float inv_count = 1.0f / ((float)(n_vectors * n_subspaces) * (float)d_code);   // (a mean per part)
     float *partial = reinterpret_cast<float *>(workspace);
     hipStream_t s = (hipStream_t)stream;
     if (d_code == 4)

@@ -41,6 +41,8 @@ _PROTOTYPES = {
     'spt_pq_loss_forward': ([_c_ptr] * 4 + [ctypes.c_int64] + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_pq_loss_forward_codes': ([_c_ptr] * 5 + [_c_int] * 6 + [_c_ptr], _c_int),
     'spt_pq_loss_backward': ([_c_ptr] * 6 + [ctypes.c_int64] + [_c_int] * 4 + [_c_ptr], _c_int),
+    'spt_pq_loss_forward_codes_parts': ([_c_ptr] * 5 + [_c_int] * 7 + [_c_ptr], _c_int),
+    'spt_pq_loss_backward_parts': ([_c_ptr] * 6 + [ctypes.c_int64] + [_c_int] * 5 + [_c_ptr], _c_int),
     'spt_sddmm_forward': (
         [_c_ptr] * 5 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int
     ),
@@ -449,6 +451,57 @@ def pq_loss_backward(z: torch.Tensor, table: torch.Tensor, grad_loss: torch.Tens
     if rc != 0:
         _raise(lib, rc, 'pq_loss_backward')
     return grad_z, grad_table
+
+
+def back_to_back(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """b starts where a ends, in the same allocation (both contiguous, same shape and dtype)"""
+    return (a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+            and a.device == b.device and b.data_ptr() == a.data_ptr() + a.numel() * a.element_size()
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr())
+
+
+def _as_pair(a: torch.Tensor) -> torch.Tensor:
+    """[2, *a.shape]: `a` and the tensor that lies behind it (`back_to_back`)"""
+    return a.as_strided((2,) + tuple(a.shape), (a.numel(),) + tuple(a.stride()))
+
+
+def pq_loss_forward_pair(q: torch.Tensor, k: torch.Tensor, table: torch.Tensor):
+    """``spt_pq_loss_forward_codes_parts`` for q, k [N, S, H, E] that lie `back_to_back`:
+    -> (loss_q + loss_k, codes_q, codes_k) from one pass over both."""
+    _require(back_to_back(q, k), 'pq_loss_forward_pair: k behind q in one buffer')
+    _check_dim(q, 4, 'q')
+    lib, dev, n_vectors, (M, C, D), nbytes = _pq_loss_args(_as_pair(q), table)
+    N, S, H, _ = q.shape
+    with _on(dev):
+        loss = torch.empty([], dtype=torch.float32, device=dev)
+        scratch = torch.empty([nbytes // 4], dtype=torch.float32, device=dev)
+        codes = torch.empty([2, N * H, S, M], dtype=torch.int32, device=dev)
+        rc = lib.spt_pq_loss_forward_codes_parts(q.data_ptr(), table.data_ptr(), loss.data_ptr(),
+                                                 scratch.data_ptr(), codes.data_ptr(), 2, N, S, H, M, C, D,
+                                                 _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'pq_loss_forward_pair')
+    return loss, codes[0], codes[1]
+
+
+def pq_loss_backward_pair(q: torch.Tensor, k: torch.Tensor, table: torch.Tensor, grad_loss: torch.Tensor,
+                          grad_q: torch.Tensor, grad_k: torch.Tensor):
+    """``spt_pq_loss_backward_parts``: the gradient of loss_q + loss_k ADDED into grad_q / grad_k (each
+    pair `back_to_back`) in one pass -> grad_table (the sum of both)."""
+    _require(back_to_back(q, k) and back_to_back(grad_q, grad_k) and grad_q.shape == q.shape
+             and grad_q.dtype == torch.float32, 'pq_loss_backward_pair: (q, k) and (grad_q, grad_k) back to back')
+    lib, dev, n_vectors, (M, C, D), nbytes = _pq_loss_args(_as_pair(q), table)
+    _check_type(grad_loss, torch.float32, 'grad_loss')
+    _require(grad_loss.numel() == 1 and grad_loss.device == q.device, 'grad_loss: device scalar')
+    with _on(dev):
+        grad_table = torch.empty_like(table)
+        scratch = torch.empty([nbytes // 4], dtype=torch.float32, device=dev)
+        rc = lib.spt_pq_loss_backward_parts(q.data_ptr(), table.data_ptr(), grad_loss.data_ptr(),
+                                            grad_q.data_ptr(), grad_table.data_ptr(), scratch.data_ptr(),
+                                            n_vectors // 2, 2, M, C, D, 1, _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'pq_loss_backward_pair')
+    return grad_table
 
 
 def sddmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,

@@ -19,6 +19,8 @@ Differences from the reference's orchestration, none of them observable:
   reference's output layout, and sddmm -> clamp -> softmax is one autograd node whose
   backward is a single fused kernel.
 """
+import os
+
 import torch
 
 from naive_gpt import ext, kernels, layers
@@ -28,6 +30,8 @@ CLAMP = 10.0         # reference: attention.py:125-127
 # the armed step's PQ loss as a second output of the attention's autograd node (_MfmaAttention);
 # False: two separate autograd functions whose q / k gradients autograd sums (tests compare both)
 FOLD_PQ_LOSS = True
+# q and k that lie back to back in one buffer: their two PQ losses in one pass (spt_pq_loss_*_parts)
+PAIR_PQ_LOSS = os.environ.get('SPT_PQ_PAIR', '1') != '0'
 
 
 class _ScaledClampedSDDMM(torch.autograd.Function):
@@ -174,7 +178,8 @@ class _MfmaAttention(torch.autograd.Function):
         ctx.scale, ctx.tiles = scale, tiles
         if ctx.armed:
             ctx.save_for_backward(q, k, v, y, row_sum, table)
-            return y.view(q.shape), loss_q + loss_k
+            # (loss_k None: loss_q is already the sum of both, from one pass over q and k)
+            return y.view(q.shape), (loss_q.clone() if loss_k is None else loss_q + loss_k)
         ctx.save_for_backward(q, k, v, y, row_sum)
         return y.view(q.shape)
 
@@ -190,7 +195,14 @@ class _MfmaAttention(torch.autograd.Function):
         grad_table = None
         if grad_loss is not None:
             grad_loss = grad_loss.contiguous()
+            if PAIR_PQ_LOSS and q.dtype == torch.float32 and ext.back_to_back(q, k) \
+                    and ext.back_to_back(grad_q, grad_k):
+                # (q and k from the joint projection, their gradients from one buffer: one pass)
+                ext.note_path('pq_loss_backward', 'pair')
+                grad_table = ext.pq_loss_backward_pair(q, k, table, grad_loss, grad_q, grad_k)
+                return None, grad_q, grad_k, grad_v, None, grad_table, None, None
             if q.dtype == torch.float32:
+                ext.note_path('pq_loss_backward', 'each')
                 _, gt_q = ext.pq_loss_backward(q, table, grad_loss, accumulate_into=grad_q)
                 _, gt_k = ext.pq_loss_backward(k, table, grad_loss, accumulate_into=grad_k)
             else:
@@ -301,9 +313,17 @@ class _SparseCore:
                 # values and codes now; the loss becomes a differentiable output of the attention's
                 # own autograd node in _sparse_apply (_MfmaAttention, armed form)
                 with torch.no_grad():
-                    loss_q, q_c = ext.pq_loss_forward(qf.contiguous(), self.quantizer.weight, want_codes=True)
-                    loss_k, k_c = ext.pq_loss_forward(kf.contiguous(), self.quantizer.weight, want_codes=True)
-                    self.register_buffer('loss', loss_q + loss_k, persistent=False)     # (until then)
+                    if PAIR_PQ_LOSS and ext.back_to_back(qf, kf):
+                        # q and k of the joint projection lie in one buffer: one pass over both
+                        ext.note_path('pq_loss_forward', 'pair')
+                        loss_q, q_c, k_c = ext.pq_loss_forward_pair(qf, kf, self.quantizer.weight)
+                        loss_k = None
+                        self.register_buffer('loss', loss_q, persistent=False)          # (until then)
+                    else:
+                        ext.note_path('pq_loss_forward', 'each')
+                        loss_q, q_c = ext.pq_loss_forward(qf.contiguous(), self.quantizer.weight, want_codes=True)
+                        loss_k, k_c = ext.pq_loss_forward(kf.contiguous(), self.quantizer.weight, want_codes=True)
+                        self.register_buffer('loss', loss_q + loss_k, persistent=False)
                 self.__dict__['_armed_losses'] = (loss_q, loss_k)
             else:
                 loss_q, q_c = self.quantizer.train_loss_and_codes(qf)

@@ -398,9 +398,23 @@ def test_pq_loss_is_an_output_of_the_attention_node(monkeypatch):
     for got in folded:
         for a, b in zip(got, plain):
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * b.abs().max().item())
+    # q and k as two halves of ONE buffer (what the joint projection hands over): one pass of the
+    # loss over both, forward and backward (spt_pq_loss_*_parts)
+    from naive_gpt import ext
+    monkeypatch.setattr(A, 'FOLD_PQ_LOSS', True)
+    qk = torch.stack([q, k]).requires_grad_(True)
+    vi = v.clone().requires_grad_(True)
+    attn.zero_grad()
+    attn.arm()
+    ext.reset_paths()
+    y = attn(qk[0], qk[1], vi, attn_mask=None)
+    ((y * w).sum() + 3.0 * attn.loss + 0.25 * (qk[0] * qk[0]).sum() + (qk[1] * w).sum()).backward()
+    assert ext.paths_taken('pq_loss_forward') == {('pq_loss_forward', 'pair'): 1}
+    assert ext.paths_taken('pq_loss_backward') == {('pq_loss_backward', 'pair'): 1}
+    for a, b in zip((qk.grad[0], qk.grad[1], vi.grad, attn.quantizer.weight.grad), plain):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * b.abs().max().item())
     # only the loss is used: the attention's share of the gradients is zero, the loss's is there
     qi = q.clone().requires_grad_(True)
-    monkeypatch.setattr(A, 'FOLD_PQ_LOSS', True)
     attn.zero_grad()
     attn.arm()
     attn(qi, k, v, attn_mask=None)

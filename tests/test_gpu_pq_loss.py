@@ -176,3 +176,32 @@ def test_loss_forward_leaves_the_pq_codes_of_the_encode_pass():
     t0 = table.clone().requires_grad_(True)
     kernels.pq_loss(z0, t0).backward()
     assert torch.equal(zr.grad, z0.grad) and torch.equal(tr.grad, t0.grad)
+
+
+def test_q_and_k_in_one_buffer_take_one_pass():
+    """spt_pq_loss_*_parts: q and k back to back (the joint projection's output) against one table:
+    the sum of the two losses, both code tensors, both input gradients (added into their targets) and
+    the summed table gradient from ONE forward and ONE backward launch -- against the calls per tensor."""
+    from naive_gpt import ext
+    torch.manual_seed(0)
+    N, S, H, M, D = 2, 256, 4, 8, 8
+    qk = torch.randn([2, N, S, H, M * D], device='cuda')
+    q, k = qk[0], qk[1]
+    table = torch.randn([M, 16, D], device='cuda')
+    assert ext.back_to_back(q, k) and not ext.back_to_back(k, q) and not ext.back_to_back(q, q.clone())
+    loss, cq, ck = ext.pq_loss_forward_pair(q, k, table)
+    lq, cq1 = ext.pq_loss_forward(q, table, want_codes=True)
+    lk, ck1 = ext.pq_loss_forward(k, table, want_codes=True)
+    assert torch.equal(cq, cq1) and torch.equal(ck, ck1)
+    assert torch.allclose(loss, lq + lk, rtol=1e-5)
+    upstream = torch.tensor(0.7, device='cuda')
+    base = torch.randn([2, N, S, H, M * D], device='cuda')
+    got = base.clone()
+    gt = ext.pq_loss_backward_pair(q, k, table, upstream, got[0], got[1])
+    want = base.clone()
+    _, gt_q = ext.pq_loss_backward(q, table, upstream, accumulate_into=want[0])
+    _, gt_k = ext.pq_loss_backward(k, table, upstream, accumulate_into=want[1])
+    assert torch.equal(got, want)
+    assert torch.allclose(gt, gt_q + gt_k, rtol=1e-4, atol=1e-6 * float(gt.abs().max()))
+    with pytest.raises(Exception):
+        ext.pq_loss_forward_pair(q, k.clone(), table)

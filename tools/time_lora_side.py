@@ -34,6 +34,7 @@ for rows, K, n in ((8192, 1024, 16), (8192, 1024, 48), (16384, 1024, 16), (16384
         'down_torch': timeit(lambda: torch.matmul(x, t)),
         'down': timeit(lambda: ext.lora_down(x, t)),
         'down_exact': timeit(lambda: ext.lora_down(x, t, exact=True)),
+        'down+image': timeit(lambda: ext.lora_down(x, t, want_image=True)),
         'down+image+norms': timeit(lambda: ext.lora_down(x, t, want_image=True, want_norms=True)),
         'split_alone': timeit(lambda: ext.split_bf16(x)),
         'GBps_down': None}
