@@ -51,10 +51,13 @@ constexpr int GG_BN = 128;
 constexpr int GG_BK = 32;
 // workgroups per CU the round arithmetic of the kernels counts on (both paths: two fit)
 constexpr int GG_SLOTS_PER_CU = 2;
-// behind the operand tiles either kernel's LDS array carries three rows of 128 floats for the
-// ReLU epilogue: |a2 row|^2 and |b2 row|^2 of the K extension's operands (written while they
-// are staged) and rowscale * |a row| of the tile's rows (loaded in the prologue)
-constexpr int GG_EXTRAS = 3 * 128;
+// behind the operand tiles either kernel's LDS array carries four rows of 128 floats: for the
+// ReLU epilogue |a2 row|^2 and |b2 row|^2 of the K extension's operands (written while they
+// are staged) and rowscale * |a row| of the tile's rows, and rowscale of the tile's rows itself
+// (1 without one) -- both loaded in the prologue: the scaling after the k-loop and every row of the
+// epilogue read them from LDS (as global loads inside the epilogue's row loop each was a
+// memory latency in the open, eight per 32 rows)
+constexpr int GG_EXTRAS = 4 * 128;
 // The ReLU queue is cut into segments with a counter each (16 words apart: a line of their own),
 // a workgroup appends to segment blockIdx % GG_FIX_SEGS: ONE returning atomic counter takes
 // ~88 increments / us from the whole chip (MI355X_MICROARCH.md, "dequeue"), and a GEMM queues
@@ -200,15 +203,14 @@ __device__ __forceinline__ float gg_exact_preact(const GroupedArgs &g, int bucke
 // coefficient may be 0: 2 sigmoid(logit) underflows below logit -104).
 template <int NI>
 __device__ __forceinline__ void gg_scale_rows(const GroupedArgs &g, f32x16 (&acc)[NI][2],
-                                              int row_lo, int row_hi, int wm) {
+                                              const float *extras, int wm) {
     if (!g.rowscale) return;
     const int fh = (threadIdx.x & 63) >> 5;
 #pragma unroll
     for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int p = row_lo + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            const float rs = g.rowscale[min(p, row_hi - 1)];
+            const float rs = extras[384 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh];
             acc[i][0][r] *= rs;
             acc[i][1][r] *= rs;
         }
@@ -267,7 +269,26 @@ __device__ __forceinline__ void gg_epilogue(const GroupedArgs &g, float *smem,
         }
         // (a wave only reads what it wrote: no workgroup barrier)
         // (not unrolled: the body is long -- with the ReLU recomputation inlined eight times the
-        // activation epilogues ran 30-45 us slower at the FFN shape)
+        // activation epilogues ran 30-45 us slower at the FFN shape; and requesting the saved
+        // activations of all eight row groups of EPI_DACT ahead of an unrolled loop was measured
+        // 15 us SLOWER than loading them inside it, 175 against 160 us)
+        // EPI_DACT: the saved activations of row group t + 1 are requested while group t is worked on
+        // (rows past the bucket end: clamped, never used)
+        auto load_saved = [&](int t) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (EPI == EPI_DACT) {
+                const int p = min(row_lo + wm + 32 * i + rrow + 4 * t, row_hi - 1);
+                const size_t at = (size_t)p * g.ldo + n;
+                if (vec_row && n + 3 < g.N) {
+                    v = *reinterpret_cast<const float4 *>(sh + at);
+                } else {
+                    v.x = n + 0 < g.N ? sh[at + 0] : 0.f; v.y = n + 1 < g.N ? sh[at + 1] : 0.f;
+                    v.z = n + 2 < g.N ? sh[at + 2] : 0.f; v.w = n + 3 < g.N ? sh[at + 3] : 0.f;
+                }
+            }
+            return v;
+        };
+        float4 sv_next = load_saved(0);
 #pragma unroll 1
         for (int t = 0; t < 8; t++) {
             const int row = rrow + 4 * t;
@@ -276,21 +297,10 @@ __device__ __forceinline__ void gg_epilogue(const GroupedArgs &g, float *smem,
             const float4 c4 = *reinterpret_cast<const float4 *>(&cs[row * CS_ROW + rcol]);
             float c[4] = {c4.x, c4.y, c4.z, c4.w};
             const float b[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
-            const float rs = (live && g.rowscale) ? g.rowscale[p] : 1.0f;
+            const float rs = extras[384 + wm + 32 * i + row];
             const size_t at = (size_t)p * g.ldo + n;
-            float sv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (EPI == EPI_DACT && live) {
-                if (vec_row && n + 3 < g.N) {
-                    {
-                        const float4 t4 = *reinterpret_cast<const float4 *>(sh + at);
-                        sv[0] = t4.x; sv[1] = t4.y; sv[2] = t4.z; sv[3] = t4.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        if (n + e < g.N) sv[e] = sh[at + e];
-                }
-            }
+            const float sv[4] = {sv_next.x, sv_next.y, sv_next.z, sv_next.w};
+            if (EPI == EPI_DACT && t < 7) sv_next = load_saved(t + 1);
             float dot_h = 0.0f, dot_s = 0.0f;
             float pre[4];
 #pragma unroll
@@ -569,9 +579,12 @@ __device__ __forceinline__ void gemm_tile_img(const GroupedArgs &g, float *smem,
     const int wave = c.wave, wm = c.wm, wn = c.wn;
 
     float *const extras = smem + GI_LDS_FLOATS;
-    if (EPI == EPI_ACT && g.act == ACT_RELU && g.a_norm && tid < BM) {
+    if (tid < BM) {
         const int p = min(row_lo + tid, row_hi - 1);
-        extras[256 + tid] = g.a_norm[g.gather ? g.gather[p] : p] * (g.rowscale ? g.rowscale[p] : 1.0f);
+        const float rs = g.rowscale ? g.rowscale[p] : 1.0f;
+        extras[384 + tid] = rs;
+        if (EPI == EPI_ACT && g.act == ACT_RELU && g.a_norm)
+            extras[256 + tid] = g.a_norm[g.gather ? g.gather[p] : p] * rs;
     }
     // ---- LDS-DMA sources.  KC tile: instruction t = wave + 4 j covers rows 8 t .. 8 t + 7,
     // lane -> row 8 t + (lane >> 3), physical chunk lane & 7.  Rows past the bucket end and
@@ -632,7 +645,7 @@ __device__ __forceinline__ void gemm_tile_img(const GroupedArgs &g, float *smem,
         }
     }
 
-    gg_scale_rows<NI>(g, acc, row_lo, row_hi, wm);
+    gg_scale_rows<NI>(g, acc, extras, wm);
 
     // ---- K extension: fp32 a2 [*, R] and b2 [n][R] split while staged into two KC tiles
     // (R <= 32: one k-step, zero beyond R) ----
@@ -718,9 +731,12 @@ __device__ __forceinline__ void gemm_tile_regs(const GroupedArgs &g, float *smem
     const float *wg = g.w + (size_t)bucket * g.gstride;
 
     float *const extras = smem + GG_REGS_LDS_FLOATS;
-    if (EPI == EPI_ACT && g.act == ACT_RELU && g.a_norm && tid < BM) {
+    if (tid < BM) {
         const int p = min(row_lo + tid, row_hi - 1);
-        extras[256 + tid] = g.a_norm[g.gather ? g.gather[p] : p] * (g.rowscale ? g.rowscale[p] : 1.0f);
+        const float rs = g.rowscale ? g.rowscale[p] : 1.0f;
+        extras[384 + tid] = rs;
+        if (EPI == EPI_ACT && g.act == ACT_RELU && g.a_norm)
+            extras[256 + tid] = g.a_norm[g.gather ? g.gather[p] : p] * rs;
     }
     // ---- staging assignment: tile = rows x GG_KQ float4 along k ----
     // (8 lanes per row; the two rows of a 16-lane ds_write_b64 group are 4 apart: 320 bytes = 64
@@ -875,7 +891,7 @@ __device__ __forceinline__ void gemm_tile_regs(const GroupedArgs &g, float *smem
         for (int q2 = 0; q2 < GG_BK / 16; q2++) mfma_group16(q2, !BN_LAYOUT);
     }
 
-    gg_scale_rows<NI>(g, acc, row_lo, row_hi, wm);
+    gg_scale_rows<NI>(g, acc, extras, wm);
 
     // ---- K extension on top: acc += A2 . B2_g^T, 32 columns of the two operands per k-step (zero
     // beyond R; R > 32 -- several rank-16 side products side by side -- only without the ReLU
