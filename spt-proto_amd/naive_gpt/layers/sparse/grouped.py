@@ -11,6 +11,7 @@ gathers and per-block cuBLAS calls (``layers/tuning/lora_ffn.py:87-111``).
 Row space: P = T * k rows, row p = the p-th (token, block) pair in block-major order
 (stable in the token id, i.e. the reference's ``x[mask]`` order inside each block).
 """
+import os
 from typing import NamedTuple
 
 import torch
@@ -89,6 +90,9 @@ def make_buckets(prob: torch.Tensor, k: int, scale: float = 1.0) -> Buckets:
 
 
 COEFF_FLOOR = 1e-12
+# h (one reader) goes to its GEMM as fp32 rows, no image: -0.36 ms per configs[2] step, A/B on one
+# box (the same for x: +0.26 ms, for dy: +-0: both keep their images)
+H_A32 = os.environ.get('SPT_H_A32', '1') != '0'
 
 
 def _floor(coeff: torch.Tensor) -> torch.Tensor:
@@ -339,7 +343,9 @@ class RoutedLoRAFFN(torch.autograd.Function):
             epilogue=ext.EPI_ACT, activation=act, keep_preact=not relu,
             a_image=x_img, w_image=ext.weight_image(w1) if imgs else None,
             a_norm=x_norm, w_norm=ext.weight_row_norms(w1) if relu else None)
-        z, h_img = _down_blocks(h, l2, bk, imgs)                             # [P, r]
+        # (h has ONE reader: no image of it -- the GEMM splits its fp32 rows itself ("A32", +11 us)
+        # and the down product runs without the image store (-20 us))
+        z, h_img = _down_blocks(h, l2, bk, imgs and not H_A32)               # [P, r]
         ys = ext.grouped_gemm_fused(
             h, w2, bk.offsets, nb, n=d, k=bs, w_group_stride=bs, w_ldn=d_ff, w_ldk=1,
             n_rows=rows, rowscale=coeff, a2=z, b2=r2, b2_group_stride=0,
@@ -460,7 +466,7 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
 
         g, sd = up(wg, ug, rg), up(ws, us, rs)
         h = activation(g) * sd
-        zw, h_img, _ = _down(h, _block_cat(ld, nb), imgs, False)
+        zw, h_img, _ = _down(h, _block_cat(ld, nb), imgs and not H_A32, False)
         z = _own_block(zw, bk.block, nb).contiguous()
         ys = ext.grouped_gemm_fused(
             h, wd, bk.offsets, nb, n=d, k=bs, w_group_stride=bs, w_ldn=d_ff, w_ldk=1,

@@ -245,9 +245,10 @@ def test_routed_ffn_at_block_dims(name):
     if c['family'] == 'opt':
         assert set(_paths('lora_down_grouped')) == {'kernel'}
     gemms = _paths('grouped_gemm')
-    # forward: every block GEMM from pre-split images; backward: the derivative GEMM(s) too, the
-    # dX products read their fp32 operand (register path) -- DESIGN.md 5.1
-    assert gemms.get('image', 0) >= (3 if c['family'] == 'opt' else 4), gemms
+    # forward: the up GEMM(s) from pre-split images, the down GEMM from the image of its weight and
+    # the fp32 rows of h ("A32": h has one reader, no image of it is made); backward: the derivative
+    # GEMM(s) from images, the dX products from their fp32 operand (register path) -- DESIGN.md 5.1
+    assert gemms.get('image', 0) >= (2 if c['family'] == 'opt' else 3) and gemms.get('a32', 0) == 1, gemms
     ext.reset_paths()
     y0, gx0, g0 = run(False)
     assert _paths('routed_ffn') == {'torch_loop': 1}
