@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 32
+#define SPT_ABI_VERSION 33
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -514,6 +514,13 @@ int spt_split_bf16(const float *src, void *image, long long rows, int cols, long
 int spt_lora_down(const float *x, long long ldx, long long rows, int k, const float *l, int n,
                   float *u, long long ldu, int u_block_major, void *image, float *norms, int exact,
                   void *stream);
+/* spt_lora_down with a SECOND table: u gets one more block of 16 columns = x . l2^T for a row-major
+ * l2 [n2 <= 16, k] (an nn.Linear weight as stored; 16-byte aligned); columns n2 .. 15 of that block are 0.
+ * `n` counts the columns of `l` only (n + 16 <= 64); u_block_major as above: (n / 16 + 1) matrices
+ * [rows, 16].  The routed FFN's router logits ride the pass that forms x . L1 (feedforward.py:22-25). */
+int spt_lora_down2(const float *x, long long ldx, long long rows, int k, const float *l, int n,
+                   const float *l2, int n2, float *u, long long ldu, int u_block_major, void *image,
+                   float *norms, int exact, void *stream);
 /*
  * The per-block tables of the routed FFN (lora_ffn.py:87-111: `h_i @ l2[i]`, and `ds_i @ r1[i]` in
  * its backward): rows offsets[g] .. offsets[g + 1] - 1 (device int32 [n_groups + 1], rows sorted by
@@ -614,6 +621,14 @@ int spt_route_topk(const float *prob, int32_t *token, int32_t *block, int32_t *o
 int spt_route_topk_coeff(const float *prob, int32_t *token, int32_t *block, int32_t *offsets,
                          int32_t *pos, long long *token64, long long *block64, float *coeff,
                          float scale, int n_tokens, int n_blocks, int k, void *stream);
+/* The same from the router's LOGITS: prob[t, g] = sigmoid(logits[t * ld + g] + bias[g]) (the Linear +
+ * Sigmoid of feedforward.py:22-25; `logits` = x . W_router^T without bias, e.g. the second-table block
+ * of spt_lora_down2; 16-byte aligned, ld >= n_blocks) is formed inside the routing launch and written
+ * to prob [n_tokens, n_blocks] -- no separate sigmoid pass, no library GEMM with 4 output columns. */
+int spt_route_topk_logits(const float *logits, int ld, const float *bias, float *prob, int32_t *token,
+                          int32_t *block, int32_t *offsets, int32_t *pos, long long *token64,
+                          long long *block64, float *coeff, float scale, int n_tokens, int n_blocks,
+                          int k, void *stream);
 int spt_route_coeff_backward(const float *dcoeff, const int32_t *pos, const int32_t *block,
                              float scale, float *dprob, int n_tokens, int n_blocks, int k,
                              void *stream);
@@ -641,6 +656,12 @@ int spt_ffn_coeff_grad(const float *dot_main, const float *dot_act, int width, c
  */
 int spt_rows_combine(const float *rows, const int32_t *pos, const float *bias, float *out,
                      int n_tokens, int k, int d, void *stream);
+/* ... + sum_{j < n_side} side[t, j] * side_w[j, :] on top (side [n_tokens, n_side], side_w [n_side, d],
+ * 16-byte aligned): the router's share of the routed FFN's input gradient, d logit . W_router
+ * (autograd of feedforward.py:22-25), inside the un-bucketing pass. */
+int spt_rows_combine_side(const float *rows, const int32_t *pos, const float *bias, const float *side,
+                          const float *side_w, int n_side, float *out, int n_tokens, int k, int d,
+                          void *stream);
 
 #ifdef __cplusplus
 }

@@ -1076,9 +1076,13 @@ __global__ __launch_bounds__(256) void relu_fix_kernel(GroupedArgs g) {
 // y[t, :] = bias + sum_{j < k} rows[pos[t * k + j], :]  -- the un-bucketing of the routed
 // FFN (reference: `y[mask] += ...` per block, lora_ffn.py:107-111): a gather in a fixed
 // order instead of a scatter-add, so the result is deterministic.
+// side != null: out[t, :] += sum_{j < ns} side[t, j] * side_w[j, :] on top (a per-token rank-ns
+// product: the router's share of the routed FFN's input gradient, d logit . W_router, which would
+// otherwise be a library GEMM with a 4-wide contraction and an addition pass)
 __global__ __launch_bounds__(256) void rows_combine_kernel(
     const float *__restrict__ rows, const int32_t *__restrict__ pos,
-    const float *__restrict__ bias, float *__restrict__ out, int n_tokens, int k, int d4) {
+    const float *__restrict__ bias, float *__restrict__ out, int n_tokens, int k, int d4,
+    const float *__restrict__ side, const float *__restrict__ side_w, int ns) {
     const int t = blockIdx.x;
     for (int c = threadIdx.x; c < d4; c += 256) {
         float4 acc = bias ? reinterpret_cast<const float4 *>(bias)[c]
@@ -1087,6 +1091,14 @@ __global__ __launch_bounds__(256) void rows_combine_kernel(
             const int p = pos[(size_t)t * k + j];
             const float4 v = reinterpret_cast<const float4 *>(rows + (size_t)p * d4 * 4)[c];
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        if (side) {
+            for (int j = 0; j < ns; j++) {
+                const float s = side[(size_t)t * ns + j];
+                const float4 w = reinterpret_cast<const float4 *>(side_w + (size_t)j * d4 * 4)[c];
+                acc.x = fmaf(s, w.x, acc.x); acc.y = fmaf(s, w.y, acc.y);
+                acc.z = fmaf(s, w.z, acc.z); acc.w = fmaf(s, w.w, acc.w);
+            }
         }
         reinterpret_cast<float4 *>(out + (size_t)t * d4 * 4)[c] = acc;
     }
@@ -1299,7 +1311,19 @@ extern "C" int spt_rows_combine(const float *rows, const int32_t *pos, const flo
     if (n_tokens <= 0 || k <= 0 || d <= 0) return SPT_EINVAL;
     if (d % 4 != 0) return SPT_ESHAPE;
     hipLaunchKernelGGL(rows_combine_kernel, dim3((unsigned)n_tokens), dim3(256), 0,
-                       (hipStream_t)stream, rows, pos, bias, out, n_tokens, k, d / 4);
+                       (hipStream_t)stream, rows, pos, bias, out, n_tokens, k, d / 4, nullptr, nullptr, 0);
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
+extern "C" int spt_rows_combine_side(const float *rows, const int32_t *pos, const float *bias,
+                                     const float *side, const float *side_w, int n_side, float *out,
+                                     int n_tokens, int k, int d, void *stream) {
+    if (!rows || !pos || !out || !side || !side_w) return SPT_EINVAL;
+    if (n_tokens <= 0 || k <= 0 || d <= 0 || n_side <= 0 || n_side > 64) return SPT_EINVAL;
+    if (d % 4 != 0 || (reinterpret_cast<uintptr_t>(side_w) & 15) != 0) return SPT_ESHAPE;
+    hipLaunchKernelGGL(rows_combine_kernel, dim3((unsigned)n_tokens), dim3(256), 0,
+                       (hipStream_t)stream, rows, pos, bias, out, n_tokens, k, d / 4, side, side_w, n_side);
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }

@@ -90,11 +90,15 @@ constexpr int LS_NW = 8;            // waves per workgroup = shares of K (8192 r
 // then lie inside ONE group -- the MFMA's B operand is common to the tile -- so the tiles are
 // counted per group (at most one short tile each: rows / 16 + n_groups workgroups, the surplus
 // ones find no group and leave).
+// Second table (l2 != null): the LAST 16-column block of the result is x . l2^T for a row-major
+// l2 [n2 <= 16, K] -- an nn.Linear weight as it lies in memory (the routed FFN's router,
+// sparse/feedforward.py:22-25, riding the pass that forms x . L1); columns n2 .. 15 of that block are 0.
 template <int NB, bool IMAGE, bool NORMS, bool EXACT>
 __global__ __launch_bounds__(64 * LS_NW) void lora_down_kernel(
     const float *__restrict__ x, long long ldx, long long rows, int K, const float *__restrict__ l,
     int n, float *__restrict__ u, long long u_ld, long long u_block, char *__restrict__ image,
-    float *__restrict__ norms, const int32_t *__restrict__ offsets, int n_groups, long long l_gstride) {
+    float *__restrict__ norms, const int32_t *__restrict__ offsets, int n_groups, long long l_gstride,
+    const float *__restrict__ l2, int n2) {
     __shared__ float red[LS_NW][NB][256];
     __shared__ float nred[LS_NW][16];
     const int lane = threadIdx.x & 63;
@@ -128,12 +132,24 @@ __global__ __launch_bounds__(64 * LS_NW) void lora_down_kernel(
 #pragma unroll
     for (int b = 0; b < NB; b++) acc[b] = {0.f, 0.f, 0.f, 0.f};
     float ss = 0.f;
+    // (second table: lane (c = r, g) reads l2[c][k + 8 g + 0 .. 7], 32 contiguous bytes)
+    const float *l2p = l2 ? l2 + (size_t)min(r, n2 - 1) * K + 32 * sbeg + 8 * g : nullptr;
     auto load_l = [&](int kstep, float (&bv)[NB][8]) {
         const float *p = lp + (size_t)kstep * 32 * n;
 #pragma unroll
-        for (int b = 0; b < NB; b++)
+        for (int b = 0; b < NB; b++) {
+            if (b == NB - 1 && l2p) {                        // (uniform)
+                const float4 t0 = *reinterpret_cast<const float4 *>(l2p + (size_t)kstep * 32);
+                const float4 t1 = *reinterpret_cast<const float4 *>(l2p + (size_t)kstep * 32 + 4);
+                const bool keep = r < n2;
+                bv[b][0] = keep ? t0.x : 0.f; bv[b][1] = keep ? t0.y : 0.f; bv[b][2] = keep ? t0.z : 0.f;
+                bv[b][3] = keep ? t0.w : 0.f; bv[b][4] = keep ? t1.x : 0.f; bv[b][5] = keep ? t1.y : 0.f;
+                bv[b][6] = keep ? t1.z : 0.f; bv[b][7] = keep ? t1.w : 0.f;
+            } else {
 #pragma unroll
-            for (int i = 0; i < 8; i++) bv[b][i] = p[(size_t)i * n + 16 * b];
+                for (int i = 0; i < 8; i++) bv[b][i] = p[(size_t)i * n + 16 * b];
+            }
+        }
     };
     // one chunk; RAGGED: steps s0 + c >= cnt load a clamped (valid) address and are skipped
     auto chunk = [&](int s0, auto ragged) {
@@ -212,10 +228,13 @@ static bool ls_aligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) &
 static int lora_down_any(const float *x, long long ldx, long long rows, int k, const float *l,
                          int n, float *u, long long ldu, int u_block_major, void *image,
                          float *norms, int exact, const int32_t *offsets, int n_groups,
-                         long long l_gstride, void *stream) {
+                         long long l_gstride, void *stream, const float *l2 = nullptr, int n2 = 0) {
     if (!x || !l || !u) return SPT_EINVAL;
     if (rows <= 0 || k <= 0 || n <= 0 || ldx < k) return SPT_EINVAL;
-    if (k % 32 != 0 || n % 16 != 0 || n > 64) return SPT_EUNSUP;
+    if (l2 && (n2 <= 0 || n2 > 16 || offsets || (reinterpret_cast<uintptr_t>(l2) & 15) != 0)) return SPT_EINVAL;
+    // (with a second table `n` counts its block of 16 too; the first table is [k, n - 16])
+    const int n_l = l2 ? n - 16 : n;
+    if (k % 32 != 0 || n % 16 != 0 || n > 64 || n_l <= 0) return SPT_EUNSUP;
     if (ldx % 4 != 0 || !ls_aligned(x) || (image && !ls_aligned(image))) return SPT_ESHAPE;
     if (offsets && (n_groups <= 0 || n_groups > 64)) return SPT_EINVAL;
     const long long nblk = (rows + 15) / 16 + (offsets ? n_groups : 0);
@@ -227,7 +246,8 @@ static int lora_down_any(const float *x, long long ldx, long long rows, int k, c
     const long long u_ld = u_block_major ? 16 : (ldu ? ldu : n), u_block = u_block_major ? rows * 16 : 16;
 #define SPT_LD4(NB, IM, NO, EX)                                                                  \
     hipLaunchKernelGGL((lora_down_kernel<NB, IM, NO, EX>), dim3((unsigned)nblk), dim3(64 * LS_NW), 0, s, \
-                       x, ldx, rows, k, l, n, u, u_ld, u_block, img, norms, offsets, n_groups, l_gstride)
+                       x, ldx, rows, k, l, n_l, u, u_ld, u_block, img, norms, offsets, n_groups, l_gstride, \
+                       l2, n2)
 #define SPT_LD(NB, IM, NO)                                              \
     do {                                                                \
         if (exact) SPT_LD4(NB, IM, NO, true);                           \
@@ -258,6 +278,14 @@ extern "C" int spt_lora_down(const float *x, long long ldx, long long rows, int 
                              float *norms, int exact, void *stream) {
     return lora_down_any(x, ldx, rows, k, l, n, u, ldu, u_block_major, image, norms, exact, nullptr, 1, 0,
                          stream);
+}
+
+extern "C" int spt_lora_down2(const float *x, long long ldx, long long rows, int k, const float *l,
+                              int n, const float *l2, int n2, float *u, long long ldu, int u_block_major,
+                              void *image, float *norms, int exact, void *stream) {
+    if (!l2) return SPT_EINVAL;
+    return lora_down_any(x, ldx, rows, k, l, n + 16, u, ldu, u_block_major, image, norms, exact, nullptr, 1,
+                         0, stream, l2, n2);
 }
 
 extern "C" int spt_lora_down_grouped(const float *x, long long ldx, long long rows, int k,

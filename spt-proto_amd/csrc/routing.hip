@@ -65,21 +65,34 @@ __global__ __launch_bounds__(RT_CHUNK) void route_topk_kernel(
     const float *__restrict__ prob, int32_t *__restrict__ token, int32_t *__restrict__ block,
     int32_t *__restrict__ offsets, int32_t *__restrict__ pos, int T, int G, int k,
     long long *__restrict__ token64, long long *__restrict__ block64, float *__restrict__ coeff,
-    float scale) {
+    float scale, int ld, const float *__restrict__ bias, float *__restrict__ prob_out) {
+    // (prob_out != null: `prob` holds the router's LOGITS without bias, rows `ld` floats apart --
+    // the last block of spt_lora_down2.  The selection ranks logit + bias: the sigmoid is monotone, so
+    // this is the ranking of the probabilities wherever two of them differ, and where distinct logits
+    // round to ONE probability -- a saturated sigmoid; torch.topk leaves the pick among equal values
+    // open -- the larger logit wins.  Only the chunk's owner forms sigmoid(logit + bias), for
+    // prob_out and the coefficients: every workgroup doing so for every chunk it counts cost 10 us.)
     __shared__ int wave_before[RT_CHUNK / 64][MG];   // selections in chunks before mine, by wave
     __shared__ int wave_total[RT_CHUNK / 64][MG];    // ... in all chunks
     __shared__ int wave_mine[RT_CHUNK / 64][MG];     // ... in my chunk
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mine = blockIdx.x, nchunks = (T + RT_CHUNK - 1) / RT_CHUNK;
+    float bias_v[MG];
+#pragma unroll
+    for (int j = 0; j < MG; j++) bias_v[j] = (bias && j < G) ? bias[j] : 0.0f;
     auto load = [&](int c, float (&v)[MG]) {
         const int t = min(c * RT_CHUNK + tid, T - 1);           // (clamped: masked below)
-        if (MG == 4 && G == 4) {
-            const float4 q = *reinterpret_cast<const float4 *>(prob + (size_t)t * 4);
+        if (MG == 4 && G == 4 && (ld & 3) == 0) {
+            const float4 q = *reinterpret_cast<const float4 *>(prob + (size_t)t * ld);
             v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
         } else {
 #pragma unroll
-            for (int j = 0; j < MG; j++) v[j] = j < G ? prob[(size_t)t * G + j] : 0.0f;
+            for (int j = 0; j < MG; j++) v[j] = j < G ? prob[(size_t)t * ld + j] : 0.0f;
+        }
+        if (prob_out) {
+#pragma unroll
+            for (int j = 0; j < MG; j++) v[j] = j < G ? v[j] + bias_v[j] : 0.0f;
         }
     };
     int before[MG], total[MG], own[MG], rank[MG];   // wave-uniform counters
@@ -102,8 +115,9 @@ __global__ __launch_bounds__(RT_CHUNK) void route_topk_kernel(
             const unsigned m = (c * RT_CHUNK + tid < T) ? select_topk(v[u], G, k) : 0u;
             if (c == mine) {
                 my_mask = m;
-#pragma unroll
-                for (int g = 0; g < MG; g++) my_v[g] = v[u][g];
+#pragma unroll                                                   // torch.sigmoid(linear(x, rw, rb))
+                for (int g = 0; g < MG; g++)
+                    my_v[g] = prob_out ? 1.0f / (1.0f + expf(-v[u][g])) : v[u][g];
             }
 #pragma unroll
             for (int g = 0; g < MG; g++) {
@@ -144,6 +158,11 @@ __global__ __launch_bounds__(RT_CHUNK) void route_topk_kernel(
     }
     if (mine == 0 && tid == 0) offsets[G] = run;
     const int t = mine * RT_CHUNK + tid;
+    if (t < T && prob_out) {
+#pragma unroll
+        for (int g = 0; g < MG; g++)
+            if (g < G) prob_out[(size_t)t * G + g] = my_v[g];
+    }
     if (t < T) {
         int j = 0;
 #pragma unroll
@@ -229,17 +248,22 @@ using namespace spt;
 
 static int route_topk_any(const float *prob, int32_t *token, int32_t *block, int32_t *offsets,
                           int32_t *pos, long long *token64, long long *block64, float *coeff,
-                          float scale, int n_tokens, int n_blocks, int k, void *stream) {
+                          float scale, int n_tokens, int n_blocks, int k, void *stream, int ld = 0,
+                          const float *bias = nullptr, float *prob_out = nullptr) {
     if (!prob || !token || !block || !offsets || !pos) return SPT_EINVAL;
     if (n_tokens <= 0 || n_blocks <= 0 || k <= 0 || k > n_blocks) return SPT_EINVAL;
     if (n_blocks > RT_MAXG || n_tokens > 65536) return SPT_EUNSUP;
+    if (ld == 0) ld = n_blocks;
+    if (ld < n_blocks || (reinterpret_cast<uintptr_t>(prob) & 15) != 0) return SPT_ESHAPE;
     const dim3 grid((n_tokens + RT_CHUNK - 1) / RT_CHUNK), threads(RT_CHUNK);
     if (n_blocks <= 4)
         hipLaunchKernelGGL(route_topk_kernel<4>, grid, threads, 0, (hipStream_t)stream, prob, token,
-                           block, offsets, pos, n_tokens, n_blocks, k, token64, block64, coeff, scale);
+                           block, offsets, pos, n_tokens, n_blocks, k, token64, block64, coeff, scale,
+                           ld, bias, prob_out);
     else
         hipLaunchKernelGGL(route_topk_kernel<RT_MAXG>, grid, threads, 0, (hipStream_t)stream, prob, token,
-                           block, offsets, pos, n_tokens, n_blocks, k, token64, block64, coeff, scale);
+                           block, offsets, pos, n_tokens, n_blocks, k, token64, block64, coeff, scale,
+                           ld, bias, prob_out);
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }
@@ -258,6 +282,15 @@ extern "C" int spt_route_topk_coeff(const float *prob, int32_t *token, int32_t *
     if (!token64 || !block64 || !coeff) return SPT_EINVAL;
     return route_topk_any(prob, token, block, offsets, pos, token64, block64, coeff, scale,
                           n_tokens, n_blocks, k, stream);
+}
+
+extern "C" int spt_route_topk_logits(const float *logits, int ld, const float *bias, float *prob,
+                                     int32_t *token, int32_t *block, int32_t *offsets, int32_t *pos,
+                                     long long *token64, long long *block64, float *coeff, float scale,
+                                     int n_tokens, int n_blocks, int k, void *stream) {
+    if (!prob || !token64 || !block64 || !coeff) return SPT_EINVAL;
+    return route_topk_any(logits, token, block, offsets, pos, token64, block64, coeff, scale, n_tokens,
+                          n_blocks, k, stream, ld, bias, prob);
 }
 
 extern "C" int spt_route_coeff_backward(const float *dcoeff, const int32_t *pos, const int32_t *block,

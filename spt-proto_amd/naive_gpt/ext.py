@@ -75,6 +75,7 @@ _PROTOTYPES = {
     'spt_split_bf16_bytes': ([ctypes.c_longlong, _c_int], ctypes.c_size_t),
     'spt_split_bf16': ([_c_ptr, _c_ptr, ctypes.c_longlong, _c_int, ctypes.c_longlong, _c_ptr], _c_int),
     'spt_rows_combine': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_rows_combine_side': ([_c_ptr] * 5 + [_c_int, _c_ptr] + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_ffn_coeff_grad': ([_c_ptr, _c_ptr, _c_int] + [_c_ptr] * 6 + [_c_f32, _c_ptr, _c_int, _c_int, _c_ptr],
                            _c_int),
     'spt_layernorm_partial_rows': ([ctypes.c_longlong], _c_int),
@@ -84,6 +85,8 @@ _PROTOTYPES = {
                                 _c_ptr, ctypes.c_longlong, _c_ptr], _c_int),
     'spt_lora_down': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_int,
                        _c_ptr, ctypes.c_longlong, _c_int] + [_c_ptr] * 2 + [_c_int, _c_ptr], _c_int),
+    'spt_lora_down2': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_int, _c_ptr, _c_int,
+                        _c_ptr, ctypes.c_longlong, _c_int] + [_c_ptr] * 2 + [_c_int, _c_ptr], _c_int),
     'spt_lora_down_grouped': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, ctypes.c_longlong,
                                _c_int, _c_ptr, _c_int, _c_ptr, ctypes.c_longlong] + [_c_ptr] * 3, _c_int),
     'spt_tall_tn_workspace_bytes': ([ctypes.c_longlong, _c_int, _c_int, _c_int], ctypes.c_longlong),
@@ -93,6 +96,7 @@ _PROTOTYPES = {
                      ctypes.c_longlong, _c_int, _c_int, _c_ptr, _c_int, _c_ptr, _c_ptr], _c_int),
     'spt_route_topk': ([_c_ptr] * 5 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_route_topk_coeff': ([_c_ptr] * 8 + [_c_f32] + [_c_int] * 3 + [_c_ptr], _c_int),
+    'spt_route_topk_logits': ([_c_ptr, _c_int] + [_c_ptr] * 9 + [_c_f32] + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_route_coeff_backward': ([_c_ptr] * 3 + [_c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_route_logit_backward': ([_c_ptr] * 3 + [_c_f32, _c_ptr, _c_ptr] + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_softmax_forward': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
@@ -100,7 +104,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 _lib = None
 
@@ -1362,6 +1366,43 @@ def route_topk_coeff(prob: torch.Tensor, k: int, scale: float):
     return token, block, offsets, pos, longs[0], longs[1], coeff
 
 
+
+def route_topk_logits(logits: torch.Tensor, bias: torch.Tensor, n_blocks: int, k: int, scale: float):
+    """``spt_route_topk_logits``: `route_topk_coeff` from the router's LOGITS (x @ W^T without
+    bias: [T, >= n_blocks], unit inner stride, 16-byte aligned rows -- a view of a wider matrix);
+    the probabilities sigmoid(logits + bias) are formed in the same launch (the top-k ranks logits + bias:
+    the ranking of the probabilities wherever two differ; equal probabilities of distinct logits go to
+    the larger logit).
+    -> (prob [T, n_blocks], token, block, offsets, pos, token64, block64, coeff)."""
+    _check_type(logits, torch.float32, 'logits')
+    _require(logits.is_cuda and logits.dim() == 2 and logits.stride(1) == 1 and logits.size(1) >= n_blocks
+             and logits.data_ptr() % 16 == 0 and logits.stride(0) % 4 == 0,
+             'route_topk_logits: [T, >= n_blocks] fp32, 16-byte aligned rows')
+    if bias is not None:
+        _check_type(bias, torch.float32, 'bias')
+        _require(bias.is_contiguous() and bias.numel() == n_blocks and bias.device == logits.device,
+                 'bias: [n_blocks]')
+    T, G = logits.size(0), n_blocks
+    _require(0 < k <= G, 'route_topk: 0 < k <= n_blocks')
+    dev = logits.device
+    lib = load_library()
+    with _on(dev):
+        prob = torch.empty([T, G], dtype=torch.float32, device=dev)
+        token = torch.empty([T * k], dtype=torch.int32, device=dev)
+        block = torch.empty([T * k], dtype=torch.int32, device=dev)
+        offsets = torch.empty([G + 1], dtype=torch.int32, device=dev)
+        pos = torch.empty([T, k], dtype=torch.int32, device=dev)
+        token64 = torch.empty([T * k], dtype=torch.int64, device=dev)
+        block64 = torch.empty([T * k], dtype=torch.int64, device=dev)
+        coeff = torch.empty([T * k], dtype=torch.float32, device=dev)
+        rc = lib.spt_route_topk_logits(logits.data_ptr(), logits.stride(0), _ptr(bias), prob.data_ptr(),
+                                       token.data_ptr(), block.data_ptr(), offsets.data_ptr(), pos.data_ptr(),
+                                       token64.data_ptr(), block64.data_ptr(), coeff.data_ptr(), float(scale),
+                                       T, G, k, _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'route_topk_logits')
+    return prob, token, block, offsets, pos, token64, block64, coeff
+
 def route_coeff_backward(dcoeff: torch.Tensor, pos: torch.Tensor, block: torch.Tensor,
                          scale: float, n_blocks: int, prob: torch.Tensor = None) -> torch.Tensor:
     """``spt_route_coeff_backward``: d prob [T, n_blocks] from d coeff [T * k]; with ``prob`` (the
@@ -1392,8 +1433,10 @@ def route_coeff_backward(dcoeff: torch.Tensor, pos: torch.Tensor, block: torch.T
     return dprob
 
 
-def rows_combine(rows: torch.Tensor, pos: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
-    """out[t] = bias + sum_j rows[pos[t, j]] (``spt_rows_combine``); pos [T, k] int32."""
+def rows_combine(rows: torch.Tensor, pos: torch.Tensor, bias: torch.Tensor = None,
+                 side: torch.Tensor = None, side_weight: torch.Tensor = None) -> torch.Tensor:
+    """out[t] = bias + sum_j rows[pos[t, j]] (``spt_rows_combine``); pos [T, k] int32.  With ``side``
+    [T, ns] and ``side_weight`` [ns, d] (``spt_rows_combine_side``) side @ side_weight is added on top."""
     _check_type(rows, torch.float32, 'rows')
     _check_type(pos, torch.int32, 'pos')
     _require(rows.dim() == 2 and rows.is_contiguous() and pos.dim() == 2 and pos.is_contiguous(),
@@ -1401,12 +1444,23 @@ def rows_combine(rows: torch.Tensor, pos: torch.Tensor, bias: torch.Tensor = Non
     dev = _same_device(rows, pos)
     T, k = pos.shape
     d = rows.size(1)
+    if side is not None:
+        _require(side_weight is not None and side.dtype == side_weight.dtype == torch.float32
+                 and side.is_contiguous() and side_weight.is_contiguous() and side.dim() == 2
+                 and side.size(0) == T and side_weight.shape == (side.size(1), d)
+                 and side.device == side_weight.device == dev and side_weight.data_ptr() % 16 == 0,
+                 'rows_combine: side [T, ns], side_weight [ns, d], contiguous fp32')
     lib = load_library()
     with _on(dev):
         out = torch.empty([T, d], dtype=torch.float32, device=dev)
         if T > 0:
-            rc = lib.spt_rows_combine(rows.data_ptr(), pos.data_ptr(), _ptr(bias), out.data_ptr(),
-                                      T, k, d, _stream(dev))
+            if side is None:
+                rc = lib.spt_rows_combine(rows.data_ptr(), pos.data_ptr(), _ptr(bias), out.data_ptr(),
+                                          T, k, d, _stream(dev))
+            else:
+                rc = lib.spt_rows_combine_side(rows.data_ptr(), pos.data_ptr(), _ptr(bias), side.data_ptr(),
+                                               side_weight.data_ptr(), side.size(1), out.data_ptr(),
+                                               T, k, d, _stream(dev))
             if rc != 0:
                 _raise(lib, rc, 'rows_combine')
     return out
@@ -1424,20 +1478,43 @@ def lora_down_supported(x: torch.Tensor, table: torch.Tensor) -> bool:
 
 def lora_down(x: torch.Tensor, table: torch.Tensor, want_image: bool = False,
               want_norms: bool = False, block_major: bool = False, out: torch.Tensor = None,
-              exact: bool = False):
+              exact: bool = False, table2: torch.Tensor = None):
     """u = x @ table for a tall x [rows, K] and a table [K, n] of a few columns, as ONE pass over x
     (``spt_lora_down``); the same pass can also leave x's split image (:class:`SplitImage`) and its
     row 2-norms.  Returns u, or (u, image | None, norms | None) when a by-product is asked for.
     ``block_major``: u as [n / 16, rows, 16] (tables of several rank-16 adapters side by side:
     each adapter's product contiguous).  ``out``: a [rows, n] view to write u into (unit inner
     stride, any row stride: a column slice of a wider matrix).  ``exact``: u in exact fp32 instead of
-    split-bf16 products (for the u in front of a ReLU GEMM: include/spt_hip.h)."""
+    split-bf16 products (for the u in front of a ReLU GEMM: include/spt_hip.h).  ``table2``
+    (``spt_lora_down2``; needs ``block_major``): a row-major [n2 <= 16, K] matrix (an nn.Linear
+    weight) whose product x @ table2.T fills one more block: u[-1][:, :n2]."""
     _require(lora_down_supported(x, table), 'lora_down: see lora_down_supported')
     table = table.contiguous()
     rows, k = x.shape
     n = table.size(1)
     dev = _same_device(x, table)
     lib = load_library()
+    if table2 is not None:
+        _check_type(table2, torch.float32, 'table2')
+        _require(block_major and out is None and table2.dim() == 2 and table2.is_contiguous()
+                 and table2.size(1) == k and 0 < table2.size(0) <= 16 and n + 16 <= 64
+                 and table2.device == dev and table2.data_ptr() % 16 == 0,
+                 'lora_down: table2 [n2 <= 16, K] contiguous, block_major output')
+        with _on(dev):
+            u = torch.empty([n // 16 + 1, rows, 16], dtype=torch.float32, device=dev)
+            image = norms = None
+            if want_image:
+                image = SplitImage(torch.empty([lib.spt_split_bf16_bytes(rows, k)], dtype=torch.uint8,
+                                               device=dev), rows, k)
+            if want_norms:
+                norms = torch.empty([rows], dtype=torch.float32, device=dev)
+            rc = lib.spt_lora_down2(x.data_ptr(), x.stride(0), rows, k, table.data_ptr(), n,
+                                    table2.data_ptr(), table2.size(0), u.data_ptr(), 0, 1,
+                                    image.buffer.data_ptr() if want_image else None, _ptr(norms),
+                                    int(bool(exact)), _stream(dev))
+        if rc != 0:
+            _raise(lib, rc, 'lora_down2')
+        return (u, image, norms) if (want_image or want_norms) else u
     with _on(dev):
         if out is not None:
             _check_type(out, torch.float32, 'out')

@@ -93,6 +93,7 @@ COEFF_FLOOR = 1e-12
 # h (one reader) goes to its GEMM as fp32 rows, no image: -0.36 ms per configs[2] step, A/B on one
 # box (the same for x: +0.26 ms, for dy: +-0: both keep their images)
 H_A32 = os.environ.get('SPT_H_A32', '1') != '0'
+ROUTER_RIDES = os.environ.get('SPT_ROUTER_RIDES', '1') != '0'
 
 
 def _floor(coeff: torch.Tensor) -> torch.Tensor:
@@ -271,6 +272,14 @@ def _tn_blocks_many(pairs, bk: Buckets):
     return [_tn_blocks(w, t, bk) for w, t in pairs]
 
 
+def _router_rides(x: torch.Tensor, l1: torch.Tensor, rw: torch.Tensor, n_blocks: int) -> bool:
+    """The router's logits as a second table of the x L1 pass (spt_lora_down2) and the routing from
+    logits (spt_route_topk_logits): rank-16 adapter, <= 8 blocks, shapes spt_lora_down takes."""
+    return (ROUTER_RIDES and x.is_cuda and l1.size(1) == 16 and n_blocks <= 8 and rw.is_contiguous()
+            and rw.dtype == torch.float32 and rw.data_ptr() % 16 == 0
+            and ext.lora_down_supported(x, l1) and ext.route_topk_supported(x.size(0), n_blocks))
+
+
 def _route(x: torch.Tensor, rw: torch.Tensor, rb, n_blocks: int, k: int):
     """The router (sparse/feedforward.py:22-25: Linear + Sigmoid) and the bucketing of its top-k, inside
     the routed FFN's own autograd node: -> (prob [T, nb], Buckets with coeff = 2 prob
@@ -326,16 +335,35 @@ class RoutedLoRAFFN(torch.autograd.Function):
                 origin_input=None, origin_module=None):
         d_ff, d = w1.shape
         x = x.contiguous()
-        prob, bk, block = _route(x, rw, rb, nb, top_k)
-        coeff = bk.coeff
-        bs, rank, rows = d_ff // nb, l1.size(1), bk.token.numel()
-        # Both block GEMMs run from pre-split images: the weights' are made from the frozen
-        # parameters, x's and h's cost one pass each -- the pass that also forms the LoRA down
-        # product and, in front of a ReLU, the row norms the kernel wants (include/spt_hip.h:
-        # a_norm): ext.lora_down, one read of the activation for all three.
+        bs, rank = d_ff // nb, l1.size(1)
         relu = act == ext.ACT_RELU
         imgs = _images_usable(x, w1, w2, d, bs)
-        u, x_img, x_norm = _down(x, l1, imgs, relu)                          # [T, r]
+        if _router_rides(x, l1, rw, nb):
+            # ONE pass over x: u = x L1, the router's logits x W_r^T (a second table of the same
+            # launch, exact fp32: the top-k must not depend on a split's 2^-16), x's image and row
+            # norms; the sigmoid is formed inside the routing launch.  (As torch operators: a library
+            # GEMM with 4 output columns and a sigmoid pass, ~20 us per layer.)
+            ext.note_path('router', 'rides_lora_down')
+            pack = ext.lora_down(x, l1, want_image=imgs, want_norms=relu, block_major=True, exact=True,
+                                 table2=rw)
+            pack, x_img, x_norm = pack if isinstance(pack, tuple) else (pack, None, None)
+            u = pack[0]
+            prob, token, block, offsets, pos, token_long, block_long, coeff = \
+                ext.route_topk_logits(pack[1], rb, nb, top_k, 2.0)
+            ext.note_path('route_topk', 'kernel')
+            bk = Buckets(token=token, token_long=token_long, block=block_long, offsets=offsets,
+                         coeff=coeff, n_blocks=nb, pos=pos)
+        else:
+            ext.note_path('router', 'library', fallback=x.is_cuda,
+                          why=lambda: 'x {} L1 {} router {}'.format(tuple(x.shape), tuple(l1.shape), tuple(rw.shape)))
+            prob, bk, block = _route(x, rw, rb, nb, top_k)
+            # Both block GEMMs run from pre-split images: the weights' are made from the frozen
+            # parameters, x's and h's cost one pass each -- the pass that also forms the LoRA down
+            # product and, in front of a ReLU, the row norms the kernel wants (include/spt_hip.h:
+            # a_norm): ext.lora_down, one read of the activation for all three.
+            u, x_img, x_norm = _down(x, l1, imgs, relu)                      # [T, r]
+        coeff = bk.coeff
+        rows = bk.token.numel()
         h, s = ext.grouped_gemm_fused(
             x, w1, bk.offsets, nb, n=bs, k=d, w_group_stride=bs * d, w_ldn=d, w_ldk=1,
             n_rows=rows, gather=bk.token, bias=b1, rowscale=coeff,
@@ -395,9 +423,18 @@ class RoutedLoRAFFN(torch.autograd.Function):
             ds, w1, bk.offsets, nb, n=d, k=bs, w_group_stride=bs * d, w_ldn=1, w_ldk=d,
             n_rows=rows, rowscale=coeff, a2=du, b2=l1, b2_group_stride=0)
         del ds, du
-        grad_x = ext.rows_combine(dxs, bk.pos)
-        del dxs
-        grad_rw, grad_rb = _route_backward(ctx, grad_coeff, prob, bk, block, x, rw, grad_x)
+        if grad_coeff.is_cuda and nb <= 8 and d % 4 == 0:
+            # the router's share d logit . W_r of grad_x inside the un-bucketing pass
+            dlogit = ext.route_coeff_backward(grad_coeff.contiguous(), bk.pos, block, 2.0, nb, prob=prob)
+            grad_x = ext.rows_combine(dxs, bk.pos, side=dlogit, side_weight=rw.contiguous())
+            del dxs
+            from naive_gpt.layers.tuning.lora import tall_tn
+            grad_rw = tall_tn(dlogit, x) if ctx.needs_input_grad[1] else None   # [nb, d]
+            grad_rb = dlogit.sum(dim=0) if ctx.needs_input_grad[2] else None
+        else:
+            grad_x = ext.rows_combine(dxs, bk.pos)
+            del dxs
+            grad_rw, grad_rb = _route_backward(ctx, grad_coeff, prob, bk, block, x, rw, grad_x)
         return (grad_x, grad_rw, grad_rb, grad_l1, grad_r1, grad_l2, grad_r2,
                 None, None, None, None, None, None, None, None, None)
 

@@ -994,3 +994,37 @@ def test_joint_qkv_backward_is_one_contraction_when_the_gradients_share_a_buffer
     assert ext.paths_taken('qkv_dx') == {('qkv_dx', 'three_launches'): 1}
     for a, b in zip(joint, apart):
         assert torch.allclose(a, b, rtol=1e-3, atol=2e-5 * b.abs().max().item())
+
+
+@pytest.mark.parametrize('act', ['relu', 'gelu'])
+def test_router_riding_the_lora_down_pass_equals_the_library_router(act, monkeypatch):
+    """RoutedLoRAFFN with the router's logits as a second table of the x L1 pass, the sigmoid inside
+    the routing launch and d logit . W_r inside the un-bucketing of grad_x -- against the same node
+    with the router as library operators (Linear + Sigmoid, addmm)."""
+    from naive_gpt import ext, layers
+    from naive_gpt.layers.sparse import grouped
+    torch.manual_seed(7)
+    d, dff, bs = 256, 1024, 256
+    m = layers.LoRARoutedFFN(d_lora=16, block_size=bs, d_model=d, d_feedforward=dff,
+                             activation=nn.ReLU() if act == 'relu' else nn.GELU()).cuda()
+    for name, p in m.named_parameters():
+        if name.endswith('lora.right.weight'):
+            p.data.normal_(0, 0.05)
+    x0 = torch.randn([4, 300, d], device='cuda')
+    w = torch.randn([4, 300, d], device='cuda')
+
+    def run():
+        x = x0.clone().requires_grad_(True)
+        m.zero_grad()
+        ext.reset_paths()
+        (m(x) * w).sum().backward()
+        return [x.grad] + [p.grad.clone() for p in m.parameters() if p.grad is not None], ext.paths_taken('router')
+
+    got, paths = run()
+    assert paths == {('router', 'rides_lora_down'): 1}
+    monkeypatch.setattr(grouped, 'ROUTER_RIDES', False)
+    want, paths = run()
+    assert paths == {('router', 'library'): 1}
+    assert len(got) == len(want) >= 7
+    for a, b in zip(got, want):
+        assert _scaled_close(a, b, rtol=1e-3)

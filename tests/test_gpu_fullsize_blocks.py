@@ -272,7 +272,16 @@ def test_routed_ffn_at_block_dims(name):
     assert _rows_close(gx1.double(), x64.grad, bad_rows=0.001 if relu else 0.0), _worst(gx1, x64.grad)
     assert set(g64) == set(g1)
     for n in g1:
-        assert _scaled_close(g1[n].double(), g64[n], frac=1e-3 if relu else 3e-4), (n, _worst(g1[n], g64[n]))
+        # (ReLU: the same one-in-millions pre-activation shows in the table gradients as ONE row --
+        # hidden unit -- of fc1.lora.right: which element it is depends on the last bit of the router
+        # coefficient, e.g. on whether the sigmoid ran in torch or inside the routing launch)
+        if relu and g1[n].dim() == 2 and g1[n].size(0) >= 1024:
+            assert _rows_close(g1[n].double(), g64[n], frac=1e-3, bad_rows=2.0 / g1[n].size(0)), \
+                (n, _worst(g1[n], g64[n]))
+        else:
+            # (... and in the router's gradients as that one token's share: 1.7e-3 of the largest
+            # element at these dimensions, measured)
+            assert _scaled_close(g1[n].double(), g64[n], frac=3e-3 if relu else 3e-4), (n, _worst(g1[n], g64[n]))
     assert _scaled_close(y0.double(), y64.detach()), _worst(y0, y64)
     assert _rows_close(gx0.double(), x64.grad, bad_rows=0.01 if relu else 0.0), _worst(gx0, x64.grad)
     for n in g0:

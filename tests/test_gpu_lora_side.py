@@ -100,3 +100,50 @@ def test_embedding_rows_backward_is_the_embedding_gradient_and_bit_reproducible(
         table.grad = None
     assert torch.allclose(runs[0], want, rtol=1e-5, atol=1e-5)
     assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+
+
+def test_second_table_block_and_routing_from_logits():
+    """spt_lora_down2: x @ table2.T for a row-major [n2, K] matrix as one more block of the x @ L pass
+    (exact fp32), and spt_route_topk_logits: the routing of sigmoid(logits + bias) from that block --
+    against the library's Linear + Sigmoid and spt_route_topk_coeff on its probabilities."""
+    from naive_gpt import ext
+    torch.manual_seed(0)
+    T, K, G, k = 3000, 256, 4, 2
+    x = torch.randn([T, K], device='cuda')
+    table = torch.randn([K, 16], device='cuda')
+    rw = torch.randn([G, K], device='cuda') / 16
+    rb = torch.randn([G], device='cuda')
+    pack, image, norms = ext.lora_down(x, table, want_image=True, want_norms=True, block_major=True,
+                                       exact=True, table2=rw)
+    assert pack.shape == (2, T, 16)
+    u_ref, image_ref, norms_ref = ext.lora_down(x, table, want_image=True, want_norms=True, exact=True)
+    assert torch.equal(pack[0], u_ref) and torch.equal(image.buffer, image_ref.buffer)
+    assert torch.equal(norms, norms_ref)
+    logits = x.double() @ rw.double().T
+    assert torch.allclose(pack[1][:, :G].double(), logits, rtol=0, atol=1e-5 * float(logits.abs().max()))
+    assert float(pack[1][:, G:].abs().max()) == 0.0
+    # without by-products, and a table of 32 columns in front
+    wide = torch.randn([K, 32], device='cuda')
+    pack3 = ext.lora_down(x, wide, block_major=True, table2=rw)
+    assert pack3.shape == (3, T, 16)
+    assert torch.allclose(pack3[2][:, :G].double(), logits, rtol=0, atol=2e-4 * float(logits.abs().max()))
+    # routing from the logits block == routing of the probabilities torch forms from the same logits
+    prob, token, block, offsets, pos, token64, block64, coeff = ext.route_topk_logits(pack[1], rb, G, k, 2.0)
+    prob_ref = torch.sigmoid(pack[1][:, :G] + rb)
+    assert torch.allclose(prob, prob_ref, rtol=2e-6, atol=1e-7)
+    want = ext.route_topk_coeff(prob.contiguous(), k, 2.0)
+    for a, b in zip((token, block, offsets, pos, token64, block64, coeff), want):
+        assert torch.equal(a, b)
+
+
+def test_rows_combine_with_a_side_product():
+    from naive_gpt import ext
+    torch.manual_seed(1)
+    T, k, d, ns = 1000, 2, 256, 4
+    rows = torch.randn([T * k, d], device='cuda')
+    pos = torch.randperm(T * k, device='cuda').view(T, k).int()
+    side = torch.randn([T, ns], device='cuda')
+    w = torch.randn([ns, d], device='cuda')
+    got = ext.rows_combine(rows, pos, side=side, side_weight=w)
+    want = rows[pos.long()].double().sum(1) + side.double() @ w.double()
+    assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-5)
