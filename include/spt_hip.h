@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 33
+#define SPT_ABI_VERSION 34
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -472,6 +472,11 @@ typedef struct SptGroupedGemm {
      * SPT_EPI_PLAIN) the second term may be r <= 64 wide: the three rank-16 products side by side. */
     int32_t a_seg_k;
     int64_t a_seg_stride;
+    /* != 0 (SPT_EPI_PLAIN, fp32 operands, r % 16 == 0): the second term's b2 in segments of 16 columns,
+     *   b2(n, j) = b2[(j / 16) * b2_seg_stride + n * b2_ldn + j % 16]
+     * -- rank-16 tables that lie b2_seg_stride floats apart (the adapters of q, k, v in a tuner's flat
+     * parameter buffer) used as one [n, r] operand without a concatenated copy. */
+    int64_t b2_seg_stride;
 } SptGroupedGemm;
 int spt_grouped_gemm_fused(const SptGroupedGemm *desc, void *stream);
 int spt_grouped_gemm_pdot_width(int n);
@@ -514,6 +519,12 @@ int spt_split_bf16(const float *src, void *image, long long rows, int cols, long
 int spt_lora_down(const float *x, long long ldx, long long rows, int k, const float *l, int n,
                   float *u, long long ldu, int u_block_major, void *image, float *norms, int exact,
                   void *stream);
+/* spt_lora_down for n_tables (<= 4) SEPARATE tables [k, 16] lying table_stride floats apart (table t at
+ * l + t * table_stride): u as n_tables block-major matrices [rows, 16], exactly what one table
+ * [k, 16 n_tables] of the concatenated columns gives -- without making that copy every step. */
+int spt_lora_down_tables(const float *x, long long ldx, long long rows, int k, const float *l,
+                         int n_tables, long long table_stride, float *u, void *image, float *norms,
+                         int exact, void *stream);
 /* spt_lora_down with a SECOND table: u gets one more block of 16 columns = x . l2^T for a row-major
  * l2 [n2 <= 16, k] (an nn.Linear weight as stored; 16-byte aligned); columns n2 .. 15 of that block are 0.
  * `n` counts the columns of `l` only (n + 16 <= 64); u_block_major as above: (n / 16 + 1) matrices

@@ -123,6 +123,7 @@ struct GroupedArgs {
     int lda2, R;
     long long b2_gstride;
     int b2_ldn;
+    long long b2_seg;       // != 0: column j of b2 lies in segment j / 16, b2_seg floats apart (register path)
     // epilogue
     int act;
     float *out2;            // EPI_ACT: pre-activation (null: not kept, e.g. ReLU)
@@ -919,8 +920,9 @@ __device__ __forceinline__ void gemm_tile_regs(const GroupedArgs &g, float *smem
                 const int n = n0 + r;
                 float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (n < g.N && k < g.R)
-                    b = *reinterpret_cast<const float4 *>(g.b2 + (size_t)bucket * g.b2_gstride +
-                                                          (size_t)n * g.b2_ldn + k);
+                    b = *reinterpret_cast<const float4 *>(
+                        g.b2 + (size_t)bucket * g.b2_gstride + (size_t)n * g.b2_ldn +
+                        (g.b2_seg ? (size_t)(k >> 4) * g.b2_seg + (k & 15) : (size_t)k));
                 put4(Bs, GG_BIMG, r * GG_ROWB + 8 * s_kq, b);
                 const float ss = group_sum<8>(b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w);
                 if (s_kq == 0) extras[128 + r] = ss;        // |b2 row|^2
@@ -1126,7 +1128,7 @@ static int resident_slots() {
 // activation as its fp32 rows (16-byte aligned, lda % 4 == 0: one LDS-DMA lane moves 16 bytes)
 static int image_path(GroupedArgs &g, int epilogue) {
     if (!g.w_img || (!g.a_img && !g.a)) return 0;
-    if (g.K % GG_BK != 0 || g.a_seg_k > 0 || (g.a2 && g.R > GG_BK)) return 0;
+    if (g.K % GG_BK != 0 || g.a_seg_k > 0 || (g.a2 && (g.R > GG_BK || g.b2_seg != 0))) return 0;
     const long long row_len = g.ldk == 1 ? g.ldn : g.ldk;       // elements of one weight row
     if (row_len <= 0 || g.gstride % 32 != 0 || row_len % 32 != 0) return 0;
     g.w_grow = g.gstride / row_len;
@@ -1160,6 +1162,7 @@ static int launch_grouped(GroupedArgs g, int epilogue, void *stream) {
     if (ext) {
         if (!g.b2 || g.R <= 0 || g.R > 2 * GG_BK) return SPT_EINVAL;
         if (g.R > GG_BK && epilogue != EPI_PLAIN) return SPT_EUNSUP;
+        if (g.b2_seg != 0 && (g.b2_seg % 4 != 0 || g.R % 16 != 0 || epilogue != EPI_PLAIN)) return SPT_ESHAPE;
         if (g.R % 4 != 0 || g.lda2 % 4 != 0 || g.lda2 < g.R || g.b2_ldn % 4 != 0 ||
             g.b2_gstride % 4 != 0)
             return SPT_ESHAPE;
@@ -1261,6 +1264,7 @@ extern "C" int spt_grouped_gemm_fused(const SptGroupedGemm *d, void *stream) {
     g.ldo = d->ldo;
     g.accumulate = d->accumulate;
     g.a_seg_k = d->a_seg_k; g.a_seg_stride = d->a_seg_stride;
+    g.b2_seg = d->b2_seg_stride;
     const long long header = GG_FIX_SEGS * 64;
     if (d->relu_queue && d->relu_queue_bytes >= header + GG_FIX_SEGS * 8) {
         g.fix_count = reinterpret_cast<unsigned *>(d->relu_queue);
@@ -1277,7 +1281,7 @@ extern "C" int spt_grouped_gemm_image_path(const SptGroupedGemm *d) {
     g.K = d->k; g.gstride = d->w_group_stride; g.ldn = d->w_ldn; g.ldk = d->w_ldk;
     g.act = d->activation;
     g.a = d->a; g.lda = d->lda;
-    g.a2 = d->a2; g.R = d->r; g.a_seg_k = d->a_seg_k;
+    g.a2 = d->a2; g.R = d->r; g.a_seg_k = d->a_seg_k; g.b2_seg = d->b2_seg_stride;
     g.a_img = reinterpret_cast<const char *>(d->a_image);
     g.w_img = reinterpret_cast<const char *>(d->w_image);
     return image_path(g, d->epilogue);

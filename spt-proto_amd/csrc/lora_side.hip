@@ -98,7 +98,10 @@ __global__ __launch_bounds__(64 * LS_NW) void lora_down_kernel(
     const float *__restrict__ x, long long ldx, long long rows, int K, const float *__restrict__ l,
     int n, float *__restrict__ u, long long u_ld, long long u_block, char *__restrict__ image,
     float *__restrict__ norms, const int32_t *__restrict__ offsets, int n_groups, long long l_gstride,
-    const float *__restrict__ l2, int n2) {
+    const float *__restrict__ l2, int n2, long long l_bstride) {
+    // (l_bstride: floats from one 16-column block of the table to the next -- 16 inside one [K, n]
+    // table; the distance between SEPARATE [K, 16] tables, e.g. the adapters of q, k, v as they lie
+    // in a tuner's flat parameter buffer: no concatenated copy of them is made)
     __shared__ float red[LS_NW][NB][256];
     __shared__ float nred[LS_NW][16];
     const int lane = threadIdx.x & 63;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(64 * LS_NW) void lora_down_kernel(
                 bv[b][6] = keep ? t1.z : 0.f; bv[b][7] = keep ? t1.w : 0.f;
             } else {
 #pragma unroll
-                for (int i = 0; i < 8; i++) bv[b][i] = p[(size_t)i * n + 16 * b];
+                for (int i = 0; i < 8; i++) bv[b][i] = p[(size_t)i * n + b * l_bstride];
             }
         }
     };
@@ -228,12 +231,16 @@ static bool ls_aligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) &
 static int lora_down_any(const float *x, long long ldx, long long rows, int k, const float *l,
                          int n, float *u, long long ldu, int u_block_major, void *image,
                          float *norms, int exact, const int32_t *offsets, int n_groups,
-                         long long l_gstride, void *stream, const float *l2 = nullptr, int n2 = 0) {
+                         long long l_gstride, void *stream, const float *l2 = nullptr, int n2 = 0,
+                         long long table_stride = 0) {
     if (!x || !l || !u) return SPT_EINVAL;
     if (rows <= 0 || k <= 0 || n <= 0 || ldx < k) return SPT_EINVAL;
     if (l2 && (n2 <= 0 || n2 > 16 || offsets || (reinterpret_cast<uintptr_t>(l2) & 15) != 0)) return SPT_EINVAL;
     // (with a second table `n` counts its block of 16 too; the first table is [k, n - 16])
-    const int n_l = l2 ? n - 16 : n;
+    // (table_stride != 0: n / 16 separate tables [k, 16], table_stride floats apart)
+    if (table_stride != 0 && (l2 || offsets || table_stride % 4 != 0)) return SPT_EINVAL;
+    const int n_l = table_stride ? 16 : (l2 ? n - 16 : n);
+    const long long l_bstride = table_stride ? table_stride : 16;
     if (k % 32 != 0 || n % 16 != 0 || n > 64 || n_l <= 0) return SPT_EUNSUP;
     if (ldx % 4 != 0 || !ls_aligned(x) || (image && !ls_aligned(image))) return SPT_ESHAPE;
     if (offsets && (n_groups <= 0 || n_groups > 64)) return SPT_EINVAL;
@@ -247,7 +254,7 @@ static int lora_down_any(const float *x, long long ldx, long long rows, int k, c
 #define SPT_LD4(NB, IM, NO, EX)                                                                  \
     hipLaunchKernelGGL((lora_down_kernel<NB, IM, NO, EX>), dim3((unsigned)nblk), dim3(64 * LS_NW), 0, s, \
                        x, ldx, rows, k, l, n_l, u, u_ld, u_block, img, norms, offsets, n_groups, l_gstride, \
-                       l2, n2)
+                       l2, n2, l_bstride)
 #define SPT_LD(NB, IM, NO)                                              \
     do {                                                                \
         if (exact) SPT_LD4(NB, IM, NO, true);                           \
@@ -286,6 +293,14 @@ extern "C" int spt_lora_down2(const float *x, long long ldx, long long rows, int
     if (!l2) return SPT_EINVAL;
     return lora_down_any(x, ldx, rows, k, l, n + 16, u, ldu, u_block_major, image, norms, exact, nullptr, 1,
                          0, stream, l2, n2);
+}
+
+extern "C" int spt_lora_down_tables(const float *x, long long ldx, long long rows, int k, const float *l,
+                                    int n_tables, long long table_stride, float *u, void *image,
+                                    float *norms, int exact, void *stream) {
+    if (n_tables <= 0 || n_tables > 4 || table_stride < (long long)k * 16) return SPT_EINVAL;
+    return lora_down_any(x, ldx, rows, k, l, 16 * n_tables, u, 0, 1, image, norms, exact, nullptr, 1, 0,
+                         stream, nullptr, 0, table_stride);
 }
 
 extern "C" int spt_lora_down_grouped(const float *x, long long ldx, long long rows, int k,

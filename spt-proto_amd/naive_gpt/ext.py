@@ -87,6 +87,8 @@ _PROTOTYPES = {
                        _c_ptr, ctypes.c_longlong, _c_int] + [_c_ptr] * 2 + [_c_int, _c_ptr], _c_int),
     'spt_lora_down2': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_int, _c_ptr, _c_int,
                         _c_ptr, ctypes.c_longlong, _c_int] + [_c_ptr] * 2 + [_c_int, _c_ptr], _c_int),
+    'spt_lora_down_tables': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_int,
+                              ctypes.c_longlong] + [_c_ptr] * 3 + [_c_int, _c_ptr], _c_int),
     'spt_lora_down_grouped': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, ctypes.c_longlong,
                                _c_int, _c_ptr, _c_int, _c_ptr, ctypes.c_longlong] + [_c_ptr] * 3, _c_int),
     'spt_tall_tn_workspace_bytes': ([ctypes.c_longlong, _c_int, _c_int, _c_int], ctypes.c_longlong),
@@ -104,7 +106,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 _lib = None
 
@@ -947,6 +949,7 @@ class _GroupedDesc(ctypes.Structure):
         ('a_image', _c_ptr), ('w_image', _c_ptr), ('a_norm', _c_ptr), ('w_norm', _c_ptr),
         ('relu_queue', _c_ptr), ('relu_queue_bytes', ctypes.c_int64), ('ldo', ctypes.c_int64),
         ('accumulate', ctypes.c_int32), ('a_seg_k', ctypes.c_int32), ('a_seg_stride', ctypes.c_int64),
+        ('b2_seg_stride', ctypes.c_int64),
     ]
 
 
@@ -1117,7 +1120,7 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                        a_norm: torch.Tensor = None, w_norm: torch.Tensor = None,
                        relu_queue_entries: int = None, out: torch.Tensor = None,
                        accumulate: bool = False, raw_dots: bool = False,
-                       a_segments: tuple = None):
+                       a_segments: tuple = None, b2_segment_stride: int = 0):
     """``spt_grouped_gemm_fused``: the block GEMM of a routed FFN with its LoRA side
     product, rowscale / bias, and the activation (EPI_ACT) or its derivative plus the two
     row dots of the coefficient gradient (EPI_DACT) folded in (include/spt_hip.h).
@@ -1127,7 +1130,8 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
     into (EPI_PLAIN; its row stride may exceed n: ``ldo`` of include/spt_hip.h); with
     ``accumulate`` the product is ADDED to what `out` holds.  ``a_segments`` = (seg_k, seg_stride):
     `a` is the first of k / seg_k matrices [rows, seg_k] that lie seg_stride floats apart (the
-    caller vouches for the others' memory), contracted one after the other."""
+    caller vouches for the others' memory), contracted one after the other.  ``b2_segment_stride``:
+    `b2` [n, 16] is the first of a2.size(1) / 16 such tables lying that many floats apart."""
     for t, name in ((a, 'a'), (weight, 'weight')):
         _check_type(t, torch.float32, name)
     _check_type(offsets, torch.int32, 'offsets')
@@ -1210,7 +1214,8 @@ def grouped_gemm_fused(a: torch.Tensor, weight: torch.Tensor, offsets: torch.Ten
                 relu_queue_bytes=queue.numel() if queue is not None else 0, ldo=out.stride(0),
                 accumulate=int(bool(accumulate)),
                 a_seg_k=a_segments[0] if a_segments else 0,
-                a_seg_stride=a_segments[1] if a_segments else 0)
+                a_seg_stride=a_segments[1] if a_segments else 0,
+                b2_seg_stride=b2_segment_stride)
             global LAST_GEMM_USED_IMAGES, LAST_GEMM_PATH
             LAST_GEMM_PATH = ('register', 'image', 'a32')[lib.spt_grouped_gemm_image_path(ctypes.byref(desc))]
             LAST_GEMM_USED_IMAGES = LAST_GEMM_PATH != 'register'
@@ -1536,6 +1541,46 @@ def lora_down(x: torch.Tensor, table: torch.Tensor, want_image: bool = False,
     if rc != 0:
         _raise(lib, rc, 'lora_down')
     return (u, image, norms) if (want_image or want_norms) else u
+
+
+def spacing_of(tensors) -> int:
+    """floats from each tensor to the next when they are contiguous fp32 tensors of one shape, disjoint
+    and equally spaced inside one allocation (e.g. parameters of a flat buffer), else 0"""
+    a = tensors[0]
+    if not all(t.is_contiguous() and t.dtype == torch.float32 and t.shape == a.shape
+               and t.untyped_storage().data_ptr() == a.untyped_storage().data_ptr() for t in tensors):
+        return 0
+    if len(tensors) < 2:
+        return 0
+    step = tensors[1].data_ptr() - a.data_ptr()
+    if step < a.numel() * 4 or step % 16 != 0:
+        return 0
+    if any(t.data_ptr() - s.data_ptr() != step for s, t in zip(tensors[:-1], tensors[1:])):
+        return 0
+    return step // 4
+
+
+def lora_down_tables(x: torch.Tensor, tables, want_image: bool = False):
+    """``spt_lora_down_tables``: x @ [t_0 | t_1 | ..] for separate equally spaced tables [K, 16]
+    (``spacing_of(tables) != 0``) -> (u [len(tables), rows, 16], image | None)."""
+    step = spacing_of(tables)
+    _require(step != 0 and lora_down_supported(x, tables[0]) and tables[0].size(1) == 16 and len(tables) <= 4,
+             'lora_down_tables: 1 .. 4 equally spaced [K, 16] tables')
+    rows, k = x.shape
+    dev = _same_device(x, tables[0])
+    lib = load_library()
+    with _on(dev):
+        u = torch.empty([len(tables), rows, 16], dtype=torch.float32, device=dev)
+        image = None
+        if want_image:
+            image = SplitImage(torch.empty([lib.spt_split_bf16_bytes(rows, k)], dtype=torch.uint8,
+                                           device=dev), rows, k)
+        rc = lib.spt_lora_down_tables(x.data_ptr(), x.stride(0), rows, k, tables[0].data_ptr(), len(tables),
+                                      step, u.data_ptr(), image.buffer.data_ptr() if want_image else None,
+                                      None, 0, _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'lora_down_tables')
+    return u, image
 
 
 def lora_down_grouped_supported(x: torch.Tensor, tables: torch.Tensor) -> bool:

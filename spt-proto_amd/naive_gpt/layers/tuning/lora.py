@@ -336,7 +336,14 @@ class _FrozenLoRAQKV(torch.autograd.Function):
         x2 = x.reshape(-1, x.size(-1))
         n, k = weights[0].shape
         rows = x2.size(0)
-        u3, image, _ = ext.lora_down(x2, torch.cat(lefts, dim=1), want_image=True, block_major=True)
+        # (adapter tables that lie equally spaced in one allocation -- a SparseTuner's flat parameter
+        # buffer -- are read where they are: no concatenated / stacked copies per step)
+        if ext.spacing_of(lefts):
+            ext.note_path('qkv_tables', 'in_place')
+            u3, image = ext.lora_down_tables(x2, lefts, want_image=True)
+        else:
+            ext.note_path('qkv_tables', 'copied')
+            u3, image, _ = ext.lora_down(x2, torch.cat(lefts, dim=1), want_image=True, block_major=True)
         # ONE grouped launch: group g = the rows of x once more (gathered: the same image rows)
         # against W_g, into rows g * rows .. of the output -- 1,536 tiles instead of three
         # launches of 512, which leave a third of the workgroup slots of every CU empty
@@ -349,11 +356,13 @@ class _FrozenLoRAQKV(torch.autograd.Function):
         joint = 2 if v_apart else 3
         r = rights[0].size(1)
         w_img = ext.weight_image(w3.view(3 * n, k))
+        r_step = ext.spacing_of(rights[:joint])
         out = ext.grouped_gemm_fused(
             x2, w3, offsets[:joint + 1], joint, n, k, n * k, k, 1, joint * rows, gather=gather[:joint * rows],
             bias=None if b3 is None else b3[:joint],
-            a2=u3[:joint].view(joint * rows, r), b2=torch.stack([t.detach() for t in rights[:joint]]),
-            b2_group_stride=n * r, a_image=image, w_image=w_img)
+            a2=u3[:joint].view(joint * rows, r),
+            b2=rights[0].detach() if r_step else torch.stack([t.detach() for t in rights[:joint]]),
+            b2_group_stride=r_step if r_step else n * r, a_image=image, w_image=w_img)
         out = out.view(joint, *x.shape[:-1], n)
         outs = [out[g] for g in range(joint)]
         if v_apart:
@@ -398,9 +407,11 @@ class _FrozenLoRAQKV(torch.autograd.Function):
                 # [3 n, k] matrix (_home3): a third of the launches, each three times as long, and
                 # no read-add-write of dX between them
                 ext.note_path('qkv_dx', 'joint')
+                l_step = ext.spacing_of(lefts)
                 grad_x = ext.grouped_gemm_fused(
                     dy2[0], weights[0].as_strided((3 * n, k), (k, 1)), one, 1, k, 3 * n, 0, 1, k, rows, a2=du_cat,
-                    b2=torch.cat([t.detach() for t in lefts], dim=1), a_segments=(n, step))
+                    b2=lefts[0].detach() if l_step else torch.cat([t.detach() for t in lefts], dim=1),
+                    b2_segment_stride=l_step, a_segments=(n, step))
             else:
                 ext.note_path('qkv_dx', 'three_launches', fallback=len(live) == 3,
                               why=lambda: 'the gradients of q, k, v are not three equally spaced matrices '

@@ -955,10 +955,13 @@ def test_segmented_contraction_and_a_48_wide_second_term():
         ext.grouped_gemm_fused(dys[0], w3, one, 1, k, 3 * n, 0, 1, k, rows, a_segments=(n + 16, rows * n))
 
 
-def test_joint_qkv_backward_is_one_contraction_when_the_gradients_share_a_buffer(monkeypatch):
+@pytest.mark.parametrize('flat', [False, True])
+def test_joint_qkv_backward_is_one_contraction_when_the_gradients_share_a_buffer(monkeypatch, flat):
     """The attention's backward hands dQ, dK, dV over as three slices of one buffer
     (ext.attention_mfma_backward): `_FrozenLoRAQKV.backward` then forms dX with ONE launch.  Same
-    gradients as the three accumulating launches."""
+    gradients as the three accumulating launches.  `flat`: the adapters live in one flat buffer (as
+    under SparseTuner): the tables are read in place (spt_lora_down_tables, SptGroupedGemm.b2_seg_stride
+    / b2_group_stride) instead of through concatenated copies."""
     from naive_gpt import ext, layers
     from naive_gpt.layers.tuning import lora
     torch.manual_seed(0)
@@ -966,6 +969,13 @@ def test_joint_qkv_backward_is_one_contraction_when_the_gradients_share_a_buffer
     linears = [layers.LoRALinear.from_pretrained(16, nn.Linear(d, d)).cuda() for _ in range(3)]
     for m in linears:
         m.lora.right.weight.data.normal_(0, 0.02)
+    if flat:
+        tables = [p for m in linears for p in (m.lora.left.weight, m.lora.right.weight)]
+        buffer = torch.cat([p.data.reshape(-1) for p in tables])
+        at = 0
+        for p in tables:
+            p.data = buffer[at:at + p.numel()].view(p.shape)
+            at += p.numel()
     x0 = torch.randn([4, 512, d], device='cuda')
     feed = torch.randn([3, 4, 512, d], device='cuda')
 
@@ -989,6 +999,8 @@ def test_joint_qkv_backward_is_one_contraction_when_the_gradients_share_a_buffer
 
     joint = run()
     assert ext.paths_taken('qkv_dx') == {('qkv_dx', 'joint'): 1}
+    assert ext.paths_taken('qkv_tables') == {('qkv_tables', 'in_place' if flat else 'copied'): 1}
+    monkeypatch.setattr(ext, 'spacing_of', lambda tensors: 0)
     monkeypatch.setattr(lora, '_equal_spacing', lambda mats: 0)
     apart = run()
     assert ext.paths_taken('qkv_dx') == {('qkv_dx', 'three_launches'): 1}
