@@ -527,7 +527,7 @@ int spt_lora_down_tables(const float *x, long long ldx, long long rows, int k, c
                          int exact, void *stream);
 /* spt_lora_down with a SECOND table: u gets one more block of 16 columns = x . l2^T for a row-major
  * l2 [n2 <= 16, k] (an nn.Linear weight as stored; 16-byte aligned); columns n2 .. 15 of that block are 0.
- * `n` counts the columns of `l` only (n + 16 <= 64); u_block_major as above: (n / 16 + 1) matrices
+ * Exact form only (exact != 0; SPT_EUNSUP otherwise).  `n` counts the columns of `l` only (n + 16 <= 64); u_block_major as above: (n / 16 + 1) matrices
  * [rows, 16].  The routed FFN's router logits ride the pass that forms x . L1 (feedforward.py:22-25). */
 int spt_lora_down2(const float *x, long long ldx, long long rows, int k, const float *l, int n,
                    const float *l2, int n2, float *u, long long ldu, int u_block_major, void *image,

@@ -93,7 +93,9 @@ constexpr int LS_NW = 8;            // waves per workgroup = shares of K (8192 r
 // Second table (l2 != null): the LAST 16-column block of the result is x . l2^T for a row-major
 // l2 [n2 <= 16, K] -- an nn.Linear weight as it lies in memory (the routed FFN's router,
 // sparse/feedforward.py:22-25, riding the pass that forms x . L1); columns n2 .. 15 of that block are 0.
-template <int NB, bool IMAGE, bool NORMS, bool EXACT>
+// (L2 is a template parameter: as a run-time branch in the table loads it took the single-table
+// kernel from 98 to 230 registers and from 11 to 20 us)
+template <int NB, bool IMAGE, bool NORMS, bool EXACT, bool L2 = false>
 __global__ __launch_bounds__(64 * LS_NW) void lora_down_kernel(
     const float *__restrict__ x, long long ldx, long long rows, int K, const float *__restrict__ l,
     int n, float *__restrict__ u, long long u_ld, long long u_block, char *__restrict__ image,
@@ -136,12 +138,12 @@ __global__ __launch_bounds__(64 * LS_NW) void lora_down_kernel(
     for (int b = 0; b < NB; b++) acc[b] = {0.f, 0.f, 0.f, 0.f};
     float ss = 0.f;
     // (second table: lane (c = r, g) reads l2[c][k + 8 g + 0 .. 7], 32 contiguous bytes)
-    const float *l2p = l2 ? l2 + (size_t)min(r, n2 - 1) * K + 32 * sbeg + 8 * g : nullptr;
+    const float *l2p = L2 ? l2 + (size_t)min(r, n2 - 1) * K + 32 * sbeg + 8 * g : nullptr;
     auto load_l = [&](int kstep, float (&bv)[NB][8]) {
         const float *p = lp + (size_t)kstep * 32 * n;
 #pragma unroll
         for (int b = 0; b < NB; b++) {
-            if (b == NB - 1 && l2p) {                        // (uniform)
+            if (L2 && b == NB - 1) {
                 const float4 t0 = *reinterpret_cast<const float4 *>(l2p + (size_t)kstep * 32);
                 const float4 t1 = *reinterpret_cast<const float4 *>(l2p + (size_t)kstep * 32 + 4);
                 const bool keep = r < n2;
@@ -251,14 +253,18 @@ static int lora_down_any(const float *x, long long ldx, long long rows, int k, c
     // u [rows, n], or (u_block_major) n / 16 contiguous matrices [rows, 16]: one per adapter
     if (ldu != 0 && (ldu < n || u_block_major)) return SPT_EINVAL;
     const long long u_ld = u_block_major ? 16 : (ldu ? ldu : n), u_block = u_block_major ? rows * 16 : 16;
-#define SPT_LD4(NB, IM, NO, EX)                                                                  \
-    hipLaunchKernelGGL((lora_down_kernel<NB, IM, NO, EX>), dim3((unsigned)nblk), dim3(64 * LS_NW), 0, s, \
+#define SPT_LD5(NB, IM, NO, EX, L2)                                                              \
+    hipLaunchKernelGGL((lora_down_kernel<NB, IM, NO, EX, L2>), dim3((unsigned)nblk), dim3(64 * LS_NW), 0, s, \
                        x, ldx, rows, k, l, n_l, u, u_ld, u_block, img, norms, offsets, n_groups, l_gstride, \
                        l2, n2, l_bstride)
+    // (a second table only in the exact form and behind at least one block of the first table: the
+    // routed FFN's router riding x . L1)
+    if (l2 && (!exact || n < 32)) return SPT_EUNSUP;
 #define SPT_LD(NB, IM, NO)                                              \
     do {                                                                \
-        if (exact) SPT_LD4(NB, IM, NO, true);                           \
-        else SPT_LD4(NB, IM, NO, false);                                \
+        if (l2) { if constexpr (NB >= 2) SPT_LD5(NB, IM, NO, true, true); } \
+        else if (exact) SPT_LD5(NB, IM, NO, true, false);               \
+        else SPT_LD5(NB, IM, NO, false, false);                         \
     } while (0)
 #define SPT_LD_NB(NB)                                                   \
     do {                                                                \
@@ -275,7 +281,7 @@ static int lora_down_any(const float *x, long long ldx, long long rows, int k, c
     }
 #undef SPT_LD_NB
 #undef SPT_LD
-#undef SPT_LD4
+#undef SPT_LD5
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }

@@ -1491,7 +1491,7 @@ def lora_down(x: torch.Tensor, table: torch.Tensor, want_image: bool = False,
     each adapter's product contiguous).  ``out``: a [rows, n] view to write u into (unit inner
     stride, any row stride: a column slice of a wider matrix).  ``exact``: u in exact fp32 instead of
     split-bf16 products (for the u in front of a ReLU GEMM: include/spt_hip.h).  ``table2``
-    (``spt_lora_down2``; needs ``block_major``): a row-major [n2 <= 16, K] matrix (an nn.Linear
+    (``spt_lora_down2``; needs ``block_major`` and ``exact``): a row-major [n2 <= 16, K] matrix (an nn.Linear
     weight) whose product x @ table2.T fills one more block: u[-1][:, :n2]."""
     _require(lora_down_supported(x, table), 'lora_down: see lora_down_supported')
     table = table.contiguous()
