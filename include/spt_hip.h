@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 34
+#define SPT_ABI_VERSION 35
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -519,6 +519,13 @@ int spt_split_bf16(const float *src, void *image, long long rows, int cols, long
 int spt_lora_down(const float *x, long long ldx, long long rows, int k, const float *l, int n,
                   float *u, long long ldu, int u_block_major, void *image, float *norms, int exact,
                   void *stream);
+/* spt_lora_down_grouped with the groups' results side by side: row r of group g goes to
+ * u[(r - offsets[g]) * ldu + g * n + c] -- for groups of equal size one matrix [rows / n_groups, n_groups * n]
+ * (ldu >= n_groups * n): dU_q | dU_k | dU_v of a joint projection's backward from ONE launch over the
+ * stacked gradients [dQ; dK; dV] (autograd of lora.py:70-80, three times). */
+int spt_lora_down_grouped_cols(const float *x, long long ldx, long long rows, int k, const float *l,
+                               long long l_group_stride, int n, const int32_t *offsets, int n_groups,
+                               float *u, long long ldu, void *stream);
 /* spt_lora_down for n_tables (<= 4) SEPARATE tables [k, 16] lying table_stride floats apart (table t at
  * l + t * table_stride): u as n_tables block-major matrices [rows, 16], exactly what one table
  * [k, 16 n_tables] of the concatenated columns gives -- without making that copy every step. */

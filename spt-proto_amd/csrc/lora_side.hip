@@ -100,7 +100,10 @@ __global__ __launch_bounds__(64 * LS_NW) void lora_down_kernel(
     const float *__restrict__ x, long long ldx, long long rows, int K, const float *__restrict__ l,
     int n, float *__restrict__ u, long long u_ld, long long u_block, char *__restrict__ image,
     float *__restrict__ norms, const int32_t *__restrict__ offsets, int n_groups, long long l_gstride,
-    const float *__restrict__ l2, int n2, long long l_bstride) {
+    const float *__restrict__ l2, int n2, long long l_bstride, int group_cols) {
+    // (group_cols, grouped form: row r of group q is stored at u[(r - offsets[q]) * u_ld + q * n + c]
+    // -- equal groups side by side as column blocks of ONE matrix: dU_q | dU_k | dU_v of a joint
+    // projection's backward from one launch over [dQ; dK; dV])
     // (l_bstride: floats from one 16-column block of the table to the next -- 16 inside one [K, n]
     // table; the distance between SEPARATE [K, 16] tables, e.g. the adapters of q, k, v as they lie
     // in a tuner's flat parameter buffer: no concatenated copy of them is made)
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(64 * LS_NW) void lora_down_kernel(
         if (grp < 0) return;
         row0 = first; rows = end;                            // (rows: one past the tile's last usable row)
         l += grp * l_gstride;
+        if (group_cols) u += (long long)grp * n - (long long)offsets[grp] * u_ld;
     }
     const long long row = min(row0 + r, rows - 1);          // (clamped rows are never stored)
     // the K / 32 k-steps dealt to the four waves as evenly as they go (K = 2752, the LLaMA-7B FFN
@@ -234,7 +238,7 @@ static int lora_down_any(const float *x, long long ldx, long long rows, int k, c
                          int n, float *u, long long ldu, int u_block_major, void *image,
                          float *norms, int exact, const int32_t *offsets, int n_groups,
                          long long l_gstride, void *stream, const float *l2 = nullptr, int n2 = 0,
-                         long long table_stride = 0) {
+                         long long table_stride = 0, int group_cols = 0) {
     if (!x || !l || !u) return SPT_EINVAL;
     if (rows <= 0 || k <= 0 || n <= 0 || ldx < k) return SPT_EINVAL;
     if (l2 && (n2 <= 0 || n2 > 16 || offsets || (reinterpret_cast<uintptr_t>(l2) & 15) != 0)) return SPT_EINVAL;
@@ -256,7 +260,7 @@ static int lora_down_any(const float *x, long long ldx, long long rows, int k, c
 #define SPT_LD5(NB, IM, NO, EX, L2)                                                              \
     hipLaunchKernelGGL((lora_down_kernel<NB, IM, NO, EX, L2>), dim3((unsigned)nblk), dim3(64 * LS_NW), 0, s, \
                        x, ldx, rows, k, l, n_l, u, u_ld, u_block, img, norms, offsets, n_groups, l_gstride, \
-                       l2, n2, l_bstride)
+                       l2, n2, l_bstride, group_cols)
     // (a second table only in the exact form and behind at least one block of the first table: the
     // routed FFN's router riding x . L1)
     if (l2 && (!exact || n < 32)) return SPT_EUNSUP;
@@ -299,6 +303,15 @@ extern "C" int spt_lora_down2(const float *x, long long ldx, long long rows, int
     if (!l2) return SPT_EINVAL;
     return lora_down_any(x, ldx, rows, k, l, n + 16, u, ldu, u_block_major, image, norms, exact, nullptr, 1,
                          0, stream, l2, n2);
+}
+
+extern "C" int spt_lora_down_grouped_cols(const float *x, long long ldx, long long rows, int k,
+                                          const float *l, long long l_group_stride, int n,
+                                          const int32_t *offsets, int n_groups, float *u, long long ldu,
+                                          void *stream) {
+    if (!offsets || ldu < (long long)n * n_groups) return SPT_EINVAL;
+    return lora_down_any(x, ldx, rows, k, l, n, u, ldu, 0, nullptr, nullptr, 0, offsets, n_groups,
+                         l_group_stride, stream, nullptr, 0, 0, 1);
 }
 
 extern "C" int spt_lora_down_tables(const float *x, long long ldx, long long rows, int k, const float *l,

@@ -87,6 +87,8 @@ _PROTOTYPES = {
                        _c_ptr, ctypes.c_longlong, _c_int] + [_c_ptr] * 2 + [_c_int, _c_ptr], _c_int),
     'spt_lora_down2': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_int, _c_ptr, _c_int,
                         _c_ptr, ctypes.c_longlong, _c_int] + [_c_ptr] * 2 + [_c_int, _c_ptr], _c_int),
+    'spt_lora_down_grouped_cols': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, ctypes.c_longlong,
+                                    _c_int, _c_ptr, _c_int, _c_ptr, ctypes.c_longlong, _c_ptr], _c_int),
     'spt_lora_down_tables': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, _c_int,
                               ctypes.c_longlong] + [_c_ptr] * 3 + [_c_int, _c_ptr], _c_int),
     'spt_lora_down_grouped': ([_c_ptr, ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_ptr, ctypes.c_longlong,
@@ -106,7 +108,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 _lib = None
 
@@ -1581,6 +1583,32 @@ def lora_down_tables(x: torch.Tensor, tables, want_image: bool = False):
     if rc != 0:
         _raise(lib, rc, 'lora_down_tables')
     return u, image
+
+
+def lora_down_stacked(xs, tables, offsets: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """``spt_lora_down_grouped_cols``: out[:, 16 g : 16 g + 16] = xs[g] @ tables[g] for G matrices
+    xs[g] [rows, K] lying back to back (``spacing_of(xs) == rows * K``) and G equally spaced tables
+    [K, 16], in one launch; offsets = [0, rows, 2 rows, ..] int32 on the device; out [rows, >= 16 G]."""
+    G = len(xs)
+    rows, k = xs[0].shape
+    step = spacing_of(tables) if G > 1 else tables[0].numel()
+    _require(G >= 1 and len(tables) == G and (G == 1 or spacing_of(xs) == rows * k) and step != 0
+             and tables[0].shape == (k, 16) and lora_down_supported(xs[0], tables[0]),
+             'lora_down_stacked: stacked inputs, equally spaced [K, 16] tables')
+    _check_type(offsets, torch.int32, 'offsets')
+    _check_type(out, torch.float32, 'out')
+    _require(offsets.numel() == G + 1 and out.is_cuda and out.dim() == 2 and out.size(0) == rows
+             and out.stride(1) == 1 and out.size(1) >= 16 * G and out.stride(0) % 4 == 0,
+             'lora_down_stacked: offsets [G + 1], out [rows, >= 16 G]')
+    dev = _same_device(xs[0], tables[0], offsets, out)
+    lib = load_library()
+    with _on(dev):
+        rc = lib.spt_lora_down_grouped_cols(xs[0].data_ptr(), xs[0].stride(0), G * rows, k, tables[0].data_ptr(),
+                                            step, 16, offsets.data_ptr(), G, out.data_ptr(), out.stride(0),
+                                            _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'lora_down_stacked')
+    return out
 
 
 def lora_down_grouped_supported(x: torch.Tensor, tables: torch.Tensor) -> bool:

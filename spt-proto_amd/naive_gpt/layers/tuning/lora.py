@@ -395,8 +395,16 @@ class _FrozenLoRAQKV(torch.autograd.Function):
         # the live dU_g = dY_g R_g side by side in one matrix: the operand of the joint `left` gradient
         du_cat = torch.empty([rows, r * len(live)], dtype=x2.dtype, device=x2.device)
         dus = [None] * 3
-        for i, g in enumerate(live):
-            dus[g] = _down_grad(dy2[g], rights[g], out=du_cat[:, i * r:(i + 1) * r])
+        if len(live) == 3 and r == 16 and _equal_spacing(dy2) == rows * n and ext.spacing_of(rights) \
+                and ext.lora_down_supported(dy2[0], rights[0]):
+            # dU_q | dU_k | dU_v from ONE launch over the stacked gradients [dQ; dK; dV] (each alone is a
+            # 512-workgroup launch for 6 us of memory time)
+            ext.note_path('lora_down', 'kernel')
+            ext.lora_down_stacked(dy2, rights, _qkv_index(rows, x2.device)[1], du_cat)
+            dus = [du_cat[:, i * r:(i + 1) * r] for i in range(3)]
+        else:
+            for i, g in enumerate(live):
+                dus[g] = _down_grad(dy2[g], rights[g], out=du_cat[:, i * r:(i + 1) * r])
         grad_x = None
         if ctx.needs_input_grad[0]:
             step = _equal_spacing(dy2) if len(live) == 3 and r == 16 else 0
