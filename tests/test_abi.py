@@ -71,3 +71,36 @@ def test_product_path_has_no_cpu_fallback():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in src.replace('oracle/', ''), f
+
+
+def test_layout_predicates_of_the_in_place_paths():
+    """`ext.back_to_back` / `ext.spacing_of` decide (on the host, from addresses only) whether q and k,
+    dQ / dK / dV or the adapter tables of a flat parameter buffer can be read in place."""
+    import torch
+    from naive_gpt import ext
+    pair = torch.zeros([2, 3, 4, 5, 8])
+    assert ext.back_to_back(pair[0], pair[1])
+    assert not ext.back_to_back(pair[1], pair[0])                    # order matters
+    assert not ext.back_to_back(pair[0], pair[0].clone())            # another allocation
+    assert not ext.back_to_back(pair[0][:, :2], pair[0][:, 2:])      # not contiguous
+    flat = torch.zeros([6 * 64 + 8])
+    tables = [flat[i * 128:i * 128 + 64].view(4, 16) for i in range(3)]      # 64 floats, 128 apart
+    assert ext.spacing_of(tables) == 128
+    assert ext.spacing_of(tables[:2]) == 128 and ext.spacing_of(tables[:1]) == 0
+    assert ext.spacing_of([tables[0], tables[2], tables[1]]) == 0    # not ascending / unequal
+    assert ext.spacing_of([tables[0], tables[1], flat[258:322].view(4, 16)]) == 0
+    assert ext.spacing_of([t.clone() for t in tables]) == 0          # separate allocations
+    assert ext.spacing_of([flat[0:64].view(4, 16), flat[66:130].view(4, 16)]) == 0   # 8-byte step: not 16-aligned
+
+
+def test_new_entries_validate_their_arguments_without_gpu():
+    from naive_gpt import ext
+    lib = ext.load_library()
+    assert lib.spt_lora_down2(None, 0, 0, 0, None, 0, None, 0, None, 0, 0, None, None, 1, None) == -1
+    assert lib.spt_tall_tn_batch(0, None, 0, None, 0, None, None, 1, 0, 0, 0, None, 0, None, None) == -1
+    assert lib.spt_route_topk_logits(None, 0, None, None, None, None, None, None, None, None, None, 1.0,
+                                     0, 0, 0, None) == -1
+    assert lib.spt_pq_loss_backward_parts(None, None, None, None, None, None, 0, 0, 0, 0, 0, 0, None) == -1
+    assert lib.spt_rows_combine_side(None, None, None, None, None, 0, None, 0, 0, 0, None) == -1
+    assert lib.spt_lora_down_tables(None, 0, 0, 0, None, 0, 0, None, None, None, 0, None) == -1
+    assert lib.spt_lora_down_grouped_cols(None, 0, 0, 0, None, 0, 0, None, 0, None, 0, None) == -1
