@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 35
+#define SPT_ABI_VERSION 36
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -666,6 +666,18 @@ int spt_ffn_coeff_grad(const float *dot_main, const float *dot_act, int width, c
                        const float *u, const float *dzt, const float *z, const int32_t *token,
                        const float *coeff, float floor_value, float *out, int n_rows, int rank,
                        void *stream);
+
+/*
+ * The gated FFN's elementwise middle (feedforward.py:120-131: h = silu(gate) * side; routed + LoRA:
+ * lora_ffn.py:196-222).  forward: h = silu(gate) * side over n_elements (% 4 == 0) contiguous floats.
+ * backward, ONE pass over [rows, n] (n % 4 == 0) instead of ~10 elementwise / reduction launches:
+ *   grad_gate = grad_h * side * silu'(gate),  grad_side = grad_h * silu(gate),
+ *   dots [3, rows] = <grad_h, h>, <grad_gate, gate>, <grad_side, side> per row
+ * (the three inner products of the router-coefficient gradient).  All pointers 16-byte aligned.
+ */
+int spt_swiglu_forward(const float *gate, const float *side, float *h, long long n_elements, void *stream);
+int spt_swiglu_backward(const float *grad_h, const float *gate, const float *side, float *grad_gate,
+                        float *grad_side, float *dots, long long rows, int n, void *stream);
 
 /*
  * Un-bucketing: out[t, :] = bias + sum_{j < k} rows[pos[t * k + j], :] (bias may be NULL).

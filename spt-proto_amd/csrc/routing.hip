@@ -242,9 +242,97 @@ __global__ __launch_bounds__(256) void ffn_coeff_grad_kernel(
     out[p] = (((acc + acc2) - d1) - d2) / fmaxf(coeff[p], floor_value);
 }
 
+// ---- the gated FFN's elementwise middle (LLaMaFeedforward: h = silu(gate) * side,
+// feedforward.py:120-131; routed + LoRA: lora_ffn.py:196-222) --------------------------------------
+// forward: h = silu(g) * s.  backward, one pass over the [P, n] tensors instead of ~10 library
+// launches: dg = dh * s * silu'(g), ds = dh * silu(g), and the three row dots the router-coefficient
+// gradient needs -- <dh, h>, <dg, g>, <ds, s> (grouped.py: RoutedLoRALLaMAFFN.backward).
+// A wave per row, float4 per lane; rows of n % 4 == 0 floats.
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_grad_f(float x) {
+    const float sg = 1.0f / (1.0f + expf(-x));
+    return sg * (1.0f + x * (1.0f - sg));
+}
+
+__global__ __launch_bounds__(256) void swiglu_forward_kernel(const float *__restrict__ g,
+                                                             const float *__restrict__ s,
+                                                             float *__restrict__ h, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4 *>(g)[i], b = reinterpret_cast<const float4 *>(s)[i];
+        reinterpret_cast<float4 *>(h)[i] =
+            make_float4(silu_f(a.x) * b.x, silu_f(a.y) * b.y, silu_f(a.z) * b.z, silu_f(a.w) * b.w);
+    }
+}
+
+__global__ __launch_bounds__(256) void swiglu_backward_kernel(
+    const float *__restrict__ dh, const float *__restrict__ g, const float *__restrict__ s,
+    float *__restrict__ dg, float *__restrict__ ds, float *__restrict__ dots, long long rows, int n) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;                                     // (a wave leaves as a whole)
+    const size_t base = (size_t)row * n;
+    float d_h = 0.0f, d_g = 0.0f, d_s = 0.0f;
+    for (int c = 4 * lane; c < n; c += 256) {
+        const float4 vdh = *reinterpret_cast<const float4 *>(dh + base + c);
+        const float4 vg = *reinterpret_cast<const float4 *>(g + base + c);
+        const float4 vs = *reinterpret_cast<const float4 *>(s + base + c);
+        const float xdh[4] = {vdh.x, vdh.y, vdh.z, vdh.w}, xg[4] = {vg.x, vg.y, vg.z, vg.w},
+                    xs[4] = {vs.x, vs.y, vs.z, vs.w};
+        float og[4], os[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float a = silu_f(xg[e]);
+            os[e] = xdh[e] * a;
+            og[e] = xdh[e] * xs[e] * silu_grad_f(xg[e]);
+            d_h = fmaf(xdh[e], a * xs[e], d_h);
+            d_g = fmaf(og[e], xg[e], d_g);
+            d_s = fmaf(os[e], xs[e], d_s);
+        }
+        *reinterpret_cast<float4 *>(dg + base + c) = make_float4(og[0], og[1], og[2], og[3]);
+        *reinterpret_cast<float4 *>(ds + base + c) = make_float4(os[0], os[1], os[2], os[3]);
+    }
+    d_h = group_sum<64>(d_h);
+    d_g = group_sum<64>(d_g);
+    d_s = group_sum<64>(d_s);
+    if (lane == 0) {
+        dots[row] = d_h;
+        dots[rows + row] = d_g;
+        dots[2 * rows + row] = d_s;
+    }
+}
+
 }  // namespace spt
 
 using namespace spt;
+
+extern "C" int spt_swiglu_forward(const float *gate, const float *side, float *h, long long n_elements,
+                                  void *stream) {
+    if (!gate || !side || !h || n_elements <= 0) return SPT_EINVAL;
+    if (n_elements % 4 != 0 || ((reinterpret_cast<uintptr_t>(gate) | reinterpret_cast<uintptr_t>(side) |
+                                 reinterpret_cast<uintptr_t>(h)) & 15) != 0)
+        return SPT_ESHAPE;
+    const long long n4 = n_elements / 4;
+    const long long blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(swiglu_forward_kernel, dim3((unsigned)(blocks > 65536 ? 65536 : blocks)), dim3(256), 0,
+                       (hipStream_t)stream, gate, side, h, n4);
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
+extern "C" int spt_swiglu_backward(const float *grad_h, const float *gate, const float *side,
+                                   float *grad_gate, float *grad_side, float *dots, long long rows, int n,
+                                   void *stream) {
+    if (!grad_h || !gate || !side || !grad_gate || !grad_side || !dots) return SPT_EINVAL;
+    if (rows <= 0 || n <= 0 || rows > 0x7FFFFFFFll * 4) return SPT_EINVAL;
+    if (n % 4 != 0 || ((reinterpret_cast<uintptr_t>(grad_h) | reinterpret_cast<uintptr_t>(gate) |
+                        reinterpret_cast<uintptr_t>(side) | reinterpret_cast<uintptr_t>(grad_gate) |
+                        reinterpret_cast<uintptr_t>(grad_side)) & 15) != 0)
+        return SPT_ESHAPE;
+    hipLaunchKernelGGL(swiglu_backward_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, grad_h, gate, side, grad_gate, grad_side, dots, rows, n);
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
 
 static int route_topk_any(const float *prob, int32_t *token, int32_t *block, int32_t *offsets,
                           int32_t *pos, long long *token64, long long *block64, float *coeff,

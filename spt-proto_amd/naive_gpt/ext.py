@@ -74,6 +74,8 @@ _PROTOTYPES = {
     'spt_grouped_gemm_image_path': ([_c_ptr], _c_int),
     'spt_split_bf16_bytes': ([ctypes.c_longlong, _c_int], ctypes.c_size_t),
     'spt_split_bf16': ([_c_ptr, _c_ptr, ctypes.c_longlong, _c_int, ctypes.c_longlong, _c_ptr], _c_int),
+    'spt_swiglu_forward': ([_c_ptr] * 3 + [ctypes.c_longlong, _c_ptr], _c_int),
+    'spt_swiglu_backward': ([_c_ptr] * 6 + [ctypes.c_longlong, _c_int, _c_ptr], _c_int),
     'spt_rows_combine': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_rows_combine_side': ([_c_ptr] * 5 + [_c_int, _c_ptr] + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_ffn_coeff_grad': ([_c_ptr, _c_ptr, _c_int] + [_c_ptr] * 6 + [_c_f32, _c_ptr, _c_int, _c_int, _c_ptr],
@@ -108,7 +110,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 _lib = None
 
@@ -1438,6 +1440,43 @@ def route_coeff_backward(dcoeff: torch.Tensor, pos: torch.Tensor, block: torch.T
     if rc != 0:
         _raise(lib, rc, 'route_coeff_backward')
     return dprob
+
+
+def swiglu_supported(g: torch.Tensor, s: torch.Tensor) -> bool:
+    return (g.is_cuda and g.dtype == s.dtype == torch.float32 and g.shape == s.shape and g.dim() == 2
+            and g.is_contiguous() and s.is_contiguous() and g.size(1) % 4 == 0 and g.numel() > 0
+            and g.data_ptr() % 16 == 0 and s.data_ptr() % 16 == 0)
+
+
+def swiglu_forward(g: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """``spt_swiglu_forward``: silu(g) * s."""
+    _require(swiglu_supported(g, s), 'swiglu: contiguous fp32 CUDA [rows, n % 4 == 0] pair')
+    dev = g.device
+    lib = load_library()
+    with _on(dev):
+        h = torch.empty_like(g)
+        rc = lib.spt_swiglu_forward(g.data_ptr(), s.data_ptr(), h.data_ptr(), g.numel(), _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'swiglu_forward')
+    return h
+
+
+def swiglu_backward(dh: torch.Tensor, g: torch.Tensor, s: torch.Tensor):
+    """``spt_swiglu_backward``: -> (dg, ds, <dh, h> [rows], <dg, g> [rows], <ds, s> [rows])."""
+    _require(swiglu_supported(g, s) and dh.shape == g.shape and dh.dtype == torch.float32
+             and dh.is_contiguous() and dh.device == g.device and dh.data_ptr() % 16 == 0,
+             'swiglu: contiguous fp32 CUDA [rows, n % 4 == 0] tensors')
+    dev = g.device
+    rows, n = g.shape
+    lib = load_library()
+    with _on(dev):
+        dg, ds = torch.empty_like(g), torch.empty_like(g)
+        dots = torch.empty([3, rows], dtype=torch.float32, device=dev)
+        rc = lib.spt_swiglu_backward(dh.data_ptr(), g.data_ptr(), s.data_ptr(), dg.data_ptr(), ds.data_ptr(),
+                                     dots.data_ptr(), rows, n, _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'swiglu_backward')
+    return dg, ds, dots[0], dots[1], dots[2]
 
 
 def rows_combine(rows: torch.Tensor, pos: torch.Tensor, bias: torch.Tensor = None,

@@ -502,7 +502,10 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
                 a_image=x_image, w_image=ext.weight_image(w) if imgs else None)
 
         g, sd = up(wg, ug, rg), up(ws, us, rs)
-        h = activation(g) * sd
+        silu = isinstance(activation, torch.nn.SiLU) and ext.swiglu_supported(g, sd)
+        ext.note_path('swiglu', 'kernel' if silu else 'torch', fallback=not silu,
+                      why=lambda: 'activation {} on {}'.format(type(activation).__name__, tuple(g.shape)))
+        h = ext.swiglu_forward(g, sd) if silu else activation(g) * sd
         zw, h_img, _ = _down(h, _block_cat(ld, nb), imgs and not H_A32, False)
         z = _own_block(zw, bk.block, nb).contiguous()
         ys = ext.grouped_gemm_fused(
@@ -537,33 +540,42 @@ class RoutedLoRALLaMAFFN(torch.autograd.Function):
             b2_group_stride=bs * rank,
             a_image=dy_img, w_image=ext.weight_image(wd) if imgs else None)
         del dy_img
-        grad_coeff = ((dh * h).sum(dim=-1) - (dz_rows * z).sum(dim=-1)) / _floor(coeff)
-        # through h = act(g) * sd
-        with torch.enable_grad():
-            g_ = g.detach().requires_grad_(True)
-            ag = activation(g_)
-            dg, = torch.autograd.grad(ag, g_, dh * sd)
-        dsd = dh * ag.detach()
-        del dh, ag, g_                       # [P, bs] each: the step's peak memory is in here
+        silu = isinstance(activation, torch.nn.SiLU) and ext.swiglu_supported(g, sd)
+        if silu:
+            # through h = silu(g) * sd, and the row dots of the coefficient gradient, in one pass
+            dg, dsd, dot_h, dot_g, dot_s = ext.swiglu_backward(dh, g, sd)
+            del dh
+        else:
+            dot_h = (dh * h).sum(dim=-1)
+            dot_g = dot_s = None
+            with torch.enable_grad():
+                g_ = g.detach().requires_grad_(True)
+                ag = activation(g_)
+                dg, = torch.autograd.grad(ag, g_, dh * sd)
+            dsd = dh * ag.detach()
+            del dh, ag, g_                   # [P, bs] each: the step's peak memory is in here
+        grad_coeff = (dot_h - (dz_rows * z).sum(dim=-1)) / _floor(coeff)
 
-        def down(dpre, pre, w, u, l_table, r_table):
+        def down(dpre, pre, w, u, l_table, r_table, dot_pre=None, into=None):
             """-> (dx rows [P, d], d coefficient [P], grad of the two LoRA tables)"""
             du, _ = _down_blocks(dpre, r_table, bk, False)
             u_rows = u.index_select(0, bk.token_long)
-            dc = ((dpre * pre).sum(dim=-1) - (du * u_rows).sum(dim=-1)) / _floor(coeff)
+            if dot_pre is None:
+                dot_pre = (dpre * pre).sum(dim=-1)
+            dc = (dot_pre - (du * u_rows).sum(dim=-1)) / _floor(coeff)
+            # (`into`: the other projection's dx rows -- this product is ADDED to them by the GEMM)
             dxs = ext.grouped_gemm_fused(
                 dpre, w, bk.offsets, nb, n=d, k=bs, w_group_stride=bs * d, w_ldn=1, w_ldk=d,
-                n_rows=rows, rowscale=coeff, a2=du, b2=l_table, b2_group_stride=0)
+                n_rows=rows, rowscale=coeff, a2=du, b2=l_table, b2_group_stride=0,
+                out=into, accumulate=into is not None)
             grad_l = _tn(x, ext.rows_combine(du, bk.pos))
             grad_r = _tn_blocks(dpre, u, bk)
             return dxs, dc, grad_l, grad_r
 
-        dxs_g, dc_g, grad_lg, grad_rg = down(dg, g, wg, ug, lg, rg)
+        dxs_g, dc_g, grad_lg, grad_rg = down(dg, g, wg, ug, lg, rg, dot_g)
         del dg
-        dxs_s, dc_s, grad_ls, grad_rs = down(dsd, sd, ws, us, ls, rs)
+        dxs_g, dc_s, grad_ls, grad_rs = down(dsd, sd, ws, us, ls, rs, dot_s, into=dxs_g)
         del dsd
-        dxs_g.add_(dxs_s)
-        del dxs_s
         grad_x = ext.rows_combine(dxs_g, bk.pos)
         del dxs_g
         grad_coeff = grad_coeff + dc_g + dc_s

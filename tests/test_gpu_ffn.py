@@ -1040,3 +1040,25 @@ def test_router_riding_the_lora_down_pass_equals_the_library_router(act, monkeyp
     assert len(got) == len(want) >= 7
     for a, b in zip(got, want):
         assert _scaled_close(a, b, rtol=1e-3)
+
+
+def test_swiglu_kernels_against_autograd():
+    """spt_swiglu_forward / _backward: h = silu(g) * s, its two input gradients and the three row dots
+    <dh, h>, <dg, g>, <ds, s> from one pass -- against torch autograd in fp64."""
+    from naive_gpt import ext
+    torch.manual_seed(2)
+    rows, n = 517, 2752
+    g = torch.randn([rows, n], device='cuda') * 3
+    s = torch.randn([rows, n], device='cuda')
+    dh = torch.randn([rows, n], device='cuda')
+    h = ext.swiglu_forward(g, s)
+    g64, s64 = g.double().requires_grad_(True), s.double().requires_grad_(True)
+    h64 = nn.functional.silu(g64) * s64
+    assert torch.allclose(h.double(), h64.detach(), rtol=1e-5, atol=1e-6)
+    dg64, ds64 = torch.autograd.grad(h64, (g64, s64), dh.double())
+    dg, ds, dot_h, dot_g, dot_s = ext.swiglu_backward(dh, g, s)
+    assert torch.allclose(dg.double(), dg64, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(ds.double(), ds64, rtol=1e-5, atol=1e-5)
+    for got, want in ((dot_h, (dh.double() * h64.detach()).sum(1)), (dot_g, (dg64 * g64.detach()).sum(1)),
+                      (dot_s, (ds64 * s64.detach()).sum(1))):
+        assert torch.allclose(got.double(), want, rtol=1e-4, atol=1e-3)
