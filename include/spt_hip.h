@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 36
+#define SPT_ABI_VERSION 37
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -666,6 +666,19 @@ int spt_ffn_coeff_grad(const float *dot_main, const float *dot_act, int width, c
                        const float *u, const float *dzt, const float *z, const int32_t *token,
                        const float *coeff, float floor_value, float *out, int n_rows, int rank,
                        void *stream);
+
+/*
+ * Rotary position embedding (position.py:24-34: y = cos[s] * x + sin[s] * rotate_half(x)) of up to
+ * three tensors [batch, seq, heads, d_head] in one launch: x[0 .. n_rot - 1] are rotated, x[n_rot ..
+ * n_parts - 1] copied, part p written to out + p * out_stride (>= batch * seq * heads * d_head floats).
+ * cos_table / sin_table [>= seq, d_head]: row s = position s.  transpose != 0: the adjoint (the
+ * backward).  Forward use: (q, k) -> one buffer [q'; k']; backward: (dq', dk', dv) -> one buffer of
+ * three equally spaced gradients for the joint projection's backward (a_seg_k).  d_head % 8 == 0, all
+ * pointers 16-byte aligned; `x` is a host array of n_parts device pointers.
+ */
+int spt_rotary(const float *const *x, int n_parts, int n_rot, float *out, long long out_stride,
+               const float *cos_table, const float *sin_table, int batch, int seq_length, int n_heads,
+               int d_head, int transpose, void *stream);
 
 /*
  * The gated FFN's elementwise middle (feedforward.py:120-131: h = silu(gate) * side; routed + LoRA:

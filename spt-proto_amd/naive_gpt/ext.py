@@ -74,6 +74,8 @@ _PROTOTYPES = {
     'spt_grouped_gemm_image_path': ([_c_ptr], _c_int),
     'spt_split_bf16_bytes': ([ctypes.c_longlong, _c_int], ctypes.c_size_t),
     'spt_split_bf16': ([_c_ptr, _c_ptr, ctypes.c_longlong, _c_int, ctypes.c_longlong, _c_ptr], _c_int),
+    'spt_rotary': ([_c_ptr, _c_int, _c_int, _c_ptr, ctypes.c_longlong, _c_ptr, _c_ptr] + [_c_int] * 5 + [_c_ptr],
+                   _c_int),
     'spt_swiglu_forward': ([_c_ptr] * 3 + [ctypes.c_longlong, _c_ptr], _c_int),
     'spt_swiglu_backward': ([_c_ptr] * 6 + [ctypes.c_longlong, _c_int, _c_ptr], _c_int),
     'spt_rows_combine': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
@@ -110,7 +112,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 _lib = None
 
@@ -1440,6 +1442,36 @@ def route_coeff_backward(dcoeff: torch.Tensor, pos: torch.Tensor, block: torch.T
     if rc != 0:
         _raise(lib, rc, 'route_coeff_backward')
     return dprob
+
+
+def rotary_supported(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dtype == cos.dtype == sin.dtype == torch.float32 and x.dim() == 4
+            and x.is_contiguous() and x.size(-1) % 8 == 0 and x.numel() > 0 and x.data_ptr() % 16 == 0
+            and cos.is_contiguous() and sin.is_contiguous() and cos.shape == sin.shape and cos.dim() == 2
+            and cos.size(0) >= x.size(1) and cos.size(1) == x.size(-1) and cos.device == x.device
+            and cos.data_ptr() % 16 == 0 and sin.data_ptr() % 16 == 0)
+
+
+def rotary(parts, n_rot: int, cos: torch.Tensor, sin: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    """``spt_rotary``: parts = 1 .. 3 tensors [N, S, H, E] of one shape; the first `n_rot` get the
+    rotary embedding of their positions (tables [>= S, E]; ``transpose``: its adjoint), the others
+    are copied -> ONE tensor [len(parts), N, S, H, E]."""
+    x0 = parts[0]
+    _require(1 <= len(parts) <= 3 and 0 <= n_rot <= len(parts)
+             and all(rotary_supported(p, cos, sin) and p.shape == x0.shape for p in parts),
+             'rotary: 1 .. 3 contiguous fp32 CUDA tensors [N, S, H, E % 8 == 0] of one shape')
+    N, S, H, E = x0.shape
+    dev = x0.device
+    lib = load_library()
+    array = ctypes.c_void_p * len(parts)
+    with _on(dev):
+        out = torch.empty([len(parts), N, S, H, E], dtype=torch.float32, device=dev)
+        rc = lib.spt_rotary(array(*[p.data_ptr() for p in parts]), len(parts), n_rot, out.data_ptr(),
+                            x0.numel(), cos.data_ptr(), sin.data_ptr(), N, S, H, E, int(bool(transpose)),
+                            _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'rotary')
+    return out
 
 
 def swiglu_supported(g: torch.Tensor, s: torch.Tensor) -> bool:

@@ -32,6 +32,8 @@ CLAMP = 10.0         # reference: attention.py:125-127
 FOLD_PQ_LOSS = True
 # q and k that lie back to back in one buffer: their two PQ losses in one pass (spt_pq_loss_*_parts)
 PAIR_PQ_LOSS = os.environ.get('SPT_PQ_PAIR', '1') != '0'
+# SparseRotaryAttentionV2: the rotary embedding of q and k as one launch (spt_rotary)
+ROTARY_KERNEL = os.environ.get('SPT_ROTARY_KERNEL', '1') != '0'
 
 
 class _ScaledClampedSDDMM(torch.autograd.Function):
@@ -506,3 +508,38 @@ class SparseRotaryAttentionV2(layers.RotaryAttention, _SparseCore):
 
     def _apply_attn(self, attn, v):
         return self._sparse_apply(attn, v)
+
+    def forward(self, q, k, v, attn_mask=None):
+        cos, sin = self.embedding.cos_cached, self.embedding.sin_cached
+        if ROTARY_KERNEL and q.shape == k.shape == v.shape and ext.rotary_supported(q, cos, sin) \
+                and ext.rotary_supported(k, cos, sin) and ext.rotary_supported(v, cos, sin):
+            # q and k rotated by ONE launch into one buffer (the PQ loss, the lookup and the attention
+            # read them as a pair), and in the backward dq, dk, dv leave in one buffer of three
+            # equally spaced gradients (the joint projection contracts them as one product)
+            ext.note_path('rotary', 'kernel')
+            q, k, v = _Rotary3.apply(q, k, v, cos, sin)
+            return self._apply_attn(self._sparse_attn(q, k), v)
+        ext.note_path('rotary', 'torch', fallback=q.is_cuda,
+                      why=lambda: 'q {} {}'.format(tuple(q.shape), q.dtype))
+        return super().forward(q, k, v, attn_mask=attn_mask)
+
+
+class _Rotary3(torch.autograd.Function):
+    """(rotary(q), rotary(k), v): position.py:24-34 twice, as one launch each way (spt_rotary)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, cos, sin):
+        ctx.save_for_backward(cos, sin)
+        out = ext.rotary([q, k], 2, cos, sin)
+        return out[0], out[1], v.view_as(v)
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        cos, sin = ctx.saved_tensors
+        if dq is None or dk is None or dv is None:
+            like = next(t for t in (dq, dk, dv) if t is not None)
+            dq = torch.zeros_like(like) if dq is None else dq
+            dk = torch.zeros_like(like) if dk is None else dk
+            dv = torch.zeros_like(like) if dv is None else dv
+        out = ext.rotary([dq.contiguous(), dk.contiguous(), dv.contiguous()], 2, cos, sin, transpose=True)
+        return out[0], out[1], out[2], None, None

@@ -498,3 +498,28 @@ def test_compact_tiles_flag_a_pattern_that_repeats_other_columns():
     tiles = ext.attention_mfma_prepare(idx, 256, lookup_pattern=True)
     assert tiles.broke_promise()
     assert not ext.attention_mfma_prepare(idx, 256).broke_promise()
+
+
+def test_rotary_kernel_equals_the_layer_and_its_autograd():
+    """spt_rotary: cos * x + sin * rotate_half(x) (position.py:24-34) of q and k in one launch, and the
+    adjoint of both plus a copy of dv in one launch -- against layers.RotaryEmbedding and autograd."""
+    from naive_gpt import ext, layers
+    from naive_gpt.layers.sparse.attention import _Rotary3
+    torch.manual_seed(0)
+    N, S, H, E = 2, 300, 4, 128
+    emb = layers.RotaryEmbedding(n_embeddings=512, d_model=E).cuda()
+    ids = torch.arange(S, device='cuda')
+    q, k, v = [torch.randn([N, S, H, E], device='cuda', requires_grad=True) for _ in range(3)]
+    wq, wk, wv = [torch.randn([N, S, H, E], device='cuda') for _ in range(3)]
+    rq, rk, rv = _Rotary3.apply(q, k, v, emb.cos_cached, emb.sin_cached)
+    assert ext.back_to_back(rq, rk)
+    ((rq * wq).sum() + (rk * wk).sum() + (rv * wv).sum()).backward()
+    got = [rq.detach(), rk.detach(), q.grad.clone(), k.grad.clone(), v.grad.clone()]
+    assert ext.spacing_of([q.grad, k.grad, v.grad]) == q.numel()       # one buffer, equally spaced
+    for t in (q, k, v):
+        t.grad = None
+    tq, tk = emb(q, ids), emb(k, ids)
+    ((tq * wq).sum() + (tk * wk).sum() + (v * wv).sum()).backward()
+    want = [tq.detach(), tk.detach(), q.grad, k.grad, v.grad]
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
