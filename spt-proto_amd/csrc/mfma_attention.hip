@@ -515,6 +515,140 @@ __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kern
     }
 }
 
+// The compact layout's builder (round 3).  Its promise -- only columns < 32 repeat inside a row --
+// means every key tile but the first holds 0 / 1 cells: ONE pass over the row tile's entries sets
+// bits ([key tile][row] words, ds_or) for the columns >= 32 and counts the columns < 32 in 32-bit
+// counters (the padding column 0 pre-summed per lane: a row of S = 2048 holds up to 256 of them);
+// the byte-count kernel above walks the entries once per eight key tiles with a ds_add per entry
+// (and, at Z = 256, a returning add and a conditional subtract): 241 us per launch at S = 2048,
+// Z = 256, B = 64, 6 % of an OPT-1.3B block's step.  Same masks, slots and pool as the kernel above
+// (tests/test_gpu_mfma_attention.py compares whole workspaces); a repeated column >= 32 shows as
+// popcount(row) != the row's count of such entries and sets the header's promise flag.
+__host__ __device__ __forceinline__ size_t cell_bits_lds_per_wave(int NT) {
+    return ((size_t)MA_WROWS * 32 + (size_t)(NT > 1 ? NT - 1 : 1) * MA_WROWS + MA_WROWS) * 4;
+}
+__global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_bits_kernel(
+    const int32_t *__restrict__ indices, unsigned long long *__restrict__ masks,
+    unsigned char *__restrict__ cells, unsigned char *__restrict__ cells_t,
+    unsigned char *__restrict__ pool, unsigned char *__restrict__ pool_t, int S, int Z, int NT,
+    int RT, int n_tiles_total) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gw = blockIdx.x * MB_WAVES + wave;
+    if (gw >= n_tiles_total) return;                    // no workgroup barrier below
+    const int b = gw / RT, rt = gw - b * RT, i0 = rt * MA_WROWS;
+    unsigned *cnt0 = reinterpret_cast<unsigned *>(smem + wave * cell_bits_lds_per_wave(NT));   // [row][key < 32]
+    unsigned *bits = cnt0 + MA_WROWS * 32;              // [key tile - 1][row]
+    const int nbuckets = min(NT, rt + 1);               // live entries have col <= row
+    unsigned *nval = bits + (size_t)(NT > 1 ? NT - 1 : 1) * MA_WROWS;   // [row]: entries with col >= 32
+    const int nrows = min(MA_WROWS, S - i0);
+    const int n4 = nrows * Z / 4;
+    const int4 *src = reinterpret_cast<const int4 *>(indices + ((size_t)b * S + i0) * Z);
+    const int c32 = lane & 31, h = lane >> 5;
+
+    for (int x = lane; x < MA_WROWS * 32 + (nbuckets - 1) * MA_WROWS; x += SPT_WAVE) cnt0[x] = 0u;
+    if (lane < MA_WROWS) nval[lane] = 0u;
+    wave_lds_fence();
+    for (int x = lane; x < n4; x += SPT_WAVE) {
+        const int4 e4 = src[x];
+        const int rl = 4 * x / Z;                       // an int4 never straddles rows
+        const int c[4] = {e4.x, e4.y, e4.z, e4.w};
+        unsigned nz = 0, nv = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (c[q] == 0) {
+                nz++;
+            } else if (c[q] > 0 && c[q] <= i0 + rl && c[q] < S) {
+                if (c[q] < 32) {
+                    atomicAdd(&cnt0[rl * 32 + c[q]], 1u);
+                } else {
+                    atomicOr(&bits[((c[q] >> 5) - 1) * MA_WROWS + rl], 1u << (c[q] & 31));
+                    nv++;
+                }
+            }
+        }
+        if (nz) atomicAdd(&cnt0[rl * 32], nz);
+        if (nv) atomicAdd(&nval[rl], nv);
+    }
+    wave_lds_fence();
+    // a repeated column >= 32 breaks the layout's promise (its second entry set no new bit)
+    {
+        unsigned pc = 0;
+        if (lane < MA_WROWS)
+            for (int t = 1; t < nbuckets; t++) pc += __popc(bits[(t - 1) * MA_WROWS + lane]);
+        const bool broke = lane < MA_WROWS && pc != nval[lane];
+        if (__ballot(broke) != 0ull && lane == 0) atomicOr(reinterpret_cast<unsigned *>(masks) - 64 + 1, 1u);
+    }
+    unsigned long long mask = 0, multi = 0;
+    unsigned char *out = cells + ((size_t)b * tri(RT) + tri(rt)) * 128;
+    unsigned char *out_t = cells_t + ((size_t)b * tri(RT) + tri(rt)) * 128;
+    // ---- key tile 0: counts ----
+    {
+        // lane (c, h): its 16 counts of row c (keys 8 g + 4 h + u), saturated to a byte
+        unsigned mine[4], tr[4];
+        bool big = false;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            unsigned wm = 0, wt = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned a = min(cnt0[c32 * 32 + 8 * g + 4 * h + u], 255u);          // row c, key ..
+                const unsigned t2 = min(cnt0[(8 * g + 4 * h + u) * 32 + c32], 255u);        // key c, row ..
+                wm |= a << (8 * u);
+                wt |= t2 << (8 * u);
+                big |= a > 1u;
+            }
+            mine[g] = wm;
+            tr[g] = wt;
+        }
+        const bool any = (mine[0] | mine[1] | mine[2] | mine[3]) != 0u;
+        if (__ballot(any) != 0ull) {
+            mask |= 1ull;
+            if (__ballot(big) != 0ull) {
+                multi |= 1ull;
+                reinterpret_cast<uint4 *>(pool + ((size_t)b * RT + rt) * MA_CELLS)[lane] =
+                    make_uint4(mine[0], mine[1], mine[2], mine[3]);
+                reinterpret_cast<uint4 *>(pool_t + ((size_t)b * RT + rt) * MA_CELLS)[lane] =
+                    make_uint4(tr[0], tr[1], tr[2], tr[3]);
+            } else {
+                // counts are 0 / 1: bytes -> bits (the kernel above, `bits16`)
+                auto nib = [](unsigned x) { return ((x * 0x01020408u) >> 24) & 0xFu; };
+                auto bits16 = [&](const unsigned (&w)[4]) {
+                    return (nib(w[0]) | (nib(w[1]) << 8) | (nib(w[2]) << 16) | (nib(w[3]) << 24)) << (4 * h);
+                };
+                unsigned rm = bits16(mine), cm = bits16(tr);
+                rm |= (unsigned)__shfl_xor((int)rm, 32, SPT_WAVE);
+                cm |= (unsigned)__shfl_xor((int)cm, 32, SPT_WAVE);
+                if (h == 0) {
+                    reinterpret_cast<unsigned *>(out)[c32] = rm;
+                    reinterpret_cast<unsigned *>(out_t)[c32] = cm;
+                }
+            }
+        }
+    }
+    // ---- key tiles 1 ..: bits ----
+    for (int t = 1; t < nbuckets; t++) {
+        const unsigned *tb = bits + (t - 1) * MA_WROWS;
+        const unsigned rm = tb[c32];                    // row c: its 32 keys of this tile
+        if (__ballot(rm != 0u) == 0ull) continue;
+        mask |= 1ull << t;
+        // key c: bit i = row i has it; each half of the wave gathers 16 rows (broadcast reads)
+        unsigned cm = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) cm |= ((tb[16 * h + i] >> c32) & 1u) << (16 * h + i);
+        cm |= (unsigned)__shfl_xor((int)cm, 32, SPT_WAVE);
+        if (h == 0) {
+            reinterpret_cast<unsigned *>(out + (size_t)t * 128)[c32] = rm;
+            reinterpret_cast<unsigned *>(out_t + (size_t)t * 128)[c32] = cm;
+        }
+    }
+    if (lane == 0) {
+        masks[2 * (size_t)gw] = mask;
+        masks[2 * (size_t)gw + 1] = multi;
+    }
+}
+
 // a tile's 16 bytes as loaded -> the four count words of this lane (byte form)
 __device__ __forceinline__ uint4 cell_words(const uint4 &v, bool multi, int lane) {
     if (multi) return v;
@@ -1692,7 +1826,13 @@ extern "C" int spt_attention_mfma_prepare(const int32_t *indices, void *tiles, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     SPT_ZERO_WORDS(tiles, MA_HEADER / 4, s);
     SPT_LAUNCH_CHECK();
-    if (Z > 255) {
+    if (layout == SPT_TILES_COMPACT && !getenv("SPT_CELL_TILES_COUNTS")) {
+        const size_t lds_bits = (size_t)MB_WAVES * cell_bits_lds_per_wave(NT);
+        SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_cell_bits_kernel,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bits));
+        hipLaunchKernelGGL(attention_cell_bits_kernel, grid, block, lds_bits, s, indices, ts.masks,
+                           ts.cells, ts.cells_t, ts.pool, ts.pool_t, S, Z, NT, RT, total);
+    } else if (Z > 255) {
         SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_cell_tiles_kernel<true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(attention_cell_tiles_kernel<true>, grid, block, lds, s, indices,
