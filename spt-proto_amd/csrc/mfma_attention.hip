@@ -1826,7 +1826,11 @@ extern "C" int spt_attention_mfma_prepare(const int32_t *indices, void *tiles, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     SPT_ZERO_WORDS(tiles, MA_HEADER / 4, s);
     SPT_LAUNCH_CHECK();
-    if (layout == SPT_TILES_COMPACT && !getenv("SPT_CELL_TILES_COUNTS")) {
+    // (at S <= 512 -- two chunks of key tiles -- the byte-count kernel is the faster one: 22.8 against
+    // 26.0 us at the configs[2] shape; SPT_CELL_TILES_COUNTS / _BITS force either for A/B runs)
+    const bool bits = layout == SPT_TILES_COMPACT && !getenv("SPT_CELL_TILES_COUNTS") &&
+                      (NT > 2 * MB_CHUNK || getenv("SPT_CELL_TILES_BITS"));
+    if (bits) {
         const size_t lds_bits = (size_t)MB_WAVES * cell_bits_lds_per_wave(NT);
         SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_cell_bits_kernel,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bits));

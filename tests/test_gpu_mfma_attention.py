@@ -458,13 +458,16 @@ def _lookup_like(B, S, Z, gen):
     return idx.view(B, S * Z)
 
 
+@pytest.mark.parametrize('builder', ['bits', 'counts'])
 @pytest.mark.parametrize('N,H,S,Z,E', [(1, 4, 512, 64, 64), (1, 2, 2048, 256, 64), (1, 2, 256, 32, 128),
                                        (1, 3, 80, 8, 64)])
-def test_compact_tiles_equal_full_tiles_on_lookup_patterns(N, H, S, Z, E):
+def test_compact_tiles_equal_full_tiles_on_lookup_patterns(N, H, S, Z, E, builder, monkeypatch):
     """SPT_TILES_COMPACT (128-byte mask slots + one byte-form slot per row tile for key tile 0)
     against SPT_TILES_FULL: bit-identical forward and backward on patterns whose only repeated
-    column is the padding column 0, at a quarter of the workspace."""
+    column is the padding column 0, at a quarter of the workspace.  Both builders of the compact
+    workspace (the bit-mask kernel, the default above S = 512, and the byte-count kernel)."""
     from naive_gpt import ext
+    monkeypatch.setenv('SPT_CELL_TILES_BITS' if builder == 'bits' else 'SPT_CELL_TILES_COUNTS', '1')
     gen = torch.Generator().manual_seed(S + Z + E)
     B = N * H
     q, k, v = [torch.randn([N, S, H, E], generator=gen).cuda() for _ in range(3)]
@@ -491,8 +494,10 @@ def test_compact_tiles_equal_full_tiles_on_lookup_patterns(N, H, S, Z, E):
     assert torch.allclose(outs[1][0].cpu(), want, rtol=1e-3, atol=1e-4)
 
 
-def test_compact_tiles_flag_a_pattern_that_repeats_other_columns():
+@pytest.mark.parametrize('builder', ['bits', 'counts'])
+def test_compact_tiles_flag_a_pattern_that_repeats_other_columns(builder, monkeypatch):
     from naive_gpt import ext
+    monkeypatch.setenv('SPT_CELL_TILES_BITS' if builder == 'bits' else 'SPT_CELL_TILES_COUNTS', '1')
     gen = torch.Generator().manual_seed(8)
     idx = causal_indices(4, 256, 32, gen).cuda()          # random repeats anywhere
     tiles = ext.attention_mfma_prepare(idx, 256, lookup_pattern=True)
