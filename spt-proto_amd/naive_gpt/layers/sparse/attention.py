@@ -237,11 +237,12 @@ class _SparseCore:
         return cached
 
     def arm(self) -> None:
-        """Arm the one-shot PQ-loss trigger from the host.  Same effect as the reference's
-        ``module.trigger.fill_(True)`` plus a host-side note that it happened, so that the next
-        forward does not have to ASK the device (a blocking read: one pipeline drain per layer
-        and step in the tuning recipe, which arms every step)."""
-        self.trigger.fill_(True)
+        """Arm the one-shot PQ-loss trigger from the host.  Same effect on the next forward as the
+        reference's ``module.trigger.fill_(True)``, as a host-side note only: the forward neither ASKS
+        the device (a blocking read: one pipeline drain per layer and step in the tuning recipe, which
+        arms every step) nor writes the buffer twice (arm, disarm: two launches per layer and step) --
+        the device buffer simply stays disarmed.  The reference's protocol (a write to `trigger`) still
+        works: `_take_trigger` sees the buffer's version move."""
         self.__dict__['_armed_hint'] = True
 
     def _take_trigger(self) -> bool:
@@ -252,10 +253,7 @@ class _SparseCore:
         sync) after a write: unarmed steps never synchronise."""
         t = self.trigger
         if self.__dict__.pop('_armed_hint', False):
-            t.fill_(False)                        # disarm on the device, no read-back
-            if not t.is_inference():
-                self.__dict__['_trigger_seen'] = ((t.data_ptr(), t._version), False)
-            return True
+            return True                           # armed by `arm()`: the device buffer was never set
         if t.is_inference():                      # no version counter to consult
             armed = bool(t.is_nonzero())
             if armed:

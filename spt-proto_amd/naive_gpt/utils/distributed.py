@@ -32,10 +32,10 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
                 t.copy_(tmp.to(torch.bool))
             else:
                 dist.broadcast(t.data, src=src, group=group)
-    # host-side notes about the triggers (layers/sparse/attention.py) describe the OLD values
+    # host-side readings of the triggers (layers/sparse/attention.py) describe the OLD values;
+    # a pending `module.arm()` is an intent of this rank's training loop, not device state: kept
     for m in module.modules():
         m.__dict__.pop('_trigger_seen', None)
-        m.__dict__.pop('_armed_hint', None)
 
 
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None,
