@@ -212,6 +212,11 @@ static int sddmm_g4_launch(const int32_t *indptr, const int32_t *indices, const 
     return SPT_OK;
 }
 
+// the dense-tile form (sddmm_tile.hip): SPT_EUNSUP for the shapes it leaves to the kernels above
+int sddmm_tile_launch(const int32_t *indptr, const int32_t *indices, const float *query,
+                      const float *key, float *out, int B, int S, int E, int nnz, float scale,
+                      float clampv, int q_heads, int k_heads, hipStream_t s);
+
 }  // namespace spt
 
 using namespace spt;
@@ -231,6 +236,11 @@ extern "C" int spt_sddmm_forward(const int32_t *indptr, const int32_t *indices,
     hipStream_t s = (hipStream_t)stream;
     if (q_heads < 0 || k_heads < 0) return SPT_EINVAL;
     if ((q_heads > 0 && B % q_heads != 0) || (k_heads > 0 && B % k_heads != 0)) return SPT_ESHAPE;
+    {
+        const int rc = sddmm_tile_launch(indptr, indices, query, key, out, B, S, E, nnz, scale, clampv,
+                                         q_heads, k_heads, s);
+        if (rc != SPT_EUNSUP) return rc;
+    }
     if (E == 64)
         return sddmm_g4_launch<4>(indptr, indices, query, key, out, B, S, nnz, scale, clampv,
                                   q_heads, k_heads, s);
