@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 37
+#define SPT_ABI_VERSION 38
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -157,7 +157,15 @@ int spt_lookup_forward(const int32_t *query, const int32_t *key, int32_t *out,
  * `scale`/`clamp`: out = clamp(scale * dot, -clamp, +clamp) when clamp > 0 (the
  * epilogue of naive_gpt/layers/sparse/attention.py:125-127); pass scale = 1,
  * clamp = 0 for the plain operator.
+ *
+ * Two forms (ABI 38).  Patterns as dense as lookup's (nnz >= S * S / 16; d_head 64, 128 <= S <= 1024, at
+ * least 160 workgroups of 512 keys) are computed as DENSE 32-row stripes of scores on the matrix
+ * cores (split-bf16, <= 2^-16 relative error per product), from which the CSR's entries are picked
+ * (csrc/sddmm_tile.hip: 36 us against 51-56 at the configs[2] shape); everything else by the fp32
+ * gather kernels (csrc/sddmm.hip).  spt_sddmm_form() tells which one a call would take
+ * (1 = matrix cores, 0 = gather); the environment variable SPT_SDDMM_GATHER forces the gather form.
  */
+int spt_sddmm_form(int batch_size, int seq_length, int d_head, int nnz);
 int spt_sddmm_forward(const int32_t *indptr, const int32_t *indices,
                       const float *query, const float *key, float *out,
                       int batch_size, int seq_length, int d_head, int nnz,

@@ -216,10 +216,15 @@ static int sddmm_g4_launch(const int32_t *indptr, const int32_t *indices, const 
 int sddmm_tile_launch(const int32_t *indptr, const int32_t *indices, const float *query,
                       const float *key, float *out, int B, int S, int E, int nnz, float scale,
                       float clampv, int q_heads, int k_heads, hipStream_t s);
+bool sddmm_tile_takes(int B, int S, int E, int nnz);
 
 }  // namespace spt
 
 using namespace spt;
+
+extern "C" int spt_sddmm_form(int batch_size, int seq_length, int d_head, int nnz) {
+    return sddmm_tile_takes(batch_size, seq_length, d_head, nnz) ? 1 : 0;
+}
 
 extern "C" int spt_sddmm_forward(const int32_t *indptr, const int32_t *indices,
                                  const float *query, const float *key, float *out,

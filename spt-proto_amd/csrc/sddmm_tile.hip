@@ -18,13 +18,29 @@
 //   * the stripe's Q rows become a bf16 image in LDS (8 KiB, one float4 per thread, double-buffered);
 //   * every wave multiplies its two key tiles with it (24 MFMAs) and parks the 32 x 64 scores in
 //     the stripe buffer [32 rows][512 keys] (fp32, 64.5 KiB, double-buffered, ds_write_b128);
-//   * one barrier; then wave w walks rows 4 w .. 4 w + 3 of the stripe: 64 entries per
-//     instruction -- a coalesced load of the column ids (requested one stripe ahead), one
-//     ds_read_b32 per entry from the stripe buffer, scale / clamp, a coalesced store.
-// LDS traffic per entry: 4 bytes instead of 256.  The next stripe's MFMAs may start while other
-// waves still pick entries: the stripe buffers alternate, and a buffer is rewritten only after the
-// barrier that every wave reaches after it has finished reading it.
-// S > 512: ceil(S / 512) workgroups per slice, each picks the entries whose column falls in its keys.
+//   * wave w walks rows 4 w .. 4 w + 3 of the stripe: 64 entries per instruction -- a coalesced
+//     load of the column ids (requested three stripes ahead), one ds_read_b32 per entry from the
+//     stripe buffer, scale / clamp, a coalesced store.
+// LDS traffic per entry: 4 bytes instead of 256.  One barrier per stripe: iteration s forms the
+// scores of stripe s + 1 and picks stripe s (the stripe buffers alternate; a buffer is rewritten
+// only behind the barrier that every wave reaches after it has finished reading it), and the two
+// waves of a SIMD take the two halves in opposite order.
+// 512 < S <= 1024: two workgroups per slice, each picks the entries whose column falls in its keys.
+//
+// Measured (configs[2] attention shape, 256 slices x 512 x 64, 64 entries per row; rocprofv3 and
+// tools/micro/time_sddmm.py): 36 us = 0.46 of the HBM roofline on the operator's 134 MB, against
+// 51-56 us (0.30-0.33) for the gather form; 19 against 31 us at S = 256, 108 against 190 at
+// S = 1024 (128 entries per row).  Where the 36 us go (s_memtime marks of one workgroup,
+// -DST_STAMP): 13 k of 69 k cycles before the first stripe (the K fragments: 33.5 MB requested by all
+// CUs at once, HBM-bound), then 3.2-3.4 k per stripe for 1.5 k cycles of MFMA per SIMD -- the rest
+// is the wave's own chain of LDS round trips, address arithmetic (~170 vector instructions per
+// stripe) and the 13-cycle ds_write_b128 of the stripe buffer (64 KiB per stripe and CU), which two
+// waves per SIMD do not hide.  Tried on the way and not kept: 256-key workgroups, two to a CU (51 us:
+// every entry's 256-byte result line is then written by two workgroups, 4 bytes at a time); four
+// extra picker waves doing all global accesses while eight matrix waves only read Q, multiply and
+// park (39-41 us: the pickers' ~330 vector instructions per stripe became the critical path); skipping
+// the key tiles right of a stripe's largest column id (causal patterns: half of the MFMAs; the
+// extra control flow cost more waits than the MFMAs saved: 39 us).
 #include "spt_common.h"
 #include <stdlib.h>
 
@@ -49,8 +65,7 @@ constexpr int ST_QLD = ST_E * 2 + 16;               // bytes per row of the Q im
 constexpr int ST_QPART = ST_ROWS * ST_QLD;          // one part (hi or lo)
 constexpr int ST_QIMG = 2 * ST_QPART;
 constexpr int ST_RPW = ST_ROWS / ST_WAVES;          // rows of a stripe a wave picks entries for
-constexpr int ST_LDS_MAIN = 2 * ST_DBUF * 4 + 2 * ST_QIMG;   // 150,528 B
-constexpr int ST_LDS = ST_LDS_MAIN + 2 * ST_WAVES * 4;       // (+ the stripes' largest column ids): one workgroup per CU
+constexpr int ST_LDS = 2 * ST_DBUF * 4 + 2 * ST_QIMG;        // 150,528 B: one workgroup per CU
 
 struct StSplit { unsigned hi, lo; };
 // two floats -> packed bf16 pairs (first value in the low half): hi = RNE, lo = RNE(x - hi)
@@ -102,7 +117,6 @@ __device__ __forceinline__ void sddmm_tile_body(
     int nnz, int key_blocks, float scale, float clampv, int q_heads, int k_heads, char *smem) {
     float *dbuf = reinterpret_cast<float *>(smem);              // [2][ST_ROWS][ST_DLD]
     char *qimg = smem + 2 * ST_DBUF * 4;                        // [2][hi | lo][ST_ROWS][ST_QLD]
-    int *smax = reinterpret_cast<int *>(smem + ST_LDS_MAIN);    // [2][ST_WAVES]: largest column id of a stripe
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c32 = lane & 31, h = lane >> 5;
@@ -181,7 +195,6 @@ __device__ __forceinline__ void sddmm_tile_body(
     for (int t = 0; t < 2; t++)
 #pragma unroll
         for (int ks = 0; ks < ST_KS; ks++) kf[t][ks] = st_split8(kraw[t][ks][0], kraw[t][ks][1]);
-    if (tid < 2 * ST_WAVES) smax[tid] = 0x7fffffff;             // (stripe 1: every key tile)
     store_q(0, q0);
     store_q(1, q1);
     __syncthreads();
@@ -189,12 +202,10 @@ __device__ __forceinline__ void sddmm_tile_body(
     // Scores of stripe s -> stripe buffer s % 2, in two halves so that the wave's own LDS traffic
     // runs under its MFMAs: `fetch` requests the eight Q fragments (a wave that picks first does
     // that before picking), `scores` contracts the first key tile, starts the second, stores the
-    // first while the second's MFMAs run, then stores the second.  Key tiles right of the stripe's
-    // largest column id (`last`; for lookup's causal patterns: half of all tiles) are skipped.
+    // first while the second's MFMAs run, then stores the second.
     StFrag qf[ST_KS];
-    auto fetch = [&](int s, int last) {
+    auto fetch = [&](int s) {
 #ifndef ST_ABL_NO_MMA
-        if (wkey0 > last) return;
         const char *qh = qimg + (s & 1) * ST_QIMG + c32 * ST_QLD + 16 * h;
 #pragma unroll
         for (int ks = 0; ks < ST_KS; ks++) {
@@ -203,9 +214,8 @@ __device__ __forceinline__ void sddmm_tile_body(
         }
 #endif
     };
-    auto scores = [&](int s, int last) {
+    auto scores = [&](int s) {
 #ifndef ST_ABL_NO_MMA
-        if (wkey0 > last) return;
         // lane (i, h) holds row i, keys 8 g + 4 h + u of its tile in register 4 g + u
         float *drow = dbuf + (s & 1) * ST_DBUF + c32 * ST_DLD + wave * ST_WKEYS + 4 * h;
         auto park = [&](const st_f32x16 &d, int t) {
@@ -223,10 +233,6 @@ __device__ __forceinline__ void sddmm_tile_body(
         for (int r = 0; r < 16; r++) { d0[r] = 0.f; d1[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < ST_KS; ks++) d0 = st_mm(kf[0][ks], qf[ks], d0);
-        if (wkey0 + 32 > last) {
-            park(d0, 0);
-            return;
-        }
         d1 = st_mm(kf[1][0], qf[0], d1);
         __builtin_amdgcn_sched_barrier(0);
         park(d0, 0);
@@ -274,74 +280,51 @@ __device__ __forceinline__ void sddmm_tile_body(
         }
 #endif
     };
-    // this wave's share of a stripe's largest column id (rows longer than a wave: not looked at)
-    auto publish = [&](int s, const StPicks &pk) {
-        int m = LONG ? 0x7fffffff : -1;
-#pragma unroll
-        for (int rr = 0; rr < ST_RPW; rr++) m = max(m, pk.start[rr] + lane < pk.end[rr] ? pk.col[rr] : -1);
-#pragma unroll
-        for (int x = 32; x >= 1; x >>= 1) m = max(m, __shfl_xor(m, x, SPT_WAVE));
-        if (lane == 0) smax[(s & 1) * ST_WAVES + wave] = m;
-    };
-    auto largest = [&](int s) {
-        int m = -1;
-#pragma unroll
-        for (int w = 0; w < ST_WAVES; w++) m = max(m, smax[(s & 1) * ST_WAVES + w]);
-        return __builtin_amdgcn_readfirstlane(m);
-    };
-
-    fetch(0, 0x7fffffff);
-    scores(0, 0x7fffffff);
+    if (wave_live) {
+        fetch(0);
+        scores(0);
+    }
     __syncthreads();
     ST_MARK();
     // Software pipeline, one barrier per iteration: iteration s forms the scores of stripe s + 1 and
     // picks the entries of stripe s.  The two waves of a SIMD (w and w + 4) take the two halves in
     // OPPOSITE order, so that one's MFMAs run under the other's loads, LDS reads and stores.
     // Global requests run ahead of their use: column ids three stripes (requested in iteration s
-    // for stripe s + 3; their largest is published at the end of iteration s + 1 and steers the
-    // scores that iteration s + 2 forms), Q rows loaded in iteration s for stripe s + 3 and written to the image at
+    // for stripe s + 3), Q rows loaded in iteration s for stripe s + 3 and written to the image at
     // the end of iteration s + 1, row pointers for stripe s + 4.  Unrolled four times by hand: the
     // register sets rotate by NAME -- rotated by copies, every copy was a wait for its load.
     const bool scores_first = wave < ST_WAVES / 2;
-    auto iteration = [&](int s, const StPicks &cur, const StPicks &ahead2, StPicks &fresh, const float4 &q_store,
-                         float4 &q_load, const int ptr_cur, int &ptr_new) {
+    auto iteration = [&](int s, const StPicks &cur, StPicks &fresh, const float4 &q_store, float4 &q_load,
+                         const int ptr_cur, int &ptr_new) {
         ST_MARK();
         q_load = load_q(s + 3);
         ptr_new = load_ptrs(s + 4);
         fresh = request(ptr_cur);
-        const bool more = s + 1 < n_stripes;
-#ifdef ST_SKIP_DEAD
-        const int last = largest(s + 1);
-#else
-        constexpr int last = 0x7fffffff;
-#endif
-        if (more && wave_live) fetch(s + 1, last);
+        const bool more = s + 1 < n_stripes && wave_live;
+        if (more) fetch(s + 1);
         if (scores_first) {
-            if (more && wave_live) scores(s + 1, last);
+            if (more) scores(s + 1);
             ST_MARK();
             pick(s, cur);
         } else {
             pick(s, cur);
             ST_MARK();
-            if (more && wave_live) scores(s + 1, last);
+            if (more) scores(s + 1);
         }
         ST_MARK();
-#ifdef ST_SKIP_DEAD
-        publish(s + 2, ahead2);
-#endif
         if (s + 2 < n_stripes) store_q(s + 2, q_store);
         ST_MARK();
         __syncthreads();
     };
     for (int s = 0; s < n_stripes; s += 4) {
-        // (stripe s in the first set, s + 2 in the second, the request for s + 3 into the third)
-        iteration(s, pk_a, pk_c, pk_d, q_a, q_b2, ptr_a, ptr_b);
+        // (the set of stripe s, the set the request for stripe s + 3 goes into)
+        iteration(s, pk_a, pk_d, q_a, q_b2, ptr_a, ptr_b);
         if (s + 1 >= n_stripes) break;
-        iteration(s + 1, pk_b, pk_d, pk_a, q_b2, q_a, ptr_b, ptr_a);
+        iteration(s + 1, pk_b, pk_a, q_b2, q_a, ptr_b, ptr_a);
         if (s + 2 >= n_stripes) break;
-        iteration(s + 2, pk_c, pk_a, pk_b, q_a, q_b2, ptr_a, ptr_b);
+        iteration(s + 2, pk_c, pk_b, q_a, q_b2, ptr_a, ptr_b);
         if (s + 3 >= n_stripes) break;
-        iteration(s + 3, pk_d, pk_b, pk_c, q_b2, q_a, ptr_b, ptr_a);
+        iteration(s + 3, pk_d, pk_c, q_b2, q_a, ptr_b, ptr_a);
     }
 }
 
@@ -363,17 +346,27 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                               k_heads, smem);
 }
 
-// -> SPT_OK, or SPT_EUNSUP when the shape is one for the gather form (sddmm.hip)
+// the shapes of this form; everything else is for the gather form (sddmm.hip)
+bool sddmm_tile_takes(int B, int S, int E, int nnz) {
+    // (S > 1024: every one of a slice's key blocks walks all of its column ids, and rows of S / 8
+    // entries take the long-row loop -- 480 us against the gather form's 433 at S = 2048, Z = 256)
+    if (E != ST_E || S < 2 * ST_WKEYS || S > 2 * ST_KEYS || B <= 0 || nnz <= 0) return false;
+    // all S x S scores of a slice are computed: worth it from a density of 1 / 16 (lookup: 1 / 8)
+    if ((long long)nnz * 16 < (long long)S * S) return false;
+    const long long nblk = (long long)B * ((S + ST_KEYS - 1) / ST_KEYS);
+    // (a workgroup needs ~30 us whatever the grid: below ~5/8 of the CUs the gather form's finer
+    // split wins -- 64 workgroups: 29 us against 20.6)
+    if (nblk < 160 || nblk > 0x7FFFFFFFll) return false;
+    return !getenv("SPT_SDDMM_GATHER");                         // (A/B switch: tools/README.md)
+}
+
+// -> SPT_OK, or SPT_EUNSUP when the shape is one for the gather form
 int sddmm_tile_launch(const int32_t *indptr, const int32_t *indices, const float *query,
                       const float *key, float *out, int B, int S, int E, int nnz, float scale,
                       float clampv, int q_heads, int k_heads, hipStream_t s) {
-    if (E != ST_E || S < 2 * ST_WKEYS) return SPT_EUNSUP;
-    // all S x S scores of a slice are computed: worth it from a density of 1 / 16 (lookup: 1 / 8)
-    if ((long long)nnz * 16 < (long long)S * S) return SPT_EUNSUP;
+    if (!sddmm_tile_takes(B, S, E, nnz)) return SPT_EUNSUP;
     const int key_blocks = (S + ST_KEYS - 1) / ST_KEYS;
     const long long nblk = (long long)B * key_blocks;
-    if (nblk < 64 || nblk > 0x7FFFFFFFll) return SPT_EUNSUP;
-    if (getenv("SPT_SDDMM_GATHER")) return SPT_EUNSUP;          // (A/B switch: tools/README.md)
     SPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sddmm_tile_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS));
     hipLaunchKernelGGL(sddmm_tile_kernel, dim3((unsigned)nblk), dim3(ST_THREADS), ST_LDS, s, indptr,

@@ -46,6 +46,7 @@ _PROTOTYPES = {
     'spt_sddmm_forward': (
         [_c_ptr] * 5 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int
     ),
+    'spt_sddmm_form': ([_c_int] * 4, _c_int),
     'spt_spmm_workspace_bytes': ([_c_int] * 5, ctypes.c_int64),
     'spt_spmm_forward': ([_c_int] + [_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr], _c_int),
     'spt_csr_transpose_workspace_bytes': ([_c_int] * 4, ctypes.c_int64),
@@ -112,7 +113,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 _lib = None
 
@@ -535,6 +536,7 @@ def sddmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,
     nnz = indices.size(-1)
     _require(indptr.size(-1) == S + 1, 'indptr.size(-1) == seq_length + 1')
     lib = load_library()
+    note_path('sddmm', 'matrix_cores' if lib.spt_sddmm_form(B, S, E, nnz) else 'gather')
     with _on(dev):
         output = torch.empty([B, nnz], dtype=torch.float32, device=dev)
         rc = lib.spt_sddmm_forward(

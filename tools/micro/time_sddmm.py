@@ -10,7 +10,7 @@ import torch  # noqa: E402
 from naive_gpt import ext  # noqa: E402
 
 N, S, H, E = (int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else (16, 512, 16, 64)))
-B, M, Z = N * H, E // 8, min(64, S // 8)
+B, M, Z = N * H, E // 8, int(os.environ.get('Z', S // 8))
 torch.manual_seed(0)
 dev = 'cuda'
 q, k = [torch.randn([B, S, E], device=dev) for _ in range(2)]
