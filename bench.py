@@ -3,6 +3,12 @@
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        # no launcher: bench.py starts its N ranks itself
+    python bench.py --config llama-7b   # BASELINE.json configs[4] (opt-1.3b: configs[3])
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU; it
+starts N child rank processes of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, as
+torch.distributed.run would), relays rank 0's single JSON line and exits with the children's code.
 
 Headline workload = BASELINE.json configs[2]: BERT-large dimensions (the reference's
 `opt-1024`: d_model 1024, 16 heads x 64, d_ff 4096, script/0-profile.py:16-19), 24 layers,
@@ -47,34 +53,76 @@ from torch import nn, optim  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
 MFMA_BF16_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+MFMA_FP32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector rate
 
-# BERT-large dimensions = the reference's `opt-1024` (script/0-profile.py:16-19)
+# The workloads BASELINE.json names.  bert-large = the reference's `opt-1024`
+# (script/0-profile.py:16-19); opt-1.3b / llama-7b = the dimensions script/1-convert.py:202-206
+# converts (facebook/opt-1.3b, open_llama_7b), random init -- no checkpoint exists offline.
+CONFIGS = {
+    'bert-large': dict(family='opt', d_model=1024, n_heads=16, d_ff=4096, layers=24, vocab=30522,
+                       seq=512, batch=16,
+                       workload='BASELINE.json configs[2]: BERT-large sparse-MHA + routed-FFN full '
+                                'fine-tune step'),
+    'opt-1.3b': dict(family='opt', d_model=2048, n_heads=32, d_ff=8192, layers=24, vocab=50272,
+                     seq=2048, batch=2,
+                     workload='BASELINE.json configs[3]: OPT-1.3B sparse-MHA + routed-FFN fine-tune '
+                              'step, seq 2048 (long-seq CSR stress)'),
+    'llama-7b': dict(family='llama', d_model=4096, n_heads=32, d_ff=11008, layers=32, vocab=32000,
+                     seq=2048, batch=1,
+                     workload='BASELINE.json configs[4]: LLaMA-7B sparse fine-tune step, seq 2048, '
+                              'data parallel with one RCCL all-reduce of the trainable gradients'),
+    # plumbing check of the launcher on CPU (tests/test_distributed.py); only with --rehearse-cpu
+    'tiny-rehearsal': dict(family='opt', d_model=32, n_heads=2, d_ff=64, layers=1, vocab=64,
+                           seq=16, batch=2, workload='launcher rehearsal (no BASELINE config)'),
+}
+FAMILY = 'opt'
 D_MODEL, H, D_FF, LAYERS, VOCAB = 1024, 16, 4096, 24, 30522
 S = 512
 E = D_MODEL // H
 M, C, D = E // 8, 16, 8
 Z = S // 8
+WORKLOAD = CONFIGS['bert-large']['workload']
+
+
+def set_config(name):
+    """Bind the module-level dimensions every record reads to one of CONFIGS."""
+    global FAMILY, D_MODEL, H, D_FF, LAYERS, VOCAB, S, E, M, Z, WORKLOAD
+    c = CONFIGS[name]
+    FAMILY, D_MODEL, H, D_FF = c['family'], c['d_model'], c['n_heads'], c['d_ff']
+    LAYERS, VOCAB, S, WORKLOAD = c['layers'], c['vocab'], c['seq'], c['workload']
+    E = D_MODEL // H
+    M = E // 8
+    Z = S // 8
+    return c
 
 
 # ------------------------------------------------------------------------------- timing
+CPU_REHEARSAL = False        # --rehearse-cpu: the launcher / DP plumbing without a GPU (tests)
+
+
+def _sync():
+    if not CPU_REHEARSAL:
+        torch.cuda.synchronize()
+
+
 def timed_loop(fn, steps, warmup, world):
     """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks."""
     for _ in range(warmup):
         fn()
-    torch.cuda.synchronize()
+    _sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    _sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
-    torch.cuda.synchronize()
+    _sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    _sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        t = torch.tensor([dt], device='cpu' if CPU_REHEARSAL else 'cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -173,9 +221,10 @@ def build_model(tuning, dev, layers=LAYERS):
     torch.manual_seed(0)
     sdpa = tuning.endswith('_sdpa')
     tuning = tuning.replace('_sdpa', '')
-    with torch.device(dev):
-        model = models.OPTModel(d_model=D_MODEL, n_heads=H, n_layers=layers, max_length=S,
-                                vocab_size=VOCAB, d_feedforward=D_FF, p_dropout=0.0)
+    with torch.device(dev):           # (a 7 B model is built on the GPU, not copied to it)
+        cls = models.LLaMAModel if FAMILY == 'llama' else models.OPTModel
+        model = cls(d_model=D_MODEL, n_heads=H, n_layers=layers, max_length=S,
+                    vocab_size=VOCAB, d_feedforward=D_FF, p_dropout=0.0)
         if tuning == 'lora':
             model = utils.upgrade_sparse(model, d_lora=16, stages=('lora',))
         elif tuning == 'sparse':
@@ -210,8 +259,9 @@ def model_record(tuning, args, world, rank, dev, gemm_timer=None):
     """`SparseTuner.training_step` of the 24-layer model; at world > 1 the tuner broadcasts
     rank 0's replica and all-reduces the trainable gradients inside every step."""
     from naive_gpt import utils
-    torch.cuda.empty_cache()
-    torch.cuda.reset_peak_memory_stats()
+    if not CPU_REHEARSAL:
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
     model = build_model(tuning, dev, args.layers)
     tuner = utils.SparseTuner(model)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
@@ -248,7 +298,7 @@ def model_record(tuning, args, world, rank, dev, gemm_timer=None):
     tokens = N * S * world * args.steps
     trainable = sum(p.numel() for p in tuner.params)
     rec.update({'value': tokens / dt, 'unit': 'tokens/s', 'ms_per_step': 1e3 * dt / args.steps,
-                'peak_hbm_gb': torch.cuda.max_memory_allocated() / 1e9,
+                'peak_hbm_gb': None if CPU_REHEARSAL else torch.cuda.max_memory_allocated() / 1e9,
                 'trainable_params': trainable,
                 'total_params': sum(p.numel() for p in model.parameters())})
     if world > 1:
@@ -264,7 +314,8 @@ def model_record(tuning, args, world, rank, dev, gemm_timer=None):
             rec['allreduce_bus_gbs'] = 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9
             rec['allreduce_sampled'] = len(tuner.allreduce_events)
     del model, tuner
-    _release()
+    if not CPU_REHEARSAL:
+        _release()
     return rec
 
 
@@ -539,6 +590,12 @@ def cpu_c1():
                       'forward, PyTorch CPU fp32, median of 10 calls'}
 
 
+def traffic_file():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
+    return os.path.relpath(files[-1], ROOT) if files else None
+
+
 def measured_traffic(kernel_prefix):
     """HBM bytes per launch from the committed PMC passes (profiles/*_traffic.json:
     FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), launch-weighted over the
@@ -555,13 +612,66 @@ def measured_traffic(kernel_prefix):
     return sum(r['hbm_bytes_per_launch'] * r.get('launches', 1) for r in rows) / calls
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`--gpus N` without a launcher: start the N rank processes of this same command line as
+    CHILDREN (this parent has made no GPU call and makes none: a process that has initialised
+    the GPU must never be replaced or forked into ranks), with the environment
+    torch.distributed.run would give them; relay rank 0's stdout (the one JSON line), send the
+    other ranks' stdout to stderr, kill the rest when a rank fails, return the worst exit code."""
+    import subprocess
+    port = os.environ.get('MASTER_PORT') or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      text=True))
+
+    def relay():            # rank 0: JSON lines to stdout, library chatter (gloo / RCCL) to stderr
+        for line in procs[0].stdout:
+            out = sys.stdout if line.lstrip().startswith('{') else sys.stderr
+            out.write(line)
+            out.flush()
+
+    import threading
+    pump = threading.Thread(target=relay, daemon=True)
+    pump.start()
+    rc, alive = 0, list(procs)
+    while alive:
+        time.sleep(0.2)
+        for proc in list(alive):
+            code = proc.poll()
+            if code is None:
+                continue
+            alive.remove(proc)
+            if code != 0:
+                rc = rc or code
+                for other in alive:            # a dead rank leaves the others in a collective
+                    other.terminate()
+    pump.join(timeout=10)
+    return rc
+
+
 def main():
+    global CPU_REHEARSAL
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=16, help='micro-batch per GPU')
-    ap.add_argument('--layers', type=int, default=LAYERS)
+    ap.add_argument('--steps', type=int, default=None, help='default 20 (bert-large) / 8')
+    ap.add_argument('--warmup', type=int, default=None, help='default 10 (bert-large) / 3')
+    ap.add_argument('--config', default='bert-large', choices=sorted(CONFIGS),
+                    help='bert-large = BASELINE configs[2] (the headline), opt-1.3b = configs[3], '
+                         'llama-7b = configs[4]')
+    ap.add_argument('--batch', type=int, default=None, help='micro-batch per GPU (default: the config\'s)')
+    ap.add_argument('--layers', type=int, default=None)
     ap.add_argument('--no-baselines', action='store_true', help='skip full / lora')
     ap.add_argument('--no-block', action='store_true')
     ap.add_argument('--no-attention', action='store_true')
@@ -573,26 +683,73 @@ def main():
     ap.add_argument('--one-device', action='store_true',
                     help='rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0 '
                          '(use with --backend gloo); not a measurement')
+    ap.add_argument('--rehearse-cpu', action='store_true',
+                    help='launcher / DP plumbing check without a GPU (tests/test_distributed.py): the '
+                         'DENSE model of the config on CPU tensors over gloo.  The sparse path has no '
+                         'CPU form; the line says "rehearsal" and is not a measurement')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--cpu-seqs', type=int, default=16)
     args = ap.parse_args()
-    if args.only:
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus))         # before anything touches a GPU
+
+    if args.config == 'tiny-rehearsal' and not args.rehearse_cpu:
+        ap.error('--config tiny-rehearsal is the launcher test\'s model: use it with --rehearse-cpu')
+    cfg = set_config(args.config)
+    headline = args.config == 'bert-large'
+    if args.steps is None:
+        args.steps = 20 if headline else 8
+    if args.warmup is None:
+        args.warmup = 10 if headline else 3
+    if args.batch is None:
+        args.batch = cfg['batch']
+    if args.layers is None:
+        args.layers = cfg['layers']
+    if args.only or args.rehearse_cpu:
         args.no_baselines = args.no_block = args.no_attention = args.no_cpu = args.no_graph = True
+    if not headline:
+        # the block / attention / graph / CPU records describe the headline workload
+        # (tools/bench_block.py, tools/bench_long.py measure them at the other dimensions)
+        args.no_block = args.no_attention = args.no_cpu = args.no_graph = True
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, 'launch {} ranks for --gpus {}'.format(args.gpus, args.gpus)
-    if args.one_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    assert world == args.gpus, 'WORLD_SIZE={} but --gpus {}'.format(world, args.gpus)
+    if args.rehearse_cpu:
+        CPU_REHEARSAL = True
+        args.backend = 'gloo'
+        args.no_gemm_events = True
+        dev = torch.device('cpu')
+    else:
+        if args.one_device:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(args.backend)
+
+    if args.rehearse_cpu:
+        rec = model_record('full', args, world, rank, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({
+                'rehearsal': 'CPU tensors over gloo, DENSE model: launcher and data-parallel '
+                             'plumbing only, NOT a measurement of the sparse path',
+                'metric': 'fine-tune tokens/sec', 'value': rec['value'], 'unit': 'tokens/s',
+                'n_gpus': 0, 'ranks': world, 'backend': 'gloo', 'steps': args.steps,
+                'warmup': args.warmup, 'ms_per_step': rec['ms_per_step'],
+                'config': {'workload': WORKLOAD, 'n_layers': args.layers, 'seq_len': S,
+                           'micro_batch_per_gpu': args.batch},
+                'clip_norm_equal_on_all_ranks': rec.get('clip_norm_equal_on_all_ranks')}))
+        return
 
     from naive_gpt import ext
     ext.load_library()        # fail loudly when the HIP library is missing
@@ -607,16 +764,17 @@ def main():
 
     N = args.batch
     result = {
-        'metric': 'fine-tune tokens/sec + peak HBM GB, BERT-large seq=512',
+        'metric': 'fine-tune tokens/sec + peak HBM GB, BERT-large seq=512' if headline else
+                  'fine-tune tokens/sec + peak HBM GB, {} dims seq={}'.format(args.config, S),
         'value': sparse['value'], 'unit': 'tokens/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': sparse['ms_per_step'],
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {
-            'workload': 'BASELINE.json configs[2]: BERT-large sparse-MHA + routed-FFN full '
-                        'fine-tune step (SparseTuner.training_step: PQ triggers armed, fwd, CE + '
+            'workload': WORKLOAD + ' (SparseTuner.training_step: PQ triggers armed, fwd, CE + '
                         '1e-2 PQ loss, bwd, gradient all-reduce, clip 1.0, AdamW), {} layers, '
                         'four-stage upgraded, random init'.format(args.layers),
+            'name': args.config, 'family': FAMILY,
             'd_model': D_MODEL, 'n_heads': H, 'd_head': E, 'd_ff': D_FF, 'n_layers': args.layers,
             'vocab': VOCAB, 'seq_len': S, 'micro_batch_per_gpu': N, 'global_batch': N * world,
             'nnz_per_row': Z, 'pq': [M, C, D], 'ffn_blocks': 4, 'ffn_top_k': 2, 'd_lora': 16,
@@ -643,13 +801,20 @@ def main():
         result['roofline'] = {
             'kernel': 'spt::grouped_gemm_kernel (routed-FFN block GEMMs + every frozen LoRA '
                       'linear of the step)',
-            'bound': 'mfma', 'achieved': gemm['executed_TFLOPs'], 'peak': MFMA_BF16_PEAK_TF,
-            'unit': 'TFLOP/s', 'frac': gemm['executed_TFLOPs'] / MFMA_BF16_PEAK_TF,
+            'bound': 'mfma', 'achieved': gemm['algorithmic_TFLOPs'], 'peak': MFMA_BF16_PEAK_TF,
+            'unit': 'TFLOP/s', 'frac': gemm['algorithmic_TFLOPs'] / MFMA_BF16_PEAK_TF,
+            'frac_algorithmic': gemm['algorithmic_TFLOPs'] / MFMA_BF16_PEAK_TF,
+            'executed_TFLOPs': gemm['executed_TFLOPs'],
+            'frac_executed': gemm['executed_TFLOPs'] / MFMA_BF16_PEAK_TF,
+            'frac_of_fp32_mfma_peak': gemm['algorithmic_TFLOPs'] / MFMA_FP32_PEAK_TF,
             'traffic': measured_traffic('spt::grouped_gemm'),
-            'what': 'achieved = bf16 MFMA flops executed (3 per fp32 product) / HIP-event time of '
-                    'every 7th launch inside the timed steps (the split passes that feed the '
-                    'image path are separate launches, not counted here); '
-                    'algorithmic = 2 * rows * n * (k + r) per launch',
+            'traffic_source': 'bytes per launch from the committed PMC passes ({}), NOT measured in '
+                              'this run'.format(traffic_file() or 'none committed'),
+            'what': 'achieved / frac = ALGORITHMIC fp32 flops, 2 * rows * n * (k + r) per launch, / '
+                    'HIP-event time of every 7th launch inside the timed steps, against the dense '
+                    'bf16 MFMA peak; executed = the bf16 MFMA flops the kernel issues for them (3 '
+                    'per fp32 product, hi/lo split) = matrix-pipe utilisation (the split passes '
+                    'that feed the image path are separate launches, not counted here)',
             'algorithmic_TFLOPs': gemm['algorithmic_TFLOPs'],
             'flops_per_launch': gemm['flops_per_launch'], 'avg_us': gemm['avg_us'],
             'calls_per_step': per_step, 'ms_per_step': gemm['total_ms'] / args.steps,

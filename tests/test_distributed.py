@@ -221,3 +221,48 @@ def test_broadcast_of_an_armed_trigger_is_seen_by_every_rank(tmp_path):
     for r in range(world):
         got = torch.load(out.format(r), weights_only=True)
         assert got == {'first': False, 'armed': True, 'again': False}, (r, got)
+
+
+# ------------------------------------------------------------------ bench.py starts its own ranks
+
+def _run_bench(*argv, env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full_env = {k: v for k, v in os.environ.items()
+                if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    full_env.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + list(argv),
+                          env=full_env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (the way the driver starts N = 1): the
+    parent starts two child ranks before touching any device, rank 0's ONE JSON line comes back on
+    the parent's stdout and says two ranks exchanged gradients.  CPU tensors over gloo on the dense
+    tiny model -- the launcher and the DP plumbing, not the sparse kernels."""
+    import json
+    res = _run_bench('--gpus', '2', '--rehearse-cpu', '--config', 'tiny-rehearsal',
+                     '--steps', '2', '--warmup', '1')
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line['ranks'] == 2 and line['backend'] == 'gloo' and line['steps'] == 2
+    assert line['clip_norm_equal_on_all_ranks'] is True
+    assert 'rehearsal' in line and line['n_gpus'] == 0      # can never be read as a measurement
+
+
+def test_bench_launcher_returns_a_failing_ranks_code():
+    """A rank that dies takes the others down with it and the parent exits non-zero (no hang in a
+    collective, no JSON line)."""
+    res = _run_bench('--gpus', '2', '--rehearse-cpu', '--config', 'tiny-rehearsal',
+                     '--steps', '1', '--warmup', '0', '--batch', '-1')
+    assert res.returncode != 0
+    assert not [l for l in res.stdout.splitlines() if l.startswith('{')]
+
+
+def test_bench_under_a_launcher_still_checks_the_world_size():
+    res = _run_bench('--gpus', '2', '--rehearse-cpu', '--config', 'tiny-rehearsal',
+                     env={'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert res.returncode != 0 and 'WORLD_SIZE=1 but --gpus 2' in res.stderr
