@@ -264,6 +264,11 @@ def model_record(tuning, args, world, rank, dev, gemm_timer=None):
         torch.cuda.reset_peak_memory_stats()
     model = build_model(tuning, dev, args.layers)
     tuner = utils.SparseTuner(model)
+    if not CPU_REHEARSAL:
+        # the peak is that of the STEPS on top of the resident model, not of the model's
+        # construction (the upgrader's transient copies: 14 GB at the LLaMA-7B dimensions)
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
     N = args.batch
 
