@@ -43,7 +43,7 @@ extern "C" {
 #define SPT_EUNSUP (-3)   /* combination the kernels do not implement */
 
 /* ABI version; bump on any signature change. */
-#define SPT_ABI_VERSION 38
+#define SPT_ABI_VERSION 39
 int spt_abi_version(void);
 const char *spt_strerror(int code);
 
@@ -303,9 +303,20 @@ int spt_sparse_attention_backward_rows(const int32_t *indices, const float *grad
  *   s_p        = clamp(scale * q[i].k[col_p]),  entries with col_p > i take no part
  *   row_sum[i] = sum_p exp(s_p)                 (softmax.cu:17-30)
  * Any uniform-row CSR with Z = nnz / S <= 256, Z % 4 == 0, d_head 64 or 128, S <= 2048;
- * repeated columns count with their multiplicity, which saturates at 255 (reachable only
- * with Z == 256: row 0 of a lookup pattern, where it changes nothing).  SPT_EUNSUP otherwise.
+ * repeated columns count with their exact multiplicity (a row that holds ONE column Z = 256
+ * times -- row 0 of a lookup pattern -- is kept as a byte count of 255 plus a per-row flag in
+ * `tiles`; ABI 39: its row_sum is exact, no longer 255 / 256 of it).  SPT_EUNSUP otherwise.
  * Layouts of q, k, v (heads) and y (y_transposed) as in spt_sparse_attention_forward.
+ *
+ * ABI 39, `bounds`: the clamp of attention.py:125-127 passes gradient only inside (-clamp, clamp),
+ * a DISCONTINUOUS function of the score, and a score formed from split operands can land on the
+ * other side of the clamp than the fp32 score.  The forward therefore leaves slice-wide bounds on
+ * the row norms of q and k in `bounds` (spt_attention_mfma_bounds_floats(batch) floats, device
+ * memory, no initialisation needed), with which the backward finds the cells whose score lies
+ * within the split's error of +-clamp and recomputes those exactly (fp64 dot, rounded to fp32,
+ * times scale: the oracle's arithmetic, oracle/spt_oracle.c sddmm) -- the gradient mask is then
+ * that of the fp32 scores.  `bounds` may be NULL in either call: the forward then skips the
+ * norms and the backward decides the mask on its split-bf16 scores as before ABI 39.
  */
 int spt_attention_mfma_supported(int seq_length, int d_head, int nnz);
 /*
@@ -326,10 +337,11 @@ enum { SPT_TILES_FULL = 0, SPT_TILES_COMPACT = 1 };
 int64_t spt_attention_mfma_tiles_bytes(int batch_size, int seq_length, int nnz, int layout);
 int spt_attention_mfma_prepare(const int32_t *indices, void *tiles, int batch_size,
                                int seq_length, int nnz, int layout, void *stream);
+int spt_attention_mfma_bounds_floats(int batch_size);
 int spt_attention_mfma_forward(const void *tiles, int layout, const float *q, const float *k,
-                               const float *v, float *y, float *row_sum, int batch_size,
-                               int seq_length, int d_head, int nnz, float scale, float clamp,
-                               int heads, int y_transposed, void *stream);
+                               const float *v, float *y, float *row_sum, float *bounds,
+                               int batch_size, int seq_length, int d_head, int nnz, float scale,
+                               float clamp, int heads, int y_transposed, void *stream);
 
 /*
  * The whole backward of spt_attention_mfma_forward: two launches, nothing of size nnz.
@@ -338,15 +350,16 @@ int spt_attention_mfma_forward(const void *tiles, int layout, const float *q, co
  *   grad_q[i] = sum_p dS_p k[col_p];  grad_k[j] = sum_{p: col_p = j} dS_p q[row_p];
  *   grad_v[j] = sum_{p: col_p = j} P_p grad_y[row_p]
  * y, grad_y: [batch, S, E], or with transposed != 0 both [batch, E, S] (S % 4 == 0).
- * q, k, v and the three gradients follow `heads` as in the forward.  row_sum is the forward's
- * output; delta [batch, S] is scratch that the first launch fills for the second.
+ * q, k, v and the three gradients follow `heads` as in the forward.  row_sum and bounds are the
+ * forward's outputs for the same q, k (bounds may be NULL, see above); delta [batch, S] is
+ * scratch that the first launch fills for the second.
  */
 int spt_attention_mfma_backward(const void *tiles, int layout, const float *q, const float *k,
                                 const float *v, const float *y, const float *grad_y,
-                                const float *row_sum, float *delta, float *grad_q,
-                                float *grad_k, float *grad_v, int batch_size, int seq_length,
-                                int d_head, int nnz, float scale, float clamp, int heads,
-                                int transposed, void *stream);
+                                const float *row_sum, const float *bounds, float *delta,
+                                float *grad_q, float *grad_k, float *grad_v, int batch_size,
+                                int seq_length, int d_head, int nnz, float scale, float clamp,
+                                int heads, int transposed, void *stream);
 
 /*
  * bf16 STORAGE variants (BASELINE configs[1] "bf16"; no reference counterpart -- the reference is
@@ -359,12 +372,13 @@ int spt_attention_mfma_backward(const void *tiles, int layout, const float *q, c
  */
 int spt_attention_mfma_forward_bf16(const void *tiles, int layout, const uint16_t *q,
                                     const uint16_t *k, const uint16_t *v, uint16_t *y,
-                                    float *row_sum, int batch_size, int seq_length, int d_head,
-                                    int nnz, float scale, float clamp, int heads,
+                                    float *row_sum, float *bounds, int batch_size, int seq_length,
+                                    int d_head, int nnz, float scale, float clamp, int heads,
                                     int y_transposed, void *stream);
 int spt_attention_mfma_backward_bf16(const void *tiles, int layout, const uint16_t *q,
                                      const uint16_t *k, const uint16_t *v, const uint16_t *y,
-                                     const uint16_t *grad_y, const float *row_sum, float *delta,
+                                     const uint16_t *grad_y, const float *row_sum,
+                                     const float *bounds, float *delta,
                                      uint16_t *grad_q, uint16_t *grad_k, uint16_t *grad_v,
                                      int batch_size, int seq_length, int d_head, int nnz,
                                      float scale, float clamp, int heads, int transposed,

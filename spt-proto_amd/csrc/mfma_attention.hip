@@ -124,6 +124,16 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// The lane id, from an instruction the compiler will not move.  For the kernels' RARE branches:
+// whatever such a branch derives from the ordinary `lane` is loop-invariant, gets hoisted out of
+// the tile loop, and then occupies registers (or scratch) for the whole kernel -- 16 hoisted shift
+// counts of the saturation fix were spilled in the prologue of the key-owned backward.
+__device__ __forceinline__ int rare_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // accumulator register r of lane half h holds tile row  (r & 3) + 8 (r >> 2) + 4 h
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -217,6 +227,16 @@ struct TileStager {
             put_rows4(buf + MA_KH, jl + MA_RPP * u, e4, r.kf[u]);
             put_rows4(buf + MA_VH, jl + MA_RPP * u, e4, r.vf[u]);
         }
+    }
+    // max over this thread's K rows of the tile of the sum of squares of its four columns
+    __device__ __forceinline__ float k_share(const TileRegs<T> &r) const {
+        float best = 0.f;
+#pragma unroll
+        for (int u = 0; u < MA_RPT; u++) {
+            const float4 x = Elem<T>::f4(r.kf[u]);
+            best = fmaxf(best, fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, x.w * x.w))));
+        }
+        return best;
     }
 };
 
@@ -384,9 +404,11 @@ __device__ __forceinline__ void load_own_rows_transposed(float (&x)[MA_E / 2], c
 // rather than counted a second time).  (A first
 // version bucketed the entries by key tile with a counting sort before counting: 33 us at
 // the bench shape, latency-bound on its LDS read-modify-write chains and wave scans.)
-// A byte saturates at 255: only Z >= 256 can reach it (row 0 of a lookup pattern, whose Z
-// entries are all column 0, and there any multiplicity >= 1 gives the same result); then the
-// add that would carry into the neighbouring key is taken back.
+// A byte saturates at 255: only Z = 256 can reach it, in a row whose 256 entries are ONE column
+// (row 0 of a lookup pattern: column 0, 256 times); then the add that would carry into the
+// neighbouring key is taken back and the row's bit is set in the row tile's word of `sat`
+//   sat [batch][RT] uint32: bit r set <=> row 32 rt + r holds ONE live cell, of multiplicity 256,
+//     stored as 255 -- the consumers add the 1 back (round 4: row_sum of such a row is exact).
 constexpr int MB_WAVES = 4;
 constexpr int MB_CHUNK = 8;                          // key tiles per pass over the entries
 constexpr int MB_CNT_WORDS = MB_CHUNK * MA_WROWS * MA_CLD;     // one orientation: 2304 words
@@ -400,8 +422,8 @@ template <bool SATURATE>
 __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kernel(
     const int32_t *__restrict__ indices, unsigned long long *__restrict__ masks,
     unsigned char *__restrict__ cells, unsigned char *__restrict__ cells_t,
-    unsigned char *__restrict__ pool, unsigned char *__restrict__ pool_t, int S, int Z, int NT,
-    int RT, int n_tiles_total) {
+    unsigned char *__restrict__ pool, unsigned char *__restrict__ pool_t,
+    unsigned *__restrict__ sat, int S, int Z, int NT, int RT, int n_tiles_total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -409,6 +431,7 @@ __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kern
     if (gw >= n_tiles_total) return;                    // no workgroup barrier below
     const int b = gw / RT, rt = gw - b * RT, i0 = rt * MA_WROWS;
     unsigned *cnt = reinterpret_cast<unsigned *>(smem + wave * prepare_lds_per_wave());
+    unsigned satrows = 0;                               // (per lane; OR-reduced at the end)
 
     // the tile's rows are one contiguous run of 32 * Z ints (Z % 4 == 0)
     const int nrows = min(MA_WROWS, S - i0);
@@ -421,12 +444,15 @@ __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kern
     const int nbuckets = min(NT, rt + 1);               // live entries have col <= row
     unsigned long long mask = 0, multi = 0;
 
-    auto count = [&](unsigned *word, unsigned sh) {
+    auto count = [&](unsigned *word, unsigned sh, int rl) {
         if (!SATURATE) {
             atomicAdd(word, 1u << sh);
         } else {
             const unsigned old = atomicAdd(word, 1u << sh);
-            if (((old >> sh) & 0xffu) == 0xffu) atomicSub(word, 1u << sh);
+            if (((old >> sh) & 0xffu) == 0xffu) {       // the row's 256th copy of this column
+                atomicSub(word, 1u << sh);
+                satrows |= 1u << rl;
+            }
         }
     };
     for (int t0 = 0; t0 < nbuckets; t0 += MB_CHUNK) {
@@ -444,7 +470,7 @@ __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kern
                 const int tl = (c[q] >> 5) - t0;
                 if (c[q] >= 0 && c[q] <= i0 + rl && c[q] < S && tl >= 0 && tl < MB_CHUNK) {
                     const unsigned jl = c[q] & 31;
-                    count(&cnt[(tl * MA_WROWS + rl) * MA_CLD + (jl >> 2)], 8 * (jl & 3));
+                    count(&cnt[(tl * MA_WROWS + rl) * MA_CLD + (jl >> 2)], 8 * (jl & 3), rl);
                 }
             }
         }
@@ -509,9 +535,12 @@ __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_tiles_kern
         }
         wave_lds_fence();
     }
+#pragma unroll
+    for (int off = 1; off < SPT_WAVE; off <<= 1) satrows |= (unsigned)__shfl_xor((int)satrows, off, SPT_WAVE);
     if (lane == 0) {
         masks[2 * (size_t)gw] = mask;
         masks[2 * (size_t)gw + 1] = multi;
+        sat[gw] = satrows;
     }
 }
 
@@ -530,8 +559,8 @@ __host__ __device__ __forceinline__ size_t cell_bits_lds_per_wave(int NT) {
 __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_bits_kernel(
     const int32_t *__restrict__ indices, unsigned long long *__restrict__ masks,
     unsigned char *__restrict__ cells, unsigned char *__restrict__ cells_t,
-    unsigned char *__restrict__ pool, unsigned char *__restrict__ pool_t, int S, int Z, int NT,
-    int RT, int n_tiles_total) {
+    unsigned char *__restrict__ pool, unsigned char *__restrict__ pool_t,
+    unsigned *__restrict__ sat, int S, int Z, int NT, int RT, int n_tiles_total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -587,21 +616,25 @@ __global__ __launch_bounds__(MB_WAVES * SPT_WAVE) void attention_cell_bits_kerne
     {
         // lane (c, h): its 16 counts of row c (keys 8 g + 4 h + u), saturated to a byte
         unsigned mine[4], tr[4];
-        bool big = false;
+        bool big = false, full = false;                 // full: row c holds a column 256 times
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             unsigned wm = 0, wt = 0;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const unsigned a = min(cnt0[c32 * 32 + 8 * g + 4 * h + u], 255u);          // row c, key ..
+                const unsigned raw = cnt0[c32 * 32 + 8 * g + 4 * h + u];                   // row c, key ..
+                const unsigned a = min(raw, 255u);
                 const unsigned t2 = min(cnt0[(8 * g + 4 * h + u) * 32 + c32], 255u);        // key c, row ..
                 wm |= a << (8 * u);
                 wt |= t2 << (8 * u);
                 big |= a > 1u;
+                full |= raw > 255u;
             }
             mine[g] = wm;
             tr[g] = wt;
         }
+        const unsigned long long fb = __ballot(full);   // (the two lane halves hold disjoint keys)
+        if (lane == 0) sat[gw] = (unsigned)fb | (unsigned)(fb >> 32);
         const bool any = (mine[0] | mine[1] | mine[2] | mine[3]) != 0u;
         if (__ballot(any) != 0ull) {
             mask |= 1ull;
@@ -668,15 +701,17 @@ __device__ __forceinline__ uint4 cell_words(const uint4 &v, bool multi, int lane
 // a consumer wave's view of its row tile's cell tiles
 struct CellTiles {
     unsigned long long mask, multi;
+    unsigned satrows;         // rows of this row tile whose one live cell holds 256 (stored 255)
     int last;                 // the row tile's own index = its last stored key tile
     int stride;               // uint4 per slot
     const uint4 *base;        // tile t of this row tile: base[t * stride + ...]
     const uint4 *pooled;      // compact layout: the byte form of key tile 0, else nullptr
     __device__ __forceinline__ CellTiles(const unsigned long long *masks,
                                          const unsigned char *cells, const unsigned char *pool,
-                                         int b, int RT, int rt, bool have) {
+                                         const unsigned *sat, int b, int RT, int rt, bool have) {
         mask = have ? masks[2 * ((size_t)b * RT + rt)] : 0ull;
         multi = have ? masks[2 * ((size_t)b * RT + rt) + 1] : 0ull;
+        satrows = have ? sat[(size_t)b * RT + rt] : 0u;
         last = have ? rt : 0;
         stride = cell_slot_bytes(pool) / 16;
         base = reinterpret_cast<const uint4 *>(
@@ -698,7 +733,38 @@ struct CellTiles {
     __device__ __forceinline__ uint4 words(const uint4 &v, int t, int lane) const {
         return cell_words(v, is_multi(min(t, last)), lane);
     }
+    // does tile t hold a cell whose stored 255 stands for 256?  (wave-uniform; false but for row 0
+    // of a Z = 256 lookup pattern)
+    __device__ __forceinline__ bool saturated(int t) const { return satrows != 0u && is_multi(min(t, last)); }
 };
+// byte u of a cell word as float (v_cvt_f32_ubyte<u>)
+template <int U>
+__device__ __forceinline__ float cell_count(unsigned word) {
+    return (float)((word >> (8 * U)) & 0xffu);
+}
+// the 16 multiplicities of a lane as floats; `fix`: the lane's cells of count 255 stand for 256
+// where the bit of their row is set (D[key, row] layout: every cell of the lane is row lane & 31;
+// D[row, key]: register 4 g + u is row 8 g + 4 h + u)
+template <bool ROW_PER_LANE>
+__device__ __forceinline__ void cell_counts(float (&m)[16], const uint4 &w4, bool fix, unsigned satrows,
+                                            int lane) {
+    const unsigned mw[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        m[4 * g + 0] = cell_count<0>(mw[g]);
+        m[4 * g + 1] = cell_count<1>(mw[g]);
+        m[4 * g + 2] = cell_count<2>(mw[g]);
+        m[4 * g + 3] = cell_count<3>(mw[g]);
+    }
+    if (fix) {                                          // (wave-uniform, rare)
+        const int rl = rare_lane();
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = ROW_PER_LANE ? (rl & 31) : 8 * (r >> 2) + 4 * (rl >> 5) + (r & 3);
+            if (m[r] == 255.0f && ((satrows >> row) & 1u)) m[r] = 256.0f;
+        }
+    }
+}
 
 // Row tile rt costs rt + 1 key tiles, so contiguous 256-row blocks would give the workgroups
 // of a slice 36 : 100 of the work at S = 512 and, two to a CU, idle CUs at the end.  Folded
@@ -729,11 +795,124 @@ struct ScoreMap {
     // the clamp passes gradient strictly inside (-clamp, clamp) (attention.py:125-127 through
     // spt_softmax_backward_clamped: |clamped| < clamp)
     __device__ __forceinline__ bool inside(float d) const { return fabsf(d) < bound; }
+    // the largest value `inside` accepts
+    __device__ __forceinline__ float bound_in() const {
+        return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, bound) - 1u);
+    }
 };
-// byte u of a cell word as float (v_cvt_f32_ubyte<u>)
-template <int U>
-__device__ __forceinline__ float cell_count(unsigned word) {
-    return (float)((word >> (8 * U)) & 0xffu);
+
+// ---- the clamp's gradient mask, decided on the EXACT score (round 4) ----
+// `v = clamp(scale * sddmm, -10, 10)` (attention.py:125-127) passes gradient only inside the clamp.
+// That mask is a discontinuous function of the score, and a score formed from split-bf16 operands
+// carries an error of up to
+//     (3 * 2^-18 [the lo * lo term and the rounding of the lo parts] + 3 E * 2^-24 [fp32 accumulation
+//     of the 3 E products, worst case]) * sum_e |q_e k_e|  <=  MA_SPLIT_ERR * |q| |k|
+// so a cell that close to +-clamp can land on the other side of it than the reference's fp32 score
+// (measured before this: 7e-3 of grad_q on a layer with 15 % of its scores on the clamp).  The
+// backward kernels therefore recompute such cells -- |d| within eps of the bound, eps from the norm of
+// the lane's own row and the slice-wide bound on the streamed operand's row norms that the forward
+// left in `bounds` -- as the oracle does: an fp64 dot in ascending e, rounded to fp32, times scale in
+// fp32, compared with the clamp.  A tile value on the wrong side is then moved onto the bound or just
+// inside it, which `exp_of` and `inside` turn into the exact mask (the value changes by less than its
+// own error; moving every recomputed cell to the bound changed probabilities by up to eps = 0.5 %).
+// Cost on the common path: one max over the lane's 16 |d| and a ballot per tile; the recomputation
+// sits behind a wave-uniform branch (about 1e-4 of the live cells of a layer with scores of
+// standard deviation 10, none at all while the scores are O(1)).
+constexpr float MA_SPLIT_ERR = (1.0f + 3.0f * MA_E / 256.0f) * 1.52587890625e-5f;
+// bounds [batch][MA_BOUND_SLOTS][2] floats, written by the forward's workgroup g of a slice:
+// [0] max over its rows of |q_i|^2, [1] an upper bound of max |k_j|^2 over the keys it staged
+constexpr int MA_BOUND_SLOTS = 8;                   // workgroups per slice: S <= 2048
+struct ClampGuard {
+    float thr;                 // a lane whose max |d| reaches thr = bound - eps calls for the recomputation
+    // own2: |own row|^2 of this lane (unscaled operand); which: 1 = the streamed operand is K, 0 = Q
+    __device__ __forceinline__ ClampGuard(const float *bounds, int b, int nslots, int which, float own2,
+                                          const ScoreMap &sm, float clampv) {
+        thr = __builtin_inff();
+        if (bounds != nullptr && clampv > 0.0f) {
+            float other2 = 0.0f;
+            for (int g = 0; g < nslots; g++)
+                other2 = fmaxf(other2, bounds[((size_t)b * MA_BOUND_SLOTS + g) * 2 + which]);
+            // the WAVE's largest own row: one threshold per wave, held in a scalar register
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) own2 = fmaxf(own2, __shfl_xor(own2, off, SPT_WAVE));
+            thr = sm.bound - MA_SPLIT_ERR * sqrtf(own2 * other2) * sm.sl2;
+            thr = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, thr)));
+        }
+    }
+    __device__ __forceinline__ bool wanted(const f32x16 &d) const {
+#ifdef MA_NO_CLAMP_GUARD                                // (A/B builds: what the check costs)
+        return false;
+#endif
+        float am = fmaxf(fabsf(d[0]), fabsf(d[1]));
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) am = fmaxf(am, fmaxf(fabsf(d[r]), fabsf(d[r + 1])));
+        return __ballot(am >= thr) != 0ull;
+    }
+};
+// extension/sddmm.cpp:27-69 as the oracle restates it: sum in fp64, e ascending, rounded once
+template <typename T>
+__device__ __forceinline__ float exact_dot(const T *a, const T *b) {
+    double acc = 0.0;
+#pragma unroll 1
+    for (int e = 0; e < MA_E; e += 4) {
+        const float4 x = ld4(a + e), y = ld4(b + e);
+        acc = fma((double)x.x, (double)y.x, acc);
+        acc = fma((double)x.y, (double)y.y, acc);
+        acc = fma((double)x.z, (double)y.z, acc);
+        acc = fma((double)x.w, (double)y.w, acc);
+    }
+    return (float)acc;
+}
+// d: the lane's 16 cells (own row x tile rows acc_row(r, h)); cw: their multiplicities as the
+// four count words (byte form); dp: the tile's second product, which has nothing to do with the
+// mask but is live here.  At the call sites the kernels hold 190-250 registers; this loop inlined
+// beside them raised the allocation past 256 (spills inside the tile loop), as a non-inlined call
+// the allocator kept the K / V fragments in scratch for the whole kernel, and in FRONT of the second
+// product (where 16-32 registers fewer are live) the branch serialised the two MFMA chains: 205
+// against 193 us for the backward pair.  So d and dp are parked in a wave-private LDS block for the
+// duration of the loop -- a hand-placed spill, paid only inside the rare branch.
+constexpr int MA_PARK = 32 * SPT_WAVE * 4;          // bytes per wave: d and dp, [register][lane]
+// own: the own operand's slice base (rows of `ld` elements), own_row0: the wave's first own row
+// (lane & 31 is added here); tile_rows: the streamed operand's tile; park0: the parking blocks'
+// base (the wave's block is chosen here).  Everything lane-dependent is derived from rare_lane().
+template <typename T>
+__device__ __forceinline__ void clamp_exact(f32x16 &d, f32x16 &dp, char *park0, int wave, const uint4 &cw,
+                                            float bound, float thr, const T *own, int own_row0, int S,
+                                            const T *tile_rows, int ld, float scale, float clampv) {
+    const unsigned w[4] = {cw.x, cw.y, cw.z, cw.w};
+    const float eps = bound - thr;
+    unsigned near = 0, in = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        if (((w[r >> 2] >> (8 * (r & 3))) & 0xffu) != 0u && fabsf(fabsf(d[r]) - bound) <= eps)
+            near |= 1u << r;
+    if (__ballot(near != 0u) == 0ull) return;       // close to the clamp, but no live cell is
+    const int lane = rare_lane();
+    float *park = reinterpret_cast<float *>(park0 + wave * MA_PARK) + lane;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        park[r * SPT_WAVE] = d[r];
+        park[(16 + r) * SPT_WAVE] = dp[r];
+    }
+    asm volatile("" ::: "memory");                  // (no store-to-load forwarding past the loop)
+    const T *own_row = own + (size_t)min(own_row0 + (lane & 31), S - 1) * ld;
+    for (unsigned rem = near; rem != 0u; rem &= rem - 1u) {
+        const int r = __builtin_ctz(rem);
+        const float sc = exact_dot(own_row, tile_rows + (size_t)acc_row(r, lane >> 5) * ld) * scale;
+        if (fabsf(sc) < clampv) in |= 1u << r;
+    }
+    asm volatile("" ::: "memory");
+    const float bound_in = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, bound) - 1u);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        // the tile value moves only where it sits on the wrong side, and then by less than its own
+        // error (onto the bound, or to the largest value inside it)
+        float v = park[r * SPT_WAVE];
+        const bool is_in = (in >> r) & 1u;
+        if (((near >> r) & 1u) && is_in != (fabsf(v) < bound)) v = copysignf(is_in ? bound_in : bound, v);
+        d[r] = v;
+        dp[r] = park[(16 + r) * SPT_WAVE];
+    }
 }
 
 // two workgroups per CU (4 waves per SIMD, 128 VGPRs): the barrier keeps the waves of one
@@ -758,14 +937,14 @@ __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_WAVES_PER_EU, MA_WAVES_PER_EU)))
 void attention_mfma_forward_kernel(
     const unsigned long long *__restrict__ masks, const unsigned char *__restrict__ cells,
-    const unsigned char *__restrict__ pool,
+    const unsigned char *__restrict__ pool, const unsigned *__restrict__ sat,
     const T *__restrict__ q, const T *__restrict__ k, const T *__restrict__ v,
-    T *__restrict__ y, float *__restrict__ row_sum, int S, float scale, float clampv,
-    int heads, int blocks_per_batch) {
+    T *__restrict__ y, float *__restrict__ row_sum, float *__restrict__ bounds, int S, float scale,
+    float clampv, int heads, int blocks_per_batch) {
     constexpr int PI = Elem<T>::PARTS;                  // parts of the K / V images
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *img = smem;                                   // [2][MA_IMG]
-    float *stat = reinterpret_cast<float *>(smem + 2 * MA_IMG);   // [waves][32]
+    float *stat = reinterpret_cast<float *>(smem + 2 * MA_IMG);   // [waves][32] | [waves][2]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c32 = lane & 31;
@@ -776,7 +955,7 @@ void attention_mfma_forward_kernel(
     const int RT = (S + MA_WROWS - 1) / MA_WROWS;
     const T *k_b = k + dv.base, *v_b = v + dv.base;
 
-    const CellTiles ct(masks, cells, pool, b, RT, i0 / MA_WROWS, i0 < S);
+    const CellTiles ct(masks, cells, pool, sat, b, RT, i0 / MA_WROWS, i0 < S);
     // tiles any row of this workgroup can see: keys <= its last row (that of wave 7)
     const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch, MA_WAVES - 1);
     const int T_ = min(RT, last_tile + 1);
@@ -786,10 +965,20 @@ void attention_mfma_forward_kernel(
     TileRegs<T> nxt = stager.load(0);
     uint4 mcur = ct.load(0, lane), mnxt;
     Frag qf[MA_KS];
+    // for the backward's exact clamp mask (ClampGuard): |q_i|^2 of the own row, and the running
+    // maximum of THIS thread's share of |k_j|^2 -- the four columns it stages, over all the rows it
+    // stages; summed over the column groups at the end that bounds every staged key's |k_j|^2
+    // (max_j sum_g <= sum_g max_j) without a cross-lane sum per tile
+    float q2 = 0.f, k2part = 0.f;
     {
         float xq[MA_E / 2];
         load_own_rows_raw(xq, q + dv.base, dv.ld, S, i0, lane);
         stager.store(img, nxt);
+        if (bounds) {
+            k2part = stager.k_share(nxt);
+#pragma unroll
+            for (int x = 0; x < MA_E / 2; x++) q2 = fmaf(xq[x], xq[x], q2);
+        }
         split_own_rows(qf, xq, sm.sl2);
     }
     __syncthreads();
@@ -815,15 +1004,12 @@ void attention_mfma_forward_kernel(
                 d = mm<PI, 2>(read_rows<PI>(buf + MA_KH, buf + MA_KL, lane, ks), qf[ks], d);
             // cells: this lane holds row i0 + c32, keys 32t + acc_row(r, h); byte 4g + u of
             // the cell word is the multiplicity of register 4g + u
-            const uint4 mm4 = ct.words(mcur, t, lane);
-            const unsigned mw[4] = {mm4.x, mm4.y, mm4.z, mm4.w};
             float p[16];
+            cell_counts<true>(p, ct.words(mcur, t, lane), ct.saturated(t), ct.satrows, lane);
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                p[4 * g + 0] = cell_count<0>(mw[g]) * sm.exp_of(d[4 * g + 0]);
-                p[4 * g + 1] = cell_count<1>(mw[g]) * sm.exp_of(d[4 * g + 1]);
-                p[4 * g + 2] = cell_count<2>(mw[g]) * sm.exp_of(d[4 * g + 2]);
-                p[4 * g + 3] = cell_count<3>(mw[g]) * sm.exp_of(d[4 * g + 3]);
+#pragma unroll
+                for (int u = 0; u < 4; u++) p[4 * g + u] *= sm.exp_of(d[4 * g + u]);
                 rs += (p[4 * g] + p[4 * g + 1]) + (p[4 * g + 2] + p[4 * g + 3]);
             }
 #pragma unroll
@@ -837,8 +1023,33 @@ void attention_mfma_forward_kernel(
             }
         }
         if (t + 1 < T_) stager.store(img + ((t + 1) & 1) * MA_IMG, nxt);
+        if (bounds) k2part = fmaxf(k2part, stager.k_share(nxt));
         mcur = mnxt;
         __syncthreads();
+    }
+
+    if (bounds) {                                       // (kernel argument: uniform)
+        // columns: lanes with equal tid % MA_EQ; rows: the other lane bits
+        float km = k2part;
+#pragma unroll
+        for (int off = MA_EQ; off < SPT_WAVE; off <<= 1) km = fmaxf(km, __shfl_xor(km, off, SPT_WAVE));
+#pragma unroll
+        for (int off = 1; off < MA_EQ; off <<= 1) km += __shfl_xor(km, off, SPT_WAVE);
+        float qm = q2 + __shfl_xor(q2, 32, SPT_WAVE);   // the two lane halves hold half a row each
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) qm = fmaxf(qm, __shfl_xor(qm, off, SPT_WAVE));
+        float *wb = stat + MA_WAVES * MA_WROWS;
+        if (lane == 0) {
+            wb[2 * wave] = qm;
+            wb[2 * wave + 1] = km;
+        }
+        __syncthreads();
+        if (tid < 2) {
+            float best = 0.f;
+#pragma unroll
+            for (int w = 0; w < MA_WAVES; w++) best = fmaxf(best, wb[2 * w + tid]);
+            bounds[((size_t)b * MA_BOUND_SLOTS + bid % blocks_per_batch) * 2 + tid] = best;
+        }
     }
 
     // ---- rows: 1 / max(1e-9, sum); the two lane halves hold disjoint keys of the same row ----
@@ -925,11 +1136,12 @@ __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_ROWS_WAVES_PER_EU, MA_ROWS_WAVES_PER_EU)))
 void attention_mfma_backward_rows_kernel(
     const unsigned long long *__restrict__ masks, const unsigned char *__restrict__ cells,
-    const unsigned char *__restrict__ pool,
+    const unsigned char *__restrict__ pool, const unsigned *__restrict__ sat,
     const T *__restrict__ q, const T *__restrict__ k, const T *__restrict__ v,
     const T *__restrict__ gy, const T *__restrict__ y,
-    const float *__restrict__ row_sum, T *__restrict__ grad_q, float *__restrict__ delta,
-    int S, float scale, float clampv, int heads, int blocks_per_batch, int half) {
+    const float *__restrict__ row_sum, const float *__restrict__ bounds, T *__restrict__ grad_q,
+    float *__restrict__ delta, int S, float scale, float clampv, int heads, int blocks_per_batch,
+    int half) {
     constexpr int PI = Elem<T>::PARTS;                  // parts of the K / V images
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *img = smem;                                   // [2][MA_IMG]
@@ -942,7 +1154,7 @@ void attention_mfma_backward_rows_kernel(
     const int RT = (S + MA_WROWS - 1) / MA_WROWS;
     const ScoreMap sm(scale, clampv);
     const int i0 = MA_WROWS * folded_row_tile(bid % blocks_per_batch, blocks_per_batch, wave);
-    const CellTiles ct(masks, cells, pool, b, RT, i0 / MA_WROWS, i0 < S);
+    const CellTiles ct(masks, cells, pool, sat, b, RT, i0 / MA_WROWS, i0 < S);
     const int last_tile = folded_row_tile(bid % blocks_per_batch, blocks_per_batch, MA_WAVES - 1);
     const int T_ = min(RT, last_tile + 1);
     const TileStager<T> stager(k + dv.base, v + dv.base, dv.ld, S, tid);
@@ -950,7 +1162,7 @@ void attention_mfma_backward_rows_kernel(
     uint4 mcur = ct.load(0, lane), mnxt;
     // own rows: dY (B operand of dP = V dY^T), delta = max(1e-9, dY . Y), Q (B operand of D)
     Frag gf[MA_KS], qf[MA_KS];
-    float delta_i;
+    float delta_i, q2 = 0.f;
     const int row = i0 + c32;
     const float rsum = row_sum[(size_t)b * S + min(row, S - 1)];
     {
@@ -981,7 +1193,13 @@ void attention_mfma_backward_rows_kernel(
         split_own_rows(qf, xq, sm.sl2);
         if (h == 0 && row < S && half == 0) delta[(size_t)b * S + row] = delta_i;
         delta_i *= pscale;
+        if (bounds) {
+#pragma unroll
+            for (int x = 0; x < MA_E / 2; x++) q2 = fmaf(xq[x], xq[x], q2);
+            q2 += __shfl_xor(q2, 32, SPT_WAVE);
+        }
     }
+    const ClampGuard cg(bounds, b, blocks_per_batch, 1, q2, sm, clampv);
     __syncthreads();
 
     f32x16 qacc[MR_QTILES];
@@ -1003,19 +1221,16 @@ void attention_mfma_backward_rows_kernel(
                 d = mm<PI, 2>(read_rows<PI>(buf + MA_KH, buf + MA_KL, lane, ks), qf[ks], d);
                 dp = mm<PI, 2>(read_rows<PI>(buf + MA_VH, buf + MA_VL, lane, ks), gf[ks], dp);
             }
-            const uint4 mm4 = ct.words(mcur, t, lane);
-            const unsigned mw[4] = {mm4.x, mm4.y, mm4.z, mm4.w};
+            const uint4 cw = ct.words(mcur, t, lane);
+            if (cg.wanted(d))                           // (wave-uniform, rare)
+                clamp_exact(d, dp, smem + 2 * MA_IMG, wave, cw, sm.bound, cg.thr, q + dv.base, i0, S,
+                            k + dv.base + (size_t)t * MA_KT * dv.ld, dv.ld, scale, clampv);
             float ds[16];
+            cell_counts<true>(ds, cw, ct.saturated(t), ct.satrows, lane);
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const float m4[4] = {cell_count<0>(mw[g]), cell_count<1>(mw[g]),
-                                     cell_count<2>(mw[g]), cell_count<3>(mw[g])};
-#pragma unroll
-                for (int x = 0; x < 4; x++) {
-                    const int r = 4 * g + x;
-                    const float pw = m4[x] * sm.exp_of(d[r]);
-                    ds[r] = sm.inside(d[r]) ? pw * (dp[r] - delta_i) : 0.0f;
-                }
+            for (int r = 0; r < 16; r++) {
+                const float pw = ds[r] * sm.exp_of(d[r]);
+                ds[r] = sm.inside(d[r]) ? pw * (dp[r] - delta_i) : 0.0f;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
@@ -1131,9 +1346,9 @@ __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_KEYS_WAVES_PER_EU, MA_KEYS_WAVES_PER_EU)))
 void attention_mfma_backward_keys_kernel(
     const unsigned long long *__restrict__ masks, const unsigned char *__restrict__ cells_t,
-    const unsigned char *__restrict__ pool_t,
+    const unsigned char *__restrict__ pool_t, const unsigned *__restrict__ sat,
     const T *__restrict__ q, const T *__restrict__ k, const T *__restrict__ v,
-    const T *__restrict__ gy, const float *__restrict__ row_sum,
+    const T *__restrict__ gy, const float *__restrict__ row_sum, const float *__restrict__ bounds,
     const float *__restrict__ delta, T *__restrict__ grad_k, T *__restrict__ grad_v,
     int S, float scale, float clampv, int heads, int blocks_per_batch, int half) {
     constexpr int PI = Elem<T>::PARTS;                  // parts of the Q image and of the V fragments
@@ -1154,9 +1369,15 @@ void attention_mfma_backward_keys_kernel(
     constexpr int NVT = MODE == 1 ? MA_ET : 2;           // 32-column tiles of grad_v produced
     const ScoreMap sm(scale, clampv);
     Frag kf[MA_KS], vf[WANT_K ? MA_KS : 1];
+    float k2 = 0.f;
     {
         float xk[MA_E / 2];
         load_own_rows_raw(xk, k + dv.base, dv.ld, S, j0, lane);
+        if (WANT_K && bounds) {
+#pragma unroll
+            for (int x = 0; x < MA_E / 2; x++) k2 = fmaf(xk[x], xk[x], k2);
+            k2 += __shfl_xor(k2, 32, SPT_WAVE);
+        }
         split_own_rows(kf, xk, sm.sl2);     // the score scale (log2 domain) folded into K
         if constexpr (WANT_K) {             // V only feeds dP, which only dS needs
             float xv[MA_E / 2];
@@ -1166,8 +1387,13 @@ void attention_mfma_backward_keys_kernel(
     }
     // the slice's row-tile masks live in registers (lane rt: mask of row tile rt), so that the
     // loop body has no load whose result it needs at once
+    // (grad_v needs P alone, which is continuous in the score: no exact mask for MODE 1)
+    const ClampGuard cg(WANT_K ? bounds : nullptr, b, blocks_per_batch, 0, k2, sm, clampv);
     const unsigned long long mask_reg = lane < RT ? masks[2 * ((size_t)b * RT + lane)] : 0ull;
     const unsigned long long multi_reg = lane < RT ? masks[2 * ((size_t)b * RT + lane) + 1] : 0ull;
+    // (does any row of the slice hold a column 256 times?  the row tile's word itself is read
+    // where it is needed: behind a branch that row 0 of a Z = 256 lookup pattern alone takes)
+    const bool any_sat = __ballot(lane < RT && sat[(size_t)b * RT + min(lane, RT - 1)] != 0u) != 0ull;
     auto lane_u64 = [&](unsigned long long reg, int rt) -> unsigned long long {
         if (rt >= RT) return 0ull;
         const unsigned lo = __builtin_amdgcn_readlane((unsigned)reg, rt);
@@ -1231,21 +1457,26 @@ void attention_mfma_backward_keys_kernel(
                                    vf[ks], dp);
             }
             // this lane: key j0 + c32, rows 8g + 4h + u of the tile in register 4g + u
+            const bool mlt = multi_of(rt);
+            const uint4 cw = cell_words(mcur, mlt, lane);
+            if constexpr (WANT_K) {
+                if (cg.wanted(d))                       // (wave-uniform, rare)
+                    clamp_exact(d, dp, smem + 2 * MK_IMG, wave, cw, sm.bound, cg.thr, k + dv.base, j0, S,
+                                q + dv.base + (size_t)rt * MA_WROWS * dv.ld, dv.ld, scale, clampv);
+            }
             const float *st = reinterpret_cast<const float *>(buf + MK_ST);
-            const uint4 mm4 = cell_words(mcur, multi_of(rt), lane);
-            const unsigned mw[4] = {mm4.x, mm4.y, mm4.z, mm4.w};
             float p[16], ds[16];
+            const bool satfix = any_sat && mlt;
+            cell_counts<false>(p, cw, satfix, satfix ? sat[(size_t)b * RT + min(rt, RT - 1)] : 0u, lane);
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
                 float4 del4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (WANT_K) del4 = *reinterpret_cast<const float4 *>(st + 8 * g4 + 4 * h);
                 const float del[4] = {del4.x, del4.y, del4.z, del4.w};
-                const float m4[4] = {cell_count<0>(mw[g4]), cell_count<1>(mw[g4]),
-                                     cell_count<2>(mw[g4]), cell_count<3>(mw[g4])};
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int r = 4 * g4 + u;
-                    p[r] = m4[u] * sm.exp_of(d[r]);          // x 1 / row_sum: in the dY images
+                    p[r] *= sm.exp_of(d[r]);                 // x 1 / row_sum: in the dY images
                     ds[r] = 0.0f;
                     if constexpr (WANT_K)                    // x scale: in the epilogue
                         ds[r] = sm.inside(d[r]) ? p[r] * (dp[r] - del[u]) : 0.0f;
@@ -1298,312 +1529,21 @@ void attention_mfma_backward_keys_kernel(
     }
 }
 
-// ===================================== fused backward ======================================
-// One launch for grad_q, grad_k and grad_v of a slice (round 3; d_head 64, fp32, S <= 512).
-// The two kernels above each recompute the score tile D and dP = dY V^T: 84 MFMAs per (row tile,
-// key tile) pair, 7 products.  Here the key-owned kernel keeps what it has computed: a wave owns a
-// key tile (K, V fragments and the grad_k, grad_v accumulators in registers, as above), the
-// workgroup of eight waves streams the slice's row tiles through LDS, and the pair's dS tile --
-// needed once more, for grad_q = dS K -- goes to a wave-private LDS tile as a [key][row] image
-// (8-byte stores of the accumulator's 4-row runs).  After the barrier the EIGHT waves share the
-// row tile's grad_q: wave (rb, cb) forms its 16 x 16 block sum over the pass's key tiles of
-// dS(rt, kt) K_kt with v_mfma_f32_16x16x32_bf16 -- A fragments of dS and B fragments of the K
-// rows images (one per wave, written in the pass prologue) both through the transposing LDS read
-// -- so no partial sums cross waves.  5 products per pair: 48 + 12 (32-cycle equivalents) = 60.
-// A slice has more key tiles than the workgroup has waves: pass p takes key tiles 8 p .. 8 p + 7
-// and the row tiles at or below them, grad_q of those rows is carried from pass to pass through
-// its own memory (read-add-write by the same lanes: no atomics, fixed order).  One workgroup
-// per slice: at B >= 256 slices (the benchmark shapes) every CU has one; the register budget is
-// what forbids more -- K, V fragments and both accumulators of 8 key tiles are 256 KiB, half
-// the CU's register file.  delta = max(1e-9, dY . Y) per row (softmax.cu:69) comes from a small
-// kernel of its own in front (the row-owned kernel produced it as a by-product).
-#if MA_E_VALUE == 64
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-constexpr int MF_STREAM = MK_IMG;                       // one stage of the row-tile stream
-constexpr int MF_DSPART = MA_KT * MA_VLD;               // one part of a dS tile [key][row]: 2304 B
-constexpr int MF_DS = 2 * MF_DSPART;                    // hi | lo: 4608 B (= a 32 x MA_TLD float tile)
-constexpr int MF_KIMG = 2 * MA_RIMG;                    // a K rows image, hi | lo: 9216 B
-constexpr int MF_OFF_DS = 2 * MF_STREAM, MF_OFF_K = MF_OFF_DS + MA_WAVES * MF_DS;
-constexpr int MF_LDS = MF_OFF_K + MA_WAVES * MF_KIMG;   // 147,712 B
-constexpr int MF_MAX_RT = 16;                           // S <= 512
-static_assert(MF_DS >= 32 * MA_TLD * 4, "the epilogue's transposing tile fits a dS tile");
-
-__device__ __forceinline__ f32x4 mma16(const uint4 &a, const uint4 &b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-// operand fragments of the 16x16x32 product: lane (i = lane & 15, kg = lane >> 4) holds the 8 k's
-// 8 kg .. 8 kg + 7 of row / column `col0 + i`, read from an image whose ROWS are the k index
-// (row stride `ld` bytes, 16-bit elements) through the transposing read
-__device__ __forceinline__ uint4 frag16_tr(const char *img, int ld, int col0, int lane) {
-    const int kg = lane >> 4, gl = lane & 15, qq = gl >> 2, pp = gl & 3;
-    const char *ptr = img + (8 * kg + qq) * ld + (col0 + 4 * pp) * 2;
-    const uint2 a = lds_tr_b64(ptr), b = lds_tr_b64(ptr + 4 * ld);
-    return make_uint4(a.x, a.y, b.x, b.y);
-}
-
-// delta[b, row] = max(1e-9, sum_e gy[b, row, e] y[b, row, e])   (softmax.cu:60-69: sum of P dP over
-// a row = dY . (P V) = dY . Y).  GT: both operands stored [B, E, S].
-template <bool GT>
-__global__ __launch_bounds__(256) void attention_delta_kernel(
-    const float *__restrict__ gy, const float *__restrict__ y, float *__restrict__ delta, int S,
-    long long total_rows) {
-    if (GT) {                                           // a thread: four consecutive rows, all e
-        const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-        const long long r4 = 4 * t;
-        if (r4 >= total_rows) return;
-        const long long b = r4 / S, i4 = r4 - b * S;    // (S % 4 == 0)
-        const float *gp = gy + b * S * MA_E + i4, *yp = y + b * S * MA_E + i4;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-        for (int e = 0; e < MA_E; e++) {
-            const float4 a = *reinterpret_cast<const float4 *>(gp + (size_t)e * S);
-            const float4 c = *reinterpret_cast<const float4 *>(yp + (size_t)e * S);
-            acc.x = fmaf(a.x, c.x, acc.x); acc.y = fmaf(a.y, c.y, acc.y);
-            acc.z = fmaf(a.z, c.z, acc.z); acc.w = fmaf(a.w, c.w, acc.w);
-        }
-        *reinterpret_cast<float4 *>(delta + r4) = make_float4(
-            fmaxf(1e-9f, acc.x), fmaxf(1e-9f, acc.y), fmaxf(1e-9f, acc.z), fmaxf(1e-9f, acc.w));
-    } else {                                            // 16 lanes per row, a float4 each
-        const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
-        const int e4 = (threadIdx.x & 15) * 4;
-        const long long rc = row < total_rows ? row : total_rows - 1;
-        const float4 a = *reinterpret_cast<const float4 *>(gy + rc * MA_E + e4);
-        const float4 c = *reinterpret_cast<const float4 *>(y + rc * MA_E + e4);
-        const float d = group_sum<16>((a.x * c.x + a.y * c.y) + (a.z * c.z + a.w * c.w));
-        if ((threadIdx.x & 15) == 0 && row < total_rows) delta[row] = fmaxf(1e-9f, d);
-    }
-}
-
-template <bool GT>
-__global__ __launch_bounds__(MA_THREADS)
-__attribute__((amdgpu_waves_per_eu(2, 2)))
-void attention_mfma_backward_fused_kernel(
-    const unsigned long long *__restrict__ masks, const unsigned char *__restrict__ cells_t,
-    const unsigned char *__restrict__ pool_t,
-    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
-    const float *__restrict__ gy, const float *__restrict__ row_sum,
-    const float *__restrict__ delta, float *__restrict__ grad_q, float *__restrict__ grad_k,
-    float *__restrict__ grad_v, int S, float scale, float clampv, int heads) {
-    typedef float T;
-    constexpr int PI = 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, c32 = lane & 31;
-    const int b = blockIdx.x;
-    const DenseView dv = dense_view(b, S, MA_E, heads);
-    const int RT = (S + MA_WROWS - 1) / MA_WROWS;
-    const ScoreMap sm(scale, clampv);
-    char *const stream = smem;
-    char *const dsbuf = smem + MF_OFF_DS + wave * MF_DS;            // this wave's dS tile
-    char *const kimg = smem + MF_OFF_K + wave * MF_KIMG;            // this wave's K rows image
-
-    const unsigned long long mask_reg = lane < RT ? masks[2 * ((size_t)b * RT + lane)] : 0ull;
-    const unsigned long long multi_reg = lane < RT ? masks[2 * ((size_t)b * RT + lane) + 1] : 0ull;
-    auto lane_u64 = [&](unsigned long long reg, int rt) -> unsigned long long {
-        if (rt >= RT) return 0ull;
-        const unsigned lo = __builtin_amdgcn_readlane((unsigned)reg, rt);
-        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(reg >> 32), rt);
-        return ((unsigned long long)hi << 32) | lo;
-    };
-    const int cstride = cell_slot_bytes(pool_t) / 16;
-    const uint4 *cell_b = reinterpret_cast<const uint4 *>(
-        cells_t + (size_t)b * tri(RT) * cell_slot_bytes(pool_t));
-    const uint4 *pool_b = pool_t ? reinterpret_cast<const uint4 *>(pool_t + (size_t)b * RT * MA_CELLS)
-                                 : nullptr;
-    const KeysStager<T, GT> stager{q + dv.base, gy + (size_t)b * S * MA_E, row_sum + (size_t)b * S,
-                                   delta + (size_t)b * S, dv.ld, S, tid};
-    const int rb = wave >> 2, cb = wave & 3;            // this wave's 16 x 16 block of a grad_q tile
-
-    for (int ps = 0; 8 * ps < RT; ps++) {
-        const int kt = 8 * ps + wave, j0 = kt * MA_KT;
-        const bool have = kt < RT;
-        auto multi_of = [&](int rt) {
-            const int rc = min(rt, RT - 1);
-            return (bool)((lane_u64(multi_reg, rc) >> min(kt, rc)) & 1ull);
-        };
-        auto live = [&](unsigned long long m, int rt) {
-            return have && rt >= kt && rt < RT && ((m >> kt) & 1ull);
-        };
-        auto cell_load = [&](int rt) {
-            const int rc = min(rt, RT - 1), kc = min(kt, rc);
-            if (multi_of(rt)) return pool_b ? pool_b[rc * 64 + lane] : cell_b[(tri(rc) + kc) * 64 + lane];
-            return cell_b[(tri(rc) + kc) * cstride + (c32 >> 2)];
-        };
-        // ---- the pass's key tile: K, V fragments; the K rows image for grad_q ----
-        Frag kf[MA_KS], vf[MA_KS];
-        {
-            float xk[MA_E / 2];
-            load_own_rows_raw(xk, k + dv.base, dv.ld, S, min(j0, max(S - 1, 0)), lane);
-            __syncthreads();                 // (the previous pass has read every K image and dS tile)
-#pragma unroll
-            for (int ks = 0; ks < MA_KS; ks++) {
-                const Frag f = split8(xk[8 * ks], xk[8 * ks + 1], xk[8 * ks + 2], xk[8 * ks + 3],
-                                      xk[8 * ks + 4], xk[8 * ks + 5], xk[8 * ks + 6], xk[8 * ks + 7]);
-                char *dst = kimg + c32 * MA_KLD + 16 * h + 32 * ks;
-                *reinterpret_cast<uint4 *>(dst) = f.hi;
-                *reinterpret_cast<uint4 *>(dst + MA_RIMG) = f.lo;
-            }
-            split_own_rows(kf, xk, sm.sl2);
-            float xv[MA_E / 2];
-            load_own_rows_raw(xv, v + dv.base, dv.ld, S, min(j0, max(S - 1, 0)), lane);
-            split_own_rows(vf, xv);
-        }
-        const int rt0 = 8 * ps;
-        stager.store(stream, stager.load(min(rt0, RT - 1)), rt0);
-        unsigned long long mcur_mask = lane_u64(mask_reg, rt0);
-        uint4 mcur = cell_load(rt0);
-        __syncthreads();
-
-        f32x16 kacc[MA_ET], vacc[MA_ET];
-#pragma unroll
-        for (int e = 0; e < MA_ET; e++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) kacc[e][r] = vacc[e][r] = 0.f;
-
-        for (int rt = rt0; rt < RT; rt++) {
-            const char *buf = stream + ((rt - rt0) & 1) * MF_STREAM;
-            const typename KeysStager<T, GT>::Regs nxt = stager.load(min(rt + 1, RT - 1));
-            const unsigned long long mnxt_mask = lane_u64(mask_reg, rt + 1);
-            const uint4 mnxt = cell_load(rt + 1);
-            // this wave's 16 x 16 block of grad_q[row tile rt] as the earlier passes left it: requested
-            // now, needed behind the pair's arithmetic and the barrier
-            float *const gq_dst = grad_q + dv.base +
-                                  (size_t)min(MA_WROWS * rt + 16 * rb + 4 * (lane >> 4), S - 1) * dv.ld +
-                                  16 * cb + (lane & 15);
-            float carried[4] = {0.f, 0.f, 0.f, 0.f};
-            if (ps > 0) {                                        // (wave-uniform)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int row = MA_WROWS * rt + 16 * rb + 4 * (lane >> 4) + j;
-                    carried[j] = grad_q[dv.base + (size_t)min(row, S - 1) * dv.ld + 16 * cb + (lane & 15)];
-                }
-            }
-            if (live(mcur_mask, rt)) {
-                f32x16 d, dp;
-#pragma unroll
-                for (int r = 0; r < 16; r++) d[r] = dp[r] = 0.f;
-#ifndef MF_NO_DDP
-#pragma unroll
-                for (int ks = 0; ks < MA_KS; ks++) {
-                    d = mm<PI, 2>(read_rows<PI>(buf + MK_QR, buf + MK_QR + MA_RIMG, lane, ks), kf[ks], d);
-                    dp = mm<2, PI>(GT ? read_rows_tr(buf + MK_G, buf + MK_G + MA_CIMG, lane, ks)
-                                      : read_rows<2>(buf + MK_G, buf + MK_G + MA_RIMG, lane, ks),
-                                   vf[ks], dp);
-                }
-#endif
-                // this lane: key j0 + c32, rows 8g + 4h + u of the tile in register 4g + u
-                const float *st = reinterpret_cast<const float *>(buf + MK_ST);
-                const uint4 mm4 = cell_words(mcur, multi_of(rt), lane);
-                const unsigned mw[4] = {mm4.x, mm4.y, mm4.z, mm4.w};
-                float p[16], ds[16];
-#pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) {
-                    const float4 del4 = *reinterpret_cast<const float4 *>(st + 8 * g4 + 4 * h);
-                    const float del[4] = {del4.x, del4.y, del4.z, del4.w};
-                    const float m4[4] = {cell_count<0>(mw[g4]), cell_count<1>(mw[g4]),
-                                         cell_count<2>(mw[g4]), cell_count<3>(mw[g4])};
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int r = 4 * g4 + u;
-#ifndef MF_NO_CELLS
-                        p[r] = m4[u] * sm.exp_of(d[r]);          // x 1 / row_sum: in the dY images
-                        ds[r] = sm.inside(d[r]) ? p[r] * (dp[r] - del[u]) : 0.0f;   // x scale: at the stores
-#else
-                        p[r] = m4[u] + d[r]; ds[r] = dp[r] - del[u];
-#endif
-                    }
-                }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; s2++) {
-                    const Frag pf = split8(p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3],
-                                           p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]);
-                    const Frag sf = split8(ds[8 * s2], ds[8 * s2 + 1], ds[8 * s2 + 2], ds[8 * s2 + 3],
-                                           ds[8 * s2 + 4], ds[8 * s2 + 5], ds[8 * s2 + 6], ds[8 * s2 + 7]);
-                    // dS -> the wave's [key][row] image: registers 8 s2 .. + 3 are rows 16 s2 + 4 h ..
-                    // + 3 of key c32, registers 8 s2 + 4 .. + 7 the rows 8 further down
-#ifndef MF_NO_DSWRITE
-                    char *drow = dsbuf + c32 * MA_VLD + (16 * s2 + 4 * h) * 2;
-                    *reinterpret_cast<uint2 *>(drow) = make_uint2(sf.hi.x, sf.hi.y);
-                    *reinterpret_cast<uint2 *>(drow + 16) = make_uint2(sf.hi.z, sf.hi.w);
-                    *reinterpret_cast<uint2 *>(drow + MF_DSPART) = make_uint2(sf.lo.x, sf.lo.y);
-                    *reinterpret_cast<uint2 *>(drow + MF_DSPART + 16) = make_uint2(sf.lo.z, sf.lo.w);
-#endif
-#ifndef MF_NO_KV
-#pragma unroll
-                    for (int eh = 0; eh < MA_ET; eh++) {
-                        vacc[eh] = mm<2, 2>(pf, GT ? read_cols(buf + MK_G, buf + MK_G + MA_CIMG,
-                                                               c32 + 32 * eh, h, s2)
-                                                   : read_cols_tr<2>(buf + MK_G, buf + MK_G + MA_RIMG,
-                                                                     32 * eh, lane, s2), vacc[eh]);
-                        kacc[eh] = mm<2, PI>(sf, read_cols_tr<PI>(buf + MK_QR, buf + MK_QR + MA_RIMG,
-                                                                  32 * eh, lane, s2), kacc[eh]);
-                    }
-#else
-                    kacc[0][s2] += __builtin_bit_cast(float, pf.hi.x ^ sf.lo.y);
-#endif
-                }
-            }
-            if (rt + 1 < RT) stager.store(stream + ((rt + 1 - rt0) & 1) * MF_STREAM, nxt, rt + 1);
-            __syncthreads();
-            // ---- grad_q of row tile rt: this wave's 16 x 16 block over the pass's live key tiles ----
-            {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                const unsigned long long mrow = mcur_mask;
-#ifndef MF_NO_DQ
-#pragma unroll 2
-                for (int kw = 0; kw < MA_WAVES; kw++) {
-                    const int ktw = 8 * ps + kw;
-                    if (ktw <= rt && ktw < RT && ((mrow >> ktw) & 1ull)) {          // (wave-uniform)
-                        const char *dsw = smem + MF_OFF_DS + kw * MF_DS;
-                        const char *kw_img = smem + MF_OFF_K + kw * MF_KIMG;
-                        const uint4 ah = frag16_tr(dsw, MA_VLD, 16 * rb, lane);
-                        const uint4 al = frag16_tr(dsw + MF_DSPART, MA_VLD, 16 * rb, lane);
-                        const uint4 bh = frag16_tr(kw_img, MA_KLD, 16 * cb, lane);
-                        const uint4 bl = frag16_tr(kw_img + MA_RIMG, MA_KLD, 16 * cb, lane);
-                        acc = mma16(al, bh, acc);
-                        acc = mma16(ah, bl, acc);
-                        acc = mma16(ah, bh, acc);
-                    }
-                }
-#endif
-                // C layout: register j of lane (i, g) = row 4 g + j, column i of the block
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int row = MA_WROWS * rt + 16 * rb + 4 * (lane >> 4) + j;
-                    if (row < S) gq_dst[(size_t)j * dv.ld] = fmaf(acc[j], scale, carried[j]);
-                }
-            }
-            mcur = mnxt;
-            mcur_mask = mnxt_mask;
-            __syncthreads();                 // the dS tiles are free for the next row tile
-        }
-        if (have && j0 < S) {
-            float *tile = reinterpret_cast<float *>(dsbuf);
-            float *gk_b = grad_k + dv.base + (size_t)j0 * dv.ld;
-            float *gv_b = grad_v + dv.base + (size_t)j0 * dv.ld;
-#pragma unroll
-            for (int eh = 0; eh < MA_ET; eh++)
-                store_acc_half(kacc[eh], scale, tile, gk_b + 32 * eh, dv.ld, S - j0, lane);
-#pragma unroll
-            for (int eh = 0; eh < MA_ET; eh++)
-                store_acc_half(vacc[eh], 1.0f, tile, gv_b + 32 * eh, dv.ld, S - j0, lane);
-        }
-    }
-}
-#endif  // MA_E_VALUE == 64
+// (Round 3 also built the backward as ONE launch per slice -- S, P, dP, dS once per tile pair, 60
+// instead of 84 MFMA-equivalents, dQ carried through LDS: 164.6 us against the two kernels' 165.0 at
+// the configs[1] shape, because neither form is bound by the matrix pipe.  DESIGN.md 5.11 keeps the
+// measurements and the ablation; the kernel left the tree in round 4.)
 
 static size_t mfma_forward_lds() {
-    return 2 * MA_IMG + (size_t)MA_WAVES * MA_WROWS * sizeof(float);
+    return 2 * MA_IMG + (size_t)MA_WAVES * (MA_WROWS + 2) * sizeof(float);
 }
 
 // ---- launchers of this head dimension (the d_head 64 unit dispatches to spt::e128's) ----
 template <typename T>
 static int launch_forward_t(const unsigned long long *masks, const unsigned char *cells,
-                            const unsigned char *pool, const T *q, const T *k, const T *v, T *y,
-                            float *row_sum, int batch_size, int S, float scale, float clamp,
-                            int heads, int y_transposed, hipStream_t s) {
+                            const unsigned char *pool, const unsigned *sat, const T *q, const T *k,
+                            const T *v, T *y, float *row_sum, float *bounds, int batch_size, int S,
+                            float scale, float clamp, int heads, int y_transposed, hipStream_t s) {
     const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
     const size_t lds = mfma_forward_lds();
     const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
@@ -1613,10 +1553,10 @@ static int launch_forward_t(const unsigned long long *masks, const unsigned char
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (y_transposed)
         hipLaunchKernelGGL((attention_mfma_forward_kernel<T, true>), grid, block, lds, s, masks,
-                           cells, pool, q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
+                           cells, pool, sat, q, k, v, y, row_sum, bounds, S, scale, clamp, heads, bpb);
     else
         hipLaunchKernelGGL((attention_mfma_forward_kernel<T, false>), grid, block, lds, s, masks,
-                           cells, pool, q, k, v, y, row_sum, S, scale, clamp, heads, bpb);
+                           cells, pool, sat, q, k, v, y, row_sum, bounds, S, scale, clamp, heads, bpb);
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }
@@ -1624,55 +1564,15 @@ static int launch_forward_t(const unsigned long long *masks, const unsigned char
 template <typename T>
 static int launch_backward_t(const unsigned long long *masks, const unsigned char *cells,
                              const unsigned char *cells_t, const unsigned char *pool,
-                             const unsigned char *pool_t, const T *q, const T *k, const T *v,
-                             const T *y, const T *grad_y, const float *row_sum, float *delta,
-                             T *grad_q, T *grad_k, T *grad_v, int batch_size, int S,
-                             float scale, float clamp, int heads, int transposed, hipStream_t s) {
+                             const unsigned char *pool_t, const unsigned *sat, const T *q, const T *k,
+                             const T *v, const T *y, const T *grad_y, const float *row_sum,
+                             const float *bounds, float *delta, T *grad_q, T *grad_k, T *grad_v,
+                             int batch_size, int S, float scale, float clamp, int heads,
+                             int transposed, hipStream_t s) {
     const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
     const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
-    const size_t lds_r = 2 * MA_IMG, lds_k = 2 * MK_IMG;
-#if MA_E_VALUE == 64
-    if constexpr (sizeof(T) == 4) {
-        // The fused form (one workgroup per slice): fp32, S <= 512.  OPT-IN (SPT_ATTENTION_BACKWARD=
-        // fused): measured inside bench.py at the configs[1] shape it takes 164.6 us against the two
-        // kernels' 165.0 -- 60 instead of 84 MFMA-equivalents per tile pair bought nothing, because
-        // neither form is bound by the matrix pipe (ablation of the fused kernel)
-        // (read at every call: tests switch it inside one process)
-        const char *e = getenv("SPT_ATTENTION_BACKWARD");
-        const bool fused = e && e[0] == 'f';
-        const int RT = (S + MA_WROWS - 1) / MA_WROWS;
-        const bool fits = RT <= MF_MAX_RT && (!transposed || (S & 3) == 0);
-        if (fits && fused) {
-            const long long rows = (long long)batch_size * S;
-            if (transposed)
-                hipLaunchKernelGGL(attention_delta_kernel<true>, dim3((unsigned)((rows / 4 + 255) / 256)),
-                                   dim3(256), 0, s, (const float *)grad_y, (const float *)y, delta, S, rows);
-            else
-                hipLaunchKernelGGL(attention_delta_kernel<false>, dim3((unsigned)((rows * 16 + 255) / 256)),
-                                   dim3(256), 0, s, (const float *)grad_y, (const float *)y, delta, S, rows);
-            SPT_LAUNCH_CHECK();
-            if (transposed) {
-                SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_mfma_backward_fused_kernel<true>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
-                hipLaunchKernelGGL(attention_mfma_backward_fused_kernel<true>, dim3((unsigned)batch_size),
-                                   block, MF_LDS, s, masks, cells_t, pool_t, (const float *)q,
-                                   (const float *)k, (const float *)v, (const float *)grad_y, row_sum,
-                                   delta, (float *)grad_q, (float *)grad_k, (float *)grad_v, S, scale,
-                                   clamp, heads);
-            } else {
-                SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_mfma_backward_fused_kernel<false>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
-                hipLaunchKernelGGL(attention_mfma_backward_fused_kernel<false>, dim3((unsigned)batch_size),
-                                   block, MF_LDS, s, masks, cells_t, pool_t, (const float *)q,
-                                   (const float *)k, (const float *)v, (const float *)grad_y, row_sum,
-                                   delta, (float *)grad_q, (float *)grad_k, (float *)grad_v, S, scale,
-                                   clamp, heads);
-            }
-            SPT_LAUNCH_CHECK();
-            return SPT_OK;
-        }
-    }
-#endif
+    const size_t lds_r = 2 * MA_IMG + (size_t)MA_WAVES * MA_PARK,
+                 lds_k = 2 * MK_IMG + (size_t)MA_WAVES * MA_PARK;
     // 64 gradient columns per launch (the accumulators of 128 would not fit the registers
     // beside the operands' fragments): d_head 128 runs each kernel twice
 #define SPT_MB(GT)                                                                              \
@@ -1682,8 +1582,8 @@ static int launch_backward_t(const unsigned long long *masks, const unsigned cha
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));                           \
         for (int half = 0; half < MA_ET / MR_QTILES; half++)                                    \
             hipLaunchKernelGGL((attention_mfma_backward_rows_kernel<T, GT>), grid, block, lds_r, \
-                               s, masks, cells, pool, q, k, v, grad_y, y, row_sum, grad_q,      \
-                               delta, S, scale, clamp, heads, bpb, half);                       \
+                               s, masks, cells, pool, sat, q, k, v, grad_y, y, row_sum, bounds, \
+                               grad_q, delta, S, scale, clamp, heads, bpb, half);               \
         if (MA_BH == 1) {                                                                       \
             SPT_KEYS(GT, 0, 0);                                                                 \
         } else {                                                                                \
@@ -1697,8 +1597,8 @@ static int launch_backward_t(const unsigned long long *masks, const unsigned cha
             (const void *)attention_mfma_backward_keys_kernel<T, GT, MODE>,                     \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));                           \
         hipLaunchKernelGGL((attention_mfma_backward_keys_kernel<T, GT, MODE>), grid, block,     \
-                           lds_k, s, masks, cells_t, pool_t, q, k, v, grad_y, row_sum, delta,   \
-                           grad_k, grad_v, S, scale, clamp, heads, bpb, HALF);                  \
+                           lds_k, s, masks, cells_t, pool_t, sat, q, k, v, grad_y, row_sum,     \
+                           bounds, delta, grad_k, grad_v, S, scale, clamp, heads, bpb, HALF);   \
     } while (0)
     if (transposed) SPT_MB(true);
     else SPT_MB(false);
@@ -1710,33 +1610,35 @@ static int launch_backward_t(const unsigned long long *masks, const unsigned cha
 
 // dtype: SPT_F32 (float tensors) or SPT_BF16 (bf16 storage; row_sum and delta stay fp32)
 int launch_forward(const unsigned long long *masks, const unsigned char *cells,
-                   const unsigned char *pool, int dtype, const void *q, const void *k,
-                   const void *v, void *y, float *row_sum, int batch_size, int S, float scale,
-                   float clamp, int heads, int y_transposed, hipStream_t s) {
+                   const unsigned char *pool, const unsigned *sat, int dtype, const void *q,
+                   const void *k, const void *v, void *y, float *row_sum, float *bounds,
+                   int batch_size, int S, float scale, float clamp, int heads, int y_transposed,
+                   hipStream_t s) {
     if (dtype == SPT_BF16)
-        return launch_forward_t<bf16_t>(masks, cells, pool, (const bf16_t *)q, (const bf16_t *)k,
-                                        (const bf16_t *)v, (bf16_t *)y, row_sum, batch_size, S,
+        return launch_forward_t<bf16_t>(masks, cells, pool, sat, (const bf16_t *)q, (const bf16_t *)k,
+                                        (const bf16_t *)v, (bf16_t *)y, row_sum, bounds, batch_size, S,
                                         scale, clamp, heads, y_transposed, s);
-    return launch_forward_t<float>(masks, cells, pool, (const float *)q, (const float *)k,
-                                   (const float *)v, (float *)y, row_sum, batch_size, S, scale,
+    return launch_forward_t<float>(masks, cells, pool, sat, (const float *)q, (const float *)k,
+                                   (const float *)v, (float *)y, row_sum, bounds, batch_size, S, scale,
                                    clamp, heads, y_transposed, s);
 }
 
 int launch_backward(const unsigned long long *masks, const unsigned char *cells,
                     const unsigned char *cells_t, const unsigned char *pool,
-                    const unsigned char *pool_t, int dtype, const void *q, const void *k,
-                    const void *v, const void *y, const void *grad_y, const float *row_sum,
-                    float *delta, void *grad_q, void *grad_k, void *grad_v, int batch_size, int S,
-                    float scale, float clamp, int heads, int transposed, hipStream_t s) {
+                    const unsigned char *pool_t, const unsigned *sat, int dtype, const void *q,
+                    const void *k, const void *v, const void *y, const void *grad_y,
+                    const float *row_sum, const float *bounds, float *delta, void *grad_q,
+                    void *grad_k, void *grad_v, int batch_size, int S, float scale, float clamp,
+                    int heads, int transposed, hipStream_t s) {
     if (dtype == SPT_BF16)
-        return launch_backward_t<bf16_t>(masks, cells, cells_t, pool, pool_t, (const bf16_t *)q,
+        return launch_backward_t<bf16_t>(masks, cells, cells_t, pool, pool_t, sat, (const bf16_t *)q,
                                          (const bf16_t *)k, (const bf16_t *)v, (const bf16_t *)y,
-                                         (const bf16_t *)grad_y, row_sum, delta, (bf16_t *)grad_q,
-                                         (bf16_t *)grad_k, (bf16_t *)grad_v, batch_size, S, scale,
-                                         clamp, heads, transposed, s);
-    return launch_backward_t<float>(masks, cells, cells_t, pool, pool_t, (const float *)q,
+                                         (const bf16_t *)grad_y, row_sum, bounds, delta,
+                                         (bf16_t *)grad_q, (bf16_t *)grad_k, (bf16_t *)grad_v,
+                                         batch_size, S, scale, clamp, heads, transposed, s);
+    return launch_backward_t<float>(masks, cells, cells_t, pool, pool_t, sat, (const float *)q,
                                     (const float *)k, (const float *)v, (const float *)y,
-                                    (const float *)grad_y, row_sum, delta, (float *)grad_q,
+                                    (const float *)grad_y, row_sum, bounds, delta, (float *)grad_q,
                                     (float *)grad_k, (float *)grad_v, batch_size, S, scale, clamp,
                                     heads, transposed, s);
 }
@@ -1744,15 +1646,17 @@ int launch_backward(const unsigned long long *masks, const unsigned char *cells,
 #if MA_E_VALUE == 64
 namespace e128 {
 int launch_forward(const unsigned long long *masks, const unsigned char *cells,
-                   const unsigned char *pool, int dtype, const void *q, const void *k,
-                   const void *v, void *y, float *row_sum, int batch_size, int S, float scale,
-                   float clamp, int heads, int y_transposed, hipStream_t s);
+                   const unsigned char *pool, const unsigned *sat, int dtype, const void *q,
+                   const void *k, const void *v, void *y, float *row_sum, float *bounds,
+                   int batch_size, int S, float scale, float clamp, int heads, int y_transposed,
+                   hipStream_t s);
 int launch_backward(const unsigned long long *masks, const unsigned char *cells,
                     const unsigned char *cells_t, const unsigned char *pool,
-                    const unsigned char *pool_t, int dtype, const void *q, const void *k,
-                    const void *v, const void *y, const void *grad_y, const float *row_sum,
-                    float *delta, void *grad_q, void *grad_k, void *grad_v, int batch_size, int S,
-                    float scale, float clamp, int heads, int transposed, hipStream_t s);
+                    const unsigned char *pool_t, const unsigned *sat, int dtype, const void *q,
+                    const void *k, const void *v, const void *y, const void *grad_y,
+                    const float *row_sum, const float *bounds, float *delta, void *grad_q,
+                    void *grad_k, void *grad_v, int batch_size, int S, float scale, float clamp,
+                    int heads, int transposed, hipStream_t s);
 }  // namespace e128
 
 static bool mfma_shape_ok(int S, int E, int nnz) {
@@ -1761,10 +1665,11 @@ static bool mfma_shape_ok(int S, int E, int nnz) {
     return Z <= MA_MAXZ && Z % 4 == 0 && S <= MA_MAXNT * MA_KT;
 }
 // Workspace: 256-byte header (word 0: layout, word 1: flags -- bit 0: a compact layout was
-// given a pattern that repeats a column outside key tile 0) | masks | cells | cells_t
+// given a pattern that repeats a column outside key tile 0) | masks, sat | cells | cells_t
 // [| pool | pool_t in the compact layout].
 struct TileSet {
     unsigned long long *masks;
+    unsigned *sat;
     unsigned char *cells, *cells_t, *pool, *pool_t;
 };
 constexpr size_t MA_HEADER = 256;
@@ -1778,12 +1683,13 @@ static size_t tile_pool_bytes(int B, int S, int layout) {
 }
 static size_t tile_mask_bytes(int B, int S) {
     const size_t RT = (S + MA_WROWS - 1) / MA_WROWS;
-    return (((size_t)B * RT * 2 * sizeof(unsigned long long)) + 255) & ~(size_t)255;
+    return (((size_t)B * RT * (2 * sizeof(unsigned long long) + sizeof(unsigned))) + 255) & ~(size_t)255;
 }
 static TileSet carve_tiles(void *ws, int B, int S, int layout) {
     TileSet t;
     char *p = static_cast<char *>(ws) + MA_HEADER;
     t.masks = reinterpret_cast<unsigned long long *>(p);
+    t.sat = reinterpret_cast<unsigned *>(t.masks + 2 * (size_t)B * ((S + MA_WROWS - 1) / MA_WROWS));
     t.cells = reinterpret_cast<unsigned char *>(p + tile_mask_bytes(B, S));
     t.cells_t = t.cells + tile_cells_bytes(B, S, layout);
     t.pool = t.pool_t = nullptr;
@@ -1835,24 +1741,26 @@ extern "C" int spt_attention_mfma_prepare(const int32_t *indices, void *tiles, i
         SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_cell_bits_kernel,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bits));
         hipLaunchKernelGGL(attention_cell_bits_kernel, grid, block, lds_bits, s, indices, ts.masks,
-                           ts.cells, ts.cells_t, ts.pool, ts.pool_t, S, Z, NT, RT, total);
+                           ts.cells, ts.cells_t, ts.pool, ts.pool_t, ts.sat, S, Z, NT, RT, total);
     } else if (Z > 255) {
         SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_cell_tiles_kernel<true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(attention_cell_tiles_kernel<true>, grid, block, lds, s, indices,
-                           ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, S, Z, NT, RT, total);
+                           ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, ts.sat, S, Z, NT, RT,
+                           total);
     } else {
         SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_cell_tiles_kernel<false>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(attention_cell_tiles_kernel<false>, grid, block, lds, s, indices,
-                           ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, S, Z, NT, RT, total);
+                           ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, ts.sat, S, Z, NT, RT,
+                           total);
     }
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }
 
 static int mfma_forward_any(const void *tiles, int layout, int dtype, const void *q,
-                            const void *k, const void *v, void *y, float *row_sum,
+                            const void *k, const void *v, void *y, float *row_sum, float *bounds,
                             int batch_size, int seq_length, int d_head, int nnz, float scale,
                             float clamp, int heads, int y_transposed, void *stream) {
     using namespace spt;
@@ -1864,17 +1772,19 @@ static int mfma_forward_any(const void *tiles, int layout, int dtype, const void
     const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length, layout);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return d_head == 64
-               ? launch_forward(ts.masks, ts.cells, ts.pool, dtype, q, k, v, y, row_sum,
+               ? launch_forward(ts.masks, ts.cells, ts.pool, ts.sat, dtype, q, k, v, y, row_sum, bounds,
                                 batch_size, seq_length, scale, clamp, heads, y_transposed, s)
-               : e128::launch_forward(ts.masks, ts.cells, ts.pool, dtype, q, k, v, y, row_sum,
-                                      batch_size, seq_length, scale, clamp, heads, y_transposed, s);
+               : e128::launch_forward(ts.masks, ts.cells, ts.pool, ts.sat, dtype, q, k, v, y, row_sum,
+                                      bounds, batch_size, seq_length, scale, clamp, heads,
+                                      y_transposed, s);
 }
 
 static int mfma_backward_any(const void *tiles, int layout, int dtype, const void *q,
                              const void *k, const void *v, const void *y, const void *grad_y,
-                             const float *row_sum, float *delta, void *grad_q, void *grad_k,
-                             void *grad_v, int batch_size, int seq_length, int d_head, int nnz,
-                             float scale, float clamp, int heads, int transposed, void *stream) {
+                             const float *row_sum, const float *bounds, float *delta, void *grad_q,
+                             void *grad_k, void *grad_v, int batch_size, int seq_length, int d_head,
+                             int nnz, float scale, float clamp, int heads, int transposed,
+                             void *stream) {
     using namespace spt;
     if (!tiles || !q || !k || !v || !y || !grad_y || !row_sum || !delta || !grad_q || !grad_k ||
         !grad_v)
@@ -1887,54 +1797,60 @@ static int mfma_backward_any(const void *tiles, int layout, int dtype, const voi
     const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length, layout);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return d_head == 64
-               ? launch_backward(ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, dtype, q, k,
-                                 v, y, grad_y, row_sum, delta, grad_q, grad_k, grad_v, batch_size,
-                                 seq_length, scale, clamp, heads, transposed, s)
-               : e128::launch_backward(ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, dtype,
-                                       q, k, v, y, grad_y, row_sum, delta, grad_q, grad_k, grad_v,
-                                       batch_size, seq_length, scale, clamp, heads, transposed, s);
+               ? launch_backward(ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, ts.sat, dtype, q,
+                                 k, v, y, grad_y, row_sum, bounds, delta, grad_q, grad_k, grad_v,
+                                 batch_size, seq_length, scale, clamp, heads, transposed, s)
+               : e128::launch_backward(ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, ts.sat,
+                                       dtype, q, k, v, y, grad_y, row_sum, bounds, delta, grad_q,
+                                       grad_k, grad_v, batch_size, seq_length, scale, clamp, heads,
+                                       transposed, s);
 }
 
 extern "C" int spt_attention_mfma_forward(const void *tiles, int layout, const float *q,
                                           const float *k, const float *v, float *y,
-                                          float *row_sum, int batch_size, int seq_length,
-                                          int d_head, int nnz, float scale, float clamp, int heads,
-                                          int y_transposed, void *stream) {
-    return mfma_forward_any(tiles, layout, SPT_F32, q, k, v, y, row_sum, batch_size, seq_length,
-                            d_head, nnz, scale, clamp, heads, y_transposed, stream);
+                                          float *row_sum, float *bounds, int batch_size,
+                                          int seq_length, int d_head, int nnz, float scale,
+                                          float clamp, int heads, int y_transposed, void *stream) {
+    return mfma_forward_any(tiles, layout, SPT_F32, q, k, v, y, row_sum, bounds, batch_size,
+                            seq_length, d_head, nnz, scale, clamp, heads, y_transposed, stream);
+}
+
+extern "C" int spt_attention_mfma_bounds_floats(int batch_size) {
+    return batch_size > 0 ? batch_size * spt::MA_BOUND_SLOTS * 2 : 0;
 }
 
 extern "C" int spt_attention_mfma_backward(const void *tiles, int layout, const float *q,
                                            const float *k, const float *v, const float *y,
-                                           const float *grad_y, const float *row_sum, float *delta,
-                                           float *grad_q, float *grad_k, float *grad_v,
-                                           int batch_size, int seq_length, int d_head, int nnz,
-                                           float scale, float clamp, int heads, int transposed,
-                                           void *stream) {
-    return mfma_backward_any(tiles, layout, SPT_F32, q, k, v, y, grad_y, row_sum, delta, grad_q,
-                             grad_k, grad_v, batch_size, seq_length, d_head, nnz, scale, clamp,
-                             heads, transposed, stream);
+                                           const float *grad_y, const float *row_sum,
+                                           const float *bounds, float *delta, float *grad_q,
+                                           float *grad_k, float *grad_v, int batch_size,
+                                           int seq_length, int d_head, int nnz, float scale,
+                                           float clamp, int heads, int transposed, void *stream) {
+    return mfma_backward_any(tiles, layout, SPT_F32, q, k, v, y, grad_y, row_sum, bounds, delta,
+                             grad_q, grad_k, grad_v, batch_size, seq_length, d_head, nnz, scale,
+                             clamp, heads, transposed, stream);
 }
 
 extern "C" int spt_attention_mfma_forward_bf16(const void *tiles, int layout, const uint16_t *q,
                                                const uint16_t *k, const uint16_t *v, uint16_t *y,
-                                               float *row_sum, int batch_size, int seq_length,
-                                               int d_head, int nnz, float scale, float clamp,
-                                               int heads, int y_transposed, void *stream) {
-    return mfma_forward_any(tiles, layout, SPT_BF16, q, k, v, y, row_sum, batch_size, seq_length,
-                            d_head, nnz, scale, clamp, heads, y_transposed, stream);
+                                               float *row_sum, float *bounds, int batch_size,
+                                               int seq_length, int d_head, int nnz, float scale,
+                                               float clamp, int heads, int y_transposed,
+                                               void *stream) {
+    return mfma_forward_any(tiles, layout, SPT_BF16, q, k, v, y, row_sum, bounds, batch_size,
+                            seq_length, d_head, nnz, scale, clamp, heads, y_transposed, stream);
 }
 
 extern "C" int spt_attention_mfma_backward_bf16(const void *tiles, int layout, const uint16_t *q,
                                                 const uint16_t *k, const uint16_t *v,
                                                 const uint16_t *y, const uint16_t *grad_y,
-                                                const float *row_sum, float *delta,
-                                                uint16_t *grad_q, uint16_t *grad_k,
+                                                const float *row_sum, const float *bounds,
+                                                float *delta, uint16_t *grad_q, uint16_t *grad_k,
                                                 uint16_t *grad_v, int batch_size, int seq_length,
                                                 int d_head, int nnz, float scale, float clamp,
                                                 int heads, int transposed, void *stream) {
-    return mfma_backward_any(tiles, layout, SPT_BF16, q, k, v, y, grad_y, row_sum, delta, grad_q,
-                             grad_k, grad_v, batch_size, seq_length, d_head, nnz, scale, clamp,
-                             heads, transposed, stream);
+    return mfma_backward_any(tiles, layout, SPT_BF16, q, k, v, y, grad_y, row_sum, bounds, delta,
+                             grad_q, grad_k, grad_v, batch_size, seq_length, d_head, nnz, scale,
+                             clamp, heads, transposed, stream);
 }
 #endif

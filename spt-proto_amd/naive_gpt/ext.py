@@ -62,13 +62,14 @@ _PROTOTYPES = {
     'spt_attention_mfma_supported': ([_c_int] * 3, _c_int),
     'spt_attention_mfma_tiles_bytes': ([_c_int] * 4, ctypes.c_int64),
     'spt_attention_mfma_prepare': ([_c_ptr] * 2 + [_c_int] * 4 + [_c_ptr], _c_int),
-    'spt_attention_mfma_forward': ([_c_ptr, _c_int] + [_c_ptr] * 5 + [_c_int] * 4 +
+    'spt_attention_mfma_bounds_floats': ([_c_int], _c_int),
+    'spt_attention_mfma_forward': ([_c_ptr, _c_int] + [_c_ptr] * 6 + [_c_int] * 4 +
                                    [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int),
-    'spt_attention_mfma_backward': ([_c_ptr, _c_int] + [_c_ptr] * 10 + [_c_int] * 4 +
+    'spt_attention_mfma_backward': ([_c_ptr, _c_int] + [_c_ptr] * 11 + [_c_int] * 4 +
                                     [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int),
-    'spt_attention_mfma_forward_bf16': ([_c_ptr, _c_int] + [_c_ptr] * 5 + [_c_int] * 4 +
+    'spt_attention_mfma_forward_bf16': ([_c_ptr, _c_int] + [_c_ptr] * 6 + [_c_int] * 4 +
                                         [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int),
-    'spt_attention_mfma_backward_bf16': ([_c_ptr, _c_int] + [_c_ptr] * 10 + [_c_int] * 4 +
+    'spt_attention_mfma_backward_bf16': ([_c_ptr, _c_int] + [_c_ptr] * 11 + [_c_int] * 4 +
                                          [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int),
     'spt_grouped_gemm_fused': ([_c_ptr, _c_ptr], _c_int),
     'spt_grouped_gemm_pdot_width': ([_c_int], _c_int),
@@ -113,7 +114,7 @@ _PROTOTYPES = {
     'spt_softmax_backward_clamped': ([_c_ptr] * 5 + [_c_f32, _c_f32, _c_ptr] + [_c_int] * 3 + [_c_ptr],
                                      _c_int),
 }
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 _lib = None
 
@@ -629,6 +630,9 @@ class MfmaTiles:
 
 
 TILES_FULL, TILES_COMPACT = 0, 1
+# (tests) False: the backward decides the clamp's gradient mask on its split-bf16 scores -- the
+# behaviour before ABI 39, kept switchable so that a test can show what the exact mask changes
+EXACT_CLAMP = True
 
 
 def attention_mfma_prepare(indices: torch.Tensor, seq_length: int,
@@ -654,6 +658,14 @@ def attention_mfma_prepare(indices: torch.Tensor, seq_length: int,
     return MfmaTiles(buf, B, int(seq_length), nnz, layout)
 
 
+def _bounds_behind(row_sum: torch.Tensor, B: int, S: int, n_bounds: int) -> int:
+    """Device address of the norm bounds that :func:`attention_mfma_forward` left behind the row
+    sums (0: `row_sum` is some other [B, S] tensor -- the backward then decides the clamp mask on
+    its split-bf16 scores, as before ABI 39)."""
+    have = row_sum.untyped_storage().nbytes() - 4 * row_sum.storage_offset()
+    return row_sum.data_ptr() + 4 * B * S if have >= 4 * (B * S + n_bounds) else 0
+
+
 def attention_mfma_forward(tiles, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                            scale: float, clamp: float, y_transposed: bool = False):
     """The attention core on the matrix cores (``spt_attention_mfma_forward``).
@@ -661,7 +673,12 @@ def attention_mfma_forward(tiles, q: torch.Tensor, k: torch.Tensor, v: torch.Ten
     q, k, v: ``[N, S, H, E]``; ``tiles``: :func:`attention_mfma_prepare` of the ``[N*H, nnz]``
     indices (or the indices themselves).  Returns ``(y, row_sum)``: y ``[N*H, S, E]`` or
     (``y_transposed``) ``[N*H, E, S]`` and the softmax denominators ``[N*H, S]`` the backward
-    needs; no ``[N*H, nnz]`` array is produced."""
+    needs; no ``[N*H, nnz]`` array is produced.
+
+    ``row_sum`` is a view of the first ``N*H*S`` floats of a slightly longer buffer: behind them
+    lie the forward's bounds on the row norms of q and k (``spt_attention_mfma_bounds_floats``),
+    with which :func:`attention_mfma_backward` decides the clamp's gradient mask exactly.  Hand the
+    SAME tensor (or one sharing its storage: ``save_for_backward`` does) to the backward."""
     _check_dim(q, 4, 'q')
     _require(q.dtype in (torch.float32, torch.bfloat16), 'q: float32 or bfloat16 (bf16 storage)')
     _require(q.dtype == k.dtype == v.dtype, 'q, k, v: same dtype')
@@ -677,13 +694,15 @@ def attention_mfma_forward(tiles, q: torch.Tensor, k: torch.Tensor, v: torch.Ten
     lib = load_library()
     with _on(dev):
         y = torch.empty([B, E, S] if y_transposed else [B, S, E], dtype=q.dtype, device=dev)
-        row_sum = torch.empty([B, S], dtype=torch.float32, device=dev)
+        stats = torch.empty([B * S + lib.spt_attention_mfma_bounds_floats(B)], dtype=torch.float32,
+                            device=dev)
+        row_sum = stats[:B * S].view(B, S)
         fn = (lib.spt_attention_mfma_forward if q.dtype == torch.float32
               else lib.spt_attention_mfma_forward_bf16)
         rc = fn(
             tiles.buffer.data_ptr(), tiles.layout, q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(),
-            row_sum.data_ptr(), B, S, E, tiles.nnz, float(scale), float(clamp), H,
-            int(bool(y_transposed)), _stream(dev))
+            row_sum.data_ptr(), row_sum.data_ptr() + 4 * B * S, B, S, E, tiles.nnz, float(scale),
+            float(clamp), H, int(bool(y_transposed)), _stream(dev))
     if rc != 0:
         _raise(lib, rc, 'attention_mfma_forward')
     return y, row_sum
@@ -695,7 +714,13 @@ def attention_mfma_backward(tiles: MfmaTiles, q: torch.Tensor, k: torch.Tensor, 
     """Backward of :func:`attention_mfma_forward` (``spt_attention_mfma_backward``).
 
     y, grad_y: the forward's output and its gradient, ``[N*H, S, E]`` or (``transposed``)
-    ``[N*H, E, S]``.  Returns ``(grad_q, grad_k, grad_v)``, each ``[N, S, H, E]``."""
+    ``[N*H, E, S]``.  Returns ``(grad_q, grad_k, grad_v)``, each ``[N, S, H, E]`` -- three views of
+    ONE ``[3, N, S, H, E]`` buffer (the joint dX product of the projections reads them as one
+    operand), so a surviving reference to any one of them keeps all three alive.
+
+    ``row_sum``: the tensor the forward returned for the same q, k (see there: the norm bounds
+    behind it make the clamp's gradient mask that of the fp32 scores; ``EXACT_CLAMP = False``, or
+    a ``row_sum`` without them, leaves the mask to the split-bf16 scores)."""
     _check_dim(q, 4, 'q')
     _require(q.dtype in (torch.float32, torch.bfloat16), 'q: float32 or bfloat16 (bf16 storage)')
     _require(q.dtype == k.dtype == v.dtype == y.dtype == grad_y.dtype, 'q, k, v, y, grad_y: same dtype')
@@ -717,9 +742,10 @@ def attention_mfma_backward(tiles: MfmaTiles, q: torch.Tensor, k: torch.Tensor, 
         delta = torch.empty([B, S], dtype=torch.float32, device=dev)
         fn = (lib.spt_attention_mfma_backward if q.dtype == torch.float32
               else lib.spt_attention_mfma_backward_bf16)
+        bounds = _bounds_behind(row_sum, B, S, lib.spt_attention_mfma_bounds_floats(B)) if EXACT_CLAMP else 0
         rc = fn(
             tiles.buffer.data_ptr(), tiles.layout, q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(),
-            grad_y.data_ptr(), row_sum.data_ptr(), delta.data_ptr(), grad_q.data_ptr(),
+            grad_y.data_ptr(), row_sum.data_ptr(), bounds, delta.data_ptr(), grad_q.data_ptr(),
             grad_k.data_ptr(), grad_v.data_ptr(), B, S, E, tiles.nnz, float(scale), float(clamp),
             H, int(bool(transposed)), _stream(dev))
     if rc != 0:

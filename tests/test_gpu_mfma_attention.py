@@ -41,31 +41,21 @@ def test_mfma_forward_matches_oracle_chain(N, H, S, Z, E, yt):
     rows = torch.arange(S).view(1, S, 1)
     live = (indices.view(N * H, S, Z) <= rows).float()
     want_sum = (want_scores.view(N * H, S, Z).exp() * live).sum(-1)
-    if Z == 256:
-        # row 0 is column 0 256 times: the byte-sized cell count saturates at 255 (documented
-        # in include/spt_hip.h); y is unaffected, its row sum is 255 / 256 of the exact one
-        assert torch.allclose(row_sum.cpu()[:, 0], want_sum[:, 0] * (255 / 256), rtol=1e-4)
-        assert torch.allclose(row_sum.cpu()[:, 1:], want_sum[:, 1:], rtol=1e-4)
-    else:
-        assert torch.allclose(row_sum.cpu(), want_sum, rtol=1e-4)
+    # (Z = 256: row 0 is column 0 256 times -- one more than a byte-sized cell count holds; the
+    # cell tiles flag such rows and the kernels add the 1 back: exact since ABI 39)
+    assert torch.allclose(row_sum.cpu(), want_sum, rtol=1e-4)
     assert torch.allclose(y.cpu(), want_y, rtol=1e-3, atol=1e-4)
     # the split-bf16 products are far inside the bar: report-level check of the actual error
     assert (y.cpu() - want_y).abs().max() < 2e-4 * want_y.abs().max()
 
 
-@pytest.mark.parametrize('form', ['split', 'fused'])
 @pytest.mark.parametrize('gt', [False, True])
 @pytest.mark.parametrize('N,H,S,Z,E', SHAPES)
-def test_mfma_backward_matches_oracle_chain(N, H, S, Z, E, gt, form, monkeypatch):
+def test_mfma_backward_matches_oracle_chain(N, H, S, Z, E, gt):
     """grad_q, grad_k, grad_v against the oracle operators chained as the reference's autograd
     does: dP = sddmm(dY, V); dS = clamp-mask(scale * softmax_backward(P, dP));
-    dQ = spmm(dS, K); dK = spmm(dS^T, Q); dV = spmm(P^T, dY).
-    form: the two kernels (row-owned + key-owned, the default) or the fused single kernel
-    (SPT_ATTENTION_BACKWARD=fused: d_head 64, S <= 512; other shapes take the two kernels anyway)."""
+    dQ = spmm(dS, K); dK = spmm(dS^T, Q); dV = spmm(P^T, dY)."""
     import numpy as np
-    if form == 'fused' and (E != 64 or S > 512):
-        pytest.skip('the fused backward covers d_head 64, S <= 512')
-    monkeypatch.setenv('SPT_ATTENTION_BACKWARD', form)
     from oracle import ext_stub
     from naive_gpt import ext
     gen = torch.Generator().manual_seed(7 * N + S + Z)
@@ -98,6 +88,93 @@ def test_mfma_backward_matches_oracle_chain(N, H, S, Z, E, gt, form, monkeypatch
         err = (got.cpu() - want).abs().max().item()
         assert torch.allclose(got.cpu(), want, rtol=1e-3, atol=2e-4 * want.abs().max().item()), \
             (name, err, want.abs().max().item())
+
+
+def _scores_on_the_clamp(N, H, S, Z, E, seed, width):
+    """q, k, indices with ONE entry of most rows moved onto the clamp: the row's q is rescaled so
+    that its LARGEST live score becomes scale * q_i . k_j = +-CLAMP * (1 + delta), delta uniform in
+    +-width (rows that would need a factor beyond 1/4 .. 12 stay as they are, so that the operands
+    keep ordinary magnitudes).  With width a few 2^-17 -- the split-bf16 products' error -- a score
+    formed from split operands falls on either side of the clamp whatever the fp32 score does."""
+    gen = torch.Generator().manual_seed(seed)
+    B = N * H
+    q, k, v = [torch.randn([N, S, H, E], generator=gen) for _ in range(3)]
+    indices = causal_indices(B, S, Z, gen)
+    scale = E ** -0.5
+    idx = indices.view(N, H, S, Z).long()
+    rows = torch.arange(S)
+    kk = k.transpose(1, 2).double()                                        # [N, H, S, E]
+    qq = q.transpose(1, 2).double()
+    kj = kk.unsqueeze(2).expand(N, H, S, S, E).gather(
+        3, idx.unsqueeze(-1).expand(N, H, S, Z, E)) if S <= 128 else None
+    if kj is not None:
+        s = (qq.unsqueeze(3) * kj).sum(-1) * scale                         # [N, H, S, Z]
+    else:                                                                  # (row blocks: memory)
+        s = torch.empty([N, H, S, Z], dtype=torch.float64)
+        for r0 in range(0, S, 64):
+            blk = idx[:, :, r0:r0 + 64]
+            kb = torch.stack([kk[n, h][blk[n, h]] for n in range(N) for h in range(H)]).view(
+                N, H, blk.size(2), Z, E)
+            s[:, :, r0:r0 + 64] = (qq[:, :, r0:r0 + 64].unsqueeze(3) * kb).sum(-1) * scale
+    s = torch.where(idx <= rows.view(1, 1, S, 1), s, torch.zeros_like(s))
+    top = s.abs().amax(-1)                                                 # [N, H, S]
+    delta = (torch.rand([N, H, S], generator=gen, dtype=torch.float64) * 2 - 1) * width
+    factor = CLAMP * (1 + delta) / top.clamp(min=1e-9)
+    factor = torch.where((factor > 0.25) & (factor < 12.0), factor, torch.ones_like(factor))
+    qq = (qq * factor.unsqueeze(-1)).float()
+    return qq.transpose(1, 2).contiguous(), k, v, indices, scale
+
+
+@pytest.mark.parametrize('gt', [False, True])
+@pytest.mark.parametrize('N,H,S,Z,E', [(2, 16, 512, 64, 64), (1, 8, 80, 8, 64), (1, 2, 2048, 256, 64),
+                                       (1, 4, 512, 64, 128), (1, 2, 96, 8, 128)])
+def test_clamp_mask_is_that_of_the_exact_scores(N, H, S, Z, E, gt):
+    """attention.py:125-127: the clamp passes gradient strictly inside (-10, 10) -- a discontinuous
+    function of the score.  Thousands of scores are placed within 2^-15 (relative) of +-10, where the
+    split-bf16 tile value and the fp32 score disagree about the side; the backward must follow the
+    fp32 score (ABI 39: cells within the split's error bound of the clamp are recomputed as the oracle
+    does).  The same inputs with the recomputation switched off differ visibly -- the test can see
+    what it tests."""
+    import numpy as np
+    from oracle import ext_stub
+    from naive_gpt import ext
+    B = N * H
+    q, k, v, indices, scale = _scores_on_the_clamp(N, H, S, Z, E, 11 * S + E, 2.0 ** -15)
+    gen = torch.Generator().manual_seed(5)
+    gy = torch.randn([B, S, E], generator=gen)
+    scores, attn, _ = oracle_chain(indices, q, k, v, scale)
+    flat = lambda t: t.transpose(1, 2).contiguous().view(B, S, E)       # noqa: E731
+    heads = lambda t: t.view(N, H, S, E).transpose(1, 2)                  # noqa: E731
+    indptr = torch.arange(0, S * Z + 1, Z, dtype=torch.int32)
+    f, t = torch.scalar_tensor(False), torch.scalar_tensor(True)
+    raw_scores = ext_stub.sddmm_forward_cuda(f, t, indptr, indices, flat(q), flat(k)) * np.float32(scale)
+    near = ((raw_scores.abs() - CLAMP).abs() < CLAMP * 2.0 ** -14)
+    assert near.sum() > 0.3 * B * S, 'the construction put too few scores on the clamp'
+    assert 0.2 < (raw_scores[near].abs() < CLAMP).float().mean() < 0.8      # both sides populated
+    dp = ext_stub.sddmm_forward_cuda(f, t, indptr, indices, gy, flat(v))
+    ds = ext_stub.softmax_backward_cuda(indptr, indices, attn, dp)
+    raw = torch.where(raw_scores.abs() < CLAMP, ds * np.float32(scale), torch.zeros_like(ds))
+    want_q = heads(ext_stub.spmm_forward_cuda(f, f, indptr, indices, raw, flat(k)))
+    want_k = heads(ext_stub.spmm_forward_cuda(t, f, indptr, indices, raw, flat(q)))
+
+    tiles = ext.attention_mfma_prepare(indices.cuda(), S)
+    y, row_sum = ext.attention_mfma_forward(tiles, q.cuda(), k.cuda(), v.cuda(), scale, CLAMP,
+                                            y_transposed=gt)
+    gy_in = (gy.transpose(1, 2).contiguous() if gt else gy).cuda()
+
+    def worst(exact):
+        ext.EXACT_CLAMP = exact
+        try:
+            gq, gk, _ = ext.attention_mfma_backward(tiles, q.cuda(), k.cuda(), v.cuda(), y, gy_in,
+                                                    row_sum, scale, CLAMP, transposed=gt)
+        finally:
+            ext.EXACT_CLAMP = True
+        return [((got.cpu() - want).abs().max() / want.abs().max()).item()
+                for got, want in ((gq, want_q), (gk, want_k))]
+
+    exact, split = worst(True), worst(False)
+    assert max(exact) < 2e-4, exact               # the bar of the other backward tests, no flips
+    assert max(split) > 20 * max(exact), (split, exact)     # without it cells change sides
 
 
 BF16_SHAPES = [                        # (N, H, S, Z, d_head): bf16 storage (BASELINE configs[1] "bf16")
@@ -139,10 +216,10 @@ def test_mfma_forward_bf16_storage_matches_oracle_on_rounded_inputs(N, H, S, Z, 
     rows = torch.arange(S).view(1, S, 1)
     live = (indices.view(N * H, S, Z) <= rows).float()
     want_sum = (want_scores.view(N * H, S, Z).exp() * live).sum(-1)
-    # a row that is column 0 Z = 256 times (row 0; row 1 when both of its draws are 0): the
-    # byte-sized cell count saturates at 255 (include/spt_hip.h), the row sum is 255 / 256 of exact
-    full = (indices.view(N * H, S, Z) == 0).sum(-1) > 255
-    want_sum = torch.where(full, want_sum * (255 / 256), want_sum)
+    # (a row that is column 0 Z = 256 times -- row 0; row 1 when both of its draws are 0 -- holds a
+    # multiplicity a byte cannot: flagged in the cell tiles and added back, exact since ABI 39)
+    if Z == 256:
+        assert ((indices.view(N * H, S, Z) == 0).sum(-1) > 255).any()
     assert torch.allclose(row_sum.cpu(), want_sum, rtol=1e-4)
     _close_bf16(y, want_y, 'y')
     # and the fp32 kernels on the widened inputs give the same values before the store's rounding
@@ -262,8 +339,9 @@ def test_cell_tiles_hold_the_multiplicity_of_every_live_cell():
     tiles = ext.attention_mfma_prepare(indices.cuda(), S)
     RT = S // 32
     raw = tiles.buffer.cpu().numpy()[256:]                   # behind the 256-byte header
-    mask_bytes = (B * RT * 16 + 255) // 256 * 256
+    mask_bytes = (B * RT * 20 + 255) // 256 * 256            # masks [B, RT, 2] u64 | sat [B, RT] u32
     masks = raw[:B * RT * 16].view('uint64').reshape(B, RT, 2)
+    assert not raw[B * RT * 16:B * RT * 20].any()            # no row holds a column 256 times
     ntile = RT * (RT + 1) // 2
     cells, cells_t = raw[mask_bytes:mask_bytes + 2 * B * ntile * 1024].reshape(2, B, ntile, 1024)
     idx = indices.view(B, S, Z).numpy()
