@@ -715,6 +715,21 @@ int spt_swiglu_backward(const float *grad_h, const float *gate, const float *sid
                         float *grad_side, float *dots, long long rows, int n, void *stream);
 
 /*
+ * Gradient of table[ids] (the `left` table of a LoRA embedding, lora.py:118-126; autograd of
+ * nn.Embedding): out [n_rows, width] = 0, then out[id] = sum of grad[order[t]] over the positions t of
+ * the SORTED id list with sorted_ids[t] == id, added in ascending t in fp64 (deterministic; a
+ * non-finite gradient row stays in its own id's row).  sorted_ids / order: int64, device memory, the
+ * stable sort of the flattened ids and its permutation; grad [n_ids, width] fp32 (row stride ldg),
+ * width % 4 == 0; workspace: spt_embedding_rows_backward_workspace_bytes(n_ids, width) bytes.  Launch
+ * shapes depend on n_ids alone (replayable as part of a captured HIP graph); ids outside [0, n_rows)
+ * are ignored.
+ */
+long long spt_embedding_rows_backward_workspace_bytes(long long n_ids, int width);
+int spt_embedding_rows_backward(const float *grad, long long ldg, const long long *sorted_ids,
+                                const long long *order, float *out, long long ldo, void *workspace,
+                                long long n_ids, int width, long long n_rows, void *stream);
+
+/*
  * Un-bucketing: out[t, :] = bias + sum_{j < k} rows[pos[t * k + j], :] (bias may be NULL).
  * Replaces the reference's per-block `y[mask] += ...` scatter (lora_ffn.py:107-111) with a
  * gather in a fixed order: deterministic, no atomics.  d % 4 == 0.

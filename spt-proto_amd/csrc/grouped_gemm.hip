@@ -1067,6 +1067,10 @@ __global__ __launch_bounds__(256) void relu_fix_kernel(GroupedArgs g) {
     for (unsigned i = wave; i < count; i += 16) {
         const int2 q = g.fix_list[(size_t)seg * g.fix_cap + i];
         const int p = q.x, n = q.y & 0xFFFFFF, bucket = (unsigned)q.y >> 24;
+        // an entry is an ADDRESS in the making: one that is not a cell of this launch's output (a
+        // stale counter or list, as the out-of-order memset node of round 3 produced) is skipped,
+        // not dereferenced
+        if (p < 0 || p >= g.P || n >= g.N || bucket >= g.G) continue;
         const float exact = gg_exact_preact(g, bucket, p, n, lane);
         if (lane == 0) {
             g.out[(size_t)p * g.ldo + n] = act_forward(g.act, exact);

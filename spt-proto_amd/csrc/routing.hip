@@ -305,6 +305,81 @@ __global__ __launch_bounds__(256) void swiglu_backward_kernel(
 
 using namespace spt;
 
+// ---- gradient of table[ids] (an embedding's rows): a segmented sum over SORTED ids ----
+// lora.py:118-126: `left(x)` of a LoRA embedding is nn.Embedding; its backward adds grad[t] into row
+// ids[t] of the table's gradient.  torch's own kernel sizes launches from a host-side count of the
+// batch's distinct ids (not capturable); atomics make the sum order a matter of timing.  Here: the
+// caller sorts the ids (stable) and passes the permutation; positions are cut into chunks at every
+// run start and every multiple of 64; pass 1 sums each chunk's rows in order (fp64), pass 2 lets
+// the first position of a run add its chunks' partial sums in order and write the row once.  Every
+// launch's shape depends on T alone, the result on nothing but the data, and a non-finite gradient
+// row stays inside its own id's row (a global running sum -- round 3's torch composition -- carried
+// it into every later id).
+namespace spt {
+constexpr int ER_CHUNK = 64;
+// thread = (position t, float4 column c4); r4 = columns / 4
+__global__ __launch_bounds__(256) void embedding_rows_partial_kernel(
+    const float *__restrict__ grad, long long ldg, const long long *__restrict__ sid,
+    const long long *__restrict__ order, double *__restrict__ partial, long long T, int r4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long t = i / r4;
+    const int c4 = (int)(i - t * r4);
+    if (t >= T) return;
+    const long long id = sid[t];
+    if (!(t == 0 || (t % ER_CHUNK) == 0 || sid[t - 1] != id)) return;      // not a chunk leader
+    const long long end = min(T, (t / ER_CHUNK + 1) * ER_CHUNK);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (long long u = t; u < end && sid[u] == id; u++) {
+        const float4 g = *reinterpret_cast<const float4 *>(grad + order[u] * ldg + 4 * c4);
+        a0 += g.x; a1 += g.y; a2 += g.z; a3 += g.w;
+    }
+    double *dst = partial + (t * r4 + c4) * 4;
+    dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
+}
+__global__ __launch_bounds__(256) void embedding_rows_finish_kernel(
+    const long long *__restrict__ sid, const double *__restrict__ partial, float *__restrict__ out,
+    long long ldo, long long T, int r4, long long n_rows) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long t = i / r4;
+    const int c4 = (int)(i - t * r4);
+    if (t >= T) return;
+    const long long id = sid[t];
+    if (!(t == 0 || sid[t - 1] != id)) return;                              // not a run's first position
+    if (id < 0 || id >= n_rows) return;
+    const double *src = partial + (t * r4 + c4) * 4;
+    double a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
+    for (long long u = (t / ER_CHUNK + 1) * ER_CHUNK; u < T && sid[u] == id; u += ER_CHUNK) {
+        const double *p = partial + (u * r4 + c4) * 4;
+        a0 += p[0]; a1 += p[1]; a2 += p[2]; a3 += p[3];
+    }
+    *reinterpret_cast<float4 *>(out + id * ldo + 4 * c4) = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+}
+}  // namespace spt
+
+extern "C" long long spt_embedding_rows_backward_workspace_bytes(long long n_ids, int width) {
+    return n_ids > 0 && width > 0 ? n_ids * width * (long long)sizeof(double) : 0;
+}
+
+extern "C" int spt_embedding_rows_backward(const float *grad, long long ldg, const long long *sorted_ids,
+                                           const long long *order, float *out, long long ldo,
+                                           void *workspace, long long n_ids, int width, long long n_rows,
+                                           void *stream) {
+    using namespace spt;
+    if (!grad || !sorted_ids || !order || !out || !workspace) return SPT_EINVAL;
+    if (n_ids <= 0 || n_rows <= 0 || width <= 0 || width % 4 || ldg % 4 || ldo % 4) return SPT_ESHAPE;
+    if (n_rows * ldo > 0x7fffffffLL || n_ids * (width / 4) > 0x7fffffffLL * 256) return SPT_EUNSUP;
+    hipStream_t s = (hipStream_t)stream;
+    SPT_ZERO_WORDS(out, n_rows * ldo, s);            // rows no id names: zero gradient
+    const int r4 = width / 4;
+    const unsigned blocks = (unsigned)((n_ids * r4 + 255) / 256);
+    hipLaunchKernelGGL(embedding_rows_partial_kernel, dim3(blocks), dim3(256), 0, s, grad, ldg, sorted_ids,
+                       order, (double *)workspace, n_ids, r4);
+    hipLaunchKernelGGL(embedding_rows_finish_kernel, dim3(blocks), dim3(256), 0, s, sorted_ids,
+                       (const double *)workspace, out, ldo, n_ids, r4, n_rows);
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
 extern "C" int spt_swiglu_forward(const float *gate, const float *side, float *h, long long n_elements,
                                   void *stream) {
     if (!gate || !side || !h || n_elements <= 0) return SPT_EINVAL;

@@ -947,7 +947,11 @@ extern "C" int spt_spmm_forward(int trans_lhs, const int32_t *indptr, const int3
     const int B = batch_size, S = seq_length, E = d_head;
     hipStream_t s = (hipStream_t)stream;
     if (nnz == 0) {
-        SPT_HIP_TRY(hipMemsetAsync(y, 0, (size_t)B * S * E * sizeof(float), s));
+        // (a kernel, not hipMemsetAsync: memset nodes lose their place in a captured graph,
+        // spt_common.h; the library makes no memset or memcpy call anywhere)
+        if ((long long)B * S * E > 0x7fffffffLL) return SPT_EUNSUP;
+        SPT_ZERO_WORDS(y, B * S * E, s);
+        SPT_LAUNCH_CHECK();
         return SPT_OK;
     }
     if (!trans_lhs)

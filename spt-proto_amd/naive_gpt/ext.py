@@ -80,6 +80,9 @@ _PROTOTYPES = {
                    _c_int),
     'spt_swiglu_forward': ([_c_ptr] * 3 + [ctypes.c_longlong, _c_ptr], _c_int),
     'spt_swiglu_backward': ([_c_ptr] * 6 + [ctypes.c_longlong, _c_int, _c_ptr], _c_int),
+    'spt_embedding_rows_backward_workspace_bytes': ([ctypes.c_longlong, _c_int], ctypes.c_longlong),
+    'spt_embedding_rows_backward': ([_c_ptr, ctypes.c_longlong, _c_ptr, _c_ptr, _c_ptr, ctypes.c_longlong, _c_ptr,
+                                     ctypes.c_longlong, _c_int, ctypes.c_longlong, _c_ptr], _c_int),
     'spt_rows_combine': ([_c_ptr] * 4 + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_rows_combine_side': ([_c_ptr] * 5 + [_c_int, _c_ptr] + [_c_int] * 3 + [_c_ptr], _c_int),
     'spt_ffn_coeff_grad': ([_c_ptr, _c_ptr, _c_int] + [_c_ptr] * 6 + [_c_f32, _c_ptr, _c_int, _c_int, _c_ptr],
@@ -212,12 +215,32 @@ def _same_device(*tensors):
     return dev
 
 
+# Launches of this library enqueued so far (every wrapper asks `_stream` for its stream once).  A
+# tuner that replays a captured step compares the count with what it was after its last replay:
+# a difference means EAGER work -- of this model or of any other in the process -- went to the stream
+# in between (utils/tuning.py: SparseTuner.training_step).
+LAUNCHES = 0
+
+
 def _stream(dev) -> int:
     # torch's current stream on `dev` as the raw hipStream_t (the C call behind
     # torch.cuda.current_stream(dev).cuda_stream, without the Stream object: ~0.3 us against 4 --
     # a fine-tune step makes ~600 of these calls)
+    global LAUNCHES
+    LAUNCHES += 1
     idx = dev.index
     return torch._C._cuda_getCurrentRawStream(idx if idx is not None else torch._C._cuda_getDevice())
+
+
+def held_by_caches() -> list:
+    """Every device tensor the module-level caches of this package hold for later calls: frozen
+    weights' row norms and (SPT_WEIGHT_IMAGES=keep) images.  A captured HIP graph that read one of
+    them reads its ADDRESS at every replay, whatever becomes of the cache entry (`drop_images()`,
+    a parameter re-homed): `SparseTuner.capture` keeps this list alive for the life of its graph."""
+    held = []
+    for cache in (_WEIGHT_IMAGES, _WEIGHT_NORMS):
+        held += [entry[2] for entry in cache.data.values()]
+    return held
 
 
 class _NoGuard:
@@ -1537,6 +1560,30 @@ def swiglu_backward(dh: torch.Tensor, g: torch.Tensor, s: torch.Tensor):
     if rc != 0:
         _raise(lib, rc, 'swiglu_backward')
     return dg, ds, dots[0], dots[1], dots[2]
+
+
+def embedding_rows_backward(grad: torch.Tensor, ids: torch.Tensor, n_rows: int) -> torch.Tensor:
+    """Gradient of ``table[ids]`` with respect to the table (``spt_embedding_rows_backward``):
+    grad ``[T, width]`` fp32, ids ``[T]`` int64 -> ``[n_rows, width]``; deterministic, shape-static."""
+    _check_dim(grad, 2, 'grad')
+    _check_type(grad, torch.float32, 'grad')
+    _check_type(ids, torch.int64, 'ids')
+    T, width = grad.shape
+    _require(ids.numel() == T and grad.stride(1) == 1, 'grad [T, width] with unit column stride, ids [T]')
+    _require(width % 4 == 0 and grad.stride(0) % 4 == 0, 'width and row stride: multiples of 4')
+    dev = _same_device(grad, ids)
+    lib = load_library()
+    with _on(dev):
+        sid, order = torch.sort(ids.reshape(-1), stable=True)
+        out = torch.empty([n_rows, width], dtype=torch.float32, device=dev)
+        ws = torch.empty([lib.spt_embedding_rows_backward_workspace_bytes(T, width)], dtype=torch.uint8,
+                         device=dev)
+        rc = lib.spt_embedding_rows_backward(grad.data_ptr(), grad.stride(0), sid.data_ptr(), order.data_ptr(),
+                                             out.data_ptr(), width, ws.data_ptr(), T, width, int(n_rows),
+                                             _stream(dev))
+    if rc != 0:
+        _raise(lib, rc, 'embedding_rows_backward')
+    return out
 
 
 def rows_combine(rows: torch.Tensor, pos: torch.Tensor, bias: torch.Tensor = None,

@@ -245,6 +245,36 @@ class _SparseCore:
         works: `_take_trigger` sees the buffer's version move."""
         self.__dict__['_armed_hint'] = True
 
+    @property
+    def armed(self) -> bool:
+        """Will the next forward form the PQ loss?  True after `arm()` OR after a write of True to
+        the `trigger` buffer (the reference's protocol, attention.py:98-104).  Reading it costs a
+        device read only when the buffer was written since the layer last looked.  `arm()` does NOT
+        show in `module.trigger` (or in a state_dict / a broadcast of it): code that inspects the
+        buffer after arming must ask here ("the one-shot trigger")."""
+        if self.__dict__.get('_armed_hint', False):
+            return True
+        t = self.trigger
+        seen = self.__dict__.get('_trigger_seen')
+        if not t.is_inference() and seen is not None and seen[0] == (t.data_ptr(), t._version):
+            return bool(seen[1])
+        return bool(t.is_nonzero())
+
+    def __deepcopy__(self, memo):
+        # `arm()` is an intent of the training loop for THIS module's next forward: a copy (a
+        # checkpointed or cloned model) starts disarmed, as a copy of the reference's module whose
+        # buffer was armed-and-consumed would; the host-side reading of the buffer is dropped too
+        # (the copy's buffer is another tensor)
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for key, value in self.__dict__.items():
+            if key in ('_armed_hint', '_trigger_seen'):
+                continue
+            new.__dict__[key] = copy.deepcopy(value, memo)
+        return new
+
     def _take_trigger(self) -> bool:
         """One-shot flag: the training loop arms the device buffer `trigger`, the layer
         disarms it (reference: attention.py:98-104, which reads it with a blocking

@@ -439,10 +439,10 @@ class _FrozenLoRAQKV(torch.autograd.Function):
                 gl = ext.tall_tn(x2, du_cat, split16=True)[0]                  # [len(live), k, 16]
             else:
                 gl = tall_tn(x2, du_cat).view(x2.size(1), len(live), r).permute(1, 0, 2)
-            rights = tall_tn_many([(dy2[g], u3[g]) for g in live])
+            g_rights = tall_tn_many([(dy2[g], u3[g]) for g in live])
             for i, g in enumerate(live):
                 grad_lefts[g] = gl[i]
-                grad_rights[g] = rights[i]
+                grad_rights[g] = g_rights[i]
         return (grad_x, None, None, None, None, None, None, *grad_lefts, *grad_rights, None)
 
 
@@ -508,10 +508,12 @@ class _LookupRows(torch.autograd.Function):
     ROCm): captured, that count is the capture batch's for ever -- a replay on other tokens reads
     its segment table past the end (round 3: `Memory access fault` / MEMORY_APERTURE_VIOLATION in
     rocprim's partition_kernel on the bench's captured step; round 2's captured step ran on the
-    same stale count without faulting).  Here every launch has a shape fixed by T alone, and the
-    result does not depend on timing: stable sort by id, one fp64 running sum down the sorted
-    rows, every run's total = difference of two of its values, added to a zeroed table at the
-    run's LAST position only (the other positions add an exact 0.0, in any order)."""
+    same stale count without faulting).  Here (`spt_embedding_rows_backward`) every launch has a shape
+    fixed by T alone and the result does not depend on timing: stable sort by id, every run of equal
+    ids summed in order in fp64 -- chunk by chunk, then chunk sums per run -- and written once.  A
+    run is summed on its own: one non-finite gradient row stays in its id's row (round 3's torch
+    composition took ONE running sum over all sorted rows and differences of it, which carried an inf
+    into every later id: ADVICE round 3)."""
 
     @staticmethod
     def forward(ctx, ids, table):
@@ -522,23 +524,12 @@ class _LookupRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         ids, = ctx.saved_tensors
-        flat = ids.reshape(-1)
-        g = grad.reshape(flat.numel(), -1)
-        sid, order = torch.sort(flat, stable=True)
-        # (the running sum along the LAST dimension of the transposed rows: torch's scan over an
-        # outer dimension took 1.06 ms for [8192, 16] doubles, over the inner one it is ~10 us)
-        total = torch.cumsum(g.index_select(0, order).double().t().contiguous(), dim=1)   # [r, T] fp64
-        pos = torch.arange(flat.numel(), device=flat.device)
-        first = torch.ones_like(sid, dtype=torch.bool)
-        first[1:] = sid[1:] != sid[:-1]
-        start = torch.cummax(torch.where(first, pos, torch.zeros_like(pos)), dim=0).values
-        before = torch.where((start > 0).unsqueeze(0), total.index_select(1, (start - 1).clamp_min(0)),
-                             torch.zeros_like(total))
-        last = torch.ones_like(first)
-        last[:-1] = first[1:]
-        runs = ((total - before) * last.unsqueeze(0)).to(g.dtype).t()         # [T, r]
+        g = grad.reshape(ids.numel(), -1)
+        if g.dtype == torch.float32 and g.size(1) % 4 == 0 and g.stride(1) == 1 and g.stride(0) % 4 == 0:
+            return None, ext.embedding_rows_backward(g, ids.reshape(-1), ctx.rows)
+        # (other widths / dtypes: torch's scatter-add; deterministic only without duplicates)
         out = torch.zeros([ctx.rows, g.size(1)], dtype=g.dtype, device=g.device)
-        out.index_add_(0, sid, runs)
+        out.index_add_(0, ids.reshape(-1), g)
         return None, out
 
 

@@ -94,6 +94,8 @@ class SparseTuner:
         self.last_grad_norm = None
         self._graph = None
         self._graph_lr = None
+        self._graph_launches = -1          # ext.LAUNCHES behind the last replay
+        self._graph_keepalive = None       # what the captured kernels read out of module-level caches
         # measurement hook (bench.py at N > 1): HIP events around the gradient exchange of every
         # `allreduce_every`-th update; `allreduce_events` = [(start, end), ...]
         self.allreduce_every = 0
@@ -180,9 +182,22 @@ class SparseTuner:
                 and pq_loss == self._graph_pq:
             if not self.model.training:
                 self.model.train()
-            self._graph_batch.copy_(batch)
+            from naive_gpt import ext
+            if ext.LAUNCHES != self._graph_launches:
+                # Eager launches of this library (this model's other batch shapes or validation, or
+                # any other model's step) reached the stream since the last replay.  Round 3 saw a
+                # replay in that position diverge from its eager twin on ROCm 7.2 -- for one
+                # allocation pattern, never behind a host synchronisation -- so the
+                # stream is drained first.  Replays back to back, a training loop's case, never wait.
+                torch.cuda.current_stream(self._graph_batch.device).synchronize()
+            # the batch enters, and the loss leaves, the graph's static tensors through elementwise
+            # KERNELS: a same-dtype copy_ / clone is a hipMemcpyAsync, the class of node (memset /
+            # memcpy beside kernel nodes) that 5.13 item 3 showed to lose its place
+            torch.add(batch, 0, out=self._graph_batch)
             self._graph.replay()
-            return self._graph_loss.clone()
+            loss = torch.add(self._graph_loss, 0)
+            self._graph_launches = ext.LAUNCHES
+            return loss
         return self._eager_step(batch, pq_loss)
 
     def _eager_step(self, batch: torch.Tensor, pq_loss: bool = True) -> torch.Tensor:
@@ -414,6 +429,12 @@ class SparseTuner:
         with torch.cuda.graph(graph):
             self._graph_loss = self._eager_step(self._graph_batch, pq_loss)
         self._graph = graph
+        # the captured kernels hold ADDRESSES: whatever they read out of the package's caches (the
+        # frozen weights' row norms of the ReLU bound, kept weight images) must outlive the cache
+        # entry -- `ext.drop_images()` under a live graph was a use-after-free waiting to happen
+        from naive_gpt import ext
+        self._graph_keepalive = ext.held_by_caches()
+        self._graph_launches = -1
 
     @torch.no_grad()
     def validation_step(self, batch: torch.Tensor) -> dict:

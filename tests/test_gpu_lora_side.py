@@ -102,6 +102,36 @@ def test_embedding_rows_backward_is_the_embedding_gradient_and_bit_reproducible(
     assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
 
 
+def test_embedding_rows_backward_long_runs_and_a_non_finite_row():
+    """Runs longer than a chunk (64 positions) and longer than several (one id 5000 times: a padding
+    token), ids at both ends of the table, against an fp64 scatter-add; and ONE non-finite gradient
+    row stays in its own id's row (a single running sum carried it into every later
+    id)."""
+    from naive_gpt import ext
+    gen = torch.Generator().manual_seed(5)
+    T, rows, width = 8192, 1000, 16
+    ids = torch.randint(0, rows, [T], generator=gen)
+    ids[100:5100] = 3                                          # 5000 copies: 79 chunks
+    ids[6000:6070] = rows - 1
+    ids[7000] = 0
+    ids = ids[torch.randperm(T, generator=gen)].cuda()
+    g = torch.randn([T, width], generator=gen).cuda()
+    want = torch.zeros([rows, width], dtype=torch.float64, device='cuda').index_add_(0, ids, g.double())
+    got = ext.embedding_rows_backward(g, ids, rows)
+    assert torch.allclose(got.double(), want, rtol=1e-6, atol=1e-6)
+    absent = torch.ones(rows, dtype=torch.bool, device='cuda')
+    absent[ids] = False
+    assert absent.any() and float(got[absent].abs().max()) == 0.0
+    bad = int((ids == 5).nonzero()[0])                         # some position of id 5
+    g[bad, 2] = float('inf')
+    g[bad, 3] = float('nan')
+    got2 = ext.embedding_rows_backward(g, ids, rows)
+    others = torch.arange(rows, device='cuda') != 5
+    assert torch.isfinite(got2[others]).all()
+    assert torch.equal(got2[others], got[others])
+    assert torch.isinf(got2[5, 2]) and torch.isnan(got2[5, 3])
+
+
 def test_second_table_block_and_routing_from_logits():
     """spt_lora_down2: x @ table2.T for a row-major [n2, K] matrix as one more block of the x @ L pass
     (exact fp32), and spt_route_topk_logits: the routing of sigmoid(logits + bias) from that block --

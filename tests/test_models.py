@@ -446,10 +446,7 @@ def test_captured_step_replays_the_eager_step(n_seq):
 
     assert not apart(), (len(apart()), apart()[:4])
     # back-to-back replays without a host synchronisation in between (bench.py's timed loop), then
-    # the same steps of the eager twin.  (NOT interleaved with the twin's eager launches: on ROCm
-    # 7.2 a replay that follows un-synchronised eager work on the same stream was seen to run some
-    # of its nodes early -- DESIGN.md 5.6; a host synchronisation between the two, or
-    # AMD_SERIALIZE_KERNEL=3, removes it.)
+    # the same steps of the eager twin
     if n_seq == 16:
         for b in batches + batches:
             graphed.training_step(b, pq_loss=True)
@@ -458,8 +455,44 @@ def test_captured_step_replays_the_eager_step(n_seq):
             eager.training_step(b, pq_loss=True)
         torch.cuda.synchronize()
         assert not apart(), (len(apart()), apart()[:4])
+        # and INTERLEAVED with the twin's eager launches, no host synchronisation of the test's own:
+        # the form round 3 saw diverge for one allocation pattern.  A replay
+        # that finds eager launches of the library on the stream since its last one drains the
+        # stream first (SparseTuner.training_step); dropping the package's caches under the live
+        # graph must not pull anything from under it (capture() pins what the kernels read)
+        from naive_gpt import ext
+        ext.drop_images()
+        for b in batches + batches:
+            eager.training_step(b, pq_loss=True)
+            graphed.training_step(b, pq_loss=True)
+        torch.cuda.synchronize()
+        assert not apart(), (len(apart()), apart()[:4])
     # a different batch shape falls back to the eager path
     other = torch.randint(3, 512, [2, 130], generator=gen).cuda()
     assert torch.isfinite(graphed.training_step(other, pq_loss=True))
     graphed.end_epoch()
     assert abs(graphed.lr - 0.9e-4) < 1e-9
+
+
+def test_arm_is_visible_through_armed_and_does_not_travel_with_copies():
+    """`module.arm()` is a host-side note (no device write): `module.trigger` stays False, which is
+    where it differs observably from the reference's `trigger.fill_(True)` (attention.py:98-104).
+    `module.armed` ORs the two; a deepcopy or a state_dict round trip of an armed module starts
+    disarmed (the note is this module's next forward's, not model state); the reference's protocol
+    -- a write to the buffer -- still arms."""
+    import copy
+    from naive_gpt import layers
+    attn = layers.SparseVanillaAttentionV2(d_head=64, d_codeword=8, n_codewords=16, p_dropout=0.0)
+    assert not attn.armed
+    attn.arm()
+    assert attn.armed and not bool(attn.trigger)
+    twin = copy.deepcopy(attn)
+    assert not twin.armed and attn.armed
+    fresh = layers.SparseVanillaAttentionV2(d_head=64, d_codeword=8, n_codewords=16, p_dropout=0.0)
+    fresh.load_state_dict(attn.state_dict())
+    assert not fresh.armed
+    assert attn._take_trigger() and not attn.armed          # one shot
+    attn.trigger.fill_(True)                                # the reference's way
+    assert attn.armed and bool(attn.trigger)
+    assert copy.deepcopy(attn).armed                        # device state DOES travel
+    assert attn._take_trigger() and not attn.armed and not bool(attn.trigger)
