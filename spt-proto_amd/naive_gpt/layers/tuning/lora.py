@@ -526,6 +526,7 @@ class _LookupRows(torch.autograd.Function):
         ids, = ctx.saved_tensors
         g = grad.reshape(ids.numel(), -1)
         if g.dtype == torch.float32 and g.size(1) % 4 == 0 and g.stride(1) == 1 and g.stride(0) % 4 == 0:
+            from naive_gpt import ext
             return None, ext.embedding_rows_backward(g, ids.reshape(-1), ctx.rows)
         # (other widths / dtypes: torch's scatter-add; deterministic only without duplicates)
         out = torch.zeros([ctx.rows, g.size(1)], dtype=g.dtype, device=g.device)
