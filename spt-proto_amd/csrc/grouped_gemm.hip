@@ -784,8 +784,9 @@ template <int F>
 __device__ __forceinline__ void gp_store1(const f32x16 (&pa)[2][2], const GpPrev &pv) {
     constexpr int i = F >> 5, j = (F >> 4) & 1, r = F & 15;
     constexpr int drow = 32 * i + (r & 3) + 8 * (r >> 2);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pa[i][j][r]), pv.rsrc, pv.voff[j],
-                                          drow * pv.ldo4, 0);
+    const float v = pa[i][j][r];        // (not bit_cast of the vector element: see the ring kernel's stores)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), pv.rsrc, pv.voff[j] + drow * pv.ldo4,
+                                          0, 0);
 }
 template <int C>
 __device__ __forceinline__ void gp_store_pair(const f32x16 (&pa)[2][2], const GpPrev &pv) {
@@ -1073,6 +1074,437 @@ __global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_pers_kernel(Groupe
     }
     if (pending)
         for (int chunk = 0; chunk < 32; chunk++) gp_store_chunk(chunk, prev, pv);
+}
+
+// ======================================================= image path, loader / consumer ring (round 4)
+// What a k-step of the kernels above costs a wave (a -DGG_STAMP_DMA build, tools/micro/gemm_stamps.py,
+// 4096 tiles of K = N = 1024): 2,354 cycles = 930 issuing its eight LDS-DMAs (a global_load_lds
+// costs its issuer ~120 cycles beside MFMAs and ds_reads; a wave that does nothing else issues one
+// in 25-60: MI355X_MICROARCH.md, "LDS-DMA piece issue cost", "ldsdma-fill") + 250 reading fragments
+// + 752 in its 24 MFMAs + 250 at the barrier: the waves that own the matrix pipe spend more time
+// feeding LDS than multiplying.  Here the two jobs are different WAVES.  One workgroup of eight waves
+// per CU, resident for the whole launch:
+//   waves 4-7, the loaders: walk the workgroup's k-steps (across tile boundaries), fill a ring of
+//     three 48 KiB stages (A 128 x 32 k | B 256 x 32 k, the layouts of the kernels above) by LDS-DMA,
+//     twelve instructions per wave and step, and publish a stage -- FULL[slot] += 1 per wave, an
+//     LDS word -- behind a counted vmcnt that leaves the next step's DMAs in flight; a slot is
+//     refilled when FREE[slot] says the four consumers have its fragments in registers.  The LoRA K
+//     extension is one more step of the tile whose stage the loaders fill with ds_writes (fp32
+//     a2 / b2 split on the way), so the consumers see nothing special.
+//   waves 0-3, the consumers: a 128 x 256 tile, each wave 64 x 128 (2 x 4 MFMA tiles, 128
+//     accumulator registers, 48 MFMAs per k-step): half a step's fragments are read while the other
+//     half's 24 MFMAs run; the next stage's FULL word is requested before an MFMA group and looked
+//     at behind it.  Arithmetic intensity against L2 is 1.33 x the 128 x 128 tile's (48 KiB per
+//     2 x 2 x 768 MFMA-cycles), the LDS reads per MFMA 0.5 instead of 0.67.
+// Consumer w and loader w + 4 share a SIMD (a workgroup's waves go round the SIMDs), so the matrix
+// pipe and the vector-memory issue port of a SIMD belong to different waves.
+// Plain epilogue (bias, rowscale, K extension), stores straight from the accumulator layout by
+// buffer stores.  The activation epilogues keep the kernels above.
+constexpr int GR_THREADS = 512;
+constexpr int GR_BM = 128, GR_BN = 256;
+constexpr int GR_A_TILE = GR_BM * 128, GR_B_TILE = GR_BN * 128, GR_STAGE = GR_A_TILE + GR_B_TILE;
+constexpr int GR_SLOTS = 3;
+constexpr int GR_FLAGS = GR_SLOTS * GR_STAGE;       // FULL[s] at +4 s, FREE[s] at +32 + 4 s
+constexpr int GR_RS = GR_FLAGS + 64;                // 4 consumer waves x 64 row scales
+constexpr int GR_LDS = GR_RS + 4 * 64 * 4;          // 148,544 B
+constexpr int gr_waitcnt(int vm, int lgkm) {        // s_waitcnt immediate (expcnt: no wait)
+    return (vm & 0xF) | ((vm >> 4) << 14) | (7 << 4) | ((lgkm & 0xF) << 8);
+}
+__device__ __forceinline__ unsigned gr_lds_addr(const void *p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+// Flag words: plain LDS operations in asm, so that hipcc neither counts them nor drains an LDS-DMA
+// in flight in front of them (cdna_hip_programming.md 5.7)
+__device__ __forceinline__ unsigned gr_flag_read(unsigned addr) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void gr_flag_add(unsigned addr) {
+    const unsigned one = 1u;
+    asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(one) : "memory");
+}
+// wave-uniform wait for flag >= need (counters only grow); a wait that lasts seconds means a broken
+// protocol: trap (a launch failure the host sees) rather than hang the GPU
+__device__ __forceinline__ void gr_wait(unsigned addr, unsigned need) {
+    for (unsigned spin = 0;; spin++) {
+        const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)gr_flag_read(addr));
+        if ((int)(v - need) >= 0) return;
+        __builtin_amdgcn_s_sleep(2);
+        if (spin > (1u << 25)) __builtin_trap();
+    }
+}
+// the tile list of a launch, item `id` (every wave of the workgroup walks the same list)
+struct GrPlan { int n_col_tiles, total; };
+struct GrTile { int bucket, row_lo, row_hi, n0; };
+__device__ __forceinline__ GrPlan gr_plan(const GroupedArgs &g) {
+    GrPlan pl;
+    pl.n_col_tiles = (g.N + GR_BN - 1) / GR_BN;
+    int row_tiles = 0;
+    for (int i = 0; i < g.G; i++) row_tiles += (g.offsets[i + 1] - g.offsets[i] + GR_BM - 1) / GR_BM;
+    pl.total = row_tiles * pl.n_col_tiles;
+    return pl;
+}
+__device__ __forceinline__ GrTile gr_tile(const GroupedArgs &g, const GrPlan &pl, int id) {
+    // (gridDim.x is a multiple of 8: id % 8 is the XCD of the workgroup that walks it)
+    const int logical = (int)xcd_remap((unsigned)id, (unsigned)pl.total);
+    GrTile t;
+    t.bucket = -1;
+    t.row_lo = t.row_hi = 0;
+    t.n0 = (logical % pl.n_col_tiles) * GR_BN;
+    int tile = logical / pl.n_col_tiles;
+    for (int i = 0; i < g.G; i++) {
+        const int lo = g.offsets[i], hi = g.offsets[i + 1];
+        const int tiles = (hi - lo + GR_BM - 1) / GR_BM;
+        if (tile < tiles) {
+            t.bucket = i;
+            t.row_lo = lo + tile * GR_BM;
+            t.row_hi = min(hi, t.row_lo + GR_BM);
+            break;
+        }
+        tile -= tiles;
+    }
+    return t;
+}
+
+// (diagnostic build -DGR_STAMP, tools/micro/gemm_stamps.py: where a loader / a consumer wave's cycles
+// go; the sums are written behind the launch's output)
+#ifdef GR_STAMP
+#define GR_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#define GR_ACC(slot, a, b) st[slot] += (b) - (a)
+#else
+#define GR_T(x)
+#define GR_ACC(slot, a, b)
+#endif
+template <bool BN_LAYOUT, bool EXT, bool A32>
+__device__ __forceinline__ void gr_loader(const GroupedArgs &g, char *lds, int lw, int lane) {
+#ifdef GR_STAMP
+    unsigned long long st[4] = {0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
+    const GrPlan pl = gr_plan(g);
+    const unsigned flags = gr_lds_addr(lds + GR_FLAGS);
+    const int nk = g.K / GG_BK;
+    unsigned t = 0;                                     // the workgroup's k-steps so far
+    for (int id = blockIdx.x; id < pl.total; id += gridDim.x) {
+        const GrTile tl = gr_tile(g, pl, id);
+        if (tl.bucket < 0) continue;
+        // ---- LDS-DMA sources of this wave: instruction lw + 4 j of a tile's 16 (A) / 32 (B) ----
+        const char *a_src[4], *b_src[8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = 8 * (lw + 4 * j) + (lane >> 3);
+            const int p = min(tl.row_lo + r, tl.row_hi - 1);
+            const long long src = g.gather ? g.gather[p] : p;
+            a_src[j] = (A32 ? reinterpret_cast<const char *>(g.a) : g.a_img) + src * g.a_rowb +
+                       (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+        }
+        const char *wg = g.w_img + (long long)tl.bucket * g.w_grow * g.w_rowb + (size_t)tl.bucket * g.w_gblk * 128;
+        if constexpr (!BN_LAYOUT) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int r = 8 * (lw + 4 * j) + (lane >> 3);
+                const long long n = min(tl.n0 + r, g.N - 1);
+                b_src[j] = wg + n * g.w_rowb + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+            }
+        } else {
+            // NC tile [32 k][1024 B]: instruction t = one k-row; lane = physical 16-byte chunk
+            const int nblocks = (g.N + 31) >> 5;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int kr = lw + 4 * j;
+                const int seg = (lane >> 2) ^ (kr & 3);
+                const int nb = min((tl.n0 >> 5) + (seg >> 1), nblocks - 1);
+                b_src[j] = wg + (long long)kr * g.w_rowb + (size_t)nb * 128 + (seg & 1) * 64 + ((lane & 3) << 4);
+            }
+        }
+        // Through REGISTERS, not by LDS-DMA: a -DGR_STAMP build of the first form of this loader
+        // (twelve global_load_lds per wave and step) spent 1,700 cycles per step issuing them --
+        // 140 each even in a wave that does nothing else: the CU's global -> LDS path moves about
+        // 30 bytes per clock, and the kernels above sit on the same ceiling (64 KiB per 2,350
+        // cycles).  global_load_dwordx4 (64 B / clk / CU) + ds_write_b128 (79 B / clk / CU) is twice
+        // that, and a loader wave has the registers: two steps' worth, 96, so that step t + 2 is
+        // requested as soon as step t has left for LDS.  Same LDS image (the swizzle sits in the
+        // source address), same flags; hipcc counts these loads itself.
+        uint4 ra0[4], rb0[8], ra1[4], rb1[8];
+#define GR_FETCH(KS, VA, VB)                                                                        \
+    do {                                                                                            \
+        const size_t ka_ = (size_t)(KS) * 128, kb_ = BN_LAYOUT ? (size_t)(KS) * GG_BK * g.w_rowb : ka_; \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) VA[j] = *reinterpret_cast<const uint4 *>(a_src[j] + ka_); \
+        _Pragma("unroll") for (int j = 0; j < 8; j++) VB[j] = *reinterpret_cast<const uint4 *>(b_src[j] + kb_); \
+    } while (0)
+#define GR_STEP(KS, VA, VB)                                                                         \
+    do {                                                                                            \
+        const int slot = (int)(t % GR_SLOTS);                                                       \
+        const unsigned use = t / GR_SLOTS;                                                          \
+        GR_T(l0);                                                                                   \
+        if (use > 0) gr_wait(flags + 32 + 4 * slot, 4 * use);                                       \
+        GR_T(l1);                                                                                   \
+        char *dst = lds + slot * GR_STAGE + 16 * lane;                                              \
+        _Pragma("unroll") for (int j = 0; j < 4; j++)                                               \
+            *reinterpret_cast<uint4 *>(dst + (lw + 4 * j) * 1024) =                                 \
+                make_uint4(VA[j].x, VA[j].y, VA[j].z, VA[j].w); /* (whole-element copies keep the array in scratch) */ \
+        _Pragma("unroll") for (int j = 0; j < 8; j++)                                               \
+            *reinterpret_cast<uint4 *>(dst + GR_A_TILE + (lw + 4 * j) * 1024) =                     \
+                make_uint4(VB[j].x, VB[j].y, VB[j].z, VB[j].w);                                     \
+        __builtin_amdgcn_s_waitcnt(gr_waitcnt(63, 0)); /* the ds_writes have landed */              \
+        if (lane == 0) gr_flag_add(flags + 4 * slot);                                               \
+        GR_T(l2);                                                                                   \
+        if ((KS) + 2 < nk) GR_FETCH((KS) + 2, VA, VB);                                              \
+        GR_T(l3);                                                                                   \
+        GR_ACC(0, l0, l1); GR_ACC(1, l1, l2); GR_ACC(2, l2, l3);                                    \
+        t++;                                                                                        \
+    } while (0)
+        GR_FETCH(0, ra0, rb0);
+        if (nk > 1) GR_FETCH(1, ra1, rb1);
+        for (int ks = 0; ks < nk; ks += 2) {
+            GR_STEP(ks, ra0, rb0);
+            if (ks + 1 < nk) GR_STEP(ks + 1, ra1, rb1);
+        }
+#undef GR_STEP
+#undef GR_FETCH
+        if (EXT) {
+            // the K extension's step: fp32 a2 [*, R] / b2 [n][R] split into two KC tiles (zero past R)
+            const int slot = (int)(t % GR_SLOTS);
+            const unsigned use = t / GR_SLOTS;
+            if (use > 0) gr_wait(flags + 32 + 4 * slot, 4 * use);
+            char *As = lds + slot * GR_STAGE, *Bs = As + GR_A_TILE;
+            const int ltid = 64 * lw + lane, kq = ltid & 7, k = 4 * kq;
+            auto put4 = [&](char *tile, int r, const float4 &v) {
+                unsigned h0, l0, h1, l1;
+                gg_split2(v.x, v.y, h0, l0);
+                gg_split2(v.z, v.w, h1, l1);
+                const int sw = (r >> 1) & 7;
+                char *row = tile + r * 128 + (kq & 1) * 8;
+                *reinterpret_cast<uint2 *>(row + (((kq >> 1) ^ sw) << 4)) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2 *>(row + (((4 + (kq >> 1)) ^ sw) << 4)) = make_uint2(l0, l1);
+            };
+#pragma unroll
+            for (int u = 0; u < GR_BM / 32; u++) {
+                const int r = (ltid >> 3) + 32 * u;
+                const int p = tl.row_lo + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < tl.row_hi && k < g.R) {
+                    const long long src = g.gather2 ? g.gather2[p] : p;
+                    v = *reinterpret_cast<const float4 *>(g.a2 + src * g.lda2 + k);
+                }
+                put4(As, r, v);
+            }
+#pragma unroll
+            for (int u = 0; u < GR_BN / 32; u++) {
+                const int r = (ltid >> 3) + 32 * u;
+                const int n = tl.n0 + r;
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < g.N && k < g.R)
+                    b = *reinterpret_cast<const float4 *>(g.b2 + (size_t)tl.bucket * g.b2_gstride +
+                                                          (size_t)n * g.b2_ldn + k);
+                put4(Bs, r, b);
+            }
+            __builtin_amdgcn_s_waitcnt(gr_waitcnt(63, 0));          // the ds_writes have landed
+            if (lane == 0) gr_flag_add(flags + 4 * slot);
+            t++;
+        }
+    }
+#ifdef GR_STAMP
+    if (lane == 0) {
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(g.out + (size_t)g.P * g.ldo) +
+                                  ((size_t)blockIdx.x * 8 + 4 + lw) * 6;
+        dst[0] = st[0]; dst[1] = st[1]; dst[2] = st[2]; dst[3] = st[3];
+        dst[4] = __builtin_amdgcn_s_memtime() - t_begin; dst[5] = t;
+    }
+#endif
+}
+
+template <int NJ>
+struct GrFrags { GgFrag a[2], b[NJ]; };
+// B fragment of an NC tile [32 k][1024 B] (256 n): gi_frag_nc with the longer k-row
+__device__ __forceinline__ uint4 gr_frag_nc(const char *tile, int ncol0, int q2, int part, int fh, int lane) {
+    const int gl = lane & 15, q = gl >> 2, p = gl & 3, nhalf = (lane >> 4) & 1;
+    const int seg = 2 * (ncol0 >> 5) + part;
+    const char *ptr = tile + (16 * q2 + 8 * fh + q) * 1024 + ((seg ^ q) << 6) + nhalf * 32 + p * 8;
+    const uint2 lo = gg_tr_b64(ptr), hi = gg_tr_b64(ptr + 4 * 1024);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+// half h (16 k) of a stage: the consumer's 2 A and 4 B fragments
+template <bool KC_B, bool A_F32>
+__device__ __forceinline__ void gr_read(GrFrags<4> &f, const char *As, const char *Bs, int h, int wm, int wn,
+                                        int frow, int fh, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        if constexpr (A_F32) {
+            f.a[i] = gi_frag_a32(As, wm + 32 * i + frow, h, fh);
+        } else {
+            f.a[i].hi = gi_frag_kc(As, wm + 32 * i + frow, h, 0, fh);
+            f.a[i].lo = gi_frag_kc(As, wm + 32 * i + frow, h, 1, fh);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if constexpr (KC_B) {
+            f.b[j].hi = gi_frag_kc(Bs, wn + 32 * j + frow, h, 0, fh);
+            f.b[j].lo = gi_frag_kc(Bs, wn + 32 * j + frow, h, 1, fh);
+        } else {
+            f.b[j].hi = gr_frag_nc(Bs, wn + 32 * j, h, 0, fh, lane);
+            f.b[j].lo = gr_frag_nc(Bs, wn + 32 * j, h, 1, fh, lane);
+        }
+    }
+}
+__device__ __forceinline__ void gr_mma(const GrFrags<4> &f, f32x16 (&acc)[2][4]) {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = gg_mma3(f.a[i], f.b[j], acc[i][j]);
+}
+
+template <bool BN_LAYOUT, bool EXT, bool A32>
+__device__ __forceinline__ void gr_consumer(const GroupedArgs &g, char *lds, int cw, int lane) {
+#ifdef GR_STAMP
+    unsigned long long st[4] = {0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
+    const GrPlan pl = gr_plan(g);
+    const unsigned flags = gr_lds_addr(lds + GR_FLAGS);
+    const int nk = g.K / GG_BK;
+    const int wm = (cw >> 1) * 64, wn = (cw & 1) * 128;
+    const int frow = lane & 31, fh = lane >> 5;
+    float *rsbuf = reinterpret_cast<float *>(lds + GR_RS) + 64 * cw;
+    unsigned t = 0;
+    for (int id = blockIdx.x; id < pl.total; id += gridDim.x) {
+        const GrTile tl = gr_tile(g, pl, id);
+        if (tl.bucket < 0) continue;
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+        // this wave's 64 row scales, through its own LDS words (read back per accumulator row)
+        if (g.rowscale) {
+            rsbuf[lane] = g.rowscale[min(tl.row_lo + wm + lane, tl.row_hi - 1)];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        GrFrags<4> f0, f1;
+        GR_T(c0);
+        gr_wait(flags + 4 * (t % GR_SLOTS), 4 * (t / GR_SLOTS + 1));
+        GR_T(c1);
+        GR_ACC(0, c0, c1);
+        {
+            const char *As = lds + (t % GR_SLOTS) * GR_STAGE;
+            gr_read<!BN_LAYOUT, A32>(f0, As, As + GR_A_TILE, 0, wm, wn, frow, fh, lane);
+        }
+        for (int ks = 0; ks < nk; ks++, t++) {
+            const int slot = (int)(t % GR_SLOTS);
+            const char *As = lds + slot * GR_STAGE;
+            const bool more = ks + 1 < nk;
+            const unsigned nslot = (t + 1) % GR_SLOTS, nneed = 4 * ((t + 1) / GR_SLOTS + 1);
+            // the next stage's FULL word: asked for now, looked at behind the MFMAs
+            unsigned fv = 0;
+            if (more) asm volatile("ds_read_b32 %0, %1" : "=v"(fv) : "v"(flags + 4 * nslot) : "memory");
+            gr_read<!BN_LAYOUT, A32>(f1, As, As + GR_A_TILE, 1, wm, wn, frow, fh, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            gr_mma(f0, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fv)::"memory");   // f1 (and fv) have landed
+            if (lane == 0) gr_flag_add(flags + 32 + 4 * slot);           // the stage may be refilled
+            if (more) {
+                GR_T(c2);
+                if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)fv) - nneed) < 0)
+                    gr_wait(flags + 4 * nslot, nneed);
+                GR_T(c3);
+                GR_ACC(1, c2, c3);
+                const char *An = lds + nslot * GR_STAGE;
+                gr_read<!BN_LAYOUT, A32>(f0, An, An + GR_A_TILE, 0, wm, wn, frow, fh, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            gr_mma(f1, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // rowscale applies to the main product alone: before the K extension
+        if (g.rowscale) {
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float rs = rsbuf[32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[i][j][r] *= rs;
+                }
+        }
+        if (EXT) {
+            const int slot = (int)(t % GR_SLOTS);
+            gr_wait(flags + 4 * slot, 4 * (t / GR_SLOTS + 1));
+            const char *As = lds + slot * GR_STAGE;
+            gr_read<true, false>(f0, As, As + GR_A_TILE, 0, wm, wn, frow, fh, lane);
+            if (g.R > 16) gr_read<true, false>(f1, As, As + GR_A_TILE, 1, wm, wn, frow, fh, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) gr_flag_add(flags + 32 + 4 * slot);
+            gr_mma(f0, acc);
+            if (g.R > 16) gr_mma(f1, acc);
+            t++;
+        }
+        if (g.bias) {
+            const float *bp = g.bias + (size_t)tl.bucket * g.N + tl.n0 + wn + frow;
+            float b4[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) b4[j] = tl.n0 + wn + 32 * j + frow < g.N ? bp[32 * j] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float rs = g.rowscale ? rsbuf[32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh] : 1.0f;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[i][j][r] = fmaf(rs, b4[j], acc[i][j][r]);
+                }
+        }
+        // ---- stores, from the accumulator layout: a dword per lane, two 128-byte row segments per
+        // instruction; rows past the bucket end fall outside the descriptor, columns past N get an
+        // offset beyond it (no branch round a store) ----
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            g.out + (long long)tl.row_lo * g.ldo, 0, (int)((long long)(tl.row_hi - tl.row_lo) * g.ldo * 4),
+            0x00020000);
+        const unsigned ldo4 = (unsigned)(g.ldo * 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int col = tl.n0 + wn + 32 * j + frow;
+            const unsigned voff = col < g.N ? (unsigned)(wm + 4 * fh) * ldo4 + 4u * (unsigned)col : 0x80000000u;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    // (through a float: __builtin_bit_cast of an ext_vector ELEMENT took element 0 for
+                    // every r -- hipcc 7.2 -- and every row of a tile got its first row's values.  The
+                    // row goes into the VECTOR offset: the range check does not see the scalar one)
+                    const float v = acc[i][j][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(
+                        __builtin_bit_cast(unsigned, v), rsrc,
+                        voff + (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * ldo4, 0, 0);
+                }
+        }
+    }
+#ifdef GR_STAMP
+    if (lane == 0) {
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(g.out + (size_t)g.P * g.ldo) +
+                                  ((size_t)blockIdx.x * 8 + cw) * 6;
+        dst[0] = st[0]; dst[1] = st[1]; dst[2] = st[2]; dst[3] = st[3];
+        dst[4] = __builtin_amdgcn_s_memtime() - t_begin; dst[5] = t;
+    }
+#endif
+}
+
+template <bool BN_LAYOUT, bool EXT, bool A32>
+__global__ __launch_bounds__(GR_THREADS, 1) void grouped_gemm_ring_kernel(GroupedArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) char gr_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < 16) reinterpret_cast<unsigned *>(gr_smem + GR_FLAGS)[threadIdx.x] = 0u;
+    __syncthreads();
+    if (wave < 4)
+        gr_consumer<BN_LAYOUT, EXT, A32>(g, gr_smem, wave, lane);
+    else
+        gr_loader<BN_LAYOUT, EXT, A32>(g, gr_smem, wave - 4, lane);
 }
 
 // ============================================================================ register path
@@ -1569,6 +2001,41 @@ static int launch_grouped(GroupedArgs g, int epilogue, void *stream) {
     if (g.slots <= 0) return SPT_EINVAL;
     const int img = image_path(g, epilogue);
     if (!img && (!g.a || !g.w)) return SPT_EUNSUP;              // images only, but not usable
+    // the loader / consumer ring: plain epilogue, image path, nothing to add into; one workgroup per CU
+    // OPT-IN (SPT_GEMM_RING=1).  Alone it is 3-5 % faster than the kernels above at every size
+    // (tools/micro/gemm_abl.py: 411 against 424 us at 4096 tiles); inside the configs[2] step it is
+    // 4.8 ms SLOWER (58.3 against 53.5 ms, GEMM 30.8 against 27.7): 128 x 256 tiles on 256 resident
+    // workgroups quantise badly at the step's shapes (FFN down: 520 tiles = 3 rounds for 2.03, q / k / v
+    // 768 = 3 for 3, o 256 = 1), and its stamps show why the lead was small to begin with -- with the
+    // loads in dedicated waves a k-step is still 2,900 cycles for 1,536 of MFMAs, because the loader's
+    // twelve vector loads take 1,370 cycles to issue (the CU's L2 -> CU path runs at ~34 B / clk on
+    // these 8-rows-per-instruction accesses, LDS-DMA or not) and its 48 KiB of ds_write_b128 another
+    // 730 on the LDS port the consumers read through.
+    static const bool ring_on = getenv("SPT_GEMM_RING") && getenv("SPT_GEMM_RING")[0] == '1';
+    if (img && epilogue == EPI_PLAIN && !g.accumulate && ring_on && (g.slots % 16) == 0 &&
+        (long long)GR_BM * g.ldo * 4 < 0x7fffffffLL && (!ext || g.R <= GG_BK)) {
+        const dim3 rgrid(g.slots / GG_SLOTS_PER_CU);
+#define SPT_GR(BN, EXT)                                                                              \
+    do {                                                                                             \
+        if (img == 1) {                                                                              \
+            SPT_HIP_TRY(hipFuncSetAttribute((const void *)grouped_gemm_ring_kernel<BN, EXT, false>,  \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, GR_LDS));    \
+            hipLaunchKernelGGL((grouped_gemm_ring_kernel<BN, EXT, false>), rgrid, dim3(GR_THREADS), GR_LDS, s, g); \
+        } else {                                                                                     \
+            SPT_HIP_TRY(hipFuncSetAttribute((const void *)grouped_gemm_ring_kernel<BN, EXT, true>,   \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, GR_LDS));    \
+            hipLaunchKernelGGL((grouped_gemm_ring_kernel<BN, EXT, true>), rgrid, dim3(GR_THREADS), GR_LDS, s, g);  \
+        }                                                                                            \
+    } while (0)
+        if (g.ldk == 1) {
+            if (ext) SPT_GR(false, true); else SPT_GR(false, false);
+        } else {
+            if (ext) SPT_GR(true, true); else SPT_GR(true, false);
+        }
+#undef SPT_GR
+        SPT_LAUNCH_CHECK();
+        return SPT_OK;
+    }
     // the persistent form: plain epilogue, image path, nothing to add into; `slots` workgroups
     // (a multiple of 8), each walking ids blockIdx, blockIdx + slots, ...
     // (opt-in while tools/micro/gemm_check.py still finds it wrong for K or N above 1024)
