@@ -594,6 +594,9 @@ __device__ __forceinline__ void gemm_tile_img(const GroupedArgs &g, float *smem,
                                               int row_lo, int row_hi, int col_tile) {
     constexpr int NI = BM / 64;                 // 32-row sub-blocks per wave
     constexpr int NA = BM / 32;                 // LDS-DMA instructions per wave: A tile
+#ifdef GG_STAMP_DMA
+    const unsigned long long t_enter = __builtin_amdgcn_s_memtime();
+#endif
     char *const lds0 = reinterpret_cast<char *>(smem);
     const int n0 = col_tile * GG_BN;
     const int tid = threadIdx.x;
@@ -689,13 +692,7 @@ __device__ __forceinline__ void gemm_tile_img(const GroupedArgs &g, float *smem,
         }
     }
 #ifdef GG_STAMP_DMA
-    if (lane == 0) {
-        // five counters per wave behind the launch's output (the caller allocates the room)
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(g.out + (size_t)g.P * g.ldo) +
-                                  ((size_t)blockIdx.x * 4 + wave) * 5;
-        dst[0] = st[0]; dst[1] = st[1]; dst[2] = st[2]; dst[3] = st[3];
-        dst[4] = __builtin_amdgcn_s_memtime() - loop0;
-    }
+    const unsigned long long loop1 = __builtin_amdgcn_s_memtime();
 #endif
 #undef GG_ST
 #undef GG_BAR
@@ -750,331 +747,31 @@ __device__ __forceinline__ void gemm_tile_img(const GroupedArgs &g, float *smem,
     if (acc[0][0][0] == 123.456f) g.out[0] = acc[0][1][3] + acc[NI - 1][0][5];
     return;
 #endif
+#ifdef GG_STAMP_DMA
+    const unsigned long long epi0 = __builtin_amdgcn_s_memtime();
+#endif
     gg_epilogue<NI, EPI>(g, smem, acc, bucket, row_lo, row_hi, col_tile, wm, wn, extras, EXT);
+#ifdef GG_STAMP_DMA
+    if (lane == 0) {
+        // eight counters per wave behind the launch's output (the caller allocates the room):
+        // the loop's four phases; loop; entry -> loop; loop -> epilogue; epilogue
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(g.out + (size_t)g.P * g.ldo) +
+                                  ((size_t)blockIdx.x * 4 + wave) * 8;
+        dst[0] = st[0]; dst[1] = st[1]; dst[2] = st[2]; dst[3] = st[3];
+        dst[4] = loop1 - loop0; dst[5] = loop0 - t_enter; dst[6] = epi0 - loop1;
+        dst[7] = __builtin_amdgcn_s_memtime() - epi0;
+    }
+#endif
 }
 
 struct GgWork {
     int bucket, row_lo, row_hi, col_tile, half;
 };
 
-// ================================================================== image path, persistent form
-// Round 4.  Ablation builds of the kernel above (tools/micro/gemm_abl.py, 4096 tiles of K = N = 1024;
-// a build without the k-loop's LDS-DMA after the first two steps, one without the epilogue, one
-// without both) took 423 us shipped, 303 without the DMA, 317 without the epilogue and 210 without
-// both: a quarter of a tile's time is its epilogue -- 64 KiB through the LDS transposer and out, with
-// the matrix pipe of the workgroup idle and, the launch running in rounds, every workgroup of the
-// chip storing at the same moment -- and another quarter waits for operand stages.  Here a workgroup
-// stays resident and walks its share of the launch's tiles; a finished tile's accumulators (bias
-// already applied) stay in REGISTERS, and are stored straight from the accumulator layout -- one
-// dword per lane, a wave-instruction = two 128-byte row segments, no LDS -- two registers per k-step
-// in the shadow of the NEXT tile's MFMAs.  Plain epilogue only (q / k / v / o projections, FFN down,
-// every dX product): the activation epilogues need row dots and saved activations and keep the
-// kernel above; so do half-height tiles of the tail and accumulating launches.
-// Where the waiting tile goes: buffer stores (out-of-range lanes are dropped by the hardware -- no
-// branch round a store, which would turn every later wait into vmcnt(0)).  The descriptor covers
-// the tile's rows inside its bucket: &out[row_lo][0], (row_hi - row_lo) * ldo floats; a lane's
-// offset is that of its column in the tile's first row, or 2^31 (beyond any descriptor) for a column
-// past N; the row of a register goes into the instruction's scalar offset.
-struct GpPrev {
-    __amdgpu_buffer_rsrc_t rsrc;
-    unsigned voff[2];           // byte offset of column wn + 32 j + (lane & 31), row wm + 4 fh
-    unsigned ldo4;              // bytes per row
-};
-template <int F>
-__device__ __forceinline__ void gp_store1(const f32x16 (&pa)[2][2], const GpPrev &pv) {
-    constexpr int i = F >> 5, j = (F >> 4) & 1, r = F & 15;
-    constexpr int drow = 32 * i + (r & 3) + 8 * (r >> 2);
-    const float v = pa[i][j][r];        // (not bit_cast of the vector element: see the ring kernel's stores)
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), pv.rsrc, pv.voff[j] + drow * pv.ldo4,
-                                          0, 0);
-}
-template <int C>
-__device__ __forceinline__ void gp_store_pair(const f32x16 (&pa)[2][2], const GpPrev &pv) {
-    gp_store1<2 * C>(pa, pv);
-    gp_store1<2 * C + 1>(pa, pv);
-}
-// chunk c of 32 (wave-uniform): the register indices must be compile-time constants
-__device__ __forceinline__ void gp_store_chunk(int c, const f32x16 (&pa)[2][2], const GpPrev &pv) {
-    switch (c) {
-#define GP_CASE(C) case C: gp_store_pair<C>(pa, pv); break;
-        GP_CASE(0) GP_CASE(1) GP_CASE(2) GP_CASE(3) GP_CASE(4) GP_CASE(5) GP_CASE(6) GP_CASE(7)
-        GP_CASE(8) GP_CASE(9) GP_CASE(10) GP_CASE(11) GP_CASE(12) GP_CASE(13) GP_CASE(14) GP_CASE(15)
-        GP_CASE(16) GP_CASE(17) GP_CASE(18) GP_CASE(19) GP_CASE(20) GP_CASE(21) GP_CASE(22) GP_CASE(23)
-        GP_CASE(24) GP_CASE(25) GP_CASE(26) GP_CASE(27) GP_CASE(28) GP_CASE(29) GP_CASE(30) GP_CASE(31)
-#undef GP_CASE
-        default: break;
-    }
-}
-// gi_step with the waiting tile's chunk between the two MFMA groups
-template <int NI, int NA, bool BN_LAYOUT, bool A32>
-__device__ __forceinline__ void gp_step(const GiLane<NI, NA> &c, char *__restrict__ dma,
-                                        const char *__restrict__ cur, bool prefetch, int k_next,
-                                        f32x16 (&acc)[NI][2], int chunk, const f32x16 (&pa)[2][2],
-                                        const GpPrev &pv) {
-    GiFrags<NI> f0, f1;
-    if (prefetch) gi_stage<NI, NA, BN_LAYOUT>(c, dma, k_next);
-    gi_read<NI, NA, !BN_LAYOUT, A32>(c, cur, cur + GI_TILE, 0, f0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0) only
-    __builtin_amdgcn_sched_barrier(0);
-    gi_read<NI, NA, !BN_LAYOUT, A32>(c, cur, cur + GI_TILE, 1, f1);
-    __builtin_amdgcn_sched_barrier(0);
-    gi_mma<NI>(f0, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    gp_store_chunk(chunk, pa, pv);                      // (chunk 32: nothing waits)
-    __builtin_amdgcn_sched_barrier(0);
-    gi_mma<NI>(f1, acc);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// One full 128 x 128 tile; `prev` / `pv` / `pending`: the tile before it, stored during this one's
-// k-loop; on return they describe THIS tile.
-template <bool BN_LAYOUT, bool EXT, bool A32>
-__device__ __forceinline__ void gemm_tile_pers(const GroupedArgs &g, float *smem, int bucket, int row_lo,
-                                               int row_hi, int col_tile, f32x16 (&prev)[2][2],
-                                               GpPrev &pv, bool &pending) {
-    constexpr int BM = GG_BM, NI = 2, NA = 4;
-    char *const lds0 = reinterpret_cast<char *>(smem);
-    const int n0 = col_tile * GG_BN;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    GiLane<NI, NA> c;
-    c.lane = lane;
-    c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    c.wm = (c.wave >> 1) * (BM / 2);
-    c.wn = (c.wave & 1) * 64;
-    c.frow = lane & 31;
-    c.fh = lane >> 5;
-    c.w_rowb = g.w_rowb;
-    const int wave = c.wave, wm = c.wm, wn = c.wn;
-
-    float *const extras = smem + GI_LDS_FLOATS;
-    __syncthreads();            // the tile before this one has read its extras and operand stages
-    if (tid < BM) {
-        const int p = min(row_lo + tid, row_hi - 1);
-        extras[384 + tid] = g.rowscale ? g.rowscale[p] : 1.0f;
-    }
-#pragma unroll
-    for (int j = 0; j < NA; j++) {
-        const int r = 8 * (wave + 4 * j) + (lane >> 3);
-        const int p = min(row_lo + r, row_hi - 1);
-        const long long src = g.gather ? g.gather[p] : p;
-        c.a_src[j] = (A32 ? reinterpret_cast<const char *>(g.a) : g.a_img) + src * g.a_rowb +
-                     (((lane & 7) ^ ((r >> 1) & 7)) << 4);
-    }
-    const char *wg = g.w_img + (long long)bucket * g.w_grow * g.w_rowb + (size_t)bucket * g.w_gblk * 128;
-    if constexpr (!BN_LAYOUT) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int r = 8 * (wave + 4 * j) + (lane >> 3);
-            const long long n = min(n0 + r, g.N - 1);
-            c.b_src[j] = wg + n * g.w_rowb + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
-        }
-    } else {
-        const int nblocks = (g.N + 31) >> 5;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int kr = 2 * (wave + 4 * j) + (lane >> 5);
-            const int pchunk = lane & 31;
-            const int seg = (pchunk >> 2) ^ (kr & 3);
-            const int nb = min((n0 >> 5) + (seg >> 1), nblocks - 1);
-            c.b_src[j] = wg + (long long)kr * g.w_rowb + (size_t)nb * 128 + (seg & 1) * 64 +
-                         ((pchunk & 3) << 4);
-        }
-    }
-
-    f32x16 acc[NI][2];
-#pragma unroll
-    for (int i = 0; i < NI; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-
-    gi_stage<NI, NA, BN_LAYOUT>(c, lds0, 0);
-    __syncthreads();
-    // the waiting tile leaves two registers per k-step (chunks 0 .. 31); a contraction shorter than
-    // 32 steps stores the rest behind the loop, a longer one is done early
-    int chunk = pending ? 0 : 32;
-    // The barrier of a step publishes the NEXT stage (this wave's LDS-DMAs must have landed) and
-    // retires this stage's reads -- it has no business waiting for the two stores of the waiting
-    // tile issued in the same step: a `__syncthreads()` brings `s_waitcnt vmcnt(0)`, which made every
-    // step as long as a store's round trip (the first build of this kernel: 427.7 us for 4096 tiles
-    // against 430.4 without the deferral, i.e. nothing).  vmcnt counts in issue order and the stores
-    // are the step's youngest memory operations: vmcnt(2) is "the DMAs have landed".
-    auto step_barrier = [&](bool stored) {
-        asm volatile("" ::: "memory");
-        if (stored)
-            __builtin_amdgcn_s_waitcnt(0x0072);         // vmcnt(2) lgkmcnt(0)
-        else
-            __builtin_amdgcn_s_waitcnt(0x0070);         // vmcnt(0) lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    for (int k0 = 0; k0 < g.K; k0 += 2 * GG_BK) {
-        gp_step<NI, NA, BN_LAYOUT, A32>(c, lds0 + GI_STAGE, lds0, k0 + GG_BK < g.K, k0 + GG_BK, acc,
-                                        chunk, prev, pv);
-        step_barrier(chunk < 32);
-        chunk = min(chunk + 1, 32);
-        if (k0 + GG_BK < g.K) {
-            gp_step<NI, NA, BN_LAYOUT, A32>(c, lds0, lds0 + GI_STAGE, k0 + 2 * GG_BK < g.K,
-                                            k0 + 2 * GG_BK, acc, chunk, prev, pv);
-            step_barrier(chunk < 32);
-            chunk = min(chunk + 1, 32);
-        }
-    }
-    for (; chunk < 32; chunk++) gp_store_chunk(chunk, prev, pv);
-
-    gg_scale_rows<NI>(g, acc, extras, wm);
-
-    if (EXT) {
-        char *As = lds0, *Bs = lds0 + GI_TILE;
-        const int kq = tid & 7, k = 4 * kq;
-        auto put4 = [&](char *tile, int r, const float4 &v) {
-            unsigned h0, l0, h1, l1;
-            gg_split2(v.x, v.y, h0, l0);
-            gg_split2(v.z, v.w, h1, l1);
-            const int sw = (r >> 1) & 7;
-            char *row = tile + r * 128 + (kq & 1) * 8;
-            *reinterpret_cast<uint2 *>(row + (((kq >> 1) ^ sw) << 4)) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2 *>(row + (((4 + (kq >> 1)) ^ sw) << 4)) = make_uint2(l0, l1);
-        };
-#pragma unroll
-        for (int u = 0; u < BM / 32; u++) {
-            const int r = (tid >> 3) + 32 * u;
-            const int p = row_lo + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < row_hi && k < g.R) {
-                const long long src = g.gather2 ? g.gather2[p] : p;
-                v = *reinterpret_cast<const float4 *>(g.a2 + src * g.lda2 + k);
-            }
-            put4(As, r, v);
-        }
-#pragma unroll
-        for (int u = 0; u < GG_BN / 32; u++) {
-            const int r = (tid >> 3) + 32 * u;
-            const int n = n0 + r;
-            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < g.N && k < g.R)
-                b = *reinterpret_cast<const float4 *>(g.b2 + (size_t)bucket * g.b2_gstride +
-                                                      (size_t)n * g.b2_ldn + k);
-            put4(Bs, r, b);
-        }
-        __syncthreads();
-        gi_contract<NI, NA, true>(c, As, Bs, 0, acc);
-        if (g.R > 16) gi_contract<NI, NA, true>(c, As, Bs, 1, acc);
-    }
-    // bias, in the accumulator layout: v = acc + rowscale * bias (the plain epilogue's fmaf(rs, b, c))
-    if (g.bias) {
-        const float *bp = g.bias + (size_t)bucket * g.N + n0 + wn + c.frow;
-        const float b0 = n0 + wn + c.frow < g.N ? bp[0] : 0.0f;
-        const float b1 = n0 + wn + 32 + c.frow < g.N ? bp[32] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < NI; i++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float rs = extras[384 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * c.fh];
-                acc[i][0][r] = fmaf(rs, b0, acc[i][0][r]);
-                acc[i][1][r] = fmaf(rs, b1, acc[i][1][r]);
-            }
-    }
-    // this tile waits now
-#pragma unroll
-    for (int i = 0; i < NI; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) prev[i][j] = acc[i][j];
-    pv.rsrc = __builtin_amdgcn_make_buffer_rsrc(g.out + (long long)row_lo * g.ldo, 0,
-                                                (int)((long long)(row_hi - row_lo) * g.ldo * 4), 0x00020000);
-    pv.ldo4 = (unsigned)(g.ldo * 4);
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int col = n0 + wn + 32 * j + c.frow;
-        pv.voff[j] = col < g.N ? (unsigned)(wm + 4 * c.fh) * pv.ldo4 + 4u * (unsigned)col : 0x80000000u;
-    }
-    pending = true;
-}
-
-// the launch's work list, item `id`: ids [0, main) the full tiles, [main, main + 2 rest) the halves
-// of the last partial round (gg_find_work's arithmetic, the id a parameter)
-struct GgPlan {
-    int n_col_tiles, main_tiles, rest;
-};
-__device__ __forceinline__ GgPlan gg_plan(const GroupedArgs &g) {
-    GgPlan pl;
-    pl.n_col_tiles = (g.N + GG_BN - 1) / GG_BN;
-    int row_tiles = 0;
-    for (int i = 0; i < g.G; i++) row_tiles += (g.offsets[i + 1] - g.offsets[i] + GG_BM - 1) / GG_BM;
-    const int total = row_tiles * pl.n_col_tiles;
-    pl.main_tiles = (total / g.slots) * g.slots;
-    pl.rest = total - pl.main_tiles;
-    return pl;
-}
-__device__ __forceinline__ GgWork gg_item(const GroupedArgs &g, const GgPlan &pl, int id) {
-    GgWork w;
-    w.bucket = -1;
-    w.row_lo = w.row_hi = w.col_tile = 0;
-    w.half = -1;
-    int logical;
-    if (id < pl.main_tiles) {
-        logical = (int)xcd_remap((unsigned)id, (unsigned)pl.main_tiles);
-    } else {
-        id -= pl.main_tiles;
-        if (id >= 2 * pl.rest) return w;
-        const int h = (int)xcd_remap((unsigned)id, (unsigned)(2 * pl.rest));
-        logical = pl.main_tiles + (h >> 1);
-        w.half = h & 1;
-    }
-    w.col_tile = logical % pl.n_col_tiles;
-    int tile = logical / pl.n_col_tiles;
-    for (int i = 0; i < g.G; i++) {
-        const int lo = g.offsets[i], hi = g.offsets[i + 1];
-        const int tiles = (hi - lo + GG_BM - 1) / GG_BM;
-        if (tile < tiles) {
-            w.bucket = i;
-            w.row_lo = lo + tile * GG_BM;
-            w.row_hi = min(hi, w.row_lo + GG_BM);
-            break;
-        }
-        tile -= tiles;
-    }
-    if (w.bucket >= 0 && w.half >= 0) {
-        w.row_lo += (GG_BM / 2) * w.half;
-        w.row_hi = min(w.row_hi, w.row_lo + GG_BM / 2);
-        if (w.row_lo >= w.row_hi) w.bucket = -1;
-    }
-    return w;
-}
-
-template <bool BN_LAYOUT, bool EXT, bool A32>
-__global__ __launch_bounds__(GG_THREADS, 2) void grouped_gemm_pers_kernel(GroupedArgs g) {
-    __shared__ __attribute__((aligned(1024))) float smem[GI_LDS_FLOATS + GG_EXTRAS];
-    const GgPlan pl = gg_plan(g);
-    const int items = pl.main_tiles + 2 * pl.rest;
-    f32x16 prev[2][2];
-    GpPrev pv;
-    pv.rsrc = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, 0, 0x00020000);
-    pv.voff[0] = pv.voff[1] = 0x80000000u;
-    pv.ldo4 = 0;
-    bool pending = false;
-    // (gridDim.x is a multiple of 8: an id keeps the XCD its workgroup runs on, as xcd_remap assumes)
-    for (int id = blockIdx.x; id < items; id += gridDim.x) {
-        const GgWork w = gg_item(g, pl, id);
-        if (w.bucket < 0) continue;
-        if (w.half < 0) {
-            gemm_tile_pers<BN_LAYOUT, EXT, A32>(g, smem, w.bucket, w.row_lo, w.row_hi, w.col_tile, prev, pv,
-                                                pending);
-        } else {
-            if (pending) {
-                for (int chunk = 0; chunk < 32; chunk++) gp_store_chunk(chunk, prev, pv);
-                pending = false;
-            }
-            __syncthreads();
-            gemm_tile_img<GG_BM / 2, BN_LAYOUT, EPI_PLAIN, EXT, A32>(g, smem, w.bucket, w.row_lo, w.row_hi,
-                                                                     w.col_tile);
-        }
-    }
-    if (pending)
-        for (int chunk = 0; chunk < 32; chunk++) gp_store_chunk(chunk, prev, pv);
-}
+// (Round 4 also built a persistent form of the kernel above whose finished tile waited in registers
+// and was stored, a dword per lane straight from the accumulator layout, in the shadow of the next
+// tile's MFMAs: 483 against 428 us at 4096 tiles, 56.2 against 55.0 ms in the step -- four times the
+// store instructions of the LDS-transposed epilogue cost more than the overlap returns.  Not kept.)
 
 // ======================================================= image path, loader / consumer ring (round 4)
 // What a k-step of the kernels above costs a wave (a -DGG_STAMP_DMA build, tools/micro/gemm_stamps.py,
@@ -2011,7 +1708,9 @@ static int launch_grouped(GroupedArgs g, int epilogue, void *stream) {
     // twelve vector loads take 1,370 cycles to issue (the CU's L2 -> CU path runs at ~34 B / clk on
     // these 8-rows-per-instruction accesses, LDS-DMA or not) and its 48 KiB of ds_write_b128 another
     // 730 on the LDS port the consumers read through.
-    static const bool ring_on = getenv("SPT_GEMM_RING") && getenv("SPT_GEMM_RING")[0] == '1';
+    // (read at every call: tests switch it inside one process)
+    const char *ring_env = getenv("SPT_GEMM_RING");
+    const bool ring_on = ring_env && ring_env[0] == '1';
     if (img && epilogue == EPI_PLAIN && !g.accumulate && ring_on && (g.slots % 16) == 0 &&
         (long long)GR_BM * g.ldo * 4 < 0x7fffffffLL && (!ext || g.R <= GG_BK)) {
         const dim3 rgrid(g.slots / GG_SLOTS_PER_CU);
@@ -2033,29 +1732,6 @@ static int launch_grouped(GroupedArgs g, int epilogue, void *stream) {
             if (ext) SPT_GR(true, true); else SPT_GR(true, false);
         }
 #undef SPT_GR
-        SPT_LAUNCH_CHECK();
-        return SPT_OK;
-    }
-    // the persistent form: plain epilogue, image path, nothing to add into; `slots` workgroups
-    // (a multiple of 8), each walking ids blockIdx, blockIdx + slots, ...
-    // (opt-in while tools/micro/gemm_check.py still finds it wrong for K or N above 1024)
-    static const bool pers_on = getenv("SPT_GEMM_PERSISTENT") && getenv("SPT_GEMM_PERSISTENT")[0] == '1';
-    if (img && epilogue == EPI_PLAIN && !g.accumulate && pers_on && (g.slots % 8) == 0 &&
-        (long long)GG_BM * g.ldo * 4 < 0x7fffffffLL) {
-        const dim3 pgrid(g.slots);
-#define SPT_GP(BN, EXT)                                                                            \
-    do {                                                                                           \
-        if (img == 1)                                                                              \
-            hipLaunchKernelGGL((grouped_gemm_pers_kernel<BN, EXT, false>), pgrid, dim3(GG_THREADS), 0, s, g); \
-        else                                                                                       \
-            hipLaunchKernelGGL((grouped_gemm_pers_kernel<BN, EXT, true>), pgrid, dim3(GG_THREADS), 0, s, g);  \
-    } while (0)
-        if (g.ldk == 1) {
-            if (ext) SPT_GP(false, true); else SPT_GP(false, false);
-        } else {
-            if (ext) SPT_GP(true, true); else SPT_GP(true, false);
-        }
-#undef SPT_GP
         SPT_LAUNCH_CHECK();
         return SPT_OK;
     }

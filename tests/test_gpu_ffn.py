@@ -1063,3 +1063,40 @@ def test_swiglu_kernels_against_autograd():
     for got, want in ((dot_h, (dh.double() * h64.detach()).sum(1)), (dot_g, (dg64 * g64.detach()).sum(1)),
                       (dot_s, (ds64 * s64.detach()).sum(1))):
         assert torch.allclose(got.double(), want, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('form', ['image', 'a32'])
+def test_ring_form_of_the_grouped_gemm_matches_fp64(form, monkeypatch):
+    """SPT_GEMM_RING=1: the loader / consumer form of the plain-epilogue GEMM (a resident workgroup of
+    four MFMA waves and four loader waves per CU, 128 x 256 tiles; opt-in) -- against an
+    fp64 product over ragged buckets, both weight orientations' forward form, with and without the LoRA
+    K extension, bias and row scales."""
+    from naive_gpt import ext
+    monkeypatch.setenv('SPT_GEMM_RING', '1')
+    torch.manual_seed(0)
+    dev = 'cuda'
+    for rows, kk, n, groups, r in [(4096, 1024, 1024, 1, 16), (8192 + 300, 1024, 2048, 4, 0), (2048 + 77, 2048, 1024, 4, 16)]:
+        cuts = [0, rows] if groups == 1 else [0, rows // 5, rows // 2 + 37, rows - 200, rows]
+        offsets = torch.tensor(cuts, dtype=torch.int32, device=dev)
+        w = torch.randn([groups, n, kk], device=dev) / kk ** 0.5
+        a = torch.randn([rows, kk], device=dev)
+        bias = torch.randn([groups, n], device=dev)
+        scale = torch.rand([rows], device=dev) + 0.5
+        kw = {'w_image': ext.split_bf16(w.view(groups * n, kk))}
+        if form == 'image':
+            kw['a_image'] = ext.split_bf16(a)
+        a2 = b2 = None
+        if r:
+            a2 = torch.randn([rows, r], device=dev)
+            b2 = torch.randn([groups, n, r], device=dev) * 0.1
+            kw.update(a2=a2, b2=b2, b2_group_stride=n * r)
+        out = ext.grouped_gemm_fused(a, w.view(groups * n, kk), offsets, groups, n, kk, n * kk, kk, 1, rows,
+                                     bias=bias, rowscale=scale, **kw)
+        assert ext.LAST_GEMM_PATH == form
+        want = torch.empty([rows, n], dtype=torch.float64, device=dev)
+        for g in range(groups):
+            sl = slice(cuts[g], cuts[g + 1])
+            want[sl] = scale[sl, None].double() * (a[sl].double() @ w[g].double().T + bias[g].double())
+            if r:
+                want[sl] += a2[sl].double() @ b2[g].double().T
+        assert float((out.double() - want).abs().max() / want.abs().max()) < 1e-4, (rows, kk, n, groups, r)

@@ -11,7 +11,7 @@ d, kk, dev = 1024, 1024, 'cuda'
 torch.manual_seed(0)
 for mt in [64, 512]:
     rows = 128 * mt
-    extra = 2 * (mt + 1) * 8 * 4 * 5 * 8 // (d * 4) + 8
+    extra = 2 * (mt + 1) * 8 * 4 * 8 * 8 // (d * 4) + 8
     one = torch.tensor([0, rows], dtype=torch.int32, device=dev)
     w = torch.randn([d, kk], device=dev); wi = ext.split_bf16(w)
     a = torch.randn([rows, kk], device=dev); ai = ext.split_bf16(a)
@@ -20,9 +20,10 @@ for mt in [64, 512]:
     for _ in range(5):
         call()
     torch.cuda.synchronize()
-    st = big[rows:].flatten().view(torch.int64)[:mt * 8 * 4 * 5].view(-1, 5).cpu().double()
+    st = big[rows:].flatten().view(torch.int64)[:mt * 8 * 4 * 8].view(-1, 8).cpu().double()
     st = st[st[:, 4] > 0]
     med = st.median(0).values
     print('%d tiles: waves %d; per tile (cycles): dma issue %.0f | frag reads %.0f | mfma %.0f | barrier %.0f | loop %.0f'
           % (mt * 8, len(st), med[0], med[1], med[2], med[3], med[4]))
-    print('   per k-step: dma %.0f reads %.0f mfma %.0f barrier %.0f total %.0f' % tuple((med / 32).tolist()))
+    print('   per k-step: dma %.0f reads %.0f mfma %.0f barrier %.0f total %.0f' % tuple((med[:5] / 32).tolist()))
+    print('   outside the loop: entry -> loop %.0f | loop -> epilogue %.0f | epilogue %.0f' % (med[5], med[6], med[7]))
