@@ -10,3 +10,5 @@ from .checkpoint import model_from_checkpoint
 from .checkpoint import save_checkpoint
 from .tuning import SparseTuner
 from .tuning import upgrade_sparse
+from .evaluate import evaluate_mmlu
+from .evaluate import load_spt_model
