@@ -711,7 +711,7 @@ struct CellTiles {
                                          const unsigned *sat, int b, int RT, int rt, bool have) {
         mask = have ? masks[2 * ((size_t)b * RT + rt)] : 0ull;
         multi = have ? masks[2 * ((size_t)b * RT + rt) + 1] : 0ull;
-        satrows = have ? sat[(size_t)b * RT + rt] : 0u;
+        satrows = have && sat ? sat[(size_t)b * RT + rt] : 0u;
         last = have ? rt : 0;
         stride = cell_slot_bytes(pool) / 16;
         base = reinterpret_cast<const uint4 *>(
@@ -742,29 +742,38 @@ template <int U>
 __device__ __forceinline__ float cell_count(unsigned word) {
     return (float)((word >> (8 * U)) & 0xffu);
 }
-// the 16 multiplicities of a lane as floats; `fix`: the lane's cells of count 255 stand for 256
-// where the bit of their row is set (D[key, row] layout: every cell of the lane is row lane & 31;
-// D[row, key]: register 4 g + u is row 8 g + 4 h + u)
-template <bool ROW_PER_LANE>
-__device__ __forceinline__ void cell_counts(float (&m)[16], const uint4 &w4, bool fix, unsigned satrows,
-                                            int lane) {
-    const unsigned mw[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        m[4 * g + 0] = cell_count<0>(mw[g]);
-        m[4 * g + 1] = cell_count<1>(mw[g]);
-        m[4 * g + 2] = cell_count<2>(mw[g]);
-        m[4 * g + 3] = cell_count<3>(mw[g]);
-    }
-    if (fix) {                                          // (wave-uniform, rare)
-        const int rl = rare_lane();
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = ROW_PER_LANE ? (rl & 31) : 8 * (r >> 2) + 4 * (rl >> 5) + (r & 3);
-            if (m[r] == 255.0f && ((satrows >> row) & 1u)) m[r] = 256.0f;
+// multiplicity of accumulator register 4 G + U of a lane, from its count word; SAT builds (Z = 256):
+// a count of 255 stands for 256 where the bit of the cell's row is set in `satrows` (`fix`: the tile
+// is in byte form and the row tile has such rows -- wave-uniform).  D[key, row] layout
+// (ROW_PER_LANE): every cell of the lane is row lane & 31; D[row, key]: register 4 g + u is row
+// 8 g + 4 h + u.  One register at a time: sixteen counts converted ahead of their sixteen
+// exponentials cost the key-owned backward 12 live registers it does not have (132.7 against 106.9 us).
+template <bool ROW_PER_LANE, bool SAT, int G, int U>
+__device__ __forceinline__ float cell_mult(unsigned word, bool fix, unsigned satrows, int lane) {
+    float m = cell_count<U>(word);
+    if constexpr (SAT) {
+        if (fix) {
+            const int row = ROW_PER_LANE ? (lane & 31) : 8 * G + 4 * (lane >> 5) + U;
+            if (m == 255.0f && ((satrows >> row) & 1u)) m = 256.0f;
         }
     }
+    return m;
 }
+// (the four registers of count word G)
+#define SPT_CELLS4(ROWPL, SAT, G, WORD, FIX, SATROWS, LANE, BODY)                               \
+    do {                                                                                        \
+        { constexpr int r = 4 * G + 0; const float m = cell_mult<ROWPL, SAT, G, 0>(WORD, FIX, SATROWS, LANE); BODY } \
+        { constexpr int r = 4 * G + 1; const float m = cell_mult<ROWPL, SAT, G, 1>(WORD, FIX, SATROWS, LANE); BODY } \
+        { constexpr int r = 4 * G + 2; const float m = cell_mult<ROWPL, SAT, G, 2>(WORD, FIX, SATROWS, LANE); BODY } \
+        { constexpr int r = 4 * G + 3; const float m = cell_mult<ROWPL, SAT, G, 3>(WORD, FIX, SATROWS, LANE); BODY } \
+    } while (0)
+#define SPT_CELLS16(ROWPL, SAT, W4, FIX, SATROWS, LANE, BODY)                                   \
+    do {                                                                                        \
+        SPT_CELLS4(ROWPL, SAT, 0, (W4).x, FIX, SATROWS, LANE, BODY);                            \
+        SPT_CELLS4(ROWPL, SAT, 1, (W4).y, FIX, SATROWS, LANE, BODY);                            \
+        SPT_CELLS4(ROWPL, SAT, 2, (W4).z, FIX, SATROWS, LANE, BODY);                            \
+        SPT_CELLS4(ROWPL, SAT, 3, (W4).w, FIX, SATROWS, LANE, BODY);                            \
+    } while (0)
 
 // Row tile rt costs rt + 1 key tiles, so contiguous 256-row blocks would give the workgroups
 // of a slice 36 : 100 of the work at S = 512 and, two to a CU, idle CUs at the end.  Folded
@@ -824,10 +833,13 @@ constexpr float MA_SPLIT_ERR = (1.0f + 3.0f * MA_E / 256.0f) * 1.52587890625e-5f
 constexpr int MA_BOUND_SLOTS = 8;                   // workgroups per slice: S <= 2048
 struct ClampGuard {
     float thr;                 // a lane whose max |d| reaches thr = bound - eps calls for the recomputation
+    bool on;                   // false: no score of this wave can reach thr at all (Cauchy-Schwarz on the
+                               // norms) -- the usual case, scores O(1): the tile loop then only tests a scalar
     // own2: |own row|^2 of this lane (unscaled operand); which: 1 = the streamed operand is K, 0 = Q
     __device__ __forceinline__ ClampGuard(const float *bounds, int b, int nslots, int which, float own2,
                                           const ScoreMap &sm, float clampv) {
         thr = __builtin_inff();
+        on = false;
         if (bounds != nullptr && clampv > 0.0f) {
             float other2 = 0.0f;
             for (int g = 0; g < nslots; g++)
@@ -835,14 +847,17 @@ struct ClampGuard {
             // the WAVE's largest own row: one threshold per wave, held in a scalar register
 #pragma unroll
             for (int off = 1; off < 32; off <<= 1) own2 = fmaxf(own2, __shfl_xor(own2, off, SPT_WAVE));
-            thr = sm.bound - MA_SPLIT_ERR * sqrtf(own2 * other2) * sm.sl2;
+            const float reach = sqrtf(own2 * other2) * sm.sl2;      // |d| <= |own| |other| scale log2e
+            thr = sm.bound - MA_SPLIT_ERR * reach;
             thr = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, thr)));
+            on = __builtin_amdgcn_readfirstlane((int)(reach * 1.0001f >= thr)) != 0;
         }
     }
     __device__ __forceinline__ bool wanted(const f32x16 &d) const {
 #ifdef MA_NO_CLAMP_GUARD                                // (A/B builds: what the check costs)
         return false;
 #endif
+        if (!on) return false;
         float am = fmaxf(fabsf(d[0]), fabsf(d[1]));
 #pragma unroll
         for (int r = 2; r < 16; r += 2) am = fmaxf(am, fmaxf(fabsf(d[r]), fabsf(d[r + 1])));
@@ -932,7 +947,10 @@ constexpr int MK_KTILES = MA_ET;    // 32-column tiles of grad_k per launch of t
 constexpr int MR_QTILES = MA_ET;    // 32-column tiles of grad_q per launch of the row-owned kernel
 #define MA_ROWS_WAVES_PER_EU 2
 #define MA_KEYS_WAVES_PER_EU 2
-template <typename T, bool YT>
+// SAT: the pattern may hold a row that is one column 256 times (Z = 256 only: the launchers pass the
+// saturated-rows words then, and a null pointer -- this parameter false -- for every shorter row:
+// the headline's kernels carry no trace of the case)
+template <typename T, bool YT, bool SAT>
 __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_WAVES_PER_EU, MA_WAVES_PER_EU)))
 void attention_mfma_forward_kernel(
@@ -1005,13 +1023,13 @@ void attention_mfma_forward_kernel(
             // cells: this lane holds row i0 + c32, keys 32t + acc_row(r, h); byte 4g + u of
             // the cell word is the multiplicity of register 4g + u
             float p[16];
-            cell_counts<true>(p, ct.words(mcur, t, lane), ct.saturated(t), ct.satrows, lane);
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-#pragma unroll
-                for (int u = 0; u < 4; u++) p[4 * g + u] *= sm.exp_of(d[4 * g + u]);
-                rs += (p[4 * g] + p[4 * g + 1]) + (p[4 * g + 2] + p[4 * g + 3]);
+            {
+                const uint4 cw = ct.words(mcur, t, lane);
+                const bool fix = SAT && ct.saturated(t);
+                SPT_CELLS16(true, SAT, cw, fix, ct.satrows, lane, p[r] = m * sm.exp_of(d[r]););
             }
+#pragma unroll
+            for (int g = 0; g < 4; g++) rs += (p[4 * g] + p[4 * g + 1]) + (p[4 * g + 2] + p[4 * g + 3]);
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
                 const Frag pf = split8(p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3],
@@ -1131,7 +1149,7 @@ void attention_mfma_forward_kernel(
 // one wave per SIMD running its MFMA and VALU phases one after the other: at 187 VGPRs a CU holds
 // one workgroup, and half of its waves (the short row tiles) finish early. ----
 // GT: grad_y and y arrive as [batch, E, S] (the transposed forward output and its gradient)
-template <typename T, bool GT>
+template <typename T, bool GT, bool SAT>
 __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_ROWS_WAVES_PER_EU, MA_ROWS_WAVES_PER_EU)))
 void attention_mfma_backward_rows_kernel(
@@ -1226,11 +1244,11 @@ void attention_mfma_backward_rows_kernel(
                 clamp_exact(d, dp, smem + 2 * MA_IMG, wave, cw, sm.bound, cg.thr, q + dv.base, i0, S,
                             k + dv.base + (size_t)t * MA_KT * dv.ld, dv.ld, scale, clampv);
             float ds[16];
-            cell_counts<true>(ds, cw, ct.saturated(t), ct.satrows, lane);
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float pw = ds[r] * sm.exp_of(d[r]);
-                ds[r] = sm.inside(d[r]) ? pw * (dp[r] - delta_i) : 0.0f;
+            {
+                const bool fix = SAT && ct.saturated(t);
+                SPT_CELLS16(true, SAT, cw, fix, ct.satrows, lane,
+                            const float pw = m * sm.exp_of(d[r]);
+                            ds[r] = sm.inside(d[r]) ? pw * (dp[r] - delta_i) : 0.0f;);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
@@ -1341,7 +1359,7 @@ struct KeysStager {
 // tile arithmetic (the combined kernel spilled 41-60 registers: 281 us per launch), so there
 // MODE 1: grad_v alone, all 128 columns (needs P only: no V fragments, no dP, no delta);
 // MODE 2: grad_k alone, 64 columns per launch.
-template <typename T, bool GT, int MODE>
+template <typename T, bool GT, int MODE, bool SAT>
 __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_KEYS_WAVES_PER_EU, MA_KEYS_WAVES_PER_EU)))
 void attention_mfma_backward_keys_kernel(
@@ -1385,35 +1403,52 @@ void attention_mfma_backward_keys_kernel(
             split_own_rows(vf, xv);         // (stored bf16: the lo parts are zero and unused)
         }
     }
+    // Round 4: the exact clamp mask put this kernel five registers past its 256; hipcc's answer was
+    // one 16-byte spill of a K / V fragment, reloaded from scratch in every iteration -- a VECTOR
+    // memory load, whose wait also waits for the row tile requested at the top of the iteration
+    // (vmcnt counts in order): 117.7 - 132.7 us against 106.9.  The last V fragment (8 registers with
+    // both parts) is parked in a wave-private LDS block instead and read back once per iteration, an
+    // LDS read among two dozen others, on lgkmcnt.
+    constexpr bool STASH_V = WANT_K && MA_E == 64 && sizeof(T) == 4;
+    char *const vstash = smem + 2 * MK_IMG + MA_WAVES * MA_PARK + wave * 2048 + 16 * lane;
+    if constexpr (STASH_V) {
+        *reinterpret_cast<uint4 *>(vstash) = make_uint4(vf[MA_KS - 1].hi.x, vf[MA_KS - 1].hi.y,
+                                                        vf[MA_KS - 1].hi.z, vf[MA_KS - 1].hi.w);
+        *reinterpret_cast<uint4 *>(vstash + 1024) = make_uint4(vf[MA_KS - 1].lo.x, vf[MA_KS - 1].lo.y,
+                                                               vf[MA_KS - 1].lo.z, vf[MA_KS - 1].lo.w);
+    }
     // the slice's row-tile masks live in registers (lane rt: mask of row tile rt), so that the
     // loop body has no load whose result it needs at once
     // (grad_v needs P alone, which is continuous in the score: no exact mask for MODE 1)
     const ClampGuard cg(WANT_K ? bounds : nullptr, b, blocks_per_batch, 0, k2, sm, clampv);
-    const unsigned long long mask_reg = lane < RT ? masks[2 * ((size_t)b * RT + lane)] : 0ull;
-    const unsigned long long multi_reg = lane < RT ? masks[2 * ((size_t)b * RT + lane) + 1] : 0ull;
-    // (does any row of the slice hold a column 256 times?  the row tile's word itself is read
-    // where it is needed: behind a branch that row 0 of a Z = 256 lookup pattern alone takes)
-    const bool any_sat = __ballot(lane < RT && sat[(size_t)b * RT + min(lane, RT - 1)] != 0u) != 0ull;
-    auto lane_u64 = [&](unsigned long long reg, int rt) -> unsigned long long {
-        if (rt >= RT) return 0ull;
-        const unsigned lo = __builtin_amdgcn_readlane((unsigned)reg, rt);
-        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(reg >> 32), rt);
-        return ((unsigned long long)hi << 32) | lo;
+    // (round 4: ONE register -- this wave's key tile needs two bits per row tile, lane rt holds bit 0:
+    // tile (rt, kt) is live, bit 1: it is stored in byte form; the 64-bit masks were four registers
+    // of a kernel that has none to spare)
+    unsigned bits_reg = 0u;
+    if (lane < RT) {
+        const unsigned long long m0 = masks[2 * ((size_t)b * RT + lane)];
+        const unsigned long long m1 = masks[2 * ((size_t)b * RT + lane) + 1];
+        bits_reg = (unsigned)((m0 >> min(kt, 63)) & 1ull) | ((unsigned)((m1 >> min(kt, lane)) & 1ull) << 1);
+    }
+    // (lane rt: the saturated-rows word of row tile rt, like the masks: no memory operation inside
+    // the tile loop -- a scalar load under the loop's rare branch made the keys kernel 10 % slower,
+    // 117.7 against 106.7 us: its wait is an lgkmcnt(0) that drains the fragment reads in flight)
+    const unsigned sat_reg = SAT && lane < RT ? sat[(size_t)b * RT + lane] : 0u;
+    const bool any_sat = SAT && __ballot(sat_reg != 0u) != 0ull;
+    // bits of tile (rt, kt) (0 past the last row tile)
+    auto mask_of = [&](int rt) -> unsigned {
+        return rt < RT ? (unsigned)__builtin_amdgcn_readlane((int)bits_reg, rt) : 0u;
     };
-    auto mask_of = [&](int rt) { return lane_u64(mask_reg, rt); };
     // is the tile (row tile rt, this wave's key tile) stored in byte form?
     auto multi_of = [&](int rt) {
-        const int rc = min(rt, RT - 1);
-        return (bool)((lane_u64(multi_reg, rc) >> min(kt, rc)) & 1ull);
+        return (bool)(((unsigned)__builtin_amdgcn_readlane((int)bits_reg, min(rt, RT - 1)) >> 1) & 1u);
     };
     const int cstride = cell_slot_bytes(pool_t) / 16;
     const uint4 *cell_b = reinterpret_cast<const uint4 *>(
         cells_t + (size_t)b * tri(RT) * cell_slot_bytes(pool_t));
     const uint4 *pool_b = pool_t ? reinterpret_cast<const uint4 *>(pool_t + (size_t)b * RT * MA_CELLS)
                                  : nullptr;
-    auto live = [&](unsigned long long m, int rt) {
-        return have && rt >= kt && rt < RT && ((m >> kt) & 1ull);
-    };
+    auto live = [&](unsigned m, int rt) { return have && rt >= kt && rt < RT && (m & 1u); };
     // always in bounds: the row tile clamped to the last one, the key tile to the diagonal
     auto cell_load = [&](int rt) {
         const int rc = min(rt, RT - 1);
@@ -1425,7 +1460,7 @@ void attention_mfma_backward_keys_kernel(
     const KeysStager<T, GT> stager{q + dv.base, gy + (size_t)b * S * MA_E, row_sum + (size_t)b * S,
                                    delta + (size_t)b * S, dv.ld, S, tid};
     stager.store(img, stager.load(min(rt0, RT - 1)), rt0);
-    unsigned long long mcur_mask = mask_of(rt0);
+    unsigned mcur_mask = mask_of(rt0);
     uint4 mcur = cell_load(rt0);
     __syncthreads();
 
@@ -1442,19 +1477,24 @@ void attention_mfma_backward_keys_kernel(
     for (int rt = rt0; rt < RT; rt++) {
         const char *buf = img + ((rt - rt0) & 1) * MK_IMG;
         const typename KeysStager<T, GT>::Regs nxt = stager.load(min(rt + 1, RT - 1));
-        const unsigned long long mnxt_mask = mask_of(rt + 1);
+        const unsigned mnxt_mask = mask_of(rt + 1);
         const uint4 mnxt = cell_load(rt + 1);
         if (live(mcur_mask, rt)) {
             f32x16 d, dp;
 #pragma unroll
             for (int r = 0; r < 16; r++) d[r] = dp[r] = 0.f;
+            Frag vlast;
+            if constexpr (STASH_V) {
+                vlast.hi = *reinterpret_cast<const uint4 *>(vstash);
+                vlast.lo = *reinterpret_cast<const uint4 *>(vstash + 1024);
+            }
 #pragma unroll
             for (int ks = 0; ks < MA_KS; ks++) {
                 d = mm<PI, 2>(read_rows<PI>(buf + MK_QR, buf + MK_QR + MA_RIMG, lane, ks), kf[ks], d);
                 if constexpr (WANT_K)
                     dp = mm<2, PI>(GT ? read_rows_tr(buf + MK_G, buf + MK_G + MA_CIMG, lane, ks)
                                       : read_rows<2>(buf + MK_G, buf + MK_G + MA_RIMG, lane, ks),
-                                   vf[ks], dp);
+                                   (STASH_V && ks == MA_KS - 1) ? vlast : vf[ks], dp);
             }
             // this lane: key j0 + c32, rows 8g + 4h + u of the tile in register 4g + u
             const bool mlt = multi_of(rt);
@@ -1465,18 +1505,27 @@ void attention_mfma_backward_keys_kernel(
                                 q + dv.base + (size_t)rt * MA_WROWS * dv.ld, dv.ld, scale, clampv);
             }
             const float *st = reinterpret_cast<const float *>(buf + MK_ST);
+            const unsigned mw[4] = {cw.x, cw.y, cw.z, cw.w};
             float p[16], ds[16];
-            const bool satfix = any_sat && mlt;
-            cell_counts<false>(p, cw, satfix, satfix ? sat[(size_t)b * RT + min(rt, RT - 1)] : 0u, lane);
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
                 float4 del4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (WANT_K) del4 = *reinterpret_cast<const float4 *>(st + 8 * g4 + 4 * h);
                 const float del[4] = {del4.x, del4.y, del4.z, del4.w};
+                float m4[4] = {cell_count<0>(mw[g4]), cell_count<1>(mw[g4]),
+                               cell_count<2>(mw[g4]), cell_count<3>(mw[g4])};
+                if constexpr (SAT) {
+                    if (any_sat && mlt) {               // (wave-uniform, rare: Z = 256 builds only)
+                        const unsigned satw = (unsigned)__builtin_amdgcn_readlane((int)sat_reg, min(rt, RT - 1));
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (m4[u] == 255.0f && ((satw >> (8 * g4 + 4 * h + u)) & 1u)) m4[u] = 256.0f;
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int r = 4 * g4 + u;
-                    p[r] *= sm.exp_of(d[r]);                 // x 1 / row_sum: in the dY images
+                    p[r] = m4[u] * sm.exp_of(d[r]);          // x 1 / row_sum: in the dY images
                     ds[r] = 0.0f;
                     if constexpr (WANT_K)                    // x scale: in the epilogue
                         ds[r] = sm.inside(d[r]) ? p[r] * (dp[r] - del[u]) : 0.0f;
@@ -1547,16 +1596,19 @@ static int launch_forward_t(const unsigned long long *masks, const unsigned char
     const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
     const size_t lds = mfma_forward_lds();
     const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
-    SPT_HIP_TRY(hipFuncSetAttribute(
-        y_transposed ? (const void *)attention_mfma_forward_kernel<T, true>
-                     : (const void *)attention_mfma_forward_kernel<T, false>,
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (y_transposed)
-        hipLaunchKernelGGL((attention_mfma_forward_kernel<T, true>), grid, block, lds, s, masks,
-                           cells, pool, sat, q, k, v, y, row_sum, bounds, S, scale, clamp, heads, bpb);
-    else
-        hipLaunchKernelGGL((attention_mfma_forward_kernel<T, false>), grid, block, lds, s, masks,
-                           cells, pool, sat, q, k, v, y, row_sum, bounds, S, scale, clamp, heads, bpb);
+#define SPT_MF(YT, SAT)                                                                          \
+    do {                                                                                         \
+        SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_mfma_forward_kernel<T, YT, SAT>, \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+        hipLaunchKernelGGL((attention_mfma_forward_kernel<T, YT, SAT>), grid, block, lds, s, masks, cells, pool, \
+                           sat, q, k, v, y, row_sum, bounds, S, scale, clamp, heads, bpb);       \
+    } while (0)
+    if (y_transposed) {
+        if (sat) SPT_MF(true, true); else SPT_MF(true, false);
+    } else {
+        if (sat) SPT_MF(false, true); else SPT_MF(false, false);
+    }
+#undef SPT_MF
     SPT_LAUNCH_CHECK();
     return SPT_OK;
 }
@@ -1572,36 +1624,39 @@ static int launch_backward_t(const unsigned long long *masks, const unsigned cha
     const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
     const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
     const size_t lds_r = 2 * MA_IMG + (size_t)MA_WAVES * MA_PARK,
-                 lds_k = 2 * MK_IMG + (size_t)MA_WAVES * MA_PARK;
+                 lds_k = 2 * MK_IMG + (size_t)MA_WAVES * (MA_PARK + 2048);
     // 64 gradient columns per launch (the accumulators of 128 would not fit the registers
     // beside the operands' fragments): d_head 128 runs each kernel twice
-#define SPT_MB(GT)                                                                              \
+#define SPT_MB(GT, SAT)                                                                         \
     do {                                                                                        \
         SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
-            (const void *)attention_mfma_backward_rows_kernel<T, GT>,                           \
+            (const void *)attention_mfma_backward_rows_kernel<T, GT, SAT>,                      \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));                           \
         for (int half = 0; half < MA_ET / MR_QTILES; half++)                                    \
-            hipLaunchKernelGGL((attention_mfma_backward_rows_kernel<T, GT>), grid, block, lds_r, \
+            hipLaunchKernelGGL((attention_mfma_backward_rows_kernel<T, GT, SAT>), grid, block, lds_r, \
                                s, masks, cells, pool, sat, q, k, v, grad_y, y, row_sum, bounds, \
                                grad_q, delta, S, scale, clamp, heads, bpb, half);               \
         if (MA_BH == 1) {                                                                       \
-            SPT_KEYS(GT, 0, 0);                                                                 \
+            SPT_KEYS(GT, 0, 0, SAT);                                                            \
         } else {                                                                                \
-            SPT_KEYS(GT, 1, 0);                                                                 \
-            for (int half = 0; half < MA_ET / MK_KTILES; half++) SPT_KEYS(GT, 2, half);         \
+            SPT_KEYS(GT, 1, 0, SAT);                                                            \
+            for (int half = 0; half < MA_ET / MK_KTILES; half++) SPT_KEYS(GT, 2, half, SAT);    \
         }                                                                                       \
     } while (0)
-#define SPT_KEYS(GT, MODE, HALF)                                                                \
+#define SPT_KEYS(GT, MODE, HALF, SAT)                                                           \
     do {                                                                                        \
         SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
-            (const void *)attention_mfma_backward_keys_kernel<T, GT, MODE>,                     \
+            (const void *)attention_mfma_backward_keys_kernel<T, GT, MODE, SAT>,                \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));                           \
-        hipLaunchKernelGGL((attention_mfma_backward_keys_kernel<T, GT, MODE>), grid, block,     \
+        hipLaunchKernelGGL((attention_mfma_backward_keys_kernel<T, GT, MODE, SAT>), grid, block, \
                            lds_k, s, masks, cells_t, pool_t, sat, q, k, v, grad_y, row_sum,     \
                            bounds, delta, grad_k, grad_v, S, scale, clamp, heads, bpb, HALF);   \
     } while (0)
-    if (transposed) SPT_MB(true);
-    else SPT_MB(false);
+    if (transposed) {
+        if (sat) SPT_MB(true, true); else SPT_MB(true, false);
+    } else {
+        if (sat) SPT_MB(false, true); else SPT_MB(false, false);
+    }
 #undef SPT_MB
 #undef SPT_KEYS
     SPT_LAUNCH_CHECK();
@@ -1769,7 +1824,8 @@ static int mfma_forward_any(const void *tiles, int layout, int dtype, const void
     if (layout != SPT_TILES_FULL && layout != SPT_TILES_COMPACT) return SPT_EINVAL;
     if (!mfma_shape_ok(seq_length, d_head, nnz)) return SPT_EUNSUP;
     if (heads > 0 && batch_size % heads != 0) return SPT_ESHAPE;
-    const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length, layout);
+    TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length, layout);
+    if (nnz / seq_length < 256) ts.sat = nullptr;       // (a byte holds every multiplicity)
     hipStream_t s = static_cast<hipStream_t>(stream);
     return d_head == 64
                ? launch_forward(ts.masks, ts.cells, ts.pool, ts.sat, dtype, q, k, v, y, row_sum, bounds,
@@ -1794,7 +1850,8 @@ static int mfma_backward_any(const void *tiles, int layout, int dtype, const voi
     if (!mfma_shape_ok(seq_length, d_head, nnz)) return SPT_EUNSUP;
     if (heads > 0 && batch_size % heads != 0) return SPT_ESHAPE;
     if (transposed && (seq_length & 3)) return SPT_EUNSUP;
-    const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length, layout);
+    TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length, layout);
+    if (nnz / seq_length < 256) ts.sat = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return d_head == 64
                ? launch_backward(ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, ts.sat, dtype, q,

@@ -724,7 +724,7 @@ def attention_mfma_forward(tiles, q: torch.Tensor, k: torch.Tensor, v: torch.Ten
               else lib.spt_attention_mfma_forward_bf16)
         rc = fn(
             tiles.buffer.data_ptr(), tiles.layout, q.data_ptr(), k.data_ptr(), v.data_ptr(), y.data_ptr(),
-            row_sum.data_ptr(), row_sum.data_ptr() + 4 * B * S, B, S, E, tiles.nnz, float(scale),
+            row_sum.data_ptr(), (row_sum.data_ptr() + 4 * B * S) if EXACT_CLAMP else 0, B, S, E, tiles.nnz, float(scale),
             float(clamp), H, int(bool(y_transposed)), _stream(dev))
     if rc != 0:
         _raise(lib, rc, 'attention_mfma_forward')
