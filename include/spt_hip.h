@@ -351,8 +351,9 @@ int spt_attention_mfma_forward(const void *tiles, int layout, const float *q, co
  *   grad_v[j] = sum_{p: col_p = j} P_p grad_y[row_p]
  * y, grad_y: [batch, S, E], or with transposed != 0 both [batch, E, S] (S % 4 == 0).
  * q, k, v and the three gradients follow `heads` as in the forward.  row_sum and bounds are the
- * forward's outputs for the same q, k (bounds may be NULL, see above); delta [batch, S] is
- * scratch that the first launch fills for the second.
+ * forward's outputs for the same q, k (bounds may be NULL, see above); delta is scratch of
+ * 2 * batch * S floats that the first launch fills for the second (the rows' 1 / row_sum, then
+ * delta / row_sum).
  */
 int spt_attention_mfma_backward(const void *tiles, int layout, const float *q, const float *k,
                                 const float *v, const float *y, const float *grad_y,

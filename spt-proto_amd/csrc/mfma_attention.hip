@@ -711,7 +711,7 @@ struct CellTiles {
                                          const unsigned *sat, int b, int RT, int rt, bool have) {
         mask = have ? masks[2 * ((size_t)b * RT + rt)] : 0ull;
         multi = have ? masks[2 * ((size_t)b * RT + rt) + 1] : 0ull;
-        satrows = have && sat ? sat[(size_t)b * RT + rt] : 0u;
+        satrows = have ? sat[(size_t)b * RT + rt] : 0u;
         last = have ? rt : 0;
         stride = cell_slot_bytes(pool) / 16;
         base = reinterpret_cast<const uint4 *>(
@@ -733,47 +733,20 @@ struct CellTiles {
     __device__ __forceinline__ uint4 words(const uint4 &v, int t, int lane) const {
         return cell_words(v, is_multi(min(t, last)), lane);
     }
-    // does tile t hold a cell whose stored 255 stands for 256?  (wave-uniform; false but for row 0
-    // of a Z = 256 lookup pattern)
-    __device__ __forceinline__ bool saturated(int t) const { return satrows != 0u && is_multi(min(t, last)); }
 };
 // byte u of a cell word as float (v_cvt_f32_ubyte<u>)
 template <int U>
 __device__ __forceinline__ float cell_count(unsigned word) {
     return (float)((word >> (8 * U)) & 0xffu);
 }
-// multiplicity of accumulator register 4 G + U of a lane, from its count word; SAT builds (Z = 256):
-// a count of 255 stands for 256 where the bit of the cell's row is set in `satrows` (`fix`: the tile
-// is in byte form and the row tile has such rows -- wave-uniform).  D[key, row] layout
-// (ROW_PER_LANE): every cell of the lane is row lane & 31; D[row, key]: register 4 g + u is row
-// 8 g + 4 h + u.  One register at a time: sixteen counts converted ahead of their sixteen
-// exponentials cost the key-owned backward 12 live registers it does not have (132.7 against 106.9 us).
-template <bool ROW_PER_LANE, bool SAT, int G, int U>
-__device__ __forceinline__ float cell_mult(unsigned word, bool fix, unsigned satrows, int lane) {
-    float m = cell_count<U>(word);
-    if constexpr (SAT) {
-        if (fix) {
-            const int row = ROW_PER_LANE ? (lane & 31) : 8 * G + 4 * (lane >> 5) + U;
-            if (m == 255.0f && ((satrows >> row) & 1u)) m = 256.0f;
-        }
-    }
-    return m;
-}
-// (the four registers of count word G)
-#define SPT_CELLS4(ROWPL, SAT, G, WORD, FIX, SATROWS, LANE, BODY)                               \
-    do {                                                                                        \
-        { constexpr int r = 4 * G + 0; const float m = cell_mult<ROWPL, SAT, G, 0>(WORD, FIX, SATROWS, LANE); BODY } \
-        { constexpr int r = 4 * G + 1; const float m = cell_mult<ROWPL, SAT, G, 1>(WORD, FIX, SATROWS, LANE); BODY } \
-        { constexpr int r = 4 * G + 2; const float m = cell_mult<ROWPL, SAT, G, 2>(WORD, FIX, SATROWS, LANE); BODY } \
-        { constexpr int r = 4 * G + 3; const float m = cell_mult<ROWPL, SAT, G, 3>(WORD, FIX, SATROWS, LANE); BODY } \
-    } while (0)
-#define SPT_CELLS16(ROWPL, SAT, W4, FIX, SATROWS, LANE, BODY)                                   \
-    do {                                                                                        \
-        SPT_CELLS4(ROWPL, SAT, 0, (W4).x, FIX, SATROWS, LANE, BODY);                            \
-        SPT_CELLS4(ROWPL, SAT, 1, (W4).y, FIX, SATROWS, LANE, BODY);                            \
-        SPT_CELLS4(ROWPL, SAT, 2, (W4).z, FIX, SATROWS, LANE, BODY);                            \
-        SPT_CELLS4(ROWPL, SAT, 3, (W4).w, FIX, SATROWS, LANE, BODY);                            \
-    } while (0)
+// A row that is ONE column 256 times (row 0 of a lookup pattern at Z = 256) keeps a byte count of 255
+// and its bit in `sat`.  Nothing in the tile loops knows: with m = 255 the forward's y and the
+// backward's P = m e / (m e) are what m = 256 gives (the count cancels), and only the row sum the
+// forward REPORTS is 255 / 256 of the true one.  So the forward stores rs * 256 / 255 for such rows,
+// and the backward kernels take rs * 255 / 256 back for them where they load the row sums -- once per
+// row, outside every loop.  (Round 4's first form fixed the count inside the loops, behind a
+// wave-uniform branch: 7-13 % on every Z = 256 launch for one cell per slice.)
+constexpr float MA_SAT_UP = 256.0f / 255.0f, MA_SAT_DOWN = 255.0f / 256.0f;
 
 // Row tile rt costs rt + 1 key tiles, so contiguous 256-row blocks would give the workgroups
 // of a slice 36 : 100 of the work at S = 512 and, two to a CU, idle CUs at the end.  Folded
@@ -947,10 +920,7 @@ constexpr int MK_KTILES = MA_ET;    // 32-column tiles of grad_k per launch of t
 constexpr int MR_QTILES = MA_ET;    // 32-column tiles of grad_q per launch of the row-owned kernel
 #define MA_ROWS_WAVES_PER_EU 2
 #define MA_KEYS_WAVES_PER_EU 2
-// SAT: the pattern may hold a row that is one column 256 times (Z = 256 only: the launchers pass the
-// saturated-rows words then, and a null pointer -- this parameter false -- for every shorter row:
-// the headline's kernels carry no trace of the case)
-template <typename T, bool YT, bool SAT>
+template <typename T, bool YT>
 __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_WAVES_PER_EU, MA_WAVES_PER_EU)))
 void attention_mfma_forward_kernel(
@@ -1022,14 +992,17 @@ void attention_mfma_forward_kernel(
                 d = mm<PI, 2>(read_rows<PI>(buf + MA_KH, buf + MA_KL, lane, ks), qf[ks], d);
             // cells: this lane holds row i0 + c32, keys 32t + acc_row(r, h); byte 4g + u of
             // the cell word is the multiplicity of register 4g + u
+            const uint4 mm4 = ct.words(mcur, t, lane);
+            const unsigned mw[4] = {mm4.x, mm4.y, mm4.z, mm4.w};
             float p[16];
-            {
-                const uint4 cw = ct.words(mcur, t, lane);
-                const bool fix = SAT && ct.saturated(t);
-                SPT_CELLS16(true, SAT, cw, fix, ct.satrows, lane, p[r] = m * sm.exp_of(d[r]););
-            }
 #pragma unroll
-            for (int g = 0; g < 4; g++) rs += (p[4 * g] + p[4 * g + 1]) + (p[4 * g + 2] + p[4 * g + 3]);
+            for (int g = 0; g < 4; g++) {
+                p[4 * g + 0] = cell_count<0>(mw[g]) * sm.exp_of(d[4 * g + 0]);
+                p[4 * g + 1] = cell_count<1>(mw[g]) * sm.exp_of(d[4 * g + 1]);
+                p[4 * g + 2] = cell_count<2>(mw[g]) * sm.exp_of(d[4 * g + 2]);
+                p[4 * g + 3] = cell_count<3>(mw[g]) * sm.exp_of(d[4 * g + 3]);
+                rs += (p[4 * g] + p[4 * g + 1]) + (p[4 * g + 2] + p[4 * g + 3]);
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
                 const Frag pf = split8(p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3],
@@ -1076,7 +1049,7 @@ void attention_mfma_forward_kernel(
     float *wstat = stat + wave * MA_WROWS;
     if (h == 0) {
         wstat[c32] = inv;
-        if (i0 + c32 < S) row_sum[(size_t)b * S + i0 + c32] = rs;
+        if (i0 + c32 < S) row_sum[(size_t)b * S + i0 + c32] = ((ct.satrows >> c32) & 1u) ? rs * MA_SAT_UP : rs;
     }
     wave_lds_fence();
     T *y_b = y + (size_t)b * S * MA_E;
@@ -1149,7 +1122,7 @@ void attention_mfma_forward_kernel(
 // one wave per SIMD running its MFMA and VALU phases one after the other: at 187 VGPRs a CU holds
 // one workgroup, and half of its waves (the short row tiles) finish early. ----
 // GT: grad_y and y arrive as [batch, E, S] (the transposed forward output and its gradient)
-template <typename T, bool GT, bool SAT>
+template <typename T, bool GT>
 __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_ROWS_WAVES_PER_EU, MA_ROWS_WAVES_PER_EU)))
 void attention_mfma_backward_rows_kernel(
@@ -1182,7 +1155,8 @@ void attention_mfma_backward_rows_kernel(
     Frag gf[MA_KS], qf[MA_KS];
     float delta_i, q2 = 0.f;
     const int row = i0 + c32;
-    const float rsum = row_sum[(size_t)b * S + min(row, S - 1)];
+    float rsum = row_sum[(size_t)b * S + min(row, S - 1)];
+    if ((ct.satrows >> c32) & 1u) rsum *= MA_SAT_DOWN;          // (the sum the tiles' counts add up to)
     {
         float xr[MA_E / 2], yr[MA_E / 2], xq[MA_E / 2];
         const size_t ob = (size_t)b * S * MA_E;
@@ -1209,7 +1183,13 @@ void attention_mfma_backward_rows_kernel(
         const float pscale = scale / fmaxf(1e-9f, rsum);
         split_own_rows(gf, xr, pscale);
         split_own_rows(qf, xq, sm.sl2);
-        if (h == 0 && row < S && half == 0) delta[(size_t)b * S + row] = delta_i;
+        // for the key-owned sibling: the row's weight 1 / row_sum (of the sum its tile counts add up
+        // to) and the weighted delta -- it stages 32 rows per iteration and divides nothing
+        if (h == 0 && row < S && half == 0) {
+            const float w = 1.0f / fmaxf(1e-9f, rsum);
+            delta[(size_t)b * S + row] = w;
+            delta[((size_t)(gridDim.x / blocks_per_batch) + b) * S + row] = w * delta_i;
+        }
         delta_i *= pscale;
         if (bounds) {
 #pragma unroll
@@ -1243,12 +1223,18 @@ void attention_mfma_backward_rows_kernel(
             if (cg.wanted(d))                           // (wave-uniform, rare)
                 clamp_exact(d, dp, smem + 2 * MA_IMG, wave, cw, sm.bound, cg.thr, q + dv.base, i0, S,
                             k + dv.base + (size_t)t * MA_KT * dv.ld, dv.ld, scale, clampv);
+            const unsigned mw[4] = {cw.x, cw.y, cw.z, cw.w};
             float ds[16];
-            {
-                const bool fix = SAT && ct.saturated(t);
-                SPT_CELLS16(true, SAT, cw, fix, ct.satrows, lane,
-                            const float pw = m * sm.exp_of(d[r]);
-                            ds[r] = sm.inside(d[r]) ? pw * (dp[r] - delta_i) : 0.0f;);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const float m4[4] = {cell_count<0>(mw[g]), cell_count<1>(mw[g]),
+                                     cell_count<2>(mw[g]), cell_count<3>(mw[g])};
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const int r = 4 * g + x;
+                    const float pw = m4[x] * sm.exp_of(d[r]);
+                    ds[r] = sm.inside(d[r]) ? pw * (dp[r] - delta_i) : 0.0f;
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
@@ -1289,12 +1275,12 @@ constexpr int MK_QR = 0, MK_G = 2 * MA_RIMG, MK_ST = 2 * MA_RIMG + 2 * MK_GSLOT,
 template <typename T, bool GT>
 struct KeysStager {
     const T *q_b, *gy_b;
-    const float *rs_b, *dl_b;
+    const float *w_b, *wd_b;    // the rows' 1 / row_sum and (1 / row_sum) delta, from the row-owned kernel
     int ld, S, tid;
     struct Regs {
         typename Elem<T>::raw4 qf[MA_RPT], gf[MA_RPT];
         float4 rs[MA_RPT];
-        float st_rs, st_dl;
+        float st_wd;
     };
     // unconditional, clamped loads (see TileStager::load); rows >= S are given weight 0 by
     // store(), so whatever finite data the clamped rows hold never counts.  Raw values only:
@@ -1310,17 +1296,16 @@ struct KeysStager {
             r.qf[u] = ld_raw4(q_b + (size_t)row * ld + e4);
             if (!GT) {
                 r.gf[u] = ld_raw4(gy_b + (size_t)row * MA_E + e4);
-                r.rs[u] = make_float4(rs_b[row], 0.f, 0.f, 0.f);
+                r.rs[u] = make_float4(w_b[row], 0.f, 0.f, 0.f);
             } else {        // [E][S]: four consecutive rows of one e (S % 4 == 0)
                 const int e = (tid >> 3) + (MA_THREADS / 8) * u;
                 const int i4 = min(i0 + (tid & 7) * 4, S - 4);
                 r.gf[u] = ld_raw4(gy_b + (size_t)e * S + i4);
-                r.rs[u] = *reinterpret_cast<const float4 *>(rs_b + i4);
+                r.rs[u] = *reinterpret_cast<const float4 *>(w_b + i4);
             }
         }
         const int sr = min(i0 + (tid & (MA_WROWS - 1)), S - 1);
-        r.st_rs = rs_b[sr];
-        r.st_dl = dl_b[sr];
+        r.st_wd = wd_b[sr];
         return r;
     }
     // 1 / row_sum is a per-row factor of both P (grad_v) and dS (grad_k): dY is staged
@@ -1329,9 +1314,7 @@ struct KeysStager {
     __device__ __forceinline__ void store(char *buf, const Regs &r, int rt) const {
         const int i0 = rt * MA_WROWS;
         const int e4 = (tid % MA_EQ) * 4;
-        auto weight = [&](float rs, int row) {
-            return row < S ? 1.0f / fmaxf(1e-9f, rs) : 0.0f;
-        };
+        auto weight = [&](float w, int row) { return row < S ? w : 0.0f; };
 #pragma unroll
         for (int u = 0; u < MA_RPT; u++) {
             const int il = tid / MA_EQ + MA_RPP * u;
@@ -1350,7 +1333,7 @@ struct KeysStager {
             }
         }
         if (tid < MA_WROWS)
-            reinterpret_cast<float *>(buf + MK_ST)[tid] = weight(r.st_rs, i0 + tid) * r.st_dl;
+            reinterpret_cast<float *>(buf + MK_ST)[tid] = weight(r.st_wd, i0 + tid);
     }
 };
 
@@ -1359,7 +1342,7 @@ struct KeysStager {
 // tile arithmetic (the combined kernel spilled 41-60 registers: 281 us per launch), so there
 // MODE 1: grad_v alone, all 128 columns (needs P only: no V fragments, no dP, no delta);
 // MODE 2: grad_k alone, 64 columns per launch.
-template <typename T, bool GT, int MODE, bool SAT>
+template <typename T, bool GT, int MODE>
 __global__ __launch_bounds__(MA_THREADS)
 __attribute__((amdgpu_waves_per_eu(MA_KEYS_WAVES_PER_EU, MA_KEYS_WAVES_PER_EU)))
 void attention_mfma_backward_keys_kernel(
@@ -1430,11 +1413,6 @@ void attention_mfma_backward_keys_kernel(
         const unsigned long long m1 = masks[2 * ((size_t)b * RT + lane) + 1];
         bits_reg = (unsigned)((m0 >> min(kt, 63)) & 1ull) | ((unsigned)((m1 >> min(kt, lane)) & 1ull) << 1);
     }
-    // (lane rt: the saturated-rows word of row tile rt, like the masks: no memory operation inside
-    // the tile loop -- a scalar load under the loop's rare branch made the keys kernel 10 % slower,
-    // 117.7 against 106.7 us: its wait is an lgkmcnt(0) that drains the fragment reads in flight)
-    const unsigned sat_reg = SAT && lane < RT ? sat[(size_t)b * RT + lane] : 0u;
-    const bool any_sat = SAT && __ballot(sat_reg != 0u) != 0ull;
     // bits of tile (rt, kt) (0 past the last row tile)
     auto mask_of = [&](int rt) -> unsigned {
         return rt < RT ? (unsigned)__builtin_amdgcn_readlane((int)bits_reg, rt) : 0u;
@@ -1457,8 +1435,8 @@ void attention_mfma_backward_keys_kernel(
     };
 
     const int rt0 = (MA_WAVES / 2) * g;                 // the first row tile any wave needs
-    const KeysStager<T, GT> stager{q + dv.base, gy + (size_t)b * S * MA_E, row_sum + (size_t)b * S,
-                                   delta + (size_t)b * S, dv.ld, S, tid};
+    const KeysStager<T, GT> stager{q + dv.base, gy + (size_t)b * S * MA_E, delta + (size_t)b * S,
+                                   delta + ((size_t)(gridDim.x / blocks_per_batch) + b) * S, dv.ld, S, tid};
     stager.store(img, stager.load(min(rt0, RT - 1)), rt0);
     unsigned mcur_mask = mask_of(rt0);
     uint4 mcur = cell_load(rt0);
@@ -1512,16 +1490,8 @@ void attention_mfma_backward_keys_kernel(
                 float4 del4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (WANT_K) del4 = *reinterpret_cast<const float4 *>(st + 8 * g4 + 4 * h);
                 const float del[4] = {del4.x, del4.y, del4.z, del4.w};
-                float m4[4] = {cell_count<0>(mw[g4]), cell_count<1>(mw[g4]),
-                               cell_count<2>(mw[g4]), cell_count<3>(mw[g4])};
-                if constexpr (SAT) {
-                    if (any_sat && mlt) {               // (wave-uniform, rare: Z = 256 builds only)
-                        const unsigned satw = (unsigned)__builtin_amdgcn_readlane((int)sat_reg, min(rt, RT - 1));
-#pragma unroll
-                        for (int u = 0; u < 4; u++)
-                            if (m4[u] == 255.0f && ((satw >> (8 * g4 + 4 * h + u)) & 1u)) m4[u] = 256.0f;
-                    }
-                }
+                const float m4[4] = {cell_count<0>(mw[g4]), cell_count<1>(mw[g4]),
+                                     cell_count<2>(mw[g4]), cell_count<3>(mw[g4])};
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int r = 4 * g4 + u;
@@ -1596,18 +1566,14 @@ static int launch_forward_t(const unsigned long long *masks, const unsigned char
     const int bpb = (S + MA_ROWS - 1) / MA_ROWS;
     const size_t lds = mfma_forward_lds();
     const dim3 grid((unsigned)batch_size * bpb), block(MA_THREADS);
-#define SPT_MF(YT, SAT)                                                                          \
+#define SPT_MF(YT)                                                                               \
     do {                                                                                         \
-        SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_mfma_forward_kernel<T, YT, SAT>, \
+        SPT_HIP_TRY(hipFuncSetAttribute((const void *)attention_mfma_forward_kernel<T, YT>,      \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
-        hipLaunchKernelGGL((attention_mfma_forward_kernel<T, YT, SAT>), grid, block, lds, s, masks, cells, pool, \
+        hipLaunchKernelGGL((attention_mfma_forward_kernel<T, YT>), grid, block, lds, s, masks, cells, pool, \
                            sat, q, k, v, y, row_sum, bounds, S, scale, clamp, heads, bpb);       \
     } while (0)
-    if (y_transposed) {
-        if (sat) SPT_MF(true, true); else SPT_MF(true, false);
-    } else {
-        if (sat) SPT_MF(false, true); else SPT_MF(false, false);
-    }
+    if (y_transposed) SPT_MF(true); else SPT_MF(false);
 #undef SPT_MF
     SPT_LAUNCH_CHECK();
     return SPT_OK;
@@ -1627,36 +1593,33 @@ static int launch_backward_t(const unsigned long long *masks, const unsigned cha
                  lds_k = 2 * MK_IMG + (size_t)MA_WAVES * (MA_PARK + 2048);
     // 64 gradient columns per launch (the accumulators of 128 would not fit the registers
     // beside the operands' fragments): d_head 128 runs each kernel twice
-#define SPT_MB(GT, SAT)                                                                         \
+#define SPT_MB(GT)                                                                              \
     do {                                                                                        \
         SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
-            (const void *)attention_mfma_backward_rows_kernel<T, GT, SAT>,                      \
+            (const void *)attention_mfma_backward_rows_kernel<T, GT>,                      \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));                           \
         for (int half = 0; half < MA_ET / MR_QTILES; half++)                                    \
-            hipLaunchKernelGGL((attention_mfma_backward_rows_kernel<T, GT, SAT>), grid, block, lds_r, \
+            hipLaunchKernelGGL((attention_mfma_backward_rows_kernel<T, GT>), grid, block, lds_r, \
                                s, masks, cells, pool, sat, q, k, v, grad_y, y, row_sum, bounds, \
                                grad_q, delta, S, scale, clamp, heads, bpb, half);               \
         if (MA_BH == 1) {                                                                       \
-            SPT_KEYS(GT, 0, 0, SAT);                                                            \
+            SPT_KEYS(GT, 0, 0);                                                                 \
         } else {                                                                                \
-            SPT_KEYS(GT, 1, 0, SAT);                                                            \
-            for (int half = 0; half < MA_ET / MK_KTILES; half++) SPT_KEYS(GT, 2, half, SAT);    \
+            SPT_KEYS(GT, 1, 0);                                                                 \
+            for (int half = 0; half < MA_ET / MK_KTILES; half++) SPT_KEYS(GT, 2, half);         \
         }                                                                                       \
     } while (0)
-#define SPT_KEYS(GT, MODE, HALF, SAT)                                                           \
+#define SPT_KEYS(GT, MODE, HALF)                                                                \
     do {                                                                                        \
         SPT_HIP_TRY(hipFuncSetAttribute(                                                        \
-            (const void *)attention_mfma_backward_keys_kernel<T, GT, MODE, SAT>,                \
+            (const void *)attention_mfma_backward_keys_kernel<T, GT, MODE>,                \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));                           \
-        hipLaunchKernelGGL((attention_mfma_backward_keys_kernel<T, GT, MODE, SAT>), grid, block, \
+        hipLaunchKernelGGL((attention_mfma_backward_keys_kernel<T, GT, MODE>), grid, block, \
                            lds_k, s, masks, cells_t, pool_t, sat, q, k, v, grad_y, row_sum,     \
                            bounds, delta, grad_k, grad_v, S, scale, clamp, heads, bpb, HALF);   \
     } while (0)
-    if (transposed) {
-        if (sat) SPT_MB(true, true); else SPT_MB(true, false);
-    } else {
-        if (sat) SPT_MB(false, true); else SPT_MB(false, false);
-    }
+    if (transposed) SPT_MB(true);
+    else SPT_MB(false);
 #undef SPT_MB
 #undef SPT_KEYS
     SPT_LAUNCH_CHECK();
@@ -1824,8 +1787,7 @@ static int mfma_forward_any(const void *tiles, int layout, int dtype, const void
     if (layout != SPT_TILES_FULL && layout != SPT_TILES_COMPACT) return SPT_EINVAL;
     if (!mfma_shape_ok(seq_length, d_head, nnz)) return SPT_EUNSUP;
     if (heads > 0 && batch_size % heads != 0) return SPT_ESHAPE;
-    TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length, layout);
-    if (nnz / seq_length < 256) ts.sat = nullptr;       // (a byte holds every multiplicity)
+    const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length, layout);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return d_head == 64
                ? launch_forward(ts.masks, ts.cells, ts.pool, ts.sat, dtype, q, k, v, y, row_sum, bounds,
@@ -1850,8 +1812,7 @@ static int mfma_backward_any(const void *tiles, int layout, int dtype, const voi
     if (!mfma_shape_ok(seq_length, d_head, nnz)) return SPT_EUNSUP;
     if (heads > 0 && batch_size % heads != 0) return SPT_ESHAPE;
     if (transposed && (seq_length & 3)) return SPT_EUNSUP;
-    TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length, layout);
-    if (nnz / seq_length < 256) ts.sat = nullptr;
+    const TileSet ts = carve_tiles(const_cast<void *>(tiles), batch_size, seq_length, layout);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return d_head == 64
                ? launch_backward(ts.masks, ts.cells, ts.cells_t, ts.pool, ts.pool_t, ts.sat, dtype, q,

@@ -762,7 +762,7 @@ def attention_mfma_backward(tiles: MfmaTiles, q: torch.Tensor, k: torch.Tensor, 
         # (one buffer: the projections' backward contracts the three as ONE matrix product when
         # they are equally spaced in memory -- layers/tuning/lora.py, `qkv_dx`)
         grad_q, grad_k, grad_v = torch.empty([3, *q.shape], dtype=q.dtype, device=dev).unbind(0)
-        delta = torch.empty([B, S], dtype=torch.float32, device=dev)
+        delta = torch.empty([2, B, S], dtype=torch.float32, device=dev)   # (scratch: spt_hip.h)
         fn = (lib.spt_attention_mfma_backward if q.dtype == torch.float32
               else lib.spt_attention_mfma_backward_bf16)
         bounds = _bounds_behind(row_sum, B, S, lib.spt_attention_mfma_bounds_floats(B)) if EXACT_CLAMP else 0
