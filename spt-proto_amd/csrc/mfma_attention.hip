@@ -797,7 +797,9 @@ struct ScoreMap {
 // fp32, compared with the clamp.  A tile value on the wrong side is then moved onto the bound or just
 // inside it, which `exp_of` and `inside` turn into the exact mask (the value changes by less than its
 // own error; moving every recomputed cell to the bound changed probabilities by up to eps = 0.5 %).
-// Cost on the common path: one max over the lane's 16 |d| and a ballot per tile; the recomputation
+// Cost on the common path: a scalar test per tile while no score of the slice can reach the clamp
+// (Cauchy-Schwarz on the norms), else the smallest distance of the lane's 16 |d| from the bound and
+// a ballot per tile; the recomputation
 // sits behind a wave-uniform branch (about 1e-4 of the live cells of a layer with scores of
 // standard deviation 10, none at all while the scores are O(1)).
 constexpr float MA_SPLIT_ERR = (1.0f + 3.0f * MA_E / 256.0f) * 1.52587890625e-5f;
@@ -805,13 +807,16 @@ constexpr float MA_SPLIT_ERR = (1.0f + 3.0f * MA_E / 256.0f) * 1.52587890625e-5f
 // [0] max over its rows of |q_i|^2, [1] an upper bound of max |k_j|^2 over the keys it staged
 constexpr int MA_BOUND_SLOTS = 8;                   // workgroups per slice: S <= 2048
 struct ClampGuard {
-    float thr;                 // a lane whose max |d| reaches thr = bound - eps calls for the recomputation
+    float thr;                 // bound - eps: a cell with | |d| - bound | <= eps calls for the recomputation
+    float bound, eps;
     bool on;                   // false: no score of this wave can reach thr at all (Cauchy-Schwarz on the
                                // norms) -- the usual case, scores O(1): the tile loop then only tests a scalar
     // own2: |own row|^2 of this lane (unscaled operand); which: 1 = the streamed operand is K, 0 = Q
     __device__ __forceinline__ ClampGuard(const float *bounds, int b, int nslots, int which, float own2,
                                           const ScoreMap &sm, float clampv) {
         thr = __builtin_inff();
+        bound = sm.bound;
+        eps = 0.0f;
         on = false;
         if (bounds != nullptr && clampv > 0.0f) {
             float other2 = 0.0f;
@@ -823,6 +828,7 @@ struct ClampGuard {
             const float reach = sqrtf(own2 * other2) * sm.sl2;      // |d| <= |own| |other| scale log2e
             thr = sm.bound - MA_SPLIT_ERR * reach;
             thr = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, thr)));
+            eps = bound - thr;                                      // (as clamp_exact forms it)
             on = __builtin_amdgcn_readfirstlane((int)(reach * 1.0001f >= thr)) != 0;
         }
     }
@@ -831,10 +837,15 @@ struct ClampGuard {
         return false;
 #endif
         if (!on) return false;
-        float am = fmaxf(fabsf(d[0]), fabsf(d[1]));
+        // TWO-sided: the smallest distance of the lane's 16 |d| from the bound.  (The first form asked
+        // for max |d| >= thr, which every tile answers with yes once scores lie BEYOND the clamp -- ten
+        // steps into the bench's training run: max |score| 15-23 in the upper layers, and the key-owned
+        // kernel went from 89 to 140-165 us there, all of it the second-level test behind the branch.)
+        float m = fminf(fabsf(fabsf(d[0]) - bound), fabsf(fabsf(d[1]) - bound));
 #pragma unroll
-        for (int r = 2; r < 16; r += 2) am = fmaxf(am, fmaxf(fabsf(d[r]), fabsf(d[r + 1])));
-        return __ballot(am >= thr) != 0ull;
+        for (int r = 2; r < 16; r += 2)
+            m = fminf(m, fminf(fabsf(fabsf(d[r]) - bound), fabsf(fabsf(d[r + 1]) - bound)));
+        return __ballot(m <= eps) != 0ull;
     }
 };
 // extension/sddmm.cpp:27-69 as the oracle restates it: sum in fp64, e ascending, rounded once
@@ -956,7 +967,11 @@ void attention_mfma_forward_kernel(
     // for the backward's exact clamp mask (ClampGuard): |q_i|^2 of the own row, and the running
     // maximum of THIS thread's share of |k_j|^2 -- the four columns it stages, over all the rows it
     // stages; summed over the column groups at the end that bounds every staged key's |k_j|^2
-    // (max_j sum_g <= sum_g max_j) without a cross-lane sum per tile
+    // (max_j sum_g <= sum_g max_j) without a cross-lane sum per tile.  About 3x the true maximum on
+    // Gaussian rows (1.75x in the norm): the guard switches on that much earlier than it has to.  The
+    // exact maximum -- |k_i|^2 of the own rows, one more read of K in the prologue -- was measured:
+    // +3 us on every forward (44 -> 48 in the step), more than the guard's per-tile test costs while
+    // it is on, so the loose bound stays.
     float q2 = 0.f, k2part = 0.f;
     {
         float xq[MA_E / 2];
