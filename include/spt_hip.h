@@ -181,7 +181,18 @@ int spt_sddmm_forward(const int32_t *indptr, const int32_t *indices,
  * The transposed product is computed as a gather over the transposed CSR structure,
  * which is built into `workspace` (spt_spmm_workspace_bytes() bytes, uninitialised;
  * may be NULL when trans_lhs == 0).
+ *
+ * Two forms of the non-transposed product (round 4).  The fp32 gather kernels (csrc/spmm.hip) are the
+ * default.  With SPT_SPMM_MFMA=1 in the environment (read at every call), patterns as dense as lookup's
+ * (nnz >= S * S / 16, mean row length <= 64, d_head 64 or 128, 64 <= S <= 2048) are multiplied as DENSE
+ * 32 x 32 tiles on the matrix cores: a wave assembles the tile of its 32 rows in LDS from the CSR
+ * entries (duplicates add) and contracts it with the bf16 image of x (split-bf16, <= 2^-16 relative
+ * error per product; csrc/mfma_attention.hip: spmm_mfma_kernel).  Opt-in because it is SLOWER at the
+ * benchmark shape (65.7 against 46.3 us, profiles/r04_ops_kernels.txt; the kernel's header says
+ * where the time goes).  spt_spmm_form() tells which form a call would take (1 = matrix cores,
+ * 0 = gather).
  */
+int spt_spmm_form(int trans_lhs, int batch_size, int seq_length, int d_head, int nnz);
 int64_t spt_spmm_workspace_bytes(int trans_lhs, int batch_size, int seq_length, int d_head,
                                  int nnz);
 int spt_spmm_forward(int trans_lhs, const int32_t *indptr,

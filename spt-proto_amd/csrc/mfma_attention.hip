@@ -1572,6 +1572,281 @@ static size_t mfma_forward_lds() {
     return 2 * MA_IMG + (size_t)MA_WAVES * (MA_WROWS + 2) * sizeof(float);
 }
 
+// ---- spmm (A . x over the CSR) on the matrix cores: the operator form of the P . V product ----
+// Replaces extension/spmm.cpp:27-69 (cusparseSpMM, non-transposed) for patterns as dense as
+// lookup's: y[b, i, :] = sum_{p in row i} values[b, p] x[b, indices[b, p], :].
+//
+// The gather form (spmm.hip) moves one 256-byte row of x through LDS per CSR entry: 2.1 GB per
+// launch at the configs[1] shape for 134 MB of HBM traffic, LDS-bandwidth bound (27 us at 100 % of
+// the LDS rate, 46.9 measured).  Here a wave owns 32 rows, x streams through LDS 32 keys at a time
+// as in the attention forward (bf16 images, transposing reads), and the wave's P tile [32 rows x
+// 32 keys] is assembled DENSE in a wave-private 4.5 KiB LDS tile: LDS traffic per entry is 4 bytes
+// in and 4 bytes out instead of 256.
+//   * The wave keeps its rows' entries in registers: lane l holds entry l of each of the 32 rows,
+//     packed as key tile << 16 | byte address in the tile.
+//   * Duplicates (the same column twice in a row: lookup pads short causal rows with column 0) are
+//     merged ONCE, in the prologue: every lane writes its lane id to owner[col], reads it back, and
+//     where another lane won adds its value to the winner's (ds_add_f32 into a 64-float scratch, a
+//     rare wave-uniform branch) and retires.  After that a (row, column) occurs once, so ...
+//   * ... per key tile each row is two vector instructions and one plain ds_write_b32, no branch:
+//     a = packed ^ (tile << 16) is the cell's address if the entry belongs to the tile and >= 65536
+//     if not; min(a, trash + 4 lane) sends the others to a per-lane trash word.  (The first form --
+//     a predicated ds_add_f32 per row and tile -- took 110 us: 41 of them the LDS atomics, 17 the
+//     exec-mask round trips.)
+//   * The tile is read back in the accumulator layout (and zeroed behind the read), split in two bf16
+//     parts and multiplied with the x image.  Key tiles no row of the wave has an entry in are skipped
+//     (a 64-bit mask formed once).
+//   * Rows of more than 64 entries take a slow loop (their further entries are re-read from global
+//     memory for every tile and added with ds_add_f32): the dispatcher only sends patterns whose MEAN
+//     row has at most 64 here, so this is for ragged patterns' few long rows.
+// Workgroups of four waves (128 rows), three to a CU; x tiles are requested two iterations ahead.
+//
+// MEASURED (round 4, rocprofv3, configs[1] shape: 256 slices x 512 rows x 64, 64 entries per row, 134 MB
+// algorithmic): 65.7 us = 0.26 of the HBM roofline, against 46.3 us (0.36) for the gather form -- the
+// dense-tile form does NOT pay for spmm the way it does for sddmm, and is therefore opt-in
+// (SPT_SPMM_MFMA=1).  Where the time goes (ablation builds, tools/variant.sh -DSN_ABL_*):
+//   22.4 us  the prologue and epilogue alone (entries in, live mask, first x tile, y out: 100 MB of
+//            the 134, latency- and HBM-bound, nothing else running meanwhile)
+//   +11.5    the duplicate merge (8 LDS round trips per wave; 2.6 us of it not hidden in the full kernel)
+//   +26      the 16 tile iterations without the scatter (P tile read / zero, split, 16 transposing
+//            reads, 12 MFMAs, x staging, one barrier: a chain of LDS round trips per wave that three
+//            waves per SIMD do not cover; the MFMAs themselves are free: 66.6 us with them against 67.7
+//            without in an early build)
+//   +15      the scatter (32 x [xor, min, ds_write_b32] per tile and wave)
+// and 1,024 workgroups on 768 slots (153 VGPRs: three waves per SIMD) run as 1.33 rounds.  The
+// first build (one predicated ds_add_f32 per row and tile, eight-wave workgroups, entries loaded row by
+// row) took 110 us: 41 of them the LDS atomics, 35 the serialised loads.  What would be needed to beat
+// the gather form: <= 128 VGPRs (the 64 entry registers packed two to a register) for two eight-wave
+// workgroups per CU in ONE round, and the next row block's entries in flight during the tile loop --
+// both against the register budget; the fused forward (attention_mfma_forward_kernel) does the same
+// product in 44 us INCLUDING the scores and the softmax because its P tile never leaves registers.
+constexpr int SN_THREADS = 256;
+constexpr int SN_WAVES = SN_THREADS / SPT_WAVE;
+constexpr int SN_ROWS = SN_WAVES * MA_WROWS;
+constexpr int SN_RPT = 32 * MA_EQ / SN_THREADS;         // float4s per thread to stage a 32 x E tile
+constexpr int SN_RPP = SN_THREADS / MA_EQ;
+constexpr int SN_PLD = 36;                              // floats per row of the dense P tile
+constexpr int SN_PT = MA_WROWS * SN_PLD * 4;            // bytes of one wave's P tile
+constexpr int SN_TRASH = SN_PT;                         // 64 words behind it: one per lane
+constexpr int SN_SUM = SN_TRASH + 256;                  // 64 floats: the duplicates' sums
+constexpr int SN_OWNER = SN_SUM + 256;                  // SN_NOWN x S bytes (rounded up to 16): owner[col]
+constexpr int SN_IMG = 2 * MA_RIMG;                     // one x tile: rows image, hi | lo
+constexpr int SN_NOWN = 4;                              // owner arrays: rows deduplicated per LDS round trip
+__host__ __device__ constexpr int sn_wave_bytes(int S) { return SN_OWNER + SN_NOWN * (((S + 15) / 16) * 16); }
+struct SnRegs { float4 xf[SN_RPT]; };
+#if MA_E_VALUE == 64
+#define SN_WAVES_PER_EU 3
+#else
+#define SN_WAVES_PER_EU 2
+#endif
+__global__ __launch_bounds__(SN_THREADS)
+__attribute__((amdgpu_waves_per_eu(SN_WAVES_PER_EU, SN_WAVES_PER_EU)))
+void spmm_mfma_kernel(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                      const float *__restrict__ values, const float *__restrict__ x,
+                      float *__restrict__ y, int S, int nnz, int x_heads, int y_heads,
+                      int blocks_per_batch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *img = smem;                                   // [2][SN_IMG]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, c32 = lane & 31;
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = bid / blocks_per_batch;
+    const int i0 = MA_WROWS * ((bid % blocks_per_batch) * SN_WAVES + wave);
+    const DenseView xv = dense_view(b, S, MA_E, x_heads), yv = dense_view(b, S, MA_E, y_heads);
+    const float *x_b = x + xv.base;
+    const int KT = (S + MA_KT - 1) / MA_KT;
+    char *ptile = smem + 2 * SN_IMG + wave * sn_wave_bytes(S);
+    const int32_t *idx_b = indices + (size_t)b * nnz;
+    const float *val_b = values + (size_t)b * nnz;
+
+    // the x tiles: thread t stages row t / (E/4) + SN_RPP u, columns 4 (t % (E/4)) .. (clamped rows:
+    // keys >= S are finite data no entry points at)
+    const int jl = tid / MA_EQ, e4 = (tid % MA_EQ) * 4;
+    auto xload = [&](int t) {
+        SnRegs r;
+#pragma unroll
+        for (int u = 0; u < SN_RPT; u++)
+            r.xf[u] = ld_raw4(x_b + (size_t)min(t * MA_KT + jl + SN_RPP * u, S - 1) * xv.ld + e4);
+        return r;
+    };
+    auto xstore = [&](char *buf, const SnRegs &r) {
+#pragma unroll
+        for (int u = 0; u < SN_RPT; u++) put_rows4(buf, jl + SN_RPP * u, e4, r.xf[u]);
+    };
+    SnRegs nxt = xload(0), nxt2 = xload(min(1, KT - 1));
+
+    // zero the P tile (4608 B: 64 lanes x 16 B x 4 + the rest; the trash words need no value)
+#pragma unroll
+    for (int o = lane * 16; o < SN_PT; o += 64 * 16) *reinterpret_cast<uint4 *>(ptile + o) = make_uint4(0u, 0u, 0u, 0u);
+    // this wave's entries: lane l holds entry l of row i0 + r (r = 0 .. 31); no match ever for the
+    // lanes past a row's end or retired as duplicates (packed = ~0)
+    unsigned packed[MA_WROWS];
+    float val[MA_WROWS];
+    unsigned long long mine = 0ull;                     // key tiles this lane has an entry in
+    int longest = 0;
+    unsigned char *owner = reinterpret_cast<unsigned char *>(ptile + SN_OWNER);
+    float *dsum = reinterpret_cast<float *>(ptile + SN_SUM);
+    // (three separate loops: the row bounds from ONE vector load, then all 64 loads of the entries in
+    // flight together, then the packing -- written as one loop the compiler waited for each row's
+    // scalar bounds and then for its column ids before it issued the next row's: 32 round trips, 35 us)
+    const int bound = indptr[min(i0 + min(lane, MA_WROWS), S)];   // lane r: where row i0 + r begins
+    int cols[MA_WROWS];
+#pragma unroll
+    for (int r = 0; r < MA_WROWS; r++) {
+        const int st = __builtin_amdgcn_readlane(bound, r);
+        const int pc = min(st + lane, nnz - 1);         // (unconditional loads)
+        cols[r] = idx_b[pc];
+        val[r] = val_b[pc];
+    }
+#pragma unroll
+    for (int r = 0; r < MA_WROWS; r++) {
+        const int st = __builtin_amdgcn_readlane(bound, r), en = __builtin_amdgcn_readlane(bound, r + 1);
+        longest = max(longest, en - st);
+        const bool ok = st + lane < en;
+        packed[r] = ok ? ((unsigned)(cols[r] >> 5) << 16) | (unsigned)(r * SN_PLD * 4 + (cols[r] & 31) * 4) : ~0u;
+    }
+    // duplicates within a row: one lane per column wins owner[col]; four rows per LDS round trip
+    // (an owner array each)
+    const int own_ld = ((S + 15) / 16) * 16;
+#ifndef SN_ABL_NO_DEDUPE
+#pragma unroll
+    for (int r0 = 0; r0 < MA_WROWS; r0 += SN_NOWN) {
+#pragma unroll
+        for (int u = 0; u < SN_NOWN; u++)
+            if (packed[r0 + u] != ~0u) owner[u * own_ld + cols[r0 + u]] = (unsigned char)lane;
+        wave_lds_fence();
+        int won[SN_NOWN];
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < SN_NOWN; u++) {
+            won[u] = packed[r0 + u] != ~0u ? (int)owner[u * own_ld + cols[r0 + u]] : lane;
+            any |= won[u] != lane;
+        }
+        if (__ballot(any) != 0ull) {                    // (wave-uniform: rows with duplicates)
+#pragma unroll
+            for (int u = 0; u < SN_NOWN; u++) {
+                dsum[lane] = 0.f;
+                wave_lds_fence();
+                if (won[u] != lane)
+                    __hip_atomic_fetch_add(dsum + won[u], val[r0 + u], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+                wave_lds_fence();
+                val[r0 + u] += dsum[lane];
+                if (won[u] != lane) packed[r0 + u] = ~0u;
+                wave_lds_fence();
+            }
+        }
+        wave_lds_fence();
+    }
+#endif
+#pragma unroll
+    for (int r = 0; r < MA_WROWS; r++) mine |= packed[r] != ~0u ? 1ull << (packed[r] >> 16) : 0ull;
+    if (longest > 64) {                                 // (wave-uniform: rare)
+        for (int r = 0; r < MA_WROWS; r++) {
+            const int i = min(i0 + r, S);
+            const int st = indptr[i], en = indptr[min(i + 1, S)];
+            for (int pos = st + 64 + lane; pos < en; pos += 64) mine |= 1ull << (idx_b[pos] >> 5);
+        }
+    }
+    unsigned long long live = 0ull;                     // ... any lane of the wave has
+    for (int t = 0; t < KT; t++)
+        if (__ballot((mine >> t) & 1ull) != 0ull) live |= 1ull << t;
+    xstore(img, nxt);
+    __syncthreads();
+
+    f32x16 yacc[MA_ET];
+#pragma unroll
+    for (int eh = 0; eh < MA_ET; eh++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) yacc[eh][r] = 0.f;
+    const unsigned trash = (unsigned)(SN_TRASH + 4 * lane);
+
+#ifdef SN_ABL_NO_TILES
+    if (S == 12345)
+#endif
+    for (int t = 0; t < KT; t++) {
+        const char *buf = img + (t & 1) * SN_IMG;
+        nxt = nxt2;                                     // tile t + 1: requested an iteration ago
+        nxt2 = xload(min(t + 2, KT - 1));
+        if ((live >> t) & 1ull) {                       // (wave-uniform)
+            const unsigned tk = (unsigned)t << 16;
+#ifdef SN_ABL_NO_LOOP
+            if (tk == 0x7fff0000u)
+#endif
+#pragma unroll
+            for (int r = 0; r < MA_WROWS; r++) {
+                // this tile's entries: a = the cell's byte address; the others: a >= 65536 -> the trash word
+                const unsigned a = min(packed[r] ^ tk, trash);
+                *reinterpret_cast<float *>(ptile + a) = val[r];
+            }
+            if (longest > 64) {
+                wave_lds_fence();
+                for (int r = 0; r < MA_WROWS; r++) {
+                    const int i = min(i0 + r, S);
+                    const int st = indptr[i], en = indptr[min(i + 1, S)];
+                    for (int pos = st + 64 + lane; pos < en; pos += 64) {
+                        const int col = idx_b[pos];
+                        if ((col >> 5) == t)
+                            __hip_atomic_fetch_add(reinterpret_cast<float *>(ptile) + r * SN_PLD + (col & 31),
+                                                   val_b[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+                }
+            }
+            wave_lds_fence();
+            // the tile in the accumulator layout: row c32, keys 32 t + acc_row(r, h) -- four float4;
+            // and zero again behind the read
+            float p[16];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float4 *cell = reinterpret_cast<float4 *>(ptile) + (c32 * SN_PLD + 8 * g + 4 * h) / 4;
+                const float4 v4 = *cell;
+                p[4 * g] = v4.x; p[4 * g + 1] = v4.y; p[4 * g + 2] = v4.z; p[4 * g + 3] = v4.w;
+                *cell = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                const Frag pf = split8(p[8 * s2], p[8 * s2 + 1], p[8 * s2 + 2], p[8 * s2 + 3],
+                                       p[8 * s2 + 4], p[8 * s2 + 5], p[8 * s2 + 6], p[8 * s2 + 7]);
+#pragma unroll
+                for (int eh = 0; eh < MA_ET; eh++)
+#ifdef SN_ABL_NO_MMA
+                    yacc[eh][s2] += __builtin_bit_cast(float, pf.hi.x ^ pf.lo.y);
+#else
+                    yacc[eh] = mm<2, 2>(pf, read_cols_tr<2>(buf, buf + MA_RIMG, 32 * eh, lane, s2), yacc[eh]);
+#endif
+            }
+        }
+        if (t + 1 < KT) xstore(img + ((t + 1) & 1) * SN_IMG, nxt);
+        __syncthreads();
+    }
+    // register r of lane (c32, h): row i0 + acc_row(r, h), column 32 eh + c32
+    float *y_b = y + yv.base;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int i = i0 + acc_row(r, h);
+        if (i < S) {
+#pragma unroll
+            for (int eh = 0; eh < MA_ET; eh++) y_b[(size_t)i * yv.ld + 32 * eh + c32] = yacc[eh][r];
+        }
+    }
+}
+
+// -> SPT_OK (indptr [S + 1] shared by the batch, as everywhere; x, y head layouts as dense_view)
+int launch_spmm_mfma(const int32_t *indptr, const int32_t *indices, const float *values, const float *x,
+                     float *y, int B, int S, int nnz, int x_heads, int y_heads, hipStream_t s) {
+    const int bpb = (S + SN_ROWS - 1) / SN_ROWS;
+    if ((long long)B * bpb > 0x7FFFFFFFll) return SPT_EUNSUP;
+    const int lds = 2 * SN_IMG + SN_WAVES * sn_wave_bytes(S);
+    SPT_HIP_TRY(hipFuncSetAttribute((const void *)spmm_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    lds));
+    hipLaunchKernelGGL(spmm_mfma_kernel, dim3((unsigned)(B * bpb)), dim3(SN_THREADS), lds, s, indptr, indices,
+                       values, x, y, S, nnz, x_heads, y_heads, bpb);
+    SPT_LAUNCH_CHECK();
+    return SPT_OK;
+}
+
 // ---- launchers of this head dimension (the d_head 64 unit dispatches to spt::e128's) ----
 template <typename T>
 static int launch_forward_t(const unsigned long long *masks, const unsigned char *cells,
@@ -1691,6 +1966,29 @@ int launch_backward(const unsigned long long *masks, const unsigned char *cells,
                     void *grad_k, void *grad_v, int batch_size, int S, float scale, float clamp,
                     int heads, int transposed, hipStream_t s);
 }  // namespace e128
+
+namespace e128 {
+int launch_spmm_mfma(const int32_t *indptr, const int32_t *indices, const float *values, const float *x,
+                     float *y, int B, int S, int nnz, int x_heads, int y_heads, hipStream_t s);
+}
+// The shapes of the matrix-core spmm (non-transposed); everything else is for the gather form
+// (spmm.hip).  All S keys of a row stripe are multiplied: worth it from a density of 1 / 16
+// (lookup: 1 / 8); a row's first 64 entries live in registers: mean row length <= 64.
+bool spmm_mfma_takes(int B, int S, int E, int nnz) {
+    if ((E != 64 && E != 128) || S < 64 || S > MA_MAXNT * MA_KT || B <= 0 || nnz <= 0) return false;
+    if ((long long)nnz * 16 < (long long)S * S || (long long)nnz > 64ll * S) return false;
+    // OPT-IN (SPT_SPMM_MFMA=1): measured at the configs[1] shape (256 slices x 512 x 64, 64 entries per
+    // row; profiles/r04_ops_kernels.txt) this form takes 65.7 us against the gather form's 46.3 -- see
+    // the kernel's header for where they go -- so the gather form stays the default.
+    const char *on = getenv("SPT_SPMM_MFMA");
+    return on && on[0] == '1';
+}
+int spmm_mfma_launch(const int32_t *indptr, const int32_t *indices, const float *values, const float *x,
+                     float *y, int B, int S, int E, int nnz, int x_heads, int y_heads, hipStream_t s) {
+    if (!spmm_mfma_takes(B, S, E, nnz)) return SPT_EUNSUP;
+    return E == 64 ? launch_spmm_mfma(indptr, indices, values, x, y, B, S, nnz, x_heads, y_heads, s)
+                   : e128::launch_spmm_mfma(indptr, indices, values, x, y, B, S, nnz, x_heads, y_heads, s);
+}
 
 static bool mfma_shape_ok(int S, int E, int nnz) {
     if ((E != 64 && E != 128) || S <= 0 || nnz <= 0 || nnz % S != 0) return false;

@@ -882,6 +882,11 @@ static int64_t product_scratch_bytes(int B, int S, int E, int nnz) {
     return (int64_t)B * nnz * (int64_t)sizeof(float);                 // permuted values
 }
 
+// the dense-tile form on the matrix cores (mfma_attention.hip)
+bool spmm_mfma_takes(int B, int S, int E, int nnz);
+int spmm_mfma_launch(const int32_t *indptr, const int32_t *indices, const float *values, const float *x,
+                     float *y, int B, int S, int E, int nnz, int x_heads, int y_heads, hipStream_t s);
+
 }  // namespace spt
 
 using namespace spt;
@@ -929,6 +934,10 @@ extern "C" int spt_spmm_transposed(const int32_t *indptr, const void *transposed
                                (hipStream_t)stream, reinterpret_cast<float *>(workspace));
 }
 
+extern "C" int spt_spmm_form(int trans_lhs, int batch_size, int seq_length, int d_head, int nnz) {
+    return !trans_lhs && spt::spmm_mfma_takes(batch_size, seq_length, d_head, nnz) ? 1 : 0;
+}
+
 extern "C" int64_t spt_spmm_workspace_bytes(int trans_lhs, int batch_size, int seq_length,
                                             int d_head, int nnz) {
     if (!trans_lhs) return 0;
@@ -954,9 +963,13 @@ extern "C" int spt_spmm_forward(int trans_lhs, const int32_t *indptr, const int3
         SPT_LAUNCH_CHECK();
         return SPT_OK;
     }
-    if (!trans_lhs)
+    if (!trans_lhs) {
+        // patterns as dense as lookup's: the dense-tile form on the matrix cores (mfma_attention.hip)
+        const int rc2 = spmm_mfma_launch(indptr, indices, values, x, y, B, S, E, nnz, x_heads, y_heads, s);
+        if (rc2 != SPT_EUNSUP) return rc2;
         return launch_gather<false>(indptr, 0, indices, nullptr, values, x, y, B, S, E, nnz,
                                     x_heads, y_heads, s);
+    }
     if (!workspace) return SPT_EINVAL;
     const TransposedCsr t = carve(workspace, B, S, nnz, E);
     float *scratch = reinterpret_cast<float *>(

@@ -47,6 +47,7 @@ _PROTOTYPES = {
         [_c_ptr] * 5 + [_c_int] * 4 + [_c_f32, _c_f32, _c_int, _c_int, _c_ptr], _c_int
     ),
     'spt_sddmm_form': ([_c_int] * 4, _c_int),
+    'spt_spmm_form': ([_c_int] * 5, _c_int),
     'spt_spmm_workspace_bytes': ([_c_int] * 5, ctypes.c_int64),
     'spt_spmm_forward': ([_c_int] + [_c_ptr] * 6 + [_c_int] * 6 + [_c_ptr], _c_int),
     'spt_csr_transpose_workspace_bytes': ([_c_int] * 4, ctypes.c_int64),
@@ -885,6 +886,7 @@ def spmm_forward_cuda(trans_lhs, trans_rhs, indptr: torch.Tensor,
         if nnz == 0:
             return output.zero_()
         workspace = None
+        note_path('spmm_t' if trans else 'spmm', 'matrix_cores' if lib.spt_spmm_form(trans, B, S, E, nnz) else 'gather')
         if trans:
             nbytes = lib.spt_spmm_workspace_bytes(trans, B, S, E, nnz)
             workspace = torch.empty([max(int(nbytes), 16)], dtype=torch.uint8, device=dev)
