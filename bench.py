@@ -849,7 +849,14 @@ def main():
             'lora = frozen base + rank-16 adapters: frozen linears on the SAME split-bf16 GEMM engine '
             'as the sparse step, naive dense attention -- speedup_vs_lora is the same-engine, '
             'same-trainable-set comparison (what sparsity itself buys); *_sdpa = the same two with '
-            "torch's fused scaled_dot_product_attention")
+            "torch's fused scaled_dot_product_attention.  speedup_vs_dense / speedup_vs_full_sdpa "
+            'compare across DIFFERENT GEMM engines (and trainable sets); the <= 50 % memory target is met '
+            'only against the naive-attention baselines (peak_hbm_vs_lora_sdpa is the same-engine figure)')
+        result['speedup_vs_dense_note'] = 'different GEMM engine: library fp32 GEMM vs split-bf16 (see baselines)'
+        result['same_engine'] = {'speedup_vs_lora': result['speedup_vs_lora'],
+                                 'peak_hbm_vs_lora': result['peak_hbm_vs_lora'],
+                                 'speedup_vs_lora_sdpa': result.get('speedup_vs_lora_sdpa'),
+                                 'peak_hbm_vs_lora_sdpa': result.get('peak_hbm_vs_lora_sdpa')}
     if single and not args.no_block:
         blk = {t: block_record(t, args, dev) for t in ('sparse', 'full', 'lora')}
         blk['what'] = ('one TransformerBlock, protocol of script/0-profile.py:203-226: fwd + bwd '
