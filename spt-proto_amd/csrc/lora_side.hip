@@ -161,11 +161,14 @@ __global__ __launch_bounds__(64 * LS_NW) void lora_down_kernel(
         }
     };
     // one chunk; RAGGED: steps s0 + c >= cnt load a clamped (valid) address and are skipped
-    auto chunk = [&](int s0, auto ragged) {
+    // (CH: K = 1024 gives a wave 4 k-steps -- as one ragged chunk of 8 that was 8 clamped duplicates among
+    // its 16 load instructions)
+    auto chunk = [&](int s0, auto ragged, auto steps) {
         constexpr bool RAGGED = decltype(ragged)::value;
-        float4 a[LS_CH][2];
+        constexpr int CH = decltype(steps)::value;
+        float4 a[CH][2];
 #pragma unroll
-        for (int c = 0; c < LS_CH; c++) {
+        for (int c = 0; c < CH; c++) {
             const int st = RAGGED ? min(s0 + c, cnt - 1) : s0 + c;
             a[c][0] = *reinterpret_cast<const float4 *>(xp + st * 32);
             a[c][1] = *reinterpret_cast<const float4 *>(xp + st * 32 + 4);
@@ -173,14 +176,14 @@ __global__ __launch_bounds__(64 * LS_NW) void lora_down_kernel(
         float bnext[NB][8];
         load_l(s0, bnext);
 #pragma unroll
-        for (int c = 0; c < LS_CH; c++) {
+        for (int c = 0; c < CH; c++) {
             if (RAGGED && s0 + c >= cnt) break;              // (wave-uniform)
             float bv[NB][8];
 #pragma unroll
             for (int b = 0; b < NB; b++)
 #pragma unroll
                 for (int i = 0; i < 8; i++) bv[b][i] = bnext[b][i];
-            if (c + 1 < LS_CH) load_l(RAGGED ? min(s0 + c + 1, cnt - 1) : s0 + c + 1, bnext);
+            if (c + 1 < CH) load_l(RAGGED ? min(s0 + c + 1, cnt - 1) : s0 + c + 1, bnext);
             const float av[8] = {a[c][0].x, a[c][0].y, a[c][0].z, a[c][0].w,
                                  a[c][1].x, a[c][1].y, a[c][1].z, a[c][1].w};
             LsFrag af;
@@ -200,8 +203,18 @@ __global__ __launch_bounds__(64 * LS_NW) void lora_down_kernel(
         }
     };
     int s0 = 0;
-    for (; s0 + LS_CH <= cnt; s0 += LS_CH) chunk(s0, std::false_type{});
-    if (s0 < cnt) chunk(s0, std::true_type{});
+    for (; s0 + LS_CH <= cnt; s0 += LS_CH) chunk(s0, std::false_type{}, std::integral_constant<int, LS_CH>{});
+    if constexpr (IMAGE) {
+        // (measured, 8192 / 16384 rows x 1024, three tables + image: 22.8 -> 18.6 and 45.6 -> 43.4 us warm,
+        // 31.5 -> 28.3 and 58 -> 52.5 cold; the plain kernel LOST with the second instantiation
+        // -- 98 -> 128 registers, 8.4 -> 12.3 us -- and keeps the one ragged chunk)
+        for (; s0 + LS_CH / 2 <= cnt; s0 += LS_CH / 2)
+            chunk(s0, std::false_type{}, std::integral_constant<int, LS_CH / 2>{});
+        if (s0 < cnt) chunk(s0, std::true_type{}, std::integral_constant<int, LS_CH / 2>{});
+    } else {
+        // (half chunks alone, one instantiation: 9.6 / 19.0 us warm against 8.8 / 14.4 -- not this either)
+        if (s0 < cnt) chunk(s0, std::true_type{}, std::integral_constant<int, LS_CH>{});
+    }
     // the waves' shares of the 16 x (16 NB) result through LDS; lane (c, g) holds rows 4g + j
 #pragma unroll
     for (int b = 0; b < NB; b++)
