@@ -167,23 +167,49 @@ __device__ __forceinline__ float act_derivative(int act, float s) {
 
 // v[p, n] as a plain fp32 computation by one wave: rowscale (sum_k a[src, k] W_g(n, k) + bias)
 // + sum_j a2[src2, j] b2[n, j], every lane 4 k's per pass, butterfly sum.  All lanes return it.
+// BATCHED: the k-contiguous weights' four passes of loads in flight together (relu_fix_kernel; the
+// epilogue's own rare fallback keeps the compact loop: inlined there the batched form cost the
+// activation GEMM registers)
+template <bool BATCHED = false>
 __device__ __forceinline__ float gg_exact_preact(const GroupedArgs &g, int bucket, int p, int n,
                                                  int lane) {
     const long long src = g.gather ? g.gather[p] : p;
     const float *ar = g.a + src * g.lda;
     const float *wr = g.w + (size_t)bucket * g.gstride + (size_t)n * g.ldn;
     float part = 0.0f;
-    for (int k = 4 * lane; k < g.K; k += 256) {
-        const float4 x = *reinterpret_cast<const float4 *>(ar + k);
-        float4 y;
-        if (g.ldk == 1) {
-            y = *reinterpret_cast<const float4 *>(wr + k);
-        } else {            // n-contiguous weights: a strided column
-            y.x = wr[(size_t)k * g.ldk]; y.y = wr[(size_t)(k + 1) * g.ldk];
-            y.z = wr[(size_t)(k + 2) * g.ldk]; y.w = wr[(size_t)(k + 3) * g.ldk];
+    if (BATCHED && g.ldk == 1) {
+        // four passes' loads in flight together (clamped addresses, zeroed past K): as one load pair
+        // per pass an element cost the wave four dependent round trips -- relu_fix_kernel took 22 us
+        // for ~40 elements per segment.  Same order of additions as the plain loop below.
+        for (int k0 = 4 * lane; k0 < g.K; k0 += 1024) {
+            float4 x[4], y[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int k = min(k0 + 256 * i, g.K - 4);
+                x[i] = *reinterpret_cast<const float4 *>(ar + k);
+                y[i] = *reinterpret_cast<const float4 *>(wr + k);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (k0 + 256 * i < g.K) {
+                    part = fmaf(x[i].x, y[i].x, part); part = fmaf(x[i].y, y[i].y, part);
+                    part = fmaf(x[i].z, y[i].z, part); part = fmaf(x[i].w, y[i].w, part);
+                }
+            }
         }
-        part = fmaf(x.x, y.x, part); part = fmaf(x.y, y.y, part);
-        part = fmaf(x.z, y.z, part); part = fmaf(x.w, y.w, part);
+    } else {
+        for (int k = 4 * lane; k < g.K; k += 256) {
+            const float4 x = *reinterpret_cast<const float4 *>(ar + k);
+            float4 y;
+            if (g.ldk == 1) {
+                y = *reinterpret_cast<const float4 *>(wr + k);
+            } else {            // n-contiguous weights: a strided column
+                y.x = wr[(size_t)k * g.ldk]; y.y = wr[(size_t)(k + 1) * g.ldk];
+                y.z = wr[(size_t)(k + 2) * g.ldk]; y.w = wr[(size_t)(k + 3) * g.ldk];
+            }
+            part = fmaf(x.x, y.x, part); part = fmaf(x.y, y.y, part);
+            part = fmaf(x.z, y.z, part); part = fmaf(x.w, y.w, part);
+        }
     }
     float side = 0.0f;
     if (g.a2 && 4 * lane < g.R) {
@@ -1577,7 +1603,7 @@ __global__ __launch_bounds__(256) void relu_fix_kernel(GroupedArgs g) {
         // stale counter or list, as the out-of-order memset node of round 3 produced) is skipped,
         // not dereferenced
         if (p < 0 || p >= g.P || n >= g.N || bucket >= g.G) continue;
-        const float exact = gg_exact_preact(g, bucket, p, n, lane);
+        const float exact = gg_exact_preact<true>(g, bucket, p, n, lane);
         if (lane == 0) {
             g.out[(size_t)p * g.ldo + n] = act_forward(g.act, exact);
             if (g.out2) g.out2[(size_t)p * g.ldo + n] = exact;
