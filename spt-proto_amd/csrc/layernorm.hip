@@ -207,6 +207,14 @@ __global__ __launch_bounds__(256) void layernorm_param_reduce_kernel(
     float a0 = 0.f, a1 = 0.f;
     if (col < width) {
         int p = rl;
+        // (eight loads in flight: two at a time the 512 partial rows were 16 dependent round trips)
+        for (; p + 112 < nparts; p += 128) {
+            float t[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) t[i] = partial[(size_t)(p + 16 * i) * width + col];
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) { a0 += t[i]; a1 += t[i + 1]; }
+        }
         for (; p + 16 < nparts; p += 32) {
             a0 += partial[(size_t)p * width + col];
             a1 += partial[(size_t)(p + 16) * width + col];
